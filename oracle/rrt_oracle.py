@@ -1,0 +1,253 @@
+"""CPU oracle for the RRTEncoder forward path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's ``cpu_baseline`` leg may
+import this module; the product path (rrt-mil_amd/) never does.
+
+Two independent restatements of the reference algorithm, written from the
+specification in SURVEY.md §3.3 (not copied from the reference sources):
+
+* ``forward_f64``   -- numpy float64, *algebraic* form (GEMM-shaped CR-MSA
+                       combine/dispatch, EPEG as an explicit stencil).  This is
+                       the ground truth the HIP kernels are compared with.
+* ``forward_eager`` -- torch fp32 on the CPU with the *same aten op sequence* as
+                       the reference (depth-wise conv2d EPEG, materialised 4-D
+                       einsum combine/dispatch, .contiguous() region copies).
+                       This is what bench.py times as the CPU baseline ("port").
+
+Parity pin: both are checked against tests/golden/*.npz, which were produced
+by importing the real reference (/root/reference/modules/rrt.py::RRTEncoder,
+torch 2.10.0 CPU) with tools/make_golden.py in the build container.
+
+Reference lines followed (file:line in /root/reference):
+  RRTEncoder.forward            modules/rrt.py:165-202
+  TransLayer.forward_trans      modules/rrt.py:117-131
+  padding / partition / reverse modules/rmsa.py:175-202, :28-54
+  InnerAttention.forward        modules/rmsa.py:91-134   (EPEG :106-108)
+  CrossRegionAttntion.forward   modules/rmsa.py:290-337
+"""
+import math
+import numpy as np
+
+
+# --------------------------------------------------------------------------- geometry
+def grid(L, region_num=8, region_size=0, min_region_num=0, min_region_ratio=0.0):
+    """(H, s, add_length) -- modules/rmsa.py:175-202 (same body at :261-288)."""
+    H = int(np.ceil(np.sqrt(L)))
+    if region_size and region_size > 0:
+        H += (-H) % region_size
+        s = region_size
+    else:
+        H += (-H) % region_num
+        s = H // region_num
+    add = H * H - L
+    if add > L / (min_region_ratio + 1e-8) or L < min_region_num:
+        H = int(np.ceil(np.sqrt(L)))
+        H += (-H) % 2
+        add = H * H - L
+        s = H
+    return H, s, add
+
+
+def partition_index(H, s):
+    """perm[slot] = padded-grid token index held by region-major slot
+    (modules/rmsa.py:28-39: view(B,H/s,s,W/s,s,C).permute(0,1,3,2,4,5))."""
+    t = np.arange(H * H).reshape(H // s, s, H // s, s)
+    return t.transpose(0, 2, 1, 3).reshape(-1)
+
+
+_DEFAULTS = dict(mlp_dim=512, region_num=8, n_layers=2, n_heads=8, epeg=True, epeg_k=15,
+                 region_size=0, min_region_num=0, min_region_ratio=0.0, qkv_bias=True,
+                 cr_msa=True, crmsa_k=3, all_shortcut=False, crmsa_mlp=False, crmsa_heads=8,
+                 epeg_bias=True)
+
+
+def _cfg(cfg):
+    c = dict(_DEFAULTS)
+    c.update(cfg or {})
+    return c
+
+
+# --------------------------------------------------------------------------- float64 truth
+def _ln64(x, g, b, eps=1e-5):
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)      # biased, like nn.LayerNorm
+    return (x - mu) / np.sqrt(var + eps) * g + b
+
+
+def _softmax64(a, axis):
+    a = a - a.max(axis=axis, keepdims=True)
+    e = np.exp(a)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None):
+    """x: [B_, P, D] -> [B_, P, D]   (modules/rmsa.py:91-134, 'attn' EPEG only)."""
+    B_, P, D = x.shape
+    hd = D // heads
+    W = st[pfx + "qkv.weight"].astype(np.float64)
+    qkv = x @ W.T
+    if pfx + "qkv.bias" in st:
+        qkv = qkv + st[pfx + "qkv.bias"].astype(np.float64)
+    qkv = qkv.reshape(B_, P, 3, heads, hd).transpose(2, 0, 3, 1, 4)       # [3,B_,h,P,hd]
+    q, k, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]
+    S = q @ k.transpose(0, 1, 3, 2)                                         # [B_,h,P,P]
+    if pfx + "pe.weight" in st:
+        w = st[pfx + "pe.weight"].astype(np.float64).reshape(heads, epeg_k)
+        half = epeg_k // 2
+        Sp = np.pad(S, ((0, 0), (0, 0), (half, half), (0, 0)))             # zero rows = region edge
+        E = np.zeros_like(S)
+        for t in range(epeg_k):                                             # stencil along the QUERY axis
+            E += w[None, :, t, None, None] * Sp[:, :, t:t + P, :]
+        if pfx + "pe.bias" in st:
+            E += st[pfx + "pe.bias"].astype(np.float64)[None, :, None, None]
+        S = S + E
+    A = _softmax64(S, -1)
+    O = (A @ v).transpose(0, 2, 1, 3).reshape(B_, P, D)
+    out = O @ st[pfx + "proj.weight"].astype(np.float64).T + st[pfx + "proj.bias"].astype(np.float64)
+    if taps is not None:
+        taps[pfx + "scores_in"] = S
+        taps[pfx + "proj_in"] = O
+    return out
+
+
+def forward_f64(x, state, cfg=None, taps=None):
+    """x: (N, D) array -> (N, D) float64.  ``state``: {reference state_dict key: array}."""
+    c = _cfg(cfg)
+    st = state
+    x = np.asarray(x, dtype=np.float64)
+    N, D = x.shape
+    x0 = x
+    for li in range(c["n_layers"] - 1):                                     # R-MSA TransLayers
+        p = f"layers.{li}."
+        u = _ln64(x, st[p + "norm.weight"].astype(np.float64), st[p + "norm.bias"].astype(np.float64))
+        H, s, add = grid(N, c["region_num"], c["region_size"], c["min_region_num"], c["min_region_ratio"])
+        up = np.concatenate([u, np.zeros((add, D))], 0)                     # pad rows are exact zeros (T5)
+        perm = partition_index(H, s)
+        U = up[perm].reshape(-1, s * s, D)
+        Z = _inner_attention64(U, st, p + "attn.attn.", c["n_heads"], c["epeg_k"], taps)
+        z = np.empty((H * H, D))
+        z[perm] = Z.reshape(-1, D)
+        x = x + z[:N]
+        if taps is not None:
+            taps[p + "out"] = x
+    if c["cr_msa"]:
+        p = "cr_msa."
+        k = c["crmsa_k"]
+        v = _ln64(x, st[p + "norm.weight"].astype(np.float64), st[p + "norm.bias"].astype(np.float64))
+        # CR-MSA never receives region_num/region_size from RRTEncoder (trap T3): always 8
+        H, s, add = grid(N, 8, 0, 0, 0.0)
+        vp = np.concatenate([v, np.zeros((add, D))], 0)
+        perm = partition_index(H, s)
+        V = vp[perm].reshape(-1, s * s, D)                                   # [R,P,D]
+        if c["crmsa_mlp"]:
+            h1 = np.tanh(V @ st[p + "attn.phi.0.weight"].astype(np.float64).T)
+            Lg = (h1 @ st[p + "attn.phi.2.weight"].astype(np.float64).T).transpose(0, 2, 1)
+        else:
+            Lg = (V @ st[p + "attn.phi"].astype(np.float64)).transpose(0, 2, 1)   # [R,k,P]
+        Cw = _softmax64(Lg, -1)                                              # combine: over P
+        Dw = _softmax64(Lg, 1)                                               # dispatch: over k
+        mn, mx = Lg.min(-1, keepdims=True), Lg.max(-1, keepdims=True)
+        Mm = (Lg - mn) / (mx - mn + 1e-8)
+        rep = (Cw @ V).transpose(1, 0, 2)                                    # [k,R,D]
+        rep2 = _inner_attention64(rep, st, p + "attn.attn.", c["crmsa_heads"], 0, taps)
+        out = np.einsum("rnp,nrd->rpd", Mm * Dw, rep2)                       # [R,P,D]
+        z = np.empty((H * H, D))
+        z[perm] = out.reshape(-1, D)
+        x = x + z[:N]
+        if taps is not None:
+            taps["cr_msa.rep"] = rep
+            taps["cr_msa.out"] = x
+    if c["all_shortcut"]:
+        x = x + x0
+    return _ln64(x, st["norm.weight"].astype(np.float64), st["norm.bias"].astype(np.float64))
+
+
+# --------------------------------------------------------------------------- eager-equivalent torch/CPU port
+def forward_eager(x, state, cfg=None):
+    """torch fp32 CPU port issuing the reference's aten op sequence; x: (N, D)
+    torch tensor or array -> torch (N, D).  Used as the timed CPU baseline."""
+    import torch
+    import torch.nn.functional as F
+    c = _cfg(cfg)
+    st = {k_: (v_ if isinstance(v_, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v_)))
+          for k_, v_ in state.items()}
+    x = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+    x = x.unsqueeze(0)                                                       # (1,N,D), modules/rrt.py:166-175
+    B, N, D = x.shape
+    x0 = x
+
+    def part(t, H, s):                                                       # modules/rmsa.py:28-39
+        t = t.view(B, H // s, s, H // s, s, D)
+        return t.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, s * s, D)
+
+    def unpart(t, H, s):                                                     # modules/rmsa.py:41-54
+        t = t.view(B, H // s, H // s, s, s, D)
+        return t.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H * H, D)
+
+    def inner(t, pfx, heads, epeg_k):                                        # modules/rmsa.py:91-134
+        B_, P, _ = t.shape
+        hd = D // heads
+        qkv = F.linear(t, st[pfx + "qkv.weight"], st.get(pfx + "qkv.bias"))
+        qkv = qkv.reshape(B_, P, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        q = q * (hd ** -0.5)
+        attn = q @ k.transpose(-2, -1)
+        if pfx + "pe.weight" in st:
+            pe = F.conv2d(attn, st[pfx + "pe.weight"], st.get(pfx + "pe.bias"),
+                          padding=(epeg_k // 2, 0), groups=heads)
+            attn = attn + pe
+        attn = attn.softmax(dim=-1)
+        o = (attn @ v).transpose(1, 2).reshape(B_, P, D)
+        return F.linear(o, st[pfx + "proj.weight"], st[pfx + "proj.bias"])
+
+    with torch.no_grad():
+        for li in range(c["n_layers"] - 1):
+            p = f"layers.{li}."
+            u = F.layer_norm(x, (D,), st[p + "norm.weight"], st[p + "norm.bias"], 1e-5)
+            H, s, add = grid(N, c["region_num"], c["region_size"], c["min_region_num"], c["min_region_ratio"])
+            if add > 0:
+                u = torch.cat([u, torch.zeros((B, add, D))], dim=1)
+            z = unpart(inner(part(u, H, s), p + "attn.attn.", c["n_heads"], c["epeg_k"]), H, s)
+            if add > 0:
+                z = z[:, :-add]
+            x = x + z
+        if c["cr_msa"]:
+            p = "cr_msa."
+            v = F.layer_norm(x, (D,), st[p + "norm.weight"], st[p + "norm.bias"], 1e-5)
+            H, s, add = grid(N, 8, 0, 0, 0.0)
+            if add > 0:
+                v = torch.cat([v, torch.zeros((B, add, D))], dim=1)
+            xr = part(v, H, s)
+            if c["crmsa_mlp"]:
+                lg = F.linear(torch.tanh(F.linear(xr, st[p + "attn.phi.0.weight"])),
+                              st[p + "attn.phi.2.weight"]).transpose(1, 2)
+            else:
+                lg = torch.einsum("wpc,cn->wpn", xr, st[p + "attn.phi"]).transpose(1, 2)
+            cw = lg.softmax(dim=-1)
+            dw = lg.softmax(dim=1)
+            mn = lg.min(dim=-1)[0].unsqueeze(-1)
+            mx = lg.max(dim=-1)[0].unsqueeze(-1)
+            mm = (lg - mn) / (mx - mn + 1e-8)
+            rep = torch.einsum("wpc,wnp->wnpc", xr, cw).sum(dim=-2).transpose(0, 1)
+            rep = inner(rep, p + "attn.attn.", c["crmsa_heads"], 0).transpose(0, 1)
+            o = torch.einsum("wnc,wnp->wnpc", rep, mm)
+            o = torch.einsum("wnpc,wnp->wnpc", o, dw).sum(dim=1)
+            z = unpart(o, H, s)
+            if add > 0:
+                z = z[:, :-add]
+            x = x + z
+        if c["all_shortcut"]:
+            x = x + x0
+        x = F.layer_norm(x, (D,), st["norm.weight"], st["norm.bias"], 1e-5)
+    return x.squeeze(0)
+
+
+def flops_per_bag(N, D=512, region_num=8, heads=8, epeg_k=15, crmsa_k=3):
+    """Algorithmic FLOPs per bag, SURVEY.md §8(d) / BASELINE.md §3."""
+    H, s, _ = grid(N, region_num)
+    Np, P = H * H, s * s
+    H8, _, _ = grid(N, 8)
+    Np8 = H8 * H8
+    k = crmsa_k
+    return (8 * Np * D * D + 4 * Np * P * D + 2 * Np * P * heads * epeg_k
+            + 6 * Np8 * D * k + 8 * k * 64 * D * D + 4 * k * 64 * 64 * D)

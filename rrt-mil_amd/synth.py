@@ -1,0 +1,106 @@
+"""Closed-form synthetic parameters and bags (pure numpy, no RNG stream).
+
+Every value is splitmix64(tensor-name hash, element index) mapped to a uniform,
+so the golden-fixture generator (tools/make_golden.py, run next to the
+reference), the tests and bench.py regenerate bit-identical arrays on any box
+without sharing a torch RNG stream.
+
+State-dict names / shapes are the reference's (modules/rrt.py:134-163,
+modules/rmsa.py:57-89, :233-259); see SURVEY.md §3.3.
+"""
+import zlib
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(z: np.ndarray) -> np.ndarray:
+    z = (z + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform(name: str, shape, lo=-1.0, hi=1.0, dtype=np.float32) -> np.ndarray:
+    """Deterministic U[lo,hi) array keyed by ``name``."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    key = np.uint64(zlib.crc32(name.encode()) & 0xFFFFFFFF) << np.uint64(32)
+    with np.errstate(over="ignore"):
+        h = _splitmix64(key + np.arange(n, dtype=np.uint64))
+    u = (h >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    return (lo + (hi - lo) * u).astype(dtype).reshape(shape)
+
+
+def normal(name: str, shape, dtype=np.float32) -> np.ndarray:
+    """Deterministic N(0,1) array (Box-Muller on two keyed uniforms)."""
+    u1 = uniform(name + "/u1", shape, 0.0, 1.0, np.float64)
+    u2 = uniform(name + "/u2", shape, 0.0, 1.0, np.float64)
+    z = np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+    return z.astype(dtype)
+
+
+def encoder_state_shapes(mlp_dim=512, n_layers=2, n_heads=8, epeg=True, epeg_k=15,
+                         cr_msa=True, crmsa_k=3, crmsa_mlp=False, qkv_bias=True,
+                         epeg_bias=True, **_unused):
+    """Ordered {state_dict key: shape} of the default-path RRTEncoder."""
+    D = mlp_dim
+    sh = {"norm.weight": (D,), "norm.bias": (D,)}
+
+    def inner(prefix, with_pe):
+        sh[prefix + "qkv.weight"] = (3 * D, D)
+        if qkv_bias:
+            sh[prefix + "qkv.bias"] = (3 * D,)
+        sh[prefix + "proj.weight"] = (D, D)
+        sh[prefix + "proj.bias"] = (D,)
+        if with_pe:
+            sh[prefix + "pe.weight"] = (n_heads, 1, epeg_k, 1)
+            if epeg_bias:
+                sh[prefix + "pe.bias"] = (n_heads,)
+
+    for i in range(n_layers - 1):
+        sh[f"layers.{i}.norm.weight"] = (D,)
+        sh[f"layers.{i}.norm.bias"] = (D,)
+        inner(f"layers.{i}.attn.attn.", epeg)
+    if cr_msa:
+        sh["cr_msa.norm.weight"] = (D,)
+        sh["cr_msa.norm.bias"] = (D,)
+        inner("cr_msa.attn.attn.", False)
+        if crmsa_mlp:
+            sh["cr_msa.attn.phi.0.weight"] = (D // 4, D)
+            sh["cr_msa.attn.phi.2.weight"] = (crmsa_k, D // 4)
+        else:
+            sh["cr_msa.attn.phi"] = (D, crmsa_k)
+    return sh
+
+
+def encoder_state(**cfg):
+    """Closed-form fp32 parameters, scaled like the reference's default inits
+    (Linear/Conv ~ U(+-1/sqrt(fan_in)); LayerNorm gamma ~ 1+-0.25, beta ~ +-0.1
+    so that gamma/beta mistakes show up in parity tests)."""
+    out = {}
+    for k, shape in encoder_state_shapes(**cfg).items():
+        if k.endswith("norm.weight"):
+            out[k] = 1.0 + uniform(k, shape, -0.25, 0.25)
+        elif k.endswith("norm.bias"):
+            out[k] = uniform(k, shape, -0.1, 0.1)
+        elif k.endswith("pe.weight"):
+            b = 1.0 / np.sqrt(shape[2])
+            out[k] = uniform(k, shape, -b, b)
+        elif k.endswith("pe.bias"):
+            out[k] = uniform(k, shape, -0.25, 0.25)
+        elif k.endswith(".bias"):
+            out[k] = uniform(k, shape, -0.05, 0.05)
+        elif k.endswith("phi"):
+            b = 1.0 / np.sqrt(shape[0])
+            out[k] = uniform(k, shape, -3 * b, 3 * b)
+        else:  # Linear weights (out, in)
+            b = 1.0 / np.sqrt(shape[-1])
+            out[k] = uniform(k, shape, -b, b)
+    return out
+
+
+def bag(n_tokens: int, dim: int = 512, tag: str = "bag", nonneg: bool = False) -> np.ndarray:
+    """Synthetic (N, D) patch-embedding bag: N(0,1), or relu(N(0,1)) like pooled
+    ResNet-50 features."""
+    x = normal(f"{tag}/{n_tokens}x{dim}", (n_tokens, dim))
+    return np.maximum(x, 0.0) if nonneg else x
