@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- slides/sec of the RRTEncoder forward on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one RRTEncoder forward (eval, fp32) over one device-resident synthetic
+bag of N=9000 x D=512 per GPU (BASELINE.json configs[1], the config the metric is
+quoted on).  Bag-parallel: every rank owns its own bags, no data-path collective
+(scaling = "weak"); the only collectives are the barrier and a MAX of the elapsed time.
+
+Besides the contract fields the JSON line carries
+  roofline     -- the dominant kernel (R-MSA qkv linear, fp32 MFMA): algorithmic FLOPs
+                  per launch / its average duration, measured live with HIP events that
+                  librrt_hip records on the launch stream inside the timed region;
+  cpu_baseline -- the oracle's eager torch-CPU port of the reference op sequence
+                  (oracle/rrt_oracle.py::forward_eager) timed on this box's host cores
+                  over a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from rrt_mil_amd import RRTEncoder, _lib, synth  # noqa: E402
+from rrt_mil_amd.geometry import region_grid  # noqa: E402
+
+N_TOKENS, DIM = 9000, 512
+CFG = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+TRAFFIC_BYTES_PER_LAUNCH = None  # HBM bytes of the dominant kernel from rocprofv3 --pmc (profiles/)
+
+
+class HipEvents:
+    """Raw hipEvent_t's (libamdhip64 via ctypes) -- torch.cuda.Event cannot be recorded
+    from inside the C ABI call."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [C.c_void_p]
+
+    def create(self):
+        ev = C.c_void_p()
+        rc = self.hip.hipEventCreate(C.byref(ev))
+        assert rc == 0, f"hipEventCreate -> {rc}"
+        return ev
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        rc = self.hip.hipEventElapsedTime(C.byref(ms), a, b)
+        assert rc == 0, f"hipEventElapsedTime -> {rc}"
+        return ms.value
+
+
+def flops_total(n):
+    """Algorithmic FLOPs per bag, SURVEY.md §8(d)."""
+    g, g8 = region_grid(n, CFG["region_num"]), region_grid(n, 8)
+    k, h, ek, D = CFG["crmsa_k"], 8, CFG["epeg_k"], DIM
+    return (8 * g.Np * D * D + 4 * g.Np * g.P * D + 2 * g.Np * g.P * h * ek
+            + 6 * g8.Np * D * k + 8 * k * 64 * D * D + 4 * k * 64 * 64 * D)
+
+
+def cpu_baseline(budget_s=20.0):
+    """Reference-equivalent CPU path (oracle port) on this host: bounded sample."""
+    from oracle import rrt_oracle  # the only place bench.py touches oracle/
+    state = synth.encoder_state(**CFG)
+    st = {k: torch.from_numpy(v) for k, v in state.items()}
+    x = torch.from_numpy(synth.bag(N_TOKENS, DIM))
+    cores = torch.get_num_threads()
+    rrt_oracle.forward_eager(x, st, CFG)             # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 200):
+        t0 = time.perf_counter()
+        rrt_oracle.forward_eager(x, st, CFG)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(1.0 / med, 3), "unit": "slides/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} bags of N={N_TOKENS} D={DIM} (median {med * 1e3:.1f} ms/bag), "
+                      f"oracle/rrt_oracle.py::forward_eager (same aten op sequence as the reference, "
+                      f"bit-identical to it in the build container), torch {torch.__version__} CPU, "
+                      f"{cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks "
+                         f"(WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL
+
+    state = synth.encoder_state(**CFG)
+    enc = RRTEncoder(**CFG).eval()
+    enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()}, strict=True)
+    enc = enc.to(dev)
+    # a few distinct device-resident bags per rank, cycled (one bag per step)
+    bags = [torch.from_numpy(synth.bag(N_TOKENS, DIM, tag=f"bench/r{rank}/b{i}")).to(dev) for i in range(4)]
+    out = torch.empty_like(bags[0])
+
+    lib = _lib.load()
+    hev = HipEvents()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = enc._workspace(N_TOKENS, dev)
+    w = enc._weights()
+    ev_pairs = [(hev.create(), hev.create()) for _ in range(args.steps)]
+    ev_arr = (C.c_void_p * _lib.EV_COUNT)()
+
+    def step(i, timed):
+        x = bags[i % len(bags)]
+        if timed:   # mark the dominant kernel: [after LN+partition, after qkv linear]
+            for j in range(_lib.EV_COUNT):
+                ev_arr[j] = None
+            ev_arr[_lib.EV_LN_PARTITION] = ev_pairs[i][0]
+            ev_arr[_lib.EV_QKV] = ev_pairs[i][1]
+            rc = lib.rrt_encoder_forward_events_f32(C.byref(enc._desc), C.byref(w), x.data_ptr(), out.data_ptr(),
+                                                    N_TOKENS, ws.data_ptr(), ws.numel(), stream, ev_arr)
+        else:
+            rc = lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), x.data_ptr(), out.data_ptr(),
+                                             N_TOKENS, ws.data_ptr(), ws.numel(), stream)
+        _lib.check(rc, "forward")
+
+    for i in range(args.warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    # dominant kernel: R-MSA qkv linear  [Np, D] x [3D, D]^T  (fp32 MFMA)
+    g = region_grid(N_TOKENS, CFG["region_num"])
+    qkv_flops = 2.0 * g.Np * (3 * DIM) * DIM
+    qkv_ms = float(np.mean([hev.elapsed_ms(a, b) for a, b in ev_pairs]))
+    achieved = qkv_flops / (qkv_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        rec = {
+            "metric": "slides/sec RRTEncoder fwd, N=9000 D=512 region_num=8",
+            "value": round(value, 2), "unit": "slides/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: RRTEncoder(mlp_dim=512, epeg_k=15, crmsa_k=3, "
+                                   "region_num=8).eval() forward, one device-resident bag N=9000 D=512 "
+                                   "per GPU per step, fp32, closed-form weights",
+                       "n_tokens": N_TOKENS, "dim": DIM, "bags_per_step": world,
+                       "parallelism": f"bag-parallel x{world} (no data-path collective)",
+                       "gflop_per_bag": round(flops_total(N_TOKENS) / 1e9, 2),
+                       "whole_path_tflops": round(flops_total(N_TOKENS) / (ms_per_step * 1e-3) / 1e12, 2)},
+            "roofline": {"bound": "mfma", "kernel": "linear_kernel<2,2,false> (R-MSA qkv: [9216,512]x[1536,512]^T)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "flops_per_launch": qkv_flops, "avg_launch_ms": round(qkv_ms, 5),
+                         "traffic": TRAFFIC_BYTES_PER_LAUNCH},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(rec), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,161 @@
+/* rrt_hip.h -- C ABI of librrt_hip.so: the MI355X (gfx950) RRTEncoder forward path.
+ *
+ * The reference (DearCaat/RRT-MIL) has no FFI: its boundary for this path is the
+ * Python class modules/rrt.py:133-202 `RRTEncoder(nn.Module)`.  These entry points
+ * are what that class's forward binds to once its internals are replaced
+ * (INTEGRATION.md shows the ctypes stub); each one cites the reference lines it
+ * replaces.  Plain pointers and sizes only, no torch types.  All pointers are
+ * DEVICE pointers (HIP) unless marked host; `stream` is a hipStream_t passed as
+ * void*.  Nothing allocates: the caller owns a workspace sized by
+ * rrt_encoder_workspace_size().  Every call is asynchronous on `stream`,
+ * re-entrant and stateless.
+ *
+ * Return value: 0 = ok; <0 = RRT_E_* (unsupported/invalid, nothing launched);
+ * >0 = hipError_t from a launch.
+ */
+#ifndef RRT_HIP_H
+#define RRT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRT_ABI_VERSION 1
+#define RRT_MAX_RMSA_LAYERS 8
+#define RRT_MAX_CRMSA_K 8
+
+enum {
+  RRT_OK = 0,
+  RRT_E_INVALID = -1,       /* null pointer / non-positive size */
+  RRT_E_UNSUPPORTED = -2,   /* configuration outside the HIP path (see rrt_strerror) */
+  RRT_E_WORKSPACE = -3      /* workspace too small */
+};
+
+/* Region-grid geometry: RegionAttntion.padding, modules/rmsa.py:175-202 (same body
+ * CrossRegionAttntion.padding :261-288).  H = padded grid side, s = region side,
+ * add = zero rows appended (H*H - L). */
+typedef struct rrt_grid {
+  int64_t L;
+  int32_t H;
+  int32_t s;
+  int32_t regions_side;
+  int64_t add;
+} rrt_grid;
+
+/* Constructor surface that changes the arithmetic: RRTEncoder.__init__,
+ * modules/rrt.py:134-163 (kwargs that reach TransLayer/InnerAttention). */
+typedef struct rrt_encoder_desc {
+  int32_t dim;             /* mlp_dim */
+  int32_t n_heads;         /* n_heads (R-MSA), head_dim = dim / n_heads */
+  int32_t n_rmsa_layers;   /* n_layers - 1 */
+  int32_t region_num;      /* R-MSA regions per side */
+  int32_t region_size;     /* >0 overrides region_num */
+  int32_t min_region_num;
+  float   min_region_ratio;
+  int32_t epeg;            /* 1: 1-D 'attn' EPEG in the R-MSA layers */
+  int32_t epeg_k;
+  int32_t cr_msa;          /* 1: CR-MSA layer present */
+  int32_t crmsa_k;
+  int32_t crmsa_heads;
+  int32_t crmsa_mlp;       /* 1: phi is the 2-layer MLP (not yet on the HIP path) */
+  int32_t all_shortcut;
+} rrt_encoder_desc;
+
+/* InnerAttention parameters, modules/rmsa.py:57-89.  Row-major, fp32.
+ * qkv_w [3*dim, dim], qkv_b [3*dim] or NULL, proj_w [dim, dim], proj_b [dim],
+ * pe_w [heads, epeg_k] or NULL, pe_b [heads] or NULL. */
+typedef struct rrt_attn_weights {
+  const float *norm_w, *norm_b;   /* the owning TransLayer's LayerNorm, modules/rrt.py:47 */
+  const float *qkv_w, *qkv_b;
+  const float *proj_w, *proj_b;
+  const float *pe_w, *pe_b;
+} rrt_attn_weights;
+
+typedef struct rrt_encoder_weights {
+  rrt_attn_weights rmsa[RRT_MAX_RMSA_LAYERS];   /* layers.{i}.* */
+  rrt_attn_weights crmsa;                         /* cr_msa.norm.*, cr_msa.attn.attn.* */
+  const float *phi;                               /* cr_msa.attn.phi [dim, crmsa_k] */
+  const float *norm_w, *norm_b;                   /* final norm.* (modules/rrt.py:139,195) */
+} rrt_encoder_weights;
+
+int         rrt_abi_version(void);
+const char *rrt_strerror(int code);          /* static string; also explains the last RRT_E_UNSUPPORTED of this thread */
+
+/* host-only: modules/rmsa.py:175-202 */
+int rrt_region_grid(int64_t L, int32_t region_num, int32_t region_size,
+                    int32_t min_region_num, float min_region_ratio, rrt_grid *out);
+
+/* host-only: bytes of workspace rrt_encoder_forward_f32 needs for a bag of n_tokens */
+int rrt_encoder_workspace_size(const rrt_encoder_desc *desc, int64_t n_tokens, size_t *bytes);
+
+/* Whole path: RRTEncoder.forward, modules/rrt.py:165-202 (eval mode, one bag).
+ * x [n_tokens, dim] -> y [n_tokens, dim]; x is not modified; y may not alias x. */
+int rrt_encoder_forward_f32(const rrt_encoder_desc *desc, const rrt_encoder_weights *w,
+                            const float *x, float *y, int64_t n_tokens,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same call, recording caller-owned hipEvent_t's at stage boundaries on `stream` (for
+ * measurement: bench.py times the dominant kernel with these).  events[RRT_EV_COUNT], any
+ * entry may be NULL.  Only the first R-MSA layer is marked. */
+enum {
+  RRT_EV_START = 0,        /* before the first kernel */
+  RRT_EV_LN_PARTITION,     /* after LayerNorm+partition */
+  RRT_EV_QKV,              /* after the R-MSA qkv linear  (the dominant kernel) */
+  RRT_EV_ATTN,             /* after the region attention core */
+  RRT_EV_PROJ,             /* after proj + un-partition + residual */
+  RRT_EV_CR_COMBINE,       /* after CR-MSA logits + combine */
+  RRT_EV_CR_INNER,         /* after the inner MSA over the representatives */
+  RRT_EV_END,              /* after dispatch + final LayerNorm */
+  RRT_EV_COUNT
+};
+int rrt_encoder_forward_events_f32(const rrt_encoder_desc *desc, const rrt_encoder_weights *w,
+                                   const float *x, float *y, int64_t n_tokens,
+                                   void *workspace, size_t workspace_bytes, void *stream,
+                                   void **events);
+
+/* ---- stage entry points (what the fused path is built from; used by the parity tests) ---- */
+
+/* LayerNorm (modules/rrt.py:121-123) + zero-pad (rmsa.py:199-200) + region_partition
+ * (rmsa.py:28-39): x [L, dim] -> u [H*H, dim] in region-major order, pad rows = 0. */
+int rrt_ln_partition_f32(const float *x, const float *gamma, const float *beta, float *u,
+                         int64_t L, int32_t dim, const rrt_grid *g, void *stream);
+
+/* nn.Linear (rmsa.py:100, :131): C[M,N] = A[M,K] . B[N,K]^T + bias[N] (bias may be NULL).
+ * q_cols>0: columns [0,q_cols) are multiplied by q_scale after the bias (rmsa.py:103). */
+int rrt_linear_f32(const float *A, const float *B, const float *bias, float *C,
+                   int64_t M, int32_t N, int32_t K, int32_t q_cols, float q_scale, void *stream);
+
+/* nn.Linear + region_reverse + un-pad + residual (rmsa.py:131, :41-54, :227-228; rrt.py:125):
+ * out[t] = resid[t] + (A . B^T + bias)[slot(t)] for the L real tokens. */
+int rrt_linear_unpartition_residual_f32(const float *A, const float *B, const float *bias,
+                                        const float *resid, float *out, int32_t N, int32_t K,
+                                        const rrt_grid *g, void *stream);
+
+/* Region attention core (rmsa.py:103-122): qkv [n_regions*P, 3*dim] (q already scaled),
+ * EPEG taps pe_w [heads, epeg_k] (NULL/0 = none; pe bias is softmax-invariant and not needed)
+ * -> o [n_regions*P, dim] (heads merged). */
+int rrt_region_attention_f32(const float *qkv, const float *pe_w, float *o,
+                             int32_t n_regions, int32_t P, int32_t dim, int32_t heads,
+                             int32_t epeg_k, void *stream);
+
+/* CR-MSA (rmsa.py:303-335): see DESIGN.md for the three kernels. */
+int rrt_crmsa_logits_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
+                         float *mean_rstd, float *logits, int64_t L, int32_t dim, int32_t k,
+                         const rrt_grid *g8, void *stream);
+int rrt_crmsa_combine_f32(const float *x1, const float *gamma, const float *beta,
+                          const float *mean_rstd, const float *logits, float *stats, float *rep,
+                          int64_t L, int32_t dim, int32_t k, const rrt_grid *g8, void *stream);
+int rrt_crmsa_dispatch_ln_f32(const float *x1, const float *x0, const float *logits,
+                              const float *stats, const float *rep2, const float *gamma,
+                              const float *beta, float *y, int64_t L, int32_t dim, int32_t k,
+                              const rrt_grid *g8, void *stream);
+/* final LayerNorm only (cr_msa=False path): y = LN(x1 (+ x0)) */
+int rrt_layernorm_f32(const float *x1, const float *x0, const float *gamma, const float *beta,
+                      float *y, int64_t L, int32_t dim, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRT_HIP_H */

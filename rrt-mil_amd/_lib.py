@@ -1,0 +1,115 @@
+"""ctypes binding of librrt_hip.so (the C ABI declared in include/rrt_hip.h).
+
+The library is the product: if it is missing this module raises -- there is no
+CPU or PyTorch fallback behind the HIP path.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librrt_hip.so")
+
+RRT_MAX_RMSA_LAYERS = 8
+RRT_MAX_CRMSA_K = 8
+ABI_VERSION = 1
+
+_f32p = C.POINTER(C.c_float)
+
+
+class Grid(C.Structure):
+    _fields_ = [("L", C.c_int64), ("H", C.c_int32), ("s", C.c_int32),
+                ("regions_side", C.c_int32), ("add", C.c_int64)]
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_heads", C.c_int32), ("n_rmsa_layers", C.c_int32),
+                ("region_num", C.c_int32), ("region_size", C.c_int32), ("min_region_num", C.c_int32),
+                ("min_region_ratio", C.c_float), ("epeg", C.c_int32), ("epeg_k", C.c_int32),
+                ("cr_msa", C.c_int32), ("crmsa_k", C.c_int32), ("crmsa_heads", C.c_int32),
+                ("crmsa_mlp", C.c_int32), ("all_shortcut", C.c_int32)]
+
+
+class AttnWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm_w", "norm_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+                                          "pe_w", "pe_b")]
+
+
+class EncoderWeights(C.Structure):
+    _fields_ = [("rmsa", AttnWeights * RRT_MAX_RMSA_LAYERS), ("crmsa", AttnWeights),
+                ("phi", C.c_void_p), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/rrt_hip.h declares
+SIGNATURES = {
+    "rrt_abi_version": (C.c_int, []),
+    "rrt_strerror": (C.c_char_p, [C.c_int]),
+    "rrt_region_grid": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.POINTER(Grid)]),
+    "rrt_encoder_workspace_size": (C.c_int, [C.POINTER(EncoderDesc), C.c_int64, C.POINTER(C.c_size_t)]),
+    "rrt_encoder_forward_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p,
+                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rrt_encoder_forward_events_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p,
+                                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                 C.POINTER(C.c_void_p)]),
+    "rrt_ln_partition_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_int32, C.POINTER(Grid), C.c_void_p]),
+    "rrt_linear_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                 C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "rrt_linear_unpartition_residual_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Grid),
+                                                      C.c_void_p]),
+    "rrt_region_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "rrt_crmsa_logits_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32,
+                                                         C.POINTER(Grid), C.c_void_p]),
+    "rrt_crmsa_combine_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32,
+                                                          C.POINTER(Grid), C.c_void_p]),
+    "rrt_crmsa_dispatch_ln_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32,
+                                                              C.POINTER(Grid), C.c_void_p]),
+    "rrt_layernorm_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p]),
+}
+
+# stage-boundary event slots of rrt_encoder_forward_events_f32 (enum in include/rrt_hip.h)
+EV_START, EV_LN_PARTITION, EV_QKV, EV_ATTN, EV_PROJ, EV_CR_COMBINE, EV_CR_INNER, EV_END, EV_COUNT = range(9)
+
+_lib = None
+
+
+class RRTHipError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """dlopen librrt_hip.so and bind every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RRTHipError(
+            f"{p} is missing: the HIP extension is the only compute path. Build it with "
+            "`python rrt-mil_amd/build.py` (needs /opt/rocm/bin/hipcc).")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rrt_abi_version() != ABI_VERSION:
+        raise RRTHipError(f"librrt_hip.so ABI {lib.rrt_abi_version()} != binding {ABI_VERSION}; rebuild")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().rrt_strerror(rc).decode()
+        if rc == -2:
+            raise NotImplementedError(f"rrt_hip {what}: {msg}")
+        raise RRTHipError(f"rrt_hip {what} failed ({rc}): {msg}")
+
+
+def region_grid(L, region_num=8, region_size=0, min_region_num=0, min_region_ratio=0.0):
+    g = Grid()
+    check(load().rrt_region_grid(L, region_num, region_size, min_region_num, min_region_ratio, C.byref(g)),
+          "rrt_region_grid")
+    return g

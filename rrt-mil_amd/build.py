@@ -1,0 +1,61 @@
+"""Build librrt_hip.so in-tree: hipcc --offload-arch=gfx950 on csrc/*.hip (no GPU needed).
+
+    python rrt-mil_amd/build.py [--force] [--verbose]
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librrt_hip.so")
+STAMP = os.path.join(HERE, "csrc", ".build_stamp")
+SOURCES = ["ln_partition.hip", "linear_f32.hip", "region_attn.hip", "crmsa.hip", "api.hip"]
+HEADERS = ["common.h", "internal.h", os.path.join("..", "..", "include", "rrt_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _digest():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    """Compile if sources changed; returns the library path."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+        with open(STAMP) as fh:
+            if fh.read().strip() == dig:
+                return LIB
+    if not os.path.exists(hipcc):
+        raise RuntimeError(f"hipcc not found at {hipcc}; cannot build librrt_hip.so")
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+        if verbose and out:
+            print(out.decode())
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -1,0 +1,349 @@
+// api.hip -- the C ABI of librrt_hip.so (include/rrt_hip.h): geometry, workspace
+// carving and the launch sequence of one RRTEncoder forward (modules/rrt.py:165-202).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "internal.h"
+
+namespace {
+
+thread_local char g_detail[256] = "";
+
+int unsupported(const char* why) {
+  snprintf(g_detail, sizeof(g_detail), "%s", why);
+  return RRT_E_UNSUPPORTED;
+}
+
+int64_t ceil_sqrt(int64_t n) {
+  int64_t r = (int64_t)floor(sqrt((double)n));
+  while (r * r > n) --r;
+  while ((r + 1) * (r + 1) <= n) ++r;
+  return r * r == n ? r : r + 1;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Workspace {
+  float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *stats, *rep, *rep_qkv, *rep_o, *rep2;
+  size_t bytes;
+};
+
+// One carve function used for both the size query (base = null) and the real carve.
+Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const rrt_grid& g8, char* base) {
+  Workspace w{};
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off = align_up(off + nfloat * sizeof(float), 256);
+    return p;
+  };
+  const size_t D = d.dim;
+  const size_t Np = (size_t)g.H * g.H, Np8 = (size_t)g8.H * g8.H;
+  const size_t R8 = (size_t)g8.regions_side * g8.regions_side;
+  if (d.n_rmsa_layers > 0) {
+    w.uo = take(Np * D);
+    w.qkv = take(Np * 3 * D);
+    w.xa = take((size_t)N * D);
+    if (d.n_rmsa_layers > 1) w.xb = take((size_t)N * D);
+  }
+  if (d.cr_msa) {
+    const size_t k = d.crmsa_k;
+    w.mean_rstd = take((size_t)N * 2);
+    w.logits = take(Np8 * k);
+    w.stats = take(R8 * k * 3);
+    w.rep = take(k * R8 * D);
+    w.rep_qkv = take(k * R8 * 3 * D);
+    w.rep_o = take(k * R8 * D);
+    w.rep2 = take(k * R8 * D);
+  }
+  w.bytes = off ? off : 256;
+  return w;
+}
+
+int check_desc(const rrt_encoder_desc* d, int64_t N) {
+  if (!d || N <= 0) return RRT_E_INVALID;
+  if (d->dim <= 0 || d->dim % 32 != 0) return unsupported("dim must be a positive multiple of 32");
+  if (d->dim > 2048) return unsupported("dim > 2048");
+  if (d->n_rmsa_layers < 0 || d->n_rmsa_layers > RRT_MAX_RMSA_LAYERS) return unsupported("n_layers-1 out of range");
+  if (d->n_rmsa_layers > 0) {
+    if (d->n_heads <= 0 || d->dim % d->n_heads != 0) return unsupported("n_heads must divide dim");
+    if (d->epeg && (d->epeg_k <= 0 || d->epeg_k % 2 == 0)) return unsupported("epeg_k must be odd");
+    if (d->region_size <= 0 && d->region_num <= 0) return unsupported("region_num must be positive");
+  }
+  if (d->cr_msa) {
+    if (d->crmsa_mlp) return unsupported("crmsa_mlp=True (MLP phi) is not on the HIP path yet");
+    if (d->crmsa_k <= 0 || d->crmsa_k > RRT_MAX_CRMSA_K) return unsupported("crmsa_k must be in [1,8]");
+    if (d->crmsa_heads <= 0 || d->dim % d->crmsa_heads != 0) return unsupported("crmsa_heads must divide dim");
+  }
+  if (N > (int64_t)1 << 24) return unsupported("bag larger than 2^24 tokens");
+  return RRT_OK;
+}
+
+hipError_t inner_attention(const float* u, int n_regions, int P, const rrt_attn_weights& w, int dim,
+                           int heads, int epeg_k, float* qkv, float* o, hipStream_t st) {
+  const int M = n_regions * P;
+  LinearEpilogue ep{};
+  ep.bias = w.qkv_b;
+  ep.q_cols = dim;
+  ep.q_scale = 1.0f / sqrtf((float)(dim / heads));   // head_dim ** -0.5, modules/rmsa.py:65,103
+  hipError_t e = launch_linear(u, w.qkv_w, qkv, M, 3 * dim, dim, ep, st);
+  if (e != hipSuccess) return e;
+  return launch_region_attention(qkv, epeg_k > 0 ? w.pe_w : nullptr, o, n_regions, P, dim, heads,
+                                 epeg_k, st);
+}
+
+}  // namespace
+
+GridDev to_dev(const rrt_grid& g) {
+  GridDev d;
+  d.L = (int)g.L;
+  d.H = g.H;
+  d.s = g.s;
+  d.rs = g.regions_side;
+  d.P = g.s * g.s;
+  d.Np = g.H * g.H;
+  return d;
+}
+
+extern "C" {
+
+int rrt_abi_version(void) { return RRT_ABI_VERSION; }
+
+const char* rrt_strerror(int code) {
+  switch (code) {
+    case RRT_OK: return "ok";
+    case RRT_E_INVALID: return "invalid argument (null pointer or non-positive size)";
+    case RRT_E_UNSUPPORTED: return g_detail[0] ? g_detail : "unsupported configuration";
+    case RRT_E_WORKSPACE: return "workspace too small (see rrt_encoder_workspace_size)";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+int rrt_region_grid(int64_t L, int32_t region_num, int32_t region_size, int32_t min_region_num,
+                    float min_region_ratio, rrt_grid* out) {
+  if (!out || L <= 0) return RRT_E_INVALID;
+  if (region_size <= 0 && region_num <= 0) return RRT_E_INVALID;
+  int64_t H = ceil_sqrt(L), s;
+  if (region_size > 0) {
+    H += ((-H) % region_size + region_size) % region_size;
+    s = region_size;
+  } else {
+    H += ((-H) % region_num + region_num) % region_num;
+    s = H / region_num;
+  }
+  int64_t add = H * H - L;
+  // "if padding much, give up region attention" (ablation escape hatch, rmsa.py:191-196);
+  // evaluated in double like the reference's Python floats
+  if ((double)add > (double)L / ((double)min_region_ratio + 1e-8) || L < min_region_num) {
+    H = ceil_sqrt(L);
+    H += H % 2;
+    add = H * H - L;
+    s = H;
+  }
+  if (H > 46340) return RRT_E_INVALID;
+  out->L = L;
+  out->H = (int32_t)H;
+  out->s = (int32_t)s;
+  out->regions_side = (int32_t)(H / s);
+  out->add = add;
+  return RRT_OK;
+}
+
+int rrt_encoder_workspace_size(const rrt_encoder_desc* desc, int64_t n_tokens, size_t* bytes) {
+  if (!bytes) return RRT_E_INVALID;
+  int rc = check_desc(desc, n_tokens);
+  if (rc) return rc;
+  rrt_grid g{}, g8{};
+  if (desc->n_rmsa_layers > 0) {
+    rc = rrt_region_grid(n_tokens, desc->region_num, desc->region_size, desc->min_region_num,
+                         desc->min_region_ratio, &g);
+    if (rc) return rc;
+  }
+  rc = rrt_region_grid(n_tokens, 8, 0, 0, 0.f, &g8);
+  if (rc) return rc;
+  *bytes = carve(*desc, n_tokens, g, g8, nullptr).bytes;
+  return RRT_OK;
+}
+
+static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weights* w, const float* x,
+                           float* y, int64_t n_tokens, void* workspace, size_t workspace_bytes,
+                           void* stream, void** events) {
+  if (!desc || !w || !x || !y || x == y) return RRT_E_INVALID;
+  int rc = check_desc(desc, n_tokens);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int D = desc->dim;
+  const int64_t N = n_tokens;
+  rrt_grid g{}, g8{};
+  if (desc->n_rmsa_layers > 0) {
+    rc = rrt_region_grid(N, desc->region_num, desc->region_size, desc->min_region_num,
+                         desc->min_region_ratio, &g);
+    if (rc) return rc;
+  }
+  // CR-MSA never receives region_num / region_size / min_region_* (modules/rrt.py:148): grid 8x8
+  rc = rrt_region_grid(N, 8, 0, 0, 0.f, &g8);
+  if (rc) return rc;
+  Workspace ws = carve(*desc, N, g, g8, nullptr);
+  if (!workspace || workspace_bytes < ws.bytes) return RRT_E_WORKSPACE;
+  ws = carve(*desc, N, g, g8, (char*)workspace);
+
+  hipError_t e = hipSuccess;
+#define RRT_TRY(call)            \
+  do {                           \
+    e = (call);                  \
+    if (e != hipSuccess) return (int)e; \
+  } while (0)
+  // optional stage-boundary events (bench.py / profiling): events[i] recorded after stage i-1
+#define RRT_MARK(i)                                                          \
+  do {                                                                       \
+    if (events && events[i]) RRT_TRY(hipEventRecord((hipEvent_t)events[i], st)); \
+  } while (0)
+  RRT_MARK(RRT_EV_START);
+
+  const float* xin = x;   // current activations [N, D]
+  // ---- R-MSA TransLayers: x = x + unpart(InnerAttention(part(pad(LN(x)))))  (rrt.py:117-125)
+  for (int li = 0; li < desc->n_rmsa_layers; ++li) {
+    const rrt_attn_weights& lw = w->rmsa[li];
+    if (!lw.norm_w || !lw.norm_b || !lw.qkv_w || !lw.proj_w || !lw.proj_b) return RRT_E_INVALID;
+    if (desc->epeg && !lw.pe_w) return RRT_E_INVALID;
+    const GridDev gd = to_dev(g);
+    float* xout = (li & 1) ? ws.xb : ws.xa;
+    RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, ws.uo, D, gd, st));
+    if (li == 0) RRT_MARK(RRT_EV_LN_PARTITION);
+    {
+      LinearEpilogue ep{};
+      ep.bias = lw.qkv_b;
+      ep.q_cols = D;
+      ep.q_scale = 1.0f / sqrtf((float)(D / desc->n_heads));   // head_dim ** -0.5, rmsa.py:65,103
+      RRT_TRY(launch_linear(ws.uo, lw.qkv_w, ws.qkv, gd.Np, 3 * D, D, ep, st));
+    }
+    if (li == 0) RRT_MARK(RRT_EV_QKV);
+    RRT_TRY(launch_region_attention(ws.qkv, desc->epeg ? lw.pe_w : nullptr, ws.uo, gd.rs * gd.rs, gd.P, D,
+                                    desc->n_heads, desc->epeg ? desc->epeg_k : 0, st));
+    if (li == 0) RRT_MARK(RRT_EV_ATTN);
+    LinearEpilogue ep{};
+    ep.bias = lw.proj_b;
+    ep.resid = xin;
+    ep.g = gd;
+    RRT_TRY(launch_linear(ws.uo, lw.proj_w, xout, gd.Np, D, D, ep, st));
+    if (li == 0) RRT_MARK(RRT_EV_PROJ);
+    xin = xout;
+  }
+  const float* x0 = desc->all_shortcut ? x : nullptr;
+  if (!w->norm_w || !w->norm_b) return RRT_E_INVALID;
+  if (!desc->cr_msa) {
+    RRT_TRY(launch_layernorm(xin, x0, w->norm_w, w->norm_b, y, (int)N, D, st));
+    RRT_MARK(RRT_EV_END);
+    return RRT_OK;
+  }
+  // ---- CR-MSA TransLayer (rmsa.py:290-337) + all_shortcut + final LayerNorm (rrt.py:190-195)
+  const rrt_attn_weights& cw = w->crmsa;
+  if (!cw.norm_w || !cw.norm_b || !cw.qkv_w || !cw.proj_w || !cw.proj_b || !w->phi) return RRT_E_INVALID;
+  const GridDev gd8 = to_dev(g8);
+  const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
+  RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, ws.mean_rstd, ws.logits, D, k, gd8, st));
+  RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, ws.mean_rstd, ws.logits, ws.stats, ws.rep, D, k,
+                               gd8, st));
+  RRT_MARK(RRT_EV_CR_COMBINE);
+  // inner MSA over the representatives: batch = k, sequence = R8 regions, no EPEG (rmsa.py:322)
+  RRT_TRY(inner_attention(ws.rep, k, R8, cw, D, desc->crmsa_heads, 0, ws.rep_qkv, ws.rep_o, st));
+  {
+    LinearEpilogue ep{};
+    ep.bias = cw.proj_b;
+    RRT_TRY(launch_linear(ws.rep_o, cw.proj_w, ws.rep2, k * R8, D, D, ep, st));
+  }
+  RRT_MARK(RRT_EV_CR_INNER);
+  RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, ws.logits, ws.stats, ws.rep2, w->norm_w, w->norm_b, y, D, k,
+                                   gd8, st));
+  RRT_MARK(RRT_EV_END);
+#undef RRT_TRY
+#undef RRT_MARK
+  return RRT_OK;
+}
+
+int rrt_encoder_forward_f32(const rrt_encoder_desc* desc, const rrt_encoder_weights* w, const float* x,
+                            float* y, int64_t n_tokens, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  return encoder_forward(desc, w, x, y, n_tokens, workspace, workspace_bytes, stream, nullptr);
+}
+
+int rrt_encoder_forward_events_f32(const rrt_encoder_desc* desc, const rrt_encoder_weights* w,
+                                   const float* x, float* y, int64_t n_tokens, void* workspace,
+                                   size_t workspace_bytes, void* stream, void** events) {
+  return encoder_forward(desc, w, x, y, n_tokens, workspace, workspace_bytes, stream, events);
+}
+
+// ------------------------------------------------------------------ stage entry points
+int rrt_ln_partition_f32(const float* x, const float* gamma, const float* beta, float* u, int64_t L,
+                         int32_t dim, const rrt_grid* g, void* stream) {
+  if (!x || !gamma || !beta || !u || !g || L != g->L || dim <= 0 || dim % 4) return RRT_E_INVALID;
+  if (dim > 2048) return unsupported("dim > 2048");
+  return (int)launch_ln_partition(x, gamma, beta, u, dim, to_dev(*g), (hipStream_t)stream);
+}
+
+int rrt_linear_f32(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N,
+                   int32_t K, int32_t q_cols, float q_scale, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return RRT_E_INVALID;
+  if (K % 32) return unsupported("linear: K must be a multiple of 32");
+  LinearEpilogue ep{};
+  ep.bias = bias;
+  ep.q_cols = q_cols;
+  ep.q_scale = q_scale;
+  return (int)launch_linear(A, B, C, (int)M, N, K, ep, (hipStream_t)stream);
+}
+
+int rrt_linear_unpartition_residual_f32(const float* A, const float* B, const float* bias,
+                                        const float* resid, float* out, int32_t N, int32_t K,
+                                        const rrt_grid* g, void* stream) {
+  if (!A || !B || !resid || !out || !g || N <= 0 || K <= 0) return RRT_E_INVALID;
+  if (K % 32) return unsupported("linear: K must be a multiple of 32");
+  LinearEpilogue ep{};
+  ep.bias = bias;
+  ep.resid = resid;
+  ep.g = to_dev(*g);
+  return (int)launch_linear(A, B, out, ep.g.Np, N, K, ep, (hipStream_t)stream);
+}
+
+int rrt_region_attention_f32(const float* qkv, const float* pe_w, float* o, int32_t n_regions, int32_t P,
+                             int32_t dim, int32_t heads, int32_t epeg_k, void* stream) {
+  if (!qkv || !o || n_regions <= 0 || P <= 0 || dim <= 0 || heads <= 0 || dim % heads) return RRT_E_INVALID;
+  if (pe_w && epeg_k > 0 && epeg_k % 2 == 0) return unsupported("epeg_k must be odd");
+  return (int)launch_region_attention(qkv, pe_w, o, n_regions, P, dim, heads, epeg_k, (hipStream_t)stream);
+}
+
+int rrt_crmsa_logits_f32(const float* x1, const float* gamma, const float* beta, const float* phi,
+                         float* mean_rstd, float* logits, int64_t L, int32_t dim, int32_t k,
+                         const rrt_grid* g8, void* stream) {
+  if (!x1 || !gamma || !beta || !phi || !mean_rstd || !logits || !g8 || L != g8->L) return RRT_E_INVALID;
+  if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4 || dim > 2048) return unsupported("crmsa: k in [1,8], dim%4==0, dim<=2048");
+  return (int)launch_crmsa_logits(x1, gamma, beta, phi, mean_rstd, logits, dim, k, to_dev(*g8),
+                                  (hipStream_t)stream);
+}
+
+int rrt_crmsa_combine_f32(const float* x1, const float* gamma, const float* beta, const float* mean_rstd,
+                          const float* logits, float* stats, float* rep, int64_t L, int32_t dim, int32_t k,
+                          const rrt_grid* g8, void* stream) {
+  if (!x1 || !gamma || !beta || !mean_rstd || !logits || !stats || !rep || !g8 || L != g8->L) return RRT_E_INVALID;
+  if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4) return unsupported("crmsa: k in [1,8], dim%4==0");
+  return (int)launch_crmsa_combine(x1, gamma, beta, mean_rstd, logits, stats, rep, dim, k, to_dev(*g8),
+                                   (hipStream_t)stream);
+}
+
+int rrt_crmsa_dispatch_ln_f32(const float* x1, const float* x0, const float* logits, const float* stats,
+                              const float* rep2, const float* gamma, const float* beta, float* y, int64_t L,
+                              int32_t dim, int32_t k, const rrt_grid* g8, void* stream) {
+  if (!x1 || !logits || !stats || !rep2 || !gamma || !beta || !y || !g8 || L != g8->L) return RRT_E_INVALID;
+  if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4 || dim > 2048) return unsupported("crmsa: k in [1,8], dim%4==0, dim<=2048");
+  return (int)launch_crmsa_dispatch_ln(x1, x0, logits, stats, rep2, gamma, beta, y, dim, k, to_dev(*g8),
+                                       (hipStream_t)stream);
+}
+
+int rrt_layernorm_f32(const float* x1, const float* x0, const float* gamma, const float* beta, float* y,
+                      int64_t L, int32_t dim, void* stream) {
+  if (!x1 || !gamma || !beta || !y || L <= 0 || dim <= 0 || dim % 4) return RRT_E_INVALID;
+  if (dim > 2048) return unsupported("dim > 2048");
+  return (int)launch_layernorm(x1, x0, gamma, beta, y, (int)L, dim, (hipStream_t)stream);
+}
+
+}  // extern "C"

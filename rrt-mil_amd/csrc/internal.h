@@ -1,0 +1,37 @@
+// internal.h -- host-side launch functions shared between the kernel files and api.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+#include "common.h"
+#include "../../include/rrt_hip.h"
+
+GridDev to_dev(const rrt_grid& g);
+
+hipError_t launch_ln_partition(const float* x, const float* gamma, const float* beta, float* u,
+                               int dim, const GridDev& g, hipStream_t st);
+
+struct LinearEpilogue {
+  const float* bias;     // [N] or null
+  int q_cols;            // columns [0,q_cols) scaled by q_scale after bias
+  float q_scale;
+  // un-partition + residual (used when resid != null): C row = token, A row = slot
+  const float* resid;
+  GridDev g;
+};
+hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
+                         const LinearEpilogue& ep, hipStream_t st);
+
+hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o, int n_regions,
+                                   int P, int dim, int heads, int epeg_k, hipStream_t st);
+
+hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float* beta,
+                               const float* phi, float* mean_rstd, float* logits, int dim, int k,
+                               const GridDev& g8, hipStream_t st);
+hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
+                                const float* mean_rstd, const float* logits, float* stats,
+                                float* rep, int dim, int k, const GridDev& g8, hipStream_t st);
+hipError_t launch_crmsa_dispatch_ln(const float* x1, const float* x0, const float* logits,
+                                    const float* stats, const float* rep2, const float* gamma,
+                                    const float* beta, float* y, int dim, int k, const GridDev& g8,
+                                    hipStream_t st);
+hipError_t launch_layernorm(const float* x1, const float* x0, const float* gamma,
+                            const float* beta, float* y, int L, int dim, hipStream_t st);

@@ -1,0 +1,70 @@
+// ln_partition.hip -- LayerNorm + zero-pad + region partition in one pass over the bag.
+//
+// Replaces: nn.LayerNorm (modules/rrt.py:121-123), the fp32 zero-pad torch.cat
+// (modules/rmsa.py:199-200) and region_partition's permute+contiguous copy
+// (modules/rmsa.py:28-39).  HBM-bound: reads L*D, writes Np*D floats, one wave per
+// token row, float4 (16 B/lane) accesses, two-pass mean/variance held in registers.
+#include "internal.h"
+
+template <int NV>   // float4 per lane: supports dim <= NV*256
+__global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           float* __restrict__ u, int dim, GridDev g) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);   // padded-grid token index
+  if (t >= g.Np) return;
+  float* dst = u + (size_t)token_to_slot(t, g) * dim;
+  if (t >= g.L) {   // pad row: exact zeros (they are NOT layer-normed in the reference)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      int c = (v * 64 + lane) * 4;
+      if (c < dim) *(float4*)(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const float* src = x + (size_t)t * dim;
+  float4 r[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int c = (v * 64 + lane) * 4;
+    r[v] = (c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sum += (r[v].x + r[v].y) + (r[v].z + r[v].w);
+  }
+  const float inv_d = 1.0f / (float)dim;
+  const float mean = wave_sum(sum) * inv_d;
+  float sq = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int c = (v * 64 + lane) * 4;
+    if (c < dim) {
+      float a = r[v].x - mean, b = r[v].y - mean, cc = r[v].z - mean, d = r[v].w - mean;
+      sq += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int c = (v * 64 + lane) * 4;
+    if (c < dim) {
+      float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
+      float4 o;
+      o.x = (r[v].x - mean) * rstd * gm.x + bt.x;
+      o.y = (r[v].y - mean) * rstd * gm.y + bt.y;
+      o.z = (r[v].z - mean) * rstd * gm.z + bt.z;
+      o.w = (r[v].w - mean) * rstd * gm.w + bt.w;
+      *(float4*)(dst + c) = o;
+    }
+  }
+}
+
+hipError_t launch_ln_partition(const float* x, const float* gamma, const float* beta, float* u,
+                               int dim, const GridDev& g, hipStream_t st) {
+  dim3 grid((g.Np + 3) / 4), block(256);
+  if (dim <= 256) ln_partition_kernel<1><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);
+  else if (dim <= 512) ln_partition_kernel<2><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);
+  else if (dim <= 1024) ln_partition_kernel<4><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);
+  else ln_partition_kernel<8><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);
+  return hipGetLastError();
+}

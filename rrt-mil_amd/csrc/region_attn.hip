@@ -1,0 +1,278 @@
+// region_attn.hip -- per-region multi-head attention with the EPEG term, fp32 MFMA.
+//
+// Replaces InnerAttention.forward's core, modules/rmsa.py:103-122:
+//     attn = (q*scale) @ k^T ; attn += Conv2d_dw(k x 1)(attn) ; softmax ; attn @ v
+//
+// Two identities remove the [R,h,P,P] score tensor the reference materialises:
+//  (1) EPEG is a depth-wise 1-D convolution along the QUERY axis of S = Q K^T
+//      (kernel (k,1), zero padded at the region edge, modules/rmsa.py:84,106-108).
+//      A stencil over the row index of S acts on the left factor only:
+//          S + T S = (Q + T Q) K^T ,  (T Q)[i,:] = sum_t w[t] Q[i+t-k/2,:]  (rows outside [0,P) = 0)
+//      so it is applied to the [P,64] Q tile (15 taps x 64 dims per query) instead
+//      of the [P,P] score tile.
+//  (2) the conv bias adds one constant per head to every score of that head; row
+//      softmax is shift invariant, so it drops out.
+// What is left is plain softmax(Q~ K^T) V per (region, head), done flash-style:
+//   * one wave = 16 queries; scores are computed TRANSPOSED (S^T = K Q~^T, A = K tile,
+//     B = Q~ fragments held in registers) with v_mfma_f32_16x16x4_f32, so lane l holds,
+//     for query (l&15), keys 4*(l>>4)+reg of every 16-key tile: the row softmax needs
+//     only 2 cross-lane steps (xor 16, xor 32) and P^T is already in the A-operand
+//     layout for P.V (no LDS round trip);
+//   * K/V stream through LDS in chunks of 16*TC keys (16-B DMA, double buffered,
+//     one barrier per chunk), online softmax across chunks (any P);
+//   * K image XOR-swizzled (slot ^ (row&15)) via the DMA source address so the
+//     row-per-lane ds_read_b128 is bank-conflict free; V is read row-contiguous;
+//   * a lane's float4 of V covers 4 head-dim tiles (d = 4*(l&15)+c), so the O tile
+//     comes out as one float4 per row: coalesced 256-B row stores.
+// Head dim 64 only (dim/heads == 64); other head dims use region_attn_generic.
+#include "internal.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr float NEG_BIG = -3.0e38f;
+
+template <int TC>
+__global__ __launch_bounds__(256) void region_attn_kernel(const float* __restrict__ qkv,
+                                                          const float* __restrict__ pe_w,
+                                                          float* __restrict__ o, int P, int dim,
+                                                          int epeg_k) {
+  constexpr int KC = 16 * TC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lds = (float*)smem;   // [2][K: KC*64 | V: KC*64]
+  constexpr int STAGE = 2 * KC * HD;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int head = blockIdx.y, reg = blockIdx.z;
+  const int ld = 3 * dim;
+  const size_t rbase = (size_t)reg * P;
+  const float* qbase = qkv + rbase * ld + head * HD;
+  const float* kbase = qbase + dim;
+  const float* vbase = qbase + 2 * dim;
+
+  const int i0 = (blockIdx.x * nw + wave) * 16;   // first query of this wave
+  const bool active = i0 < P;
+  const int qi = i0 + (lane & 15);
+  const int lg = lane >> 4;
+
+  // ---- stage chunk 0 (all waves) -------------------------------------------------
+  auto stage = [&](int ch, float* buf) {
+    const int j0 = ch * KC;
+    for (int q = wave; q < KC / 4; q += nw) {          // 64 slots = 4 rows per wave-instruction
+      int S = q * 64 + lane;
+      int row = S >> 4, p = S & 15;
+      int j = j0 + row;
+      j = j < P ? j : P - 1;                            // tail keys: re-read last row, masked below
+      dma16(kbase + (size_t)j * ld + ((p ^ (row & 15)) << 2), buf + q * 256);
+      dma16(vbase + (size_t)j * ld + (p << 2), buf + KC * HD + q * 256);
+    }
+  };
+  stage(0, lds);
+
+  // ---- Q~ fragments (B operand): bq[c] = Q~[qi][16c + 4*lg .. +3] ---------------------
+  float4 bq[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active && qi < P) {
+    const int dof = 4 * lg;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bq[c] = *(const float4*)(qbase + (size_t)qi * ld + 16 * c + dof);
+    if (epeg_k > 0) {
+      const int half = epeg_k >> 1;
+      const float* w = pe_w + head * epeg_k;
+      for (int t = 0; t < epeg_k; ++t) {
+        int r = qi + t - half;
+        if (r >= 0 && r < P) {
+          const float wt = w[t];
+          const float* qr = qbase + (size_t)r * ld + dof;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float4 v = *(const float4*)(qr + 16 * c);
+            bq[c].x += wt * v.x; bq[c].y += wt * v.y; bq[c].z += wt * v.z; bq[c].w += wt * v.w;
+          }
+        }
+      }
+    }
+  }
+
+  float m_run = NEG_BIG, l_run = 0.f;
+  f32x4 oacc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nch = (P + KC - 1) / KC;
+  for (int ch = 0; ch < nch; ++ch) {
+    wait_vm0();
+    __syncthreads();
+    float* cur = lds + (ch & 1) * STAGE;
+    if (ch + 1 < nch) stage(ch + 1, lds + ((ch + 1) & 1) * STAGE);
+    if (!active) continue;
+    const float* Ks = cur;
+    const float* Vs = cur + KC * HD;
+    const int j0 = ch * KC;
+
+    // S^T tiles: s[jt][r] = score(query lane&15, key j0 + 16*jt + 4*lg + r)
+    f32x4 s[TC];
+#pragma unroll
+    for (int jt = 0; jt < TC; ++jt) {
+      s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int row = jt * 16 + (lane & 15);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float4 a = *(const float4*)(Ks + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+        s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[c].x, s[jt], 0, 0, 0);
+        s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[c].y, s[jt], 0, 0, 0);
+        s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[c].z, s[jt], 0, 0, 0);
+        s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[c].w, s[jt], 0, 0, 0);
+      }
+    }
+    // mask tail keys, chunk max
+    float cmax = NEG_BIG;
+#pragma unroll
+    for (int jt = 0; jt < TC; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int j = j0 + jt * 16 + 4 * lg + r;
+        if (j >= P) s[jt][r] = NEG_BIG;
+        cmax = fmaxf(cmax, s[jt][r]);
+      }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    const float m_new = fmaxf(m_run, cmax);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < TC; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = __expf(s[jt][r] - m_new);
+        s[jt][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;   // per-lane partial (this lane's keys); lanes of a query share alpha
+    // rescale O: row r' of the O tile is query 4*lg + r', whose alpha lives in lane (4*lg + r')
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float ar = __shfl(alpha, 4 * lg + r);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) oacc[c][r] *= ar;
+    }
+    // O += P V   (A = P^T regs, B = V rows; float4 of V = 4 head-dim tiles)
+#pragma unroll
+    for (int jt = 0; jt < TC; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = jt * 16 + 4 * lg + r;
+        float4 v = *(const float4*)(Vs + row * HD + ((lane & 15) << 2));
+        const float p = s[jt][r];
+        oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.x, oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.y, oacc[1], 0, 0, 0);
+        oacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.z, oacc[2], 0, 0, 0);
+        oacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.w, oacc[3], 0, 0, 0);
+      }
+  }
+  if (!active) return;
+  float l_tot = l_run + __shfl_xor(l_run, 16);
+  l_tot += __shfl_xor(l_tot, 32);
+  const float inv = 1.0f / l_tot;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float ir = __shfl(inv, 4 * lg + r);
+    const int i = i0 + 4 * lg + r;
+    if (i < P) {
+      float4 out = make_float4(oacc[0][r] * ir, oacc[1][r] * ir, oacc[2][r] * ir, oacc[3][r] * ir);
+      *(float4*)(o + (rbase + i) * dim + head * HD + ((lane & 15) << 2)) = out;
+    }
+  }
+}
+
+// Generic head-dim fallback (hd != 64: e.g. crmsa_heads=1 -> hd=dim, or dim=64 -> hd=8).
+// One wave per query; VALU only.  Correctness path, not tuned.
+__global__ __launch_bounds__(256) void region_attn_generic_kernel(const float* __restrict__ qkv,
+                                                                  const float* __restrict__ pe_w,
+                                                                  float* __restrict__ o, int P,
+                                                                  int dim, int hd, int epeg_k) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Ppad = (P + 3) & ~3;
+  float* qs = (float*)smem + wave * (hd + Ppad);   // q~ [hd]
+  float* ps = qs + hd;                               // scores / probabilities [P]
+  const int head = blockIdx.y, reg = blockIdx.z;
+  const int qi = blockIdx.x * 4 + wave;
+  if (qi >= P) return;
+  const int ld = 3 * dim;
+  const size_t rbase = (size_t)reg * P;
+  const float* qbase = qkv + rbase * ld + head * hd;
+  const float* kbase = qbase + dim;
+  const float* vbase = qbase + 2 * dim;
+  const int half = epeg_k >> 1;
+  for (int d = lane; d < hd; d += 64) {
+    float a = qbase[(size_t)qi * ld + d];
+    for (int t = 0; t < epeg_k; ++t) {
+      int r = qi + t - half;
+      if (r >= 0 && r < P) a += pe_w[head * epeg_k + t] * qbase[(size_t)r * ld + d];
+    }
+    qs[d] = a;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float mx = NEG_BIG;
+  for (int j = lane; j < P; j += 64) {
+    const float* kr = kbase + (size_t)j * ld;
+    float a = 0.f;
+    for (int d = 0; d < hd; ++d) a += qs[d] * kr[d];
+    ps[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < P; j += 64) {
+    float p = __expf(ps[j] - mx);
+    ps[j] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < hd; d += 64) {
+    float a = 0.f;
+    for (int j = 0; j < P; ++j) a += ps[j] * vbase[(size_t)j * ld + d];
+    o[(rbase + qi) * dim + head * hd + d] = a * inv;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o, int n_regions,
+                                   int P, int dim, int heads, int epeg_k, hipStream_t st) {
+  const int hd = dim / heads;
+  if (pe_w == nullptr) epeg_k = 0;
+  if (hd != HD) {
+    const int Ppad = (P + 3) & ~3;
+    size_t lds = (size_t)4 * (hd + Ppad) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)region_attn_generic_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    region_attn_generic_kernel<<<dim3((P + 3) / 4, heads, n_regions), 256, lds, st>>>(
+        qkv, pe_w, o, P, dim, hd, epeg_k);
+    return hipGetLastError();
+  }
+  const int ntiles = (P + 15) / 16;
+  // waves per block: avoid idle waves (P=144 -> 9 tiles -> 3 waves x 3 blocks)
+  int nw = 4;
+  if (ntiles < 4) nw = ntiles;
+  else if (ntiles % 4 != 0 && ntiles % 3 == 0) nw = 3;
+  const int nqb = (ntiles + nw - 1) / nw;
+  dim3 grid(nqb, heads, n_regions), block(nw * 64);
+  if (P <= 16) {
+    region_attn_kernel<1><<<grid, block, 2 * 2 * 16 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+  } else if (P <= 32) {
+    region_attn_kernel<2><<<grid, block, 2 * 2 * 32 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+  } else {
+    region_attn_kernel<3><<<grid, block, 2 * 2 * 48 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+  }
+  return hipGetLastError();
+}

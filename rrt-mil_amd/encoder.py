@@ -1,0 +1,253 @@
+"""RRTEncoder -- drop-in for the reference's modules/rrt.py:133-202 on MI355X.
+
+Same constructor signature, parameter names / shapes (state_dict-compatible,
+strict=True), ``final_dim`` attribute and (N,D) / (B,N,D) / (B,C,H,W) -> same-shape
+forward.  The parameter holders are real nn.LayerNorm / nn.Linear / nn.Conv2d
+sub-modules under the reference's names (so ``.apply(initialize_weights)``,
+optimizers and checkpoints behave identically); the forward itself is ONE call
+into librrt_hip.so (rrt_encoder_forward_f32, include/rrt_hip.h) per bag on the
+current HIP stream.  There is no PyTorch/CPU fallback: CPU tensors, training-mode
+dropout and the reference's ablation branches raise.
+"""
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+def initialize_weights(module):
+    """modules/rrt.py:9-23: xavier-normal Linear/Conv2d, zero bias, LayerNorm (1, 0)."""
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            nn.init.xavier_normal_(m.weight)
+            if m.bias is not None:
+                m.bias.data.zero_()
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+
+class InnerAttention(nn.Module):
+    """Parameter holder mirroring modules/rmsa.py:56-89 (qkv, proj, pe)."""
+
+    def __init__(self, dim, head_dim=None, num_heads=8, qkv_bias=True, proj_drop=0., epeg=True,
+                 epeg_k=15, epeg_2d=False, epeg_bias=True, epeg_type='attn', **_ignored):
+        super().__init__()
+        if epeg and (epeg_2d or epeg_type != 'attn'):
+            raise NotImplementedError("only the default 1-D 'attn' EPEG is on the HIP path "
+                                      "(epeg_2d / epeg_type='value_*' are reference ablations)")
+        head_dim = head_dim or dim // num_heads
+        if head_dim * num_heads != dim:
+            raise NotImplementedError("head_dim * num_heads must equal dim")
+        self.dim, self.num_heads, self.head_dim = dim, num_heads, head_dim
+        self.scale = head_dim ** -0.5
+        self.qkv = nn.Linear(dim, head_dim * num_heads * 3, bias=qkv_bias)
+        self.proj = nn.Linear(head_dim * num_heads, dim)
+        self.proj_drop_p = proj_drop
+        self.epeg_k = epeg_k
+        self.pe = (nn.Conv2d(num_heads, num_heads, (epeg_k, 1), padding=(epeg_k // 2, 0),
+                             groups=num_heads, bias=epeg_bias) if epeg else None)
+
+    def extra_repr(self):
+        return f'dim={self.dim}, num_heads={self.num_heads}'
+
+
+class RegionAttntion(nn.Module):
+    """Holder mirroring modules/rmsa.py:152-173 (name kept as spelled in the reference)."""
+
+    def __init__(self, dim, head_dim=None, num_heads=8, region_size=0, qkv_bias=True, drop=0.,
+                 region_num=8, epeg=False, min_region_num=0, min_region_ratio=0., region_attn='native',
+                 **kwargs):
+        super().__init__()
+        if region_attn != 'native':
+            raise NotImplementedError("region_attn='ntrans' (Nystrom ablation) is out of scope")
+        self.dim, self.num_heads = dim, num_heads
+        self.region_size = region_size if region_size > 0 else None
+        self.region_num = region_num
+        self.min_region_num, self.min_region_ratio = min_region_num, min_region_ratio
+        self.attn = InnerAttention(dim, head_dim=head_dim, num_heads=num_heads, qkv_bias=qkv_bias,
+                                   proj_drop=drop, epeg=epeg, **kwargs)
+
+
+class CrossRegionAttntion(nn.Module):
+    """Holder mirroring modules/rmsa.py:232-259."""
+
+    def __init__(self, dim, head_dim=None, num_heads=8, region_size=0, qkv_bias=True, drop=0.,
+                 region_num=8, epeg=False, min_region_num=0, min_region_ratio=0., crmsa_k=3,
+                 crmsa_mlp=False, region_attn='native', **kwargs):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.region_size = region_size if region_size > 0 else None
+        self.region_num = region_num
+        self.min_region_num, self.min_region_ratio = min_region_num, min_region_ratio
+        self.attn = InnerAttention(dim, head_dim=head_dim, num_heads=num_heads, qkv_bias=qkv_bias,
+                                   proj_drop=drop, epeg=epeg, **kwargs)
+        self.crmsa_mlp = crmsa_mlp
+        self.crmsa_k = crmsa_k
+        if crmsa_mlp:
+            self.phi = nn.Sequential(nn.Linear(dim, dim // 4, bias=False), nn.Tanh(),
+                                     nn.Linear(dim // 4, crmsa_k, bias=False))
+        else:
+            self.phi = nn.Parameter(torch.empty((dim, crmsa_k)))
+            nn.init.kaiming_uniform_(self.phi, a=math.sqrt(5))
+
+
+class TransLayer(nn.Module):
+    """Holder mirroring modules/rrt.py:43-110: pre-norm residual attention block."""
+
+    def __init__(self, norm_layer=nn.LayerNorm, dim=512, head=8, drop_out=0.1, drop_path=0., ffn=False,
+                 ffn_act='gelu', mlp_ratio=4., trans_dim=64, attn='rmsa', n_region=8, epeg=False,
+                 region_size=0, min_region_num=0, min_region_ratio=0, qkv_bias=True, crmsa_k=3,
+                 epeg_k=15, **kwargs):
+        super().__init__()
+        if ffn:
+            raise NotImplementedError("ffn=True (ablation MLP block) is not on the HIP path")
+        if drop_path > 0.:
+            raise NotImplementedError("drop_path > 0 (training-only stochastic depth) is not on the HIP path")
+        self.norm = norm_layer(dim)
+        self.norm2 = nn.Identity()
+        common = dict(dim=dim, num_heads=head, drop=drop_out, region_num=n_region, head_dim=dim // head,
+                      epeg=epeg, region_size=region_size, min_region_num=min_region_num,
+                      min_region_ratio=min_region_ratio, qkv_bias=qkv_bias)
+        if attn == 'rmsa':
+            self.attn = RegionAttntion(epeg_k=epeg_k, **common, **kwargs)
+        elif attn == 'crmsa':
+            self.attn = CrossRegionAttntion(crmsa_k=crmsa_k, **common, **kwargs)
+        elif attn == 'ntrans':
+            raise NotImplementedError("attn='ntrans' (Nystrom ablation) is out of scope")
+        else:
+            raise NotImplementedError
+        self.drop_path = nn.Identity()
+        self.ffn = ffn
+        self.mlp = nn.Identity()
+
+
+class RRTEncoder(nn.Module):
+    def __init__(self, mlp_dim=512, pos_pos=0, pos='none', peg_k=7, attn='rmsa', region_num=8,
+                 drop_out=0.1, n_layers=2, n_heads=8, drop_path=0., ffn=False, ffn_act='gelu',
+                 mlp_ratio=4., trans_dim=64, epeg=True, epeg_k=15, region_size=0, min_region_num=0,
+                 min_region_ratio=0, qkv_bias=True, peg_bias=True, peg_1d=False, cr_msa=True,
+                 crmsa_k=3, all_shortcut=False, crmsa_mlp=False, crmsa_heads=8, need_init=False,
+                 **kwargs):
+        super().__init__()
+        if pos not in ('none', None):
+            raise NotImplementedError("pos='ppeg'/'peg'/'sincos' are reference ablations, not on the HIP path")
+        self.final_dim = mlp_dim
+        self.norm = nn.LayerNorm(self.final_dim)
+        self.all_shortcut = all_shortcut
+        self.layers = nn.Sequential(*[
+            TransLayer(dim=mlp_dim, head=n_heads, drop_out=drop_out, drop_path=drop_path, ffn=ffn,
+                       ffn_act=ffn_act, mlp_ratio=mlp_ratio, trans_dim=trans_dim, attn=attn,
+                       n_region=region_num, epeg=epeg, region_size=region_size,
+                       min_region_num=min_region_num, min_region_ratio=min_region_ratio,
+                       qkv_bias=qkv_bias, epeg_k=epeg_k, **kwargs)
+            for _ in range(n_layers - 1)])
+        # the reference does not forward region_num / epeg / region_size / min_region_* here
+        # (modules/rrt.py:148): CR-MSA always runs an 8x8 grid without EPEG
+        self.cr_msa = (TransLayer(dim=mlp_dim, head=crmsa_heads, drop_out=drop_out, drop_path=drop_path,
+                                  ffn=ffn, ffn_act=ffn_act, mlp_ratio=mlp_ratio, trans_dim=trans_dim,
+                                  attn='crmsa', qkv_bias=qkv_bias, crmsa_k=crmsa_k, crmsa_mlp=crmsa_mlp,
+                                  **kwargs) if cr_msa else nn.Identity())
+        self.pos_embedding = nn.Identity()
+        self.pos_pos = pos_pos
+        self.drop_out = drop_out
+        self._desc = _lib.EncoderDesc(
+            dim=mlp_dim, n_heads=n_heads, n_rmsa_layers=n_layers - 1, region_num=region_num,
+            region_size=region_size, min_region_num=min_region_num, min_region_ratio=min_region_ratio,
+            epeg=int(bool(epeg)), epeg_k=epeg_k, cr_msa=int(bool(cr_msa)), crmsa_k=crmsa_k,
+            crmsa_heads=crmsa_heads, crmsa_mlp=int(bool(crmsa_mlp)), all_shortcut=int(bool(all_shortcut)))
+        self._ws = None           # cached workspace tensor (grown on demand, per device)
+        if need_init:
+            self.apply(initialize_weights)
+
+    # ------------------------------------------------------------------ C-ABI plumbing
+    @staticmethod
+    def _ptr(t):
+        if t is None:
+            return None
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.RRTHipError("parameters must be contiguous fp32 (bf16 configs: not built yet)")
+        return t.data_ptr()
+
+    def _attn_weights(self, layer):
+        ia = layer.attn.attn
+        w = _lib.AttnWeights()
+        w.norm_w, w.norm_b = self._ptr(layer.norm.weight), self._ptr(layer.norm.bias)
+        w.qkv_w, w.qkv_b = self._ptr(ia.qkv.weight), self._ptr(ia.qkv.bias)
+        w.proj_w, w.proj_b = self._ptr(ia.proj.weight), self._ptr(ia.proj.bias)
+        if ia.pe is not None:
+            w.pe_w, w.pe_b = self._ptr(ia.pe.weight), self._ptr(ia.pe.bias)   # [h,1,k,1] == [h,k]
+        return w
+
+    def _weights(self):
+        w = _lib.EncoderWeights()
+        for i, layer in enumerate(self.layers.children()):
+            w.rmsa[i] = self._attn_weights(layer)
+        if self._desc.cr_msa:
+            w.crmsa = self._attn_weights(self.cr_msa)
+            if not self._desc.crmsa_mlp:
+                w.phi = self._ptr(self.cr_msa.attn.phi)
+        w.norm_w, w.norm_b = self._ptr(self.norm.weight), self._ptr(self.norm.bias)
+        return w
+
+    def _workspace(self, n_tokens, device):
+        lib = _lib.load()
+        need = C.c_size_t()
+        _lib.check(lib.rrt_encoder_workspace_size(C.byref(self._desc), n_tokens, C.byref(need)),
+                   "rrt_encoder_workspace_size")
+        if self._ws is None or self._ws.device != device or self._ws.numel() < need.value:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def forward_bag(self, x2d, out=None):
+        """One bag: x2d (N, D) fp32 device tensor -> (N, D).  Enqueued on the current stream."""
+        lib = _lib.load()
+        if not x2d.is_cuda:
+            raise _lib.RRTHipError("rrt_mil_amd.RRTEncoder runs on MI355X only: move the bag to a "
+                                   "'cuda' (HIP) device; there is no CPU fallback")
+        if x2d.dtype != torch.float32:
+            raise NotImplementedError("fp32 bags only (bf16/autocast configs are not built yet)")
+        if self.training and self.drop_out > 0:
+            raise NotImplementedError("training-mode forward (proj dropout p=%.2f + autograd) is not built; "
+                                      "call .eval()" % self.drop_out)
+        if torch.is_grad_enabled() and (x2d.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # inference path: no autograd graph is recorded
+            pass
+        x2d = x2d.contiguous()
+        n, d = x2d.shape
+        if d != self.final_dim:
+            raise ValueError(f"expected feature dim {self.final_dim}, got {d}")
+        y = out if out is not None else torch.empty_like(x2d)
+        ws = self._workspace(n, x2d.device)
+        w = self._weights()
+        stream = torch.cuda.current_stream(x2d.device).cuda_stream
+        rc = lib.rrt_encoder_forward_f32(C.byref(self._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
+                                         ws.data_ptr(), ws.numel(), stream)
+        _lib.check(rc, "rrt_encoder_forward_f32")
+        return y
+
+    @torch.no_grad()
+    def forward(self, x):
+        # rank handling: modules/rrt.py:166-175 and :197-201
+        shape_len = 3
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+            shape_len = 2
+        if x.dim() == 4:
+            x = x.reshape(x.size(0), x.size(1), -1).transpose(1, 2)
+            shape_len = 4
+        batch, num_patches, ch = x.shape
+        if batch != 1:
+            # the reference mixes the bags of a batch inside CR-MSA (regions of all bags share one
+            # attention sequence, modules/rmsa.py:316-322); every reference trainer uses batch_size=1
+            raise NotImplementedError("batch > 1: pass bags one at a time (reference semantics at B>1 "
+                                      "couple the bags inside CR-MSA)")
+        y = self.forward_bag(x[0]).unsqueeze(0)
+        if shape_len == 2:
+            y = y.squeeze(0)
+        elif shape_len == 4:
+            y = y.transpose(1, 2).reshape(batch, ch, int(num_patches ** 0.5), int(num_patches ** 0.5))
+        return y

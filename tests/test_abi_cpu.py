@@ -1,0 +1,112 @@
+"""CPU: the C-ABI library loads and exports every symbol include/rrt_hip.h declares;
+host-only entry points (geometry, workspace size, error strings) behave; the Python
+boundary mirrors the reference's constructor / state_dict surface.  No GPU compute."""
+import ctypes as C
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+import rrt_mil_amd
+from rrt_mil_amd import RRTEncoder, _lib, synth
+from rrt_mil_amd.build import build
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "rrt_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rrt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rrt_abi_version() == _lib.ABI_VERSION
+
+
+def test_c_geometry_matches_reference_padding(lib):
+    tab = load_golden("G0_geometry")["table"]
+    for L, rn, rs, mrn, mrr, H, rsz, add in tab:
+        g = _lib.region_grid(int(L), int(rn), int(rs), int(mrn), float(mrr))
+        assert (g.H, g.s, g.add) == (int(H), int(rsz), int(add)), (L, rn, rs, mrn, mrr)
+        assert g.regions_side * g.s == g.H
+
+
+def test_workspace_and_errors(lib):
+    enc = RRTEncoder()
+    n = C.c_size_t()
+    assert lib.rrt_encoder_workspace_size(C.byref(enc._desc), 9000, C.byref(n)) == 0
+    # u/o + qkv + x1 dominate: (9216*512*4 + 9000*512) floats
+    assert n.value >= (9216 * 512 * 4 + 9000 * 512) * 4
+    assert lib.rrt_encoder_workspace_size(C.byref(enc._desc), 0, C.byref(n)) == -1
+    bad = RRTEncoder(crmsa_mlp=True)
+    rc = lib.rrt_encoder_workspace_size(C.byref(bad._desc), 100, C.byref(n))
+    assert rc == -2 and b"crmsa_mlp" in lib.rrt_strerror(rc)
+    with pytest.raises(NotImplementedError):
+        _lib.check(rc, "x")
+    assert lib.rrt_region_grid(0, 8, 0, 0, 0.0, C.byref(_lib.Grid())) == -1
+    # null device pointers are rejected before anything is launched
+    assert lib.rrt_encoder_forward_f32(C.byref(enc._desc), None, None, None, 10, None, 0, None) == -1
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(_lib.RRTHipError):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_constructor_signature_matches_reference():
+    # modules/rrt.py:134 -- names, order and defaults
+    ref = ("mlp_dim=512,pos_pos=0,pos='none',peg_k=7,attn='rmsa',region_num=8,drop_out=0.1,n_layers=2,"
+           "n_heads=8,drop_path=0.,ffn=False,ffn_act='gelu',mlp_ratio=4.,trans_dim=64,epeg=True,epeg_k=15,"
+           "region_size=0,min_region_num=0,min_region_ratio=0,qkv_bias=True,peg_bias=True,peg_1d=False,"
+           "cr_msa=True,crmsa_k=3,all_shortcut=False,crmsa_mlp=False,crmsa_heads=8,need_init=False")
+    want = [(kv.split("=")[0], eval(kv.split("=")[1])) for kv in ref.split(",")]
+    sig = inspect.signature(RRTEncoder.__init__)
+    got = [(n, p.default) for n, p in sig.parameters.items() if n not in ("self", "kwargs")]
+    assert got == want
+    assert any(p.kind is p.VAR_KEYWORD for p in sig.parameters.values())
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(mlp_dim=64), dict(n_layers=3), dict(cr_msa=False),
+                                 dict(epeg=False), dict(qkv_bias=False), dict(crmsa_k=5, epeg_k=21),
+                                 dict(crmsa_mlp=True)])
+def test_state_dict_surface(cfg):
+    """Reference checkpoints load with strict=True: same keys, same shapes."""
+    enc = RRTEncoder(**cfg)
+    shapes = synth.encoder_state_shapes(**cfg)
+    sd = enc.state_dict()
+    assert list(sd.keys()) == list(shapes.keys()) or set(sd.keys()) == set(shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    assert enc.final_dim == cfg.get("mlp_dim", 512)
+
+
+def test_default_param_count():
+    enc = RRTEncoder()
+    assert sum(p.numel() for p in enc.parameters()) == 2105984
+    assert len(enc.state_dict()) == 17
+
+
+def test_need_init_matches_reference_rule():
+    enc = RRTEncoder(mlp_dim=64, need_init=True)
+    assert float(enc.layers[0].attn.attn.qkv.bias.abs().max()) == 0.0
+    assert float(enc.norm.weight.min()) == 1.0
+
+
+def test_cpu_tensor_and_ablations_raise():
+    enc = RRTEncoder(mlp_dim=64).eval()
+    with pytest.raises(_lib.RRTHipError):
+        enc(torch.zeros(1, 10, 64))
+    for kw in (dict(pos='ppeg'), dict(ffn=True), dict(attn='ntrans'), dict(epeg_2d=True),
+               dict(epeg_type='value_bf'), dict(region_attn='ntrans')):
+        with pytest.raises(NotImplementedError):
+            RRTEncoder(mlp_dim=64, **kw)
