@@ -83,7 +83,7 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RRT_HIP_LIB") or LIB_PATH   # RRT_HIP_LIB: ablation builds (tools/)
     if not os.path.exists(p):
         raise RRTHipError(
             f"{p} is missing: the HIP extension is the only compute path. Build it with "

@@ -76,7 +76,7 @@ int check_desc(const rrt_encoder_desc* d, int64_t N) {
     if (d->crmsa_k <= 0 || d->crmsa_k > RRT_MAX_CRMSA_K) return unsupported("crmsa_k must be in [1,8]");
     if (d->crmsa_heads <= 0 || d->dim % d->crmsa_heads != 0) return unsupported("crmsa_heads must divide dim");
   }
-  if (N > (int64_t)1 << 24) return unsupported("bag larger than 2^24 tokens");
+  if (N > (int64_t)4000000) return unsupported("bag larger than 4e6 tokens");
   return RRT_OK;
 }
 
@@ -103,6 +103,10 @@ GridDev to_dev(const rrt_grid& g) {
   d.rs = g.regions_side;
   d.P = g.s * g.s;
   d.Np = g.H * g.H;
+  d.inv_H = 1.0f / (float)d.H;
+  d.inv_s = 1.0f / (float)d.s;
+  d.inv_rs = 1.0f / (float)d.rs;
+  d.inv_P = 1.0f / (float)d.P;
   return d;
 }
 

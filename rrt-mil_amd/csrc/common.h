@@ -16,20 +16,30 @@ struct GridDev {
   int rs;   // regions per side
   int P;    // tokens per region (s*s)
   int Np;   // H*H
+  float inv_H, inv_s, inv_rs, inv_P;   // reciprocals for the division-free index maps
 };
+
+// n / d for 0 <= n < 2^24 via a float reciprocal + one correction step (exact; ~6 VALU
+// instead of the ~40 of an integer division -- the index maps sit in GEMM epilogues)
+__device__ __forceinline__ int fdiv(int n, int d, float inv_d) {
+  int q = (int)((float)n * inv_d);
+  int r = n - q * d;
+  q += (r >= d) - (r < 0);
+  return q;
+}
 
 // padded-grid token index -> region-major slot (region_partition, rmsa.py:28-39)
 __device__ __forceinline__ int token_to_slot(int t, const GridDev& g) {
-  int i = t / g.H, j = t - i * g.H;
-  int ri = i / g.s, pi = i - ri * g.s;
-  int rj = j / g.s, pj = j - rj * g.s;
+  int i = fdiv(t, g.H, g.inv_H), j = t - i * g.H;
+  int ri = fdiv(i, g.s, g.inv_s), pi = i - ri * g.s;
+  int rj = fdiv(j, g.s, g.inv_s), pj = j - rj * g.s;
   return (ri * g.rs + rj) * g.P + pi * g.s + pj;
 }
 // region-major slot -> padded-grid token index (region_reverse, rmsa.py:41-54)
 __device__ __forceinline__ int slot_to_token(int slot, const GridDev& g) {
-  int reg = slot / g.P, p = slot - reg * g.P;
-  int ri = reg / g.rs, rj = reg - ri * g.rs;
-  int pi = p / g.s, pj = p - pi * g.s;
+  int reg = fdiv(slot, g.P, g.inv_P), p = slot - reg * g.P;
+  int ri = fdiv(reg, g.rs, g.inv_rs), rj = reg - ri * g.rs;
+  int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
   return (ri * g.s + pi) * g.H + rj * g.s + pj;
 }
 
@@ -50,12 +60,39 @@ __device__ __forceinline__ float wave_min(float v) {
 }
 
 // 16-byte global -> LDS DMA (global_load_lds_dwordx4): the LDS destination is the
-// wave-uniform `lds_wave_base` + lane*16; the global source is per lane.
-__device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base,
-                                   16, 0, 0);
+// wave-uniform byte address `lds_addr` (held in M0) + lane*16; the global source is per lane.
+// Issued through inline asm on purpose: with the builtin, hipcc drains vmcnt(0) before the
+// next ds_read (it cannot prove the DMA targets the *other* LDS buffer), which serialises
+// the prefetch with the MFMA phase.  The asm form is invisible to that bookkeeping, so the
+// kernels wait for it themselves: wait_vm0() before the barrier that publishes a tile.
+__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_addr /* wave-uniform */) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+// Same DMA with the address split as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit
+// byte offset): the per-K-tile advance is then one scalar add instead of per-lane 64-bit math.
+__device__ __forceinline__ void dma16s(const void* sbase /* wave-uniform */, unsigned voff,
+                                       unsigned lds_addr /* wave-uniform */) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %2"
+      :
+      : "v"(voff), "s"(lds_addr), "s"(sbase)
+      : "memory");
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// LDS byte address of a __shared__ pointer
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
 
 #define LN_EPS 1e-5f

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
     const float4 gm = *(const float4*)(gamma + col), bt = *(const float4*)(beta + col);
     const int ri = reg / g.rs, rj = reg - ri * g.rs;
     for (int p = rg; p < g.P; p += 8) {
-      int pi = p / g.s, pj = p - pi * g.s;
+      int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
       int t = (ri * g.s + pi) * g.H + rj * g.s + pj;
       if (t >= g.L) continue;                       // pad token: v = 0 contributes nothing
       const float mean = mean_rstd[2 * (size_t)t], rstd = mean_rstd[2 * (size_t)t + 1];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
   int reg = 0;
   if (CRMSA) {
     const int slot = token_to_slot(t, g);
-    reg = slot / g.P;
+    reg = fdiv(slot, g.P, g.inv_P);
     const float* lg = logits + (size_t)slot * k;
     float mx = -3.0e38f;
 #pragma unroll
@@ -313,5 +313,6 @@ hipError_t launch_layernorm(const float* x1, const float* x0, const float* gamma
                             const float* beta, float* y, int L, int dim, hipStream_t st) {
   GridDev g{};
   g.L = L;
+  g.H = g.s = g.rs = g.P = 1;
   return launch_dispatch<false>(x1, x0, nullptr, nullptr, nullptr, gamma, beta, y, L, dim, 0, g, st);
 }

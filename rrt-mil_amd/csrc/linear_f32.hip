@@ -4,169 +4,273 @@
 // in the un-partition epilogue, region_reverse + un-pad + the TransLayer residual
 // (modules/rmsa.py:41-54, :227-228; modules/rrt.py:125).
 //
-// MFMA-bound (exact fp32: v_mfma_f32_32x32x2_f32, 157 TFLOP/s chip peak).  Both
-// operands are K-contiguous ("NT"), so A and B tiles are staged identically:
-//   * global -> LDS by 16-byte DMA (global_load_lds_dwordx4), double-buffered, BK = 32;
+// MFMA-bound (exact fp32: v_mfma_f32_16x16x4_f32, 157 TFLOP/s chip peak, bitwise an
+// fmaf chain).  Both operands are K-contiguous ("NT"), so A and B tiles are staged
+// identically:
+//   * global -> LDS by 16-byte DMA (global_load_lds_dwordx4 issued from inline asm so the
+//     prefetch of K-tile t+1 really overlaps the MFMAs of tile t; SGPR base + per-lane
+//     offset addressing, offsets hoisted out of the K loop), double buffered, BK = 32;
 //   * the LDS image is [row][8 x 16-B slots]; slot p of a row holds logical k-slot
-//     p ^ ((row>>1)&7).  The XOR is applied to the per-lane *global source* address
-//     (the DMA destination is lane-linear) and again on the ds_read_b128 side, which
-//     makes every 16-lane read group hit 16 distinct 16-B bank slots (conflict-free);
-//   * a lane's float4 (4 consecutive k) feeds 4 MFMAs: lanes 0-31 carry k-slot 2*kk,
-//     lanes 32-63 k-slot 2*kk+1 -- the K-sum is order-free, so no transposes.
-// Each of the 4 waves owns a (TM*32) x (TN*32) sub-tile; block tile = 2x2 waves.
-// 1-D grid with an XCD-aware (bijective) remap so the blocks of one XCD walk the N
-// tiles of the same A row-panel (A panel + all of W stay in that XCD's 4 MiB L2).
+//     p ^ ((row>>1)&7).  The XOR is applied to the per-lane *global source* address (the
+//     DMA destination is lane-linear) and again on the ds_read_b128 side: each 16-lane
+//     read group then touches 16 distinct 16-B bank slots (SQ_LDS_BANK_CONFLICT = 0);
+//   * a lane's float4 (4 consecutive k) feeds 4 MFMAs; lane group g = lane>>4 carries
+//     k-slot 4*kk+g, so one b128 read per 16-row fragment covers 16 k.  The K-sum is
+//     order-free, so no transposes are needed.
+// Block = 4 waves side by side along N; each wave owns a (16*MT) x (16*NT) sub-tile, the
+// block tile is (16*MT) x (64*NT).
+//
+// PERSISTENT grid: at most 2 blocks per CU (512), each walking a static list of tiles.
+// Measured on MI355X: a non-persistent grid of 768 tiles (3 per CU) runs exactly as long
+// as one of 1020 (4 per CU) -- the hardware dispatcher refills freed slots greedily,
+// packing the last tiles two-per-CU -- and each tile pays ~15 us of un-overlapped
+// prologue (first DMA) + epilogue (store-issue bound).  Here the tile shape is chosen so
+// tiles divide evenly over the resident blocks (north star: 144 x 64 tiles, 1536 = 3 per
+// block for qkv, 512 = 1 per block for proj) and the first DMA of a block's next tile is
+// issued before the epilogue of the current one.
+// The XCD-aware schedule gives the 64 resident blocks of an XCD a contiguous run of
+// tiles per round (same A row-panels, all of W) so they share that XCD's 4 MiB L2.
 #include "internal.h"
 
 namespace {
 
 constexpr int BK = 32;
+constexpr int MAX_GRID = 512;   // 2 resident blocks per CU
 
-template <int TM, int TN>
-struct Tile {
-  static constexpr int BM = 64 * TM;   // 2 waves along M
-  static constexpr int BN = 64 * TN;   // 2 waves along N
-  static constexpr int LDS_BYTES = 2 * (BM + BN) * BK * 4;
-};
-
-// Stage one [ROWS x BK] tile: ROWS*8 16-B slots, 64 slots per wave-instruction.
-template <int ROWS>
-__device__ __forceinline__ void stage_tile(const float* __restrict__ src, int ld, int row0, int nrows,
-                                           int k0, float* lds, int wave, int lane) {
-  constexpr int NINSTR = ROWS * 8 / 64;   // wave-instructions for the tile
-#pragma unroll
-  for (int q = wave; q < NINSTR; q += 4) {
-    int S = q * 64 + lane;
-    int row = S >> 3, p = S & 7;
-    int c = p ^ ((row >> 1) & 7);
-    int gr = row0 + row;
-    gr = gr < nrows ? gr : nrows - 1;                 // tail rows: re-read the last row (never stored)
-    dma16(src + (size_t)gr * ld + k0 + c * 4, lds + q * 256);
-  }
-}
-
-template <int TM, int TN, bool UNPART>
+template <int MT, int NT, bool UNPART>
 __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict__ A,
                                                         const float* __restrict__ B,
                                                         float* __restrict__ C, int M, int N, int K,
-                                                        int tiles_n, int nblocks, LinearEpilogue ep) {
-  using T = Tile<TM, TN>;
+                                                        int tiles_n, int ntiles, LinearEpilogue ep) {
+  constexpr int BM = 16 * MT, BN = 64 * NT;
+  constexpr int STAGE = (BM + BN) * BK;   // floats per pipeline stage
+  constexpr int NA = BM / 8, NB = BN / 8; // DMA wave-instructions per A / B tile (8 rows each)
+  constexpr int QA = (NA + 3) / 4, QB = NB / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* lds = (float*)smem;   // [2][A: BM*BK | B: BN*BK]
-  constexpr int STAGE = (T::BM + T::BN) * BK;
+  float* lds = (float*)smem;              // [2][A: BM*BK | B: BN*BK]
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const unsigned lds_b = lds_addr_of(lds);
 
-  // XCD-aware bijective remap: hardware places block b on XCD b%8; give each XCD a
-  // contiguous run of logical tiles.
-  int b = blockIdx.x;
+  // static XCD-aware schedule.  Block b sits on XCD b%8 (observed placement; only speed
+  // depends on it).  Round i hands XCD x the contiguous tiles [i*G + x*G/8, +G/8).
+  const int G = gridDim.x;
+  int first;
   {
-    int q = nblocks >> 3, r = nblocks & 7, xcd = b & 7, idx = b >> 3;
-    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int b = blockIdx.x, q = G >> 3, r = G & 7, xcd = b & 7, idx = b >> 3;
+    first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = b / tiles_n, tn = b - tm * tiles_n;
-  const int m0 = tm * T::BM, n0 = tn * T::BN;
 
-  f32x16 acc[TM][TN];
+  // per-lane DMA source offsets (bytes from the tile's first row / k = 0), hoisted
+  unsigned aoff[QA], boff[QB];
+  auto tile_offsets = [&](int m0, int n0) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int qi = 0; qi < QA; ++qi) {
+      int S = (qi * 4 + wave) * 64 + lane;
+      int row = S >> 3, p = S & 7;
+      int gr = m0 + row;
+      gr = gr < M ? gr : M - 1;             // tail rows: re-read the last row (never stored)
+      aoff[qi] = (unsigned)(gr - m0) * (unsigned)K * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+    }
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int qi = 0; qi < QB; ++qi) {
+      int S = (qi * 4 + wave) * 64 + lane;
+      int row = S >> 3, p = S & 7;
+      int gr = n0 + row;
+      gr = gr < N ? gr : N - 1;
+      boff[qi] = (unsigned)(gr - n0) * (unsigned)K * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+    }
+  };
+  // (gr - m0) may be negative only when m0 >= M, which never happens for a valid tile
+  auto stage = [&](const float* abase, const float* bbase, unsigned buf) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int qi = 0; qi < QA; ++qi)
+      if (qi * 4 + wave < NA) dma16s(abase, aoff[qi], buf + (qi * 4 + wave) * 1024);
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) dma16s(bbase, boff[qi], buf + BM * BK * 4 + (qi * 4 + wave) * 1024);
+  };
 
   const int nk = K / BK;
-  stage_tile<T::BM>(A, K, m0, M, 0, lds, wave, lane);
-  stage_tile<T::BN>(B, K, n0, N, 0, lds + T::BM * BK, wave, lane);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    wait_vm0();
-    __syncthreads();   // tile kt landed for every wave; everyone is done reading the other buffer
-    float* cur = lds + (kt & 1) * STAGE;
-    if (kt + 1 < nk) {
-      float* nxt = lds + ((kt + 1) & 1) * STAGE;
-      stage_tile<T::BM>(A, K, m0, M, (kt + 1) * BK, nxt, wave, lane);
-      stage_tile<T::BN>(B, K, n0, N, (kt + 1) * BK, nxt + T::BM * BK, wave, lane);
-    }
-    const float* As = cur;
-    const float* Bs = cur + T::BM * BK;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float4 af[TM], bf[TN];
-      const int cslot = 2 * kk + (lane >> 5);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        int row = wr * (32 * TM) + i * 32 + (lane & 31);
-        af[i] = *(const float4*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        int row = wc * (32 * TN) + j * 32 + (lane & 31);
-        bf[j] = *(const float4*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
+  int it = 0;   // running K-tile counter: pipeline stage = it & 1
+  int tile = first;
+  int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  if (tile < ntiles) {
+    tile_offsets(tm * BM, tn * BN);
+    stage(A + (size_t)tm * BM * K, B + (size_t)tn * BN * K, lds_b);
   }
 
-  // epilogue.  32x32 C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  for (; tile < ntiles; tile += G) {
+    const int m0 = tm * BM, n0 = tn * BN;
+    const float* abase = A + (size_t)m0 * K;
+    const float* bbase = B + (size_t)n0 * K;
+    const int ntile = tile + G;
+    const int ntm = ntile / tiles_n, ntn = ntile - ntm * tiles_n;
+
+    f32x4 acc[MT][NT];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wc * (32 * TN) + j * 32 + (lane & 31);
-    const bool n_ok = n < N;
-    const float bias = (ep.bias && n_ok) ? ep.bias[n] : 0.f;
-    const float scale = (n < ep.q_cols) ? ep.q_scale : 1.0f;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      wait_vm0();
+      __syncthreads();   // K-tile `it` landed for every wave; everyone is done with the other buffer
+      const float* As = lds + (it & 1) * STAGE;
+      const float* Bs = As + BM * BK;
+      const unsigned nxt = lds_b + ((it + 1) & 1) * STAGE * 4;
+      if (kt + 1 < nk) {         // prefetch the next K tile; lands under the MFMAs below
+        stage(abase + (kt + 1) * BK, bbase + (kt + 1) * BK, nxt);
+      } else if (ntile < ntiles) {   // last K tile: prefetch the NEXT tile's first K tile
+        tile_offsets(ntm * BM, ntn * BN);
+        stage(A + (size_t)ntm * BM * K, B + (size_t)ntn * BN * K, nxt);
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && n_ok) {
-          float v = (acc[i][j][r] + bias) * scale;
-          if (UNPART) {
-            int t = slot_to_token(m, ep.g);
-            if (t < ep.g.L) C[(size_t)t * N + n] = ep.resid[(size_t)t * N + n] + v;
-          } else {
-            C[(size_t)m * N + n] = v;
-          }
+      for (int kk = 0; kk < 2; ++kk) {
+        float4 af[MT], bf[NT];
+        const int cslot = 4 * kk + lg;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          int row = wave * (16 * NT) + j * 16 + lr;
+          bf[j] = *(const float4*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
         }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          int row = i * 16 + lr;
+          af[i] = *(const float4*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
       }
     }
+
+    // epilogue.  16x16 C layout: col = lane&15, row = 4*(lane>>4) + reg
+    float bias[NT], scale[NT];
+    int ncol[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      ncol[j] = n0 + wave * (16 * NT) + j * 16 + lr;
+      bias[j] = (ep.bias && ncol[j] < N) ? ep.bias[ncol[j]] : 0.f;
+      scale[j] = (ncol[j] < ep.q_cols) ? ep.q_scale : 1.0f;
+    }
+    if (!UNPART) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + i * 16 + 4 * lg + r;
+          if (m < M) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              if (ncol[j] < N) C[(size_t)m * N + ncol[j]] = (acc[i][j][r] + bias[j]) * scale[j];
+          }
+        }
+    } else {
+      // rows are region-major slots: map each to its token once, batch the residual loads
+      // (clamped, branch-free) ahead of the stores
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        int tok[4];
+        float res[4][NT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + i * 16 + 4 * lg + r;
+          int t = slot_to_token(m < M ? m : M - 1, ep.g);
+          tok[r] = (m < M && t < ep.g.L) ? t : -1;
+          const int tl = tok[r] < 0 ? 0 : tok[r];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) res[r][j] = ep.resid[(size_t)tl * N + (ncol[j] < N ? ncol[j] : 0)];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (tok[r] >= 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              if (ncol[j] < N) C[(size_t)tok[r] * N + ncol[j]] = res[r][j] + (acc[i][j][r] + bias[j]) * scale[j];
+          }
+      }
+    }
+    tm = ntm;
+    tn = ntn;
   }
 }
 
-template <int TM, int TN, bool UNPART>
-hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, int K,
+template <int MT, int NT, bool UNPART>
+hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, int K, int grid_cap,
                       const LinearEpilogue& ep, hipStream_t st) {
-  using T = Tile<TM, TN>;
-  int tiles_m = (M + T::BM - 1) / T::BM, tiles_n = (N + T::BN - 1) / T::BN;
-  int nblocks = tiles_m * tiles_n;
-  auto kern = linear_kernel<TM, TN, UNPART>;
-  static bool attr_done = false;   // one-time opt-in for >64 KiB dynamic LDS is not needed (<= 64 KiB)
-  (void)attr_done;
-  kern<<<dim3(nblocks), dim3(256), T::LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, nblocks, ep);
+  constexpr int BM = 16 * MT, BN = 64 * NT;
+  constexpr int LDS_BYTES = 2 * (BM + BN) * BK * 4;
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU must fit the 160 KiB LDS");
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int ntiles = tiles_m * tiles_n;
+  const int grid = ntiles < grid_cap ? ntiles : grid_cap;
+  auto kern = linear_kernel<MT, NT, UNPART>;
+  if (LDS_BYTES > 64 * 1024) {
+    static bool done = false;   // benign race: idempotent attribute
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      done = true;
+    }
+  }
+  kern<<<dim3(grid), dim3(256), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
   return hipGetLastError();
+}
+
+struct Cfg { int mt, nt, cap; };
+
+// Tile shape + resident-block count that give the busiest CU the least MFMA work:
+//   grid = min(tiles, cap), rounds = ceil(tiles / grid), blocks per CU = ceil(grid / 256)
+//   cost = rounds * blocks_per_cu * MT * NT      [co-resident blocks share the CU's matrix pipes]
+// Candidates are ordered by preference; a later one must be strictly cheaper to win.
+Cfg choose(int M, int N) {
+  static const Cfg cands[] = {{9, 1, 512}, {8, 1, 512}, {9, 2, 512}, {8, 2, 512}, {9, 2, 256},
+                              {8, 2, 256}, {4, 1, 512}, {2, 1, 512}};
+  Cfg best = cands[0];
+  long best_cost = -1;
+  for (const Cfg& c : cands) {
+    long tiles = (long)((M + 16 * c.mt - 1) / (16 * c.mt)) * ((N + 64 * c.nt - 1) / (64 * c.nt));
+    long grid = tiles < c.cap ? tiles : c.cap;
+    long cost = ((tiles + grid - 1) / grid) * ((grid + 255) / 256) * c.mt * c.nt;
+    if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
+  }
+  return best;
 }
 
 }  // namespace
 
 hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
                          const LinearEpilogue& ep, hipStream_t st) {
-  const bool unpart = ep.resid != nullptr;
-  // small-M (CR-MSA representatives: M = 64*k): 64x64 tiles fill more CUs
-  const bool small = (long)((M + 127) / 128) * ((N + 127) / 128) < 128;
-  if (small) {
-    return unpart ? launch_cfg<1, 1, true>(A, B, C, M, N, K, ep, st)
-                  : launch_cfg<1, 1, false>(A, B, C, M, N, K, ep, st);
-  }
-  return unpart ? launch_cfg<2, 2, true>(A, B, C, M, N, K, ep, st)
-                : launch_cfg<2, 2, false>(A, B, C, M, N, K, ep, st);
+  const bool u = ep.resid != nullptr;
+  const Cfg c = choose(M, N);
+#define RRT_CASE(MT_, NT_)                                                                  \
+  if (c.mt == MT_ && c.nt == NT_)                                                           \
+    return u ? launch_cfg<MT_, NT_, true>(A, B, C, M, N, K, c.cap, ep, st)                  \
+             : launch_cfg<MT_, NT_, false>(A, B, C, M, N, K, c.cap, ep, st)
+  RRT_CASE(9, 1);
+  RRT_CASE(8, 1);
+  RRT_CASE(9, 2);
+  RRT_CASE(8, 2);
+  RRT_CASE(4, 1);
+  RRT_CASE(2, 1);
+#undef RRT_CASE
+  return hipErrorInvalidValue;
 }

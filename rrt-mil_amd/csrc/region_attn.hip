@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nw = blockDim.x >> 6;
+  const int nw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
   const int head = blockIdx.y, reg = blockIdx.z;
   const int ld = 3 * dim;
   const size_t rbase = (size_t)reg * P;
@@ -58,18 +58,19 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
   const int lg = lane >> 4;
 
   // ---- stage chunk 0 (all waves) -------------------------------------------------
-  auto stage = [&](int ch, float* buf) {
+  const unsigned lds_b = lds_addr_of(lds);
+  auto stage = [&](int ch, unsigned buf) {
     const int j0 = ch * KC;
     for (int q = wave; q < KC / 4; q += nw) {          // 64 slots = 4 rows per wave-instruction
       int S = q * 64 + lane;
       int row = S >> 4, p = S & 15;
       int j = j0 + row;
       j = j < P ? j : P - 1;                            // tail keys: re-read last row, masked below
-      dma16(kbase + (size_t)j * ld + ((p ^ (row & 15)) << 2), buf + q * 256);
-      dma16(vbase + (size_t)j * ld + (p << 2), buf + KC * HD + q * 256);
+      dma16(kbase + (size_t)j * ld + ((p ^ (row & 15)) << 2), buf + q * 1024);
+      dma16(vbase + (size_t)j * ld + (p << 2), buf + (KC * HD + q * 256) * 4);
     }
   };
-  stage(0, lds);
+  stage(0, lds_b);
 
   // ---- Q~ fragments (B operand): bq[c] = Q~[qi][16c + 4*lg .. +3] ---------------------
   float4 bq[4];
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
     wait_vm0();
     __syncthreads();
     float* cur = lds + (ch & 1) * STAGE;
-    if (ch + 1 < nch) stage(ch + 1, lds + ((ch + 1) & 1) * STAGE);
+    if (ch + 1 < nch) stage(ch + 1, lds_b + ((ch + 1) & 1) * STAGE * 4);
     if (!active) continue;
     const float* Ks = cur;
     const float* Vs = cur + KC * HD;
