@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = (float*)smem;   // [2][K: KC*64 | V: KC*64]
   constexpr int STAGE = 2 * KC * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -52,12 +53,12 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
   const float* kbase = qbase + dim;
   const float* vbase = qbase + 2 * dim;
 
-  const int i0 = (blockIdx.x * nw + wave) * 16;   // first query of this wave
+  const int ib0 = blockIdx.x * nw * 16;           // first query of this block
+  const int i0 = ib0 + wave * 16;                 // first query of this wave
   const bool active = i0 < P;
   const int qi = i0 + (lane & 15);
   const int lg = lane >> 4;
 
-  // ---- stage chunk 0 (all waves) -------------------------------------------------
   const unsigned lds_b = lds_addr_of(lds);
   auto stage = [&](int ch, unsigned buf) {
     const int j0 = ch * KC;
@@ -72,30 +73,56 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
   };
   stage(0, lds_b);
 
-  // ---- Q~ fragments (B operand): bq[c] = Q~[qi][16c + 4*lg .. +3] ---------------------
+  // ---- Q~ fragments (B operand): bq[c] = log2(e) * Q~[qi][16c + 4*lg .. +3] -------------
+  // Q~ = Q + EPEG stencil over the query axis (see header).  The Q rows the block needs
+  // ([ib0 - k/2, ib0 + 16*nw + k/2) clipped to the region) are staged once through LDS --
+  // in the second K/V buffer, which is idle until chunk 1 is prefetched -- with the same
+  // XOR swizzle as K, so the 15 taps are conflict-free ds_read_b128 instead of global loads.
   float4 bq[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) bq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active && qi < P) {
-    const int dof = 4 * lg;
+  {
+    const int half = epeg_k >> 1;
+    const int r_lo = max(ib0 - half, 0);
+    const int r_hi = min(ib0 + nw * 16 + half, P);          // exclusive
+    const int nrows = r_hi - r_lo;                           // <= 2*KC (checked at launch)
+    const unsigned qbuf = lds_b + STAGE * 4;
+    for (int q = wave; q * 4 < nrows; q += nw) {
+      int S = q * 64 + lane;
+      int row = S >> 4, p = S & 15;
+      int r = r_lo + row;
+      r = r < P ? r : P - 1;
+      dma16(qbase + (size_t)r * ld + ((p ^ (row & 15)) << 2), qbuf + q * 1024);
+    }
+    wait_vm0();
+    __syncthreads();
+    if (active && qi < P) {
+      const float* Qs = lds + STAGE;
+      const int lrow = qi - r_lo;                            // this lane's query row in the LDS image
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bq[c] = *(const float4*)(qbase + (size_t)qi * ld + 16 * c + dof);
-    if (epeg_k > 0) {
-      const int half = epeg_k >> 1;
-      const float* w = pe_w + head * epeg_k;
-      for (int t = 0; t < epeg_k; ++t) {
-        int r = qi + t - half;
-        if (r >= 0 && r < P) {
-          const float wt = w[t];
-          const float* qr = qbase + (size_t)r * ld + dof;
+      for (int c = 0; c < 4; ++c)
+        bq[c] = *(const float4*)(Qs + lrow * HD + (((4 * c + lg) ^ (lrow & 15)) << 2));
+      if (epeg_k > 0) {
+        const float* w = pe_w + head * epeg_k;
+        for (int t = 0; t < epeg_k; ++t) {
+          const int r = qi + t - half;
+          if (r >= 0 && r < P) {
+            const float wt = w[t];
+            const int rr = r - r_lo;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            float4 v = *(const float4*)(qr + 16 * c);
-            bq[c].x += wt * v.x; bq[c].y += wt * v.y; bq[c].z += wt * v.z; bq[c].w += wt * v.w;
+            for (int c = 0; c < 4; ++c) {
+              float4 v = *(const float4*)(Qs + rr * HD + (((4 * c + lg) ^ (rr & 15)) << 2));
+              bq[c].x += wt * v.x; bq[c].y += wt * v.y; bq[c].z += wt * v.z; bq[c].w += wt * v.w;
+            }
           }
         }
       }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {   // scores in log2 units: softmax via exp2
+        bq[c].x *= LOG2E; bq[c].y *= LOG2E; bq[c].z *= LOG2E; bq[c].w *= LOG2E;
+      }
     }
+    // the barrier at the top of chunk 0 orders these reads before chunk 1 overwrites the buffer
   }
 
   float m_run = NEG_BIG, l_run = 0.f;
@@ -114,52 +141,63 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
     const float* Vs = cur + KC * HD;
     const int j0 = ch * KC;
 
-    // S^T tiles: s[jt][r] = score(query lane&15, key j0 + 16*jt + 4*lg + r)
+    // S^T tiles: s[jt][r] = log2e * score(query lane&15, key j0 + 16*jt + 4*lg + r).
+    // jt innermost: consecutive MFMAs hit different accumulators (40-cycle dependent latency)
     f32x4 s[TC];
 #pragma unroll
-    for (int jt = 0; jt < TC; ++jt) {
-      s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int row = jt * 16 + (lane & 15);
+    for (int jt = 0; jt < TC; ++jt) s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float4 a = *(const float4*)(Ks + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
-        s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[c].x, s[jt], 0, 0, 0);
-        s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[c].y, s[jt], 0, 0, 0);
-        s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[c].z, s[jt], 0, 0, 0);
-        s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[c].w, s[jt], 0, 0, 0);
+    for (int c = 0; c < 4; ++c) {
+      float4 a[TC];
+#pragma unroll
+      for (int jt = 0; jt < TC; ++jt) {
+        const int row = jt * 16 + (lane & 15);
+        a[jt] = *(const float4*)(Ks + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
       }
+#pragma unroll
+      for (int jt = 0; jt < TC; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].x, bq[c].x, s[jt], 0, 0, 0);
+#pragma unroll
+      for (int jt = 0; jt < TC; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].y, bq[c].y, s[jt], 0, 0, 0);
+#pragma unroll
+      for (int jt = 0; jt < TC; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].z, bq[c].z, s[jt], 0, 0, 0);
+#pragma unroll
+      for (int jt = 0; jt < TC; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].w, bq[c].w, s[jt], 0, 0, 0);
     }
-    // mask tail keys, chunk max
+    if (j0 + KC > P) {   // tail chunk only: mask keys >= P
+#pragma unroll
+      for (int jt = 0; jt < TC; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j0 + jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;
+    }
     float cmax = NEG_BIG;
 #pragma unroll
     for (int jt = 0; jt < TC; ++jt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int j = j0 + jt * 16 + 4 * lg + r;
-        if (j >= P) s[jt][r] = NEG_BIG;
-        cmax = fmaxf(cmax, s[jt][r]);
-      }
+      for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[jt][r]);
     cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
     cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
     const float m_new = fmaxf(m_run, cmax);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
     for (int jt = 0; jt < TC; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float p = __expf(s[jt][r] - m_new);
+        float p = __builtin_amdgcn_exp2f(s[jt][r] - m_new);
         s[jt][r] = p;
         psum += p;
       }
     l_run = l_run * alpha + psum;   // per-lane partial (this lane's keys); lanes of a query share alpha
-    // rescale O: row r' of the O tile is query 4*lg + r', whose alpha lives in lane (4*lg + r')
+    if (ch > 0) {
+      // rescale O: row r' of the O tile is query 4*lg + r', whose alpha lives in lane (4*lg + r')
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float ar = __shfl(alpha, 4 * lg + r);
+      for (int r = 0; r < 4; ++r) {
+        float ar = __shfl(alpha, 4 * lg + r);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) oacc[c][r] *= ar;
+        for (int c = 0; c < 4; ++c) oacc[c][r] *= ar;
+      }
     }
     // O += P V   (A = P^T regs, B = V rows; float4 of V = 4 head-dim tiles)
 #pragma unroll
@@ -266,6 +304,12 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
   int nw = 4;
   if (ntiles < 4) nw = ntiles;
   else if (ntiles % 4 != 0 && ntiles % 3 == 0) nw = 3;
+  // the block's Q rows (16*nw queries + EPEG halo) are staged in one K/V stage buffer (2*KC rows)
+  {
+    const int kc = P <= 16 ? 16 : (P <= 32 ? 32 : 48);
+    while (nw > 1 && (P < 16 * nw + epeg_k - 1 ? P : 16 * nw + epeg_k - 1) > 2 * kc) --nw;
+    if ((P < 16 * nw + epeg_k - 1 ? P : 16 * nw + epeg_k - 1) > 2 * kc) return hipErrorInvalidValue;
+  }
   const int nqb = (ntiles + nw - 1) / nw;
   dim3 grid(nqb, heads, n_regions), block(nw * 64);
   if (P <= 16) {
