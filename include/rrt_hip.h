@@ -140,15 +140,20 @@ int rrt_region_attention_f32(const float *qkv, const float *pe_w, float *o,
                              int32_t n_regions, int32_t P, int32_t dim, int32_t heads,
                              int32_t epeg_k, void *stream);
 
-/* CR-MSA (rmsa.py:303-335): see DESIGN.md for the three kernels. */
+/* CR-MSA (rmsa.py:303-335), three kernels around the inner MSA (g8 = the 8x8 grid):
+ *  logits  : LayerNorm statistics mean_rstd [L,2] and logits [Np8, k] in region-major order
+ *            (zero rows for pad tokens);
+ *  combine : per region the combine softmax over its P tokens -> rep [k, R8, dim], and the
+ *            per-token dispatch weights wdisp [Np8, k] = minmax_p(logit) * softmax_k(logit);
+ *  dispatch: y = LN(x1 + sum_n wdisp[.,n] * rep2[n, region] (+ x0)), the final norm fused. */
 int rrt_crmsa_logits_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
                          float *mean_rstd, float *logits, int64_t L, int32_t dim, int32_t k,
                          const rrt_grid *g8, void *stream);
 int rrt_crmsa_combine_f32(const float *x1, const float *gamma, const float *beta,
-                          const float *mean_rstd, const float *logits, float *stats, float *rep,
+                          const float *mean_rstd, const float *logits, float *wdisp, float *rep,
                           int64_t L, int32_t dim, int32_t k, const rrt_grid *g8, void *stream);
-int rrt_crmsa_dispatch_ln_f32(const float *x1, const float *x0, const float *logits,
-                              const float *stats, const float *rep2, const float *gamma,
+int rrt_crmsa_dispatch_ln_f32(const float *x1, const float *x0, const float *wdisp,
+                              const float *rep2, const float *gamma,
                               const float *beta, float *y, int64_t L, int32_t dim, int32_t k,
                               const rrt_grid *g8, void *stream);
 /* final LayerNorm only (cr_msa=False path): y = LN(x1 (+ x0)) */

@@ -63,7 +63,7 @@ SIGNATURES = {
                                                          C.POINTER(Grid), C.c_void_p]),
     "rrt_crmsa_combine_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32,
                                                           C.POINTER(Grid), C.c_void_p]),
-    "rrt_crmsa_dispatch_ln_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32,
+    "rrt_crmsa_dispatch_ln_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32,
                                                               C.POINTER(Grid), C.c_void_p]),
     "rrt_layernorm_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p]),
 }

@@ -25,7 +25,7 @@ int64_t ceil_sqrt(int64_t n) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
-  float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *stats, *rep, *rep_qkv, *rep_o, *rep2;
+  float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2;
   size_t bytes;
 };
 
@@ -51,7 +51,7 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     const size_t k = d.crmsa_k;
     w.mean_rstd = take((size_t)N * 2);
     w.logits = take(Np8 * k);
-    w.stats = take(R8 * k * 3);
+    w.wdisp = take(Np8 * k);
     w.rep = take(k * R8 * D);
     w.rep_qkv = take(k * R8 * 3 * D);
     w.rep_o = take(k * R8 * D);
@@ -247,7 +247,7 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
   const GridDev gd8 = to_dev(g8);
   const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
   RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, ws.mean_rstd, ws.logits, D, k, gd8, st));
-  RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, ws.mean_rstd, ws.logits, ws.stats, ws.rep, D, k,
+  RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, ws.mean_rstd, ws.logits, ws.wdisp, ws.rep, D, k,
                                gd8, st));
   RRT_MARK(RRT_EV_CR_COMBINE);
   // inner MSA over the representatives: batch = k, sequence = R8 regions, no EPEG (rmsa.py:322)
@@ -258,7 +258,7 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
     RRT_TRY(launch_linear(ws.rep_o, cw.proj_w, ws.rep2, k * R8, D, D, ep, st));
   }
   RRT_MARK(RRT_EV_CR_INNER);
-  RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, ws.logits, ws.stats, ws.rep2, w->norm_w, w->norm_b, y, D, k,
+  RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, ws.wdisp, ws.rep2, w->norm_w, w->norm_b, y, D, k,
                                    gd8, st));
   RRT_MARK(RRT_EV_END);
 #undef RRT_TRY
@@ -326,20 +326,20 @@ int rrt_crmsa_logits_f32(const float* x1, const float* gamma, const float* beta,
 }
 
 int rrt_crmsa_combine_f32(const float* x1, const float* gamma, const float* beta, const float* mean_rstd,
-                          const float* logits, float* stats, float* rep, int64_t L, int32_t dim, int32_t k,
+                          const float* logits, float* wdisp, float* rep, int64_t L, int32_t dim, int32_t k,
                           const rrt_grid* g8, void* stream) {
-  if (!x1 || !gamma || !beta || !mean_rstd || !logits || !stats || !rep || !g8 || L != g8->L) return RRT_E_INVALID;
+  if (!x1 || !gamma || !beta || !mean_rstd || !logits || !wdisp || !rep || !g8 || L != g8->L) return RRT_E_INVALID;
   if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4) return unsupported("crmsa: k in [1,8], dim%4==0");
-  return (int)launch_crmsa_combine(x1, gamma, beta, mean_rstd, logits, stats, rep, dim, k, to_dev(*g8),
+  return (int)launch_crmsa_combine(x1, gamma, beta, mean_rstd, logits, wdisp, rep, dim, k, to_dev(*g8),
                                    (hipStream_t)stream);
 }
 
-int rrt_crmsa_dispatch_ln_f32(const float* x1, const float* x0, const float* logits, const float* stats,
+int rrt_crmsa_dispatch_ln_f32(const float* x1, const float* x0, const float* wdisp,
                               const float* rep2, const float* gamma, const float* beta, float* y, int64_t L,
                               int32_t dim, int32_t k, const rrt_grid* g8, void* stream) {
-  if (!x1 || !logits || !stats || !rep2 || !gamma || !beta || !y || !g8 || L != g8->L) return RRT_E_INVALID;
+  if (!x1 || !wdisp || !rep2 || !gamma || !beta || !y || !g8 || L != g8->L) return RRT_E_INVALID;
   if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4 || dim > 2048) return unsupported("crmsa: k in [1,8], dim%4==0, dim<=2048");
-  return (int)launch_crmsa_dispatch_ln(x1, x0, logits, stats, rep2, gamma, beta, y, dim, k, to_dev(*g8),
+  return (int)launch_crmsa_dispatch_ln(x1, x0, wdisp, rep2, gamma, beta, y, dim, k, to_dev(*g8),
                                        (hipStream_t)stream);
 }
 

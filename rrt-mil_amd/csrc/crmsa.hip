@@ -13,14 +13,19 @@
 //
 //   crmsa_logits_kernel    : 1 wave / token.  LN statistics + k dot products; writes
 //                            mean/rstd [L,2] and Lg in REGION-MAJOR order [Np8, k].
-//   crmsa_combine_kernel   : 1 block / (region, 128-column slab).  Region softmax/min/max
-//                            statistics from Lg, then the weighted row sum over P tokens.
-//   crmsa_dispatch_ln_kernel: 1 wave / token.  k-term axpy + residual (+shortcut) + LayerNorm.
+//   crmsa_combine_kernel   : 1 block / (region, 64-column slab).  Region softmax/min/max
+//                            statistics from Lg, the per-token dispatch weights M*Dk [Np8, k],
+//                            then the weighted row sum over the region's P tokens.
+//   crmsa_dispatch_ln_kernel: 2 tokens / wave.  k-term axpy + residual (+shortcut) + LayerNorm.
 #include "internal.h"
 
 namespace {
 
 constexpr int KMAX = RRT_MAX_CRMSA_K;
+
+// rows handled by one wave (independent loads in flight per wave = RW * NV float4)
+constexpr int RW = 4;
+constexpr int RW_DISPATCH = 2;
 
 template <int NV>
 __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restrict__ x1,
@@ -30,77 +35,115 @@ __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restri
                                                            float* __restrict__ mean_rstd,
                                                            float* __restrict__ logits, int dim, int k,
                                                            GridDev g) {
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= g.Np) return;
-  float* lg = logits + (size_t)token_to_slot(t, g) * k;
-  if (t >= g.L) {   // zero pad token -> zero logits
-    if (lane < k) lg[lane] = 0.f;
-    return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* phi_t = (float*)smem;                    // [k][dim]: phi transposed, one float4 read per (n, chunk)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int idx = threadIdx.x; idx < dim * k; idx += 256) {
+    int d = idx / k, n = idx - d * k;
+    phi_t[n * dim + d] = phi[idx];
   }
-  const float* src = x1 + (size_t)t * dim;
-  float4 r[NV];
-  float sum = 0.f;
+  __syncthreads();
+  const int t0 = (blockIdx.x * 4 + wave) * RW;
+  float4 r[RW][NV];
+  float sum[RW];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    int c = (v * 64 + lane) * 4;
-    r[v] = (c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    sum += (r[v].x + r[v].y) + (r[v].z + r[v].w);
-  }
-  const float inv_d = 1.0f / (float)dim;
-  const float mean = wave_sum(sum) * inv_d;
-  float sq = 0.f;
+  for (int i = 0; i < RW; ++i) {
+    const int t = t0 + i;
+    sum[i] = 0.f;
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    int c = (v * 64 + lane) * 4;
-    if (c < dim) {
-      float a = r[v].x - mean, b = r[v].y - mean, cc = r[v].z - mean, d = r[v].w - mean;
-      sq += (a * a + b * b) + (cc * cc + d * d);
+    for (int v = 0; v < NV; ++v) {
+      int c = (v * 64 + lane) * 4;
+      r[i][v] = (t < g.L && c < dim) ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sum[i] += (r[i][v].x + r[i][v].y) + (r[i][v].z + r[i][v].w);
     }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
-  float acc[KMAX];
+  const float inv_d = 1.0f / (float)dim;
+  float mean[RW], sq[RW], rstd[RW];
 #pragma unroll
-  for (int n = 0; n < KMAX; ++n) acc[n] = 0.f;
+  for (int i = 0; i < RW; ++i) mean[i] = wave_sum(sum[i]) * inv_d;
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    int c = (v * 64 + lane) * 4;
-    if (c < dim) {
-      float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
-      float u[4] = {(r[v].x - mean) * rstd * gm.x + bt.x, (r[v].y - mean) * rstd * gm.y + bt.y,
-                    (r[v].z - mean) * rstd * gm.z + bt.z, (r[v].w - mean) * rstd * gm.w + bt.w};
+  for (int i = 0; i < RW; ++i) {
+    sq[i] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float* ph = phi + (size_t)(c + e) * k;
-#pragma unroll
-        for (int n = 0; n < KMAX; ++n)
-          if (n < k) acc[n] += u[e] * ph[n];
+    for (int v = 0; v < NV; ++v) {
+      int c = (v * 64 + lane) * 4;
+      if (c < dim) {
+        float a = r[i][v].x - mean[i], b = r[i][v].y - mean[i], cc = r[i][v].z - mean[i], d = r[i][v].w - mean[i];
+        sq[i] += (a * a + b * b) + (cc * cc + d * d);
       }
     }
   }
 #pragma unroll
-  for (int n = 0; n < KMAX; ++n)
-    if (n < k) acc[n] = wave_sum(acc[n]);
-  if (lane == 0) {
-    mean_rstd[2 * (size_t)t] = mean;
-    mean_rstd[2 * (size_t)t + 1] = rstd;
+  for (int i = 0; i < RW; ++i) rstd[i] = 1.0f / sqrtf(wave_sum(sq[i]) * inv_d + LN_EPS);
+  // normalise in place: r <- LN(x1) rows
 #pragma unroll
-    for (int n = 0; n < KMAX; ++n)
-      if (n < k) lg[n] = acc[n];
+  for (int v = 0; v < NV; ++v) {
+    int c = (v * 64 + lane) * 4;
+    if (c < dim) {
+      const float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        r[i][v].x = (r[i][v].x - mean[i]) * rstd[i] * gm.x + bt.x;
+        r[i][v].y = (r[i][v].y - mean[i]) * rstd[i] * gm.y + bt.y;
+        r[i][v].z = (r[i][v].z - mean[i]) * rstd[i] * gm.z + bt.z;
+        r[i][v].w = (r[i][v].w - mean[i]) * rstd[i] * gm.w + bt.w;
+      }
+    }
+  }
+  for (int n = 0; n < k; ++n) {
+    float acc[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      int c = (v * 64 + lane) * 4;
+      if (c < dim) {
+        const float4 ph = *(const float4*)(phi_t + n * dim + c);
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+          acc[i] += (r[i][v].x * ph.x + r[i][v].y * ph.y) + (r[i][v].z * ph.z + r[i][v].w * ph.w);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const float a = wave_sum(acc[i]);
+      const int t = t0 + i;
+      if (lane == 0 && t < g.Np)      // pad tokens (t >= L) carry zero rows -> zero logits
+        logits[(size_t)token_to_slot(t, g) * k + n] = (t < g.L) ? a : 0.f;
+    }
+  }
+  if (lane < RW) {
+    const int t = t0 + lane;
+    if (t < g.L) {
+      float m = mean[0], rs = rstd[0];
+#pragma unroll
+      for (int i = 1; i < RW; ++i)
+        if (lane == i) { m = mean[i]; rs = rstd[i]; }
+      mean_rstd[2 * (size_t)t] = m;
+      mean_rstd[2 * (size_t)t + 1] = rs;
+    }
   }
 }
 
-// stats layout per (region, n): {max, min, 1/sum_p exp(Lg - max)}
+// One block per (region, 64-column slab): phase 1 builds the combine coefficients
+//   W[n][p] = softmax_p(Lg)[n,p] * rstd_p   (0 for pad tokens), c0[n] = sum_p W*mean_p, c1[n] = sum_p C
+// in LDS; phase 2 is the [k x P] . [P x 64] contraction over raw x1 rows with 16 row groups x 16
+// float4 column lanes, every thread's row loads independent (deep memory-level parallelism);
+// LN's affine is applied once at the end:  rep = gamma * (W.X1 - c0) + beta * c1.
 __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restrict__ x1,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
                                                             const float* __restrict__ mean_rstd,
                                                             const float* __restrict__ logits,
-                                                            float* __restrict__ stats,
+                                                            float* __restrict__ wdisp,
                                                             float* __restrict__ rep, int dim, int k,
                                                             GridDev g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Wc = (float*)smem;                         // [P][KMAX] combine coefficient x rstd
+  int* tok = (int*)(Wc + (size_t)g.P * KMAX);       // [P] token index or -1 (pad)
+  float4* part = (float4*)(tok + ((g.P + 3) & ~3)); // [16 row groups][KMAX][16 col lanes]
   __shared__ float s_stat[KMAX][3];
-  __shared__ float4 s_part[8][KMAX][32];   // [row-group][n][column lane]
+  __shared__ float s_c0[KMAX][4], s_c1[KMAX][4];    // per-wave partials of c0, c1
   const int reg = blockIdx.x, slab = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int R = g.rs * g.rs;
@@ -119,155 +162,212 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
     float se = 0.f;
     for (int p = lane; p < g.P; p += 64) se += __expf(lg[(size_t)p * k + n] - mx);
     se = wave_sum(se);
-    if (lane == 0) {
-      s_stat[n][0] = mx; s_stat[n][1] = mn; s_stat[n][2] = 1.0f / se;
-      if (slab == 0) {
-        float* st = stats + ((size_t)reg * k + n) * 3;
-        st[0] = mx; st[1] = mn; st[2] = 1.0f / se;
-      }
-    }
+    if (lane == 0) { s_stat[n][0] = mx; s_stat[n][1] = mn; s_stat[n][2] = 1.0f / se; }
   }
   __syncthreads();
-
-  // weighted row sum: thread = (row group rg of 8, column lane cl of 32) on a 128-column slab
-  const int cl = tid & 31, rg = tid >> 5;
-  const int col = slab * 128 + cl * 4;
+  // dispatch weights of this region's tokens (one slab does it):
+  //   wdisp[slot][n] = minmax_p(Lg)[n,p] * softmax_n(Lg)[n,p]      (rmsa.py:310-314, :324-325)
+  if (slab == 0) {
+    for (int p = tid; p < g.P; p += 256) {
+      float v[KMAX], e[KMAX];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int n = 0; n < KMAX; ++n)
+        if (n < k) { v[n] = lg[(size_t)p * k + n]; mx = fmaxf(mx, v[n]); }
+      float se = 0.f;
+#pragma unroll
+      for (int n = 0; n < KMAX; ++n)
+        if (n < k) { e[n] = __expf(v[n] - mx); se += e[n]; }
+      const float inv = 1.0f / se;
+#pragma unroll
+      for (int n = 0; n < KMAX; ++n)
+        if (n < k)
+          wdisp[((size_t)reg * g.P + p) * k + n] =
+              (v[n] - s_stat[n][1]) / (s_stat[n][0] - s_stat[n][1] + 1e-8f) * (e[n] * inv);
+    }
+  }
+  // phase 1: coefficients
+  {
+    const int ri = reg / g.rs, rj = reg - ri * g.rs;
+    float c0[KMAX], c1[KMAX];
+#pragma unroll
+    for (int n = 0; n < KMAX; ++n) c0[n] = c1[n] = 0.f;
+    for (int p = tid; p < g.P; p += 256) {
+      int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
+      int t = (ri * g.s + pi) * g.H + rj * g.s + pj;
+      const bool real = t < g.L;
+      tok[p] = real ? t : -1;
+      const float mean = real ? mean_rstd[2 * (size_t)t] : 0.f;
+      const float rstd = real ? mean_rstd[2 * (size_t)t + 1] : 0.f;
+#pragma unroll
+      for (int n = 0; n < KMAX; ++n)
+        if (n < k) {
+          float c = real ? __expf(lg[(size_t)p * k + n] - s_stat[n][0]) * s_stat[n][2] : 0.f;
+          Wc[p * KMAX + n] = c * rstd;
+          c0[n] += c * rstd * mean;
+          c1[n] += c;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < KMAX; ++n)
+      if (n < k) {
+        float a = wave_sum(c0[n]), b = wave_sum(c1[n]);
+        if (lane == 0) { s_c0[n][wave] = a; s_c1[n][wave] = b; }
+      }
+  }
+  __syncthreads();
+  // phase 2: contraction over the region's rows
+  const int cl = tid & 15, rg = tid >> 4;
+  const int col = slab * 64 + cl * 4;
   float4 acc[KMAX];
 #pragma unroll
   for (int n = 0; n < KMAX; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < dim) {
-    const float4 gm = *(const float4*)(gamma + col), bt = *(const float4*)(beta + col);
-    const int ri = reg / g.rs, rj = reg - ri * g.rs;
-    for (int p = rg; p < g.P; p += 8) {
-      int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
-      int t = (ri * g.s + pi) * g.H + rj * g.s + pj;
-      if (t >= g.L) continue;                       // pad token: v = 0 contributes nothing
-      const float mean = mean_rstd[2 * (size_t)t], rstd = mean_rstd[2 * (size_t)t + 1];
-      float4 xv = *(const float4*)(x1 + (size_t)t * dim + col);
-      float4 v;
-      v.x = (xv.x - mean) * rstd * gm.x + bt.x;
-      v.y = (xv.y - mean) * rstd * gm.y + bt.y;
-      v.z = (xv.z - mean) * rstd * gm.z + bt.z;
-      v.w = (xv.w - mean) * rstd * gm.w + bt.w;
+    for (int p0 = rg; p0 < g.P; p0 += 64) {        // 4 independent rows per trip
+      float4 xv[4];
+      int pp[4];
 #pragma unroll
-      for (int n = 0; n < KMAX; ++n)
-        if (n < k) {
-          float c = __expf(lg[(size_t)p * k + n] - s_stat[n][0]) * s_stat[n][2];
-          acc[n].x += c * v.x; acc[n].y += c * v.y; acc[n].z += c * v.z; acc[n].w += c * v.w;
+      for (int u = 0; u < 4; ++u) {
+        pp[u] = p0 + 16 * u;
+        const int t = pp[u] < g.P ? tok[pp[u]] : -1;
+        xv[u] = t >= 0 ? *(const float4*)(x1 + (size_t)t * dim + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < 0) pp[u] = -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (pp[u] >= 0) {
+#pragma unroll
+          for (int n = 0; n < KMAX; ++n)
+            if (n < k) {
+              const float w = Wc[pp[u] * KMAX + n];
+              acc[n].x += w * xv[u].x; acc[n].y += w * xv[u].y; acc[n].z += w * xv[u].z; acc[n].w += w * xv[u].w;
+            }
         }
     }
   }
 #pragma unroll
   for (int n = 0; n < KMAX; ++n)
-    if (n < k) s_part[rg][n][cl] = acc[n];
+    if (n < k) part[(rg * KMAX + n) * 16 + cl] = acc[n];
   __syncthreads();
-  // reduce the 8 row groups: thread (n, cl) for n < k
-  for (int idx = tid; idx < k * 32; idx += 256) {
-    int n = idx >> 5, c = idx & 31;
-    int cc = slab * 128 + c * 4;
+  // reduce the 16 row groups: thread (n, cl) for n < k
+  for (int idx = tid; idx < k * 16; idx += 256) {
+    int n = idx >> 4, c = idx & 15;
+    int cc = slab * 64 + c * 4;
     if (cc >= dim) continue;
-    float4 a = s_part[0][n][c];
+    float4 a = part[n * 16 + c];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) {
-      float4 b = s_part[q][n][c];
+    for (int q = 1; q < 16; ++q) {
+      float4 b = part[(q * KMAX + n) * 16 + c];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    *(float4*)(rep + ((size_t)n * R + reg) * dim + cc) = a;   // rep [k, R, D]
+    const float c0 = (s_c0[n][0] + s_c0[n][1]) + (s_c0[n][2] + s_c0[n][3]);
+    const float c1 = (s_c1[n][0] + s_c1[n][1]) + (s_c1[n][2] + s_c1[n][3]);
+    const float4 gm = *(const float4*)(gamma + cc), bt = *(const float4*)(beta + cc);
+    float4 out;
+    out.x = gm.x * (a.x - c0) + bt.x * c1;
+    out.y = gm.y * (a.y - c0) + bt.y * c1;
+    out.z = gm.z * (a.z - c0) + bt.z * c1;
+    out.w = gm.w * (a.w - c0) + bt.w * c1;
+    *(float4*)(rep + ((size_t)n * R + reg) * dim + cc) = out;   // rep [k, R, D]
   }
 }
 
 template <int NV, bool CRMSA>
 __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
-    const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ logits,
-    const float* __restrict__ stats, const float* __restrict__ rep2, const float* __restrict__ gamma,
+    const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ wdisp,
+    const float* __restrict__ rep2, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ y, int L, int dim, int k, GridDev g) {
+  constexpr int RW = RW_DISPATCH;
   const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= L) return;
-  float wgt[KMAX];
-  int reg = 0;
-  if (CRMSA) {
-    const int slot = token_to_slot(t, g);
-    reg = fdiv(slot, g.P, g.inv_P);
-    const float* lg = logits + (size_t)slot * k;
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int n = 0; n < KMAX; ++n)
-      if (n < k) { wgt[n] = lg[n]; mx = fmaxf(mx, wgt[n]); }
-    float se = 0.f;
-    float e[KMAX];
-#pragma unroll
-    for (int n = 0; n < KMAX; ++n)
-      if (n < k) { e[n] = __expf(wgt[n] - mx); se += e[n]; }
-    const float inv = 1.0f / se;
-#pragma unroll
-    for (int n = 0; n < KMAX; ++n)
-      if (n < k) {
-        const float* st = stats + ((size_t)reg * k + n) * 3;
-        float mm = (wgt[n] - st[1]) / (st[0] - st[1] + 1e-8f);
-        wgt[n] = mm * (e[n] * inv);
-      }
-  }
+  const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (t0 >= L) return;
   const int R = g.rs * g.rs;
-  float4 r[NV];
-  float sum = 0.f;
+  float4 r[RW][NV];
+  // issue every row load first (x1, shortcut), then the dispatch weights
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    int c = (v * 64 + lane) * 4;
-    if (c < dim) {
-      float4 a = *(const float4*)(x1 + (size_t)t * dim + c);
-      if (CRMSA) {
+  for (int i = 0; i < RW; ++i) {
+    const int t = t0 + i < L ? t0 + i : L - 1;
 #pragma unroll
-        for (int n = 0; n < KMAX; ++n)
-          if (n < k) {
-            float4 rp = *(const float4*)(rep2 + ((size_t)n * R + reg) * dim + c);
-            a.x += wgt[n] * rp.x; a.y += wgt[n] * rp.y; a.z += wgt[n] * rp.z; a.w += wgt[n] * rp.w;
-          }
-      }
-      if (x0) {
+    for (int v = 0; v < NV; ++v) {
+      int c = (v * 64 + lane) * 4;
+      r[i][v] = c < dim ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x0 && c < dim) {
         float4 s = *(const float4*)(x0 + (size_t)t * dim + c);
-        a.x += s.x; a.y += s.y; a.z += s.z; a.w += s.w;
+        r[i][v].x += s.x; r[i][v].y += s.y; r[i][v].z += s.z; r[i][v].w += s.w;
       }
-      r[v] = a;
-    } else {
-      r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    sum += (r[v].x + r[v].y) + (r[v].z + r[v].w);
+  }
+  if (CRMSA) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int t = t0 + i < L ? t0 + i : L - 1;
+      const int slot = token_to_slot(t, g);
+      const int reg = fdiv(slot, g.P, g.inv_P);
+      const float* wd = wdisp + (size_t)slot * k;
+#pragma unroll
+      for (int n = 0; n < KMAX; ++n)
+        if (n < k) {
+          const float w = wd[n];
+          const float* rp = rep2 + ((size_t)n * R + reg) * dim;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            int c = (v * 64 + lane) * 4;
+            if (c < dim) {
+              const float4 q = *(const float4*)(rp + c);
+              r[i][v].x += w * q.x; r[i][v].y += w * q.y; r[i][v].z += w * q.z; r[i][v].w += w * q.w;
+            }
+          }
+        }
+    }
   }
   const float inv_d = 1.0f / (float)dim;
-  const float mean = wave_sum(sum) * inv_d;
-  float sq = 0.f;
+  float mean[RW], rstd[RW];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    int c = (v * 64 + lane) * 4;
-    if (c < dim) {
-      float a = r[v].x - mean, b = r[v].y - mean, cc = r[v].z - mean, d = r[v].w - mean;
-      sq += (a * a + b * b) + (cc * cc + d * d);
-    }
+  for (int i = 0; i < RW; ++i) {
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) sum += (r[i][v].x + r[i][v].y) + (r[i][v].z + r[i][v].w);
+    mean[i] = wave_sum(sum) * inv_d;
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      int c = (v * 64 + lane) * 4;
+      if (c < dim) {
+        float a = r[i][v].x - mean[i], b = r[i][v].y - mean[i], cc = r[i][v].z - mean[i], d = r[i][v].w - mean[i];
+        sq += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    rstd[i] = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
+  }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
     if (c < dim) {
-      float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
-      float4 o;
-      o.x = (r[v].x - mean) * rstd * gm.x + bt.x;
-      o.y = (r[v].y - mean) * rstd * gm.y + bt.y;
-      o.z = (r[v].z - mean) * rstd * gm.z + bt.z;
-      o.w = (r[v].w - mean) * rstd * gm.w + bt.w;
-      *(float4*)(y + (size_t)t * dim + c) = o;
+      const float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
+#pragma unroll
+      for (int i = 0; i < RW; ++i)
+        if (t0 + i < L) {
+          float4 o;
+          o.x = (r[i][v].x - mean[i]) * rstd[i] * gm.x + bt.x;
+          o.y = (r[i][v].y - mean[i]) * rstd[i] * gm.y + bt.y;
+          o.z = (r[i][v].z - mean[i]) * rstd[i] * gm.z + bt.z;
+          o.w = (r[i][v].w - mean[i]) * rstd[i] * gm.w + bt.w;
+          *(float4*)(y + (size_t)(t0 + i) * dim + c) = o;
+        }
     }
   }
 }
 
 template <bool CRMSA>
-hipError_t launch_dispatch(const float* x1, const float* x0, const float* logits, const float* stats,
+hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
                            const float* rep2, const float* gamma, const float* beta, float* y, int L,
                            int dim, int k, const GridDev& g, hipStream_t st) {
-  dim3 grid((L + 3) / 4), block(256);
-#define RRT_DISPATCH(NV)                                                                          \
-  crmsa_dispatch_ln_kernel<NV, CRMSA><<<grid, block, 0, st>>>(x1, x0, logits, stats, rep2, gamma, \
+  dim3 grid((L + 4 * RW_DISPATCH - 1) / (4 * RW_DISPATCH)), block(256);
+#define RRT_DISPATCH(NV)                                                                    \
+  crmsa_dispatch_ln_kernel<NV, CRMSA><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, \
                                                               beta, y, L, dim, k, g)
   if (dim <= 256) RRT_DISPATCH(1);
   else if (dim <= 512) RRT_DISPATCH(2);
@@ -282,9 +382,10 @@ hipError_t launch_dispatch(const float* x1, const float* x0, const float* logits
 hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float* beta,
                                const float* phi, float* mean_rstd, float* logits, int dim, int k,
                                const GridDev& g8, hipStream_t st) {
-  dim3 grid((g8.Np + 3) / 4), block(256);
+  dim3 grid((g8.Np + 4 * RW - 1) / (4 * RW)), block(256);
+  const size_t lds = (size_t)dim * k * sizeof(float);
 #define RRT_LOGITS(NV) \
-  crmsa_logits_kernel<NV><<<grid, block, 0, st>>>(x1, gamma, beta, phi, mean_rstd, logits, dim, k, g8)
+  crmsa_logits_kernel<NV><<<grid, block, lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, dim, k, g8)
   if (dim <= 256) RRT_LOGITS(1);
   else if (dim <= 512) RRT_LOGITS(2);
   else if (dim <= 1024) RRT_LOGITS(4);
@@ -294,19 +395,24 @@ hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float*
 }
 
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
-                                const float* mean_rstd, const float* logits, float* stats,
+                                const float* mean_rstd, const float* logits, float* wdisp,
                                 float* rep, int dim, int k, const GridDev& g8, hipStream_t st) {
-  dim3 grid(g8.rs * g8.rs, (dim + 127) / 128), block(256);
-  crmsa_combine_kernel<<<grid, block, 0, st>>>(x1, gamma, beta, mean_rstd, logits, stats, rep, dim,
-                                               k, g8);
+  dim3 grid(g8.rs * g8.rs, (dim + 63) / 64), block(256);
+  const size_t lds = ((size_t)g8.P * KMAX + ((g8.P + 3) & ~3)) * 4 + (size_t)16 * KMAX * 16 * sizeof(float4);
+  if (lds > 150 * 1024) return hipErrorInvalidValue;   // P8 > ~3500 tokens per region (N > 220k)
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)crmsa_combine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  crmsa_combine_kernel<<<grid, block, lds, st>>>(x1, gamma, beta, mean_rstd, logits, wdisp, rep, dim,
+                                                 k, g8);
   return hipGetLastError();
 }
 
-hipError_t launch_crmsa_dispatch_ln(const float* x1, const float* x0, const float* logits,
-                                    const float* stats, const float* rep2, const float* gamma,
+hipError_t launch_crmsa_dispatch_ln(const float* x1, const float* x0, const float* wdisp,
+                                    const float* rep2, const float* gamma,
                                     const float* beta, float* y, int dim, int k, const GridDev& g8,
                                     hipStream_t st) {
-  return launch_dispatch<true>(x1, x0, logits, stats, rep2, gamma, beta, y, g8.L, dim, k, g8, st);
+  return launch_dispatch<true>(x1, x0, wdisp, rep2, gamma, beta, y, g8.L, dim, k, g8, st);
 }
 
 hipError_t launch_layernorm(const float* x1, const float* x0, const float* gamma,
@@ -314,5 +420,5 @@ hipError_t launch_layernorm(const float* x1, const float* x0, const float* gamma
   GridDev g{};
   g.L = L;
   g.H = g.s = g.rs = g.P = 1;
-  return launch_dispatch<false>(x1, x0, nullptr, nullptr, nullptr, gamma, beta, y, L, dim, 0, g, st);
+  return launch_dispatch<false>(x1, x0, nullptr, nullptr, gamma, beta, y, L, dim, 0, g, st);
 }

@@ -27,10 +27,10 @@ hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float*
                                const float* phi, float* mean_rstd, float* logits, int dim, int k,
                                const GridDev& g8, hipStream_t st);
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
-                                const float* mean_rstd, const float* logits, float* stats,
+                                const float* mean_rstd, const float* logits, float* wdisp,
                                 float* rep, int dim, int k, const GridDev& g8, hipStream_t st);
-hipError_t launch_crmsa_dispatch_ln(const float* x1, const float* x0, const float* logits,
-                                    const float* stats, const float* rep2, const float* gamma,
+hipError_t launch_crmsa_dispatch_ln(const float* x1, const float* x0, const float* wdisp,
+                                    const float* rep2, const float* gamma,
                                     const float* beta, float* y, int dim, int k, const GridDev& g8,
                                     hipStream_t st);
 hipError_t launch_layernorm(const float* x1, const float* x0, const float* gamma,

@@ -176,14 +176,14 @@ def test_crmsa_stages(L, D, k):
     d_phi, d_x0, d_rep2, d_gm3, d_bt3 = dev(phi), dev(x0), dev(rep2), dev(gm3), dev(bt3)
     mr = torch.full((L, 2), float("nan"), device=DEV)
     lg = torch.full((Np8, k), float("nan"), device=DEV)
-    st = torch.full((R8, k, 3), float("nan"), device=DEV)
+    wd = torch.full((Np8, k), float("nan"), device=DEV)
     rep = torch.full((k, R8, D), float("nan"), device=DEV)
     y = torch.full((L, D), float("nan"), device=DEV)
     _lib.check(lib.rrt_crmsa_logits_f32(p(d_x1), p(d_gm), p(d_bt), p(d_phi), p(mr), p(lg), L, D, k,
                                         C.byref(g8), stream()), "logits")
-    _lib.check(lib.rrt_crmsa_combine_f32(p(d_x1), p(d_gm), p(d_bt), p(mr), p(lg), p(st), p(rep), L, D, k,
+    _lib.check(lib.rrt_crmsa_combine_f32(p(d_x1), p(d_gm), p(d_bt), p(mr), p(lg), p(wd), p(rep), L, D, k,
                                          C.byref(g8), stream()), "combine")
-    _lib.check(lib.rrt_crmsa_dispatch_ln_f32(p(d_x1), p(d_x0), p(lg), p(st), p(d_rep2), p(d_gm3),
+    _lib.check(lib.rrt_crmsa_dispatch_ln_f32(p(d_x1), p(d_x0), p(wd), p(d_rep2), p(d_gm3),
                                              p(d_bt3), p(y), L, D, k, C.byref(g8), stream()), "dispatch")
     torch.cuda.synchronize()
     # float64 restatement of rmsa.py:303-335
@@ -201,6 +201,7 @@ def test_crmsa_stages(L, D, k):
     Dw /= Dw.sum(1, keepdims=True)
     mn, mx = Lg.min(-1, keepdims=True), Lg.max(-1, keepdims=True)
     Mm = (Lg - mn) / (mx - mn + 1e-8)
+    _cmp(wd.cpu().numpy().reshape(R8, P8, k).transpose(0, 2, 1), Mm * Dw, 2e-5, "crmsa dispatch weights")
     out = np.einsum("rnp,nrd->rpd", Mm * Dw, rep2.astype(np.float64))
     z = np.empty((Np8, D))
     z[perm] = out.reshape(-1, D)
