@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from rrt_mil_amd import RRTEncoder, _lib, synth  # noqa: E402
+from rrt_mil_amd import RRTEncoder, _lib, sharding, synth  # noqa: E402
 from rrt_mil_amd.geometry import region_grid  # noqa: E402
 
 N_TOKENS, DIM = 9000, 512
@@ -161,10 +161,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, device=dev)   # whole-job time = slowest rank
     assert torch.isfinite(out).all()
 
     # dominant kernel: R-MSA qkv linear  [Np, D] x [3D, D]^T  (fp32 MFMA)

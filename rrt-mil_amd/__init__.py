@@ -2,10 +2,10 @@
 
     from rrt_mil_amd import RRTEncoder      # drop-in for modules/rrt.py::RRTEncoder
 """
-from . import geometry, synth  # noqa: F401
+from . import geometry, sharding, synth  # noqa: F401
 from . import _lib  # noqa: F401
 from .encoder import (CrossRegionAttntion, InnerAttention, RegionAttntion, RRTEncoder,  # noqa: F401
                       TransLayer, initialize_weights)
 
 __all__ = ["RRTEncoder", "TransLayer", "RegionAttntion", "CrossRegionAttntion", "InnerAttention",
-           "initialize_weights", "geometry", "synth"]
+           "initialize_weights", "geometry", "sharding", "synth"]
