@@ -30,6 +30,9 @@
 // issued before the epilogue of the current one.
 // The XCD-aware schedule gives the 64 resident blocks of an XCD a contiguous run of
 // tiles per round (same A row-panels, all of W) so they share that XCD's 4 MiB L2.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "internal.h"
 
 namespace {
@@ -242,6 +245,10 @@ struct Cfg { int mt, nt, cap; };
 //   cost = rounds * blocks_per_cu * MT * NT      [co-resident blocks share the CU's matrix pipes]
 // Candidates are ordered by preference; a later one must be strictly cheaper to win.
 Cfg choose(int M, int N) {
+  if (const char* e = getenv("RRT_LINEAR_CFG")) {   // tuning hook: "mt,nt,cap"
+    Cfg c{};
+    if (sscanf(e, "%d,%d,%d", &c.mt, &c.nt, &c.cap) == 3) return c;
+  }
   static const Cfg cands[] = {{9, 1, 512}, {8, 1, 512}, {9, 2, 512}, {8, 2, 512}, {9, 2, 256},
                               {8, 2, 256}, {4, 1, 512}, {2, 1, 512}};
   Cfg best = cands[0];

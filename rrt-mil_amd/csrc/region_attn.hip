@@ -25,6 +25,9 @@
 //   * a lane's float4 of V covers 4 head-dim tiles (d = 4*(l&15)+c), so the O tile
 //     comes out as one float4 per row: coalesced 256-B row stores.
 // Head dim 64 only (dim/heads == 64); other head dims use region_attn_generic.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "internal.h"
 
 namespace {
@@ -81,7 +84,15 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
   float4 bq[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) bq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  {
+  if (epeg_k <= 0) {   // no EPEG (e.g. the CR-MSA inner attention): Q fragments straight from global
+    if (active && qi < P) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bq[c] = *(const float4*)(qbase + (size_t)qi * ld + 16 * c + 4 * lg);
+        bq[c].x *= LOG2E; bq[c].y *= LOG2E; bq[c].z *= LOG2E; bq[c].w *= LOG2E;
+      }
+    }
+  } else {
     const int half = epeg_k >> 1;
     const int r_lo = max(ib0 - half, 0);
     const int r_hi = min(ib0 + nw * 16 + half, P);          // exclusive
@@ -310,9 +321,18 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
     while (nw > 1 && (P < 16 * nw + epeg_k - 1 ? P : 16 * nw + epeg_k - 1) > 2 * kc) --nw;
     if ((P < 16 * nw + epeg_k - 1 ? P : 16 * nw + epeg_k - 1) > 2 * kc) return hipErrorInvalidValue;
   }
+  int tc_force = 0;
+  if (const char* e = getenv("RRT_ATTN_CFG")) {   // tuning hook: "tc,nw"
+    int a = 0, b = 0;
+    if (sscanf(e, "%d,%d", &a, &b) == 2) { tc_force = a; nw = b; }
+  }
   const int nqb = (ntiles + nw - 1) / nw;
   dim3 grid(nqb, heads, n_regions), block(nw * 64);
-  if (P <= 16) {
+  if (tc_force == 2) {
+    region_attn_kernel<2><<<grid, block, 2 * 2 * 32 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+  } else if (tc_force == 1) {
+    region_attn_kernel<1><<<grid, block, 2 * 2 * 16 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+  } else if (P <= 16) {
     region_attn_kernel<1><<<grid, block, 2 * 2 * 16 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
   } else if (P <= 32) {
     region_attn_kernel<2><<<grid, block, 2 * 2 * 32 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
