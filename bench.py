@@ -38,7 +38,9 @@ from rrt_mil_amd.geometry import region_grid  # noqa: E402
 N_TOKENS, DIM = 9000, 512
 CFG = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
-TRAFFIC_BYTES_PER_LAUNCH = None  # HBM bytes of the dominant kernel from rocprofv3 --pmc (profiles/)
+# HBM-side bytes of the dominant kernel per launch from rocprofv3 --pmc (separate FETCH_SIZE and
+# WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_c_traffic_pmc.txt
+TRAFFIC_BYTES_PER_LAUNCH = 154.7e6
 
 
 class HipEvents:
