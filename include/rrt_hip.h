@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 1
+#define RRT_ABI_VERSION 2
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -59,7 +59,7 @@ typedef struct rrt_encoder_desc {
   int32_t cr_msa;          /* 1: CR-MSA layer present */
   int32_t crmsa_k;
   int32_t crmsa_heads;
-  int32_t crmsa_mlp;       /* 1: phi is the 2-layer MLP (not yet on the HIP path) */
+  int32_t crmsa_mlp;       /* 1: phi is Linear(dim, dim/4) -> Tanh -> Linear(dim/4, k), rmsa.py:248-252 */
   int32_t all_shortcut;
 } rrt_encoder_desc;
 
@@ -76,7 +76,9 @@ typedef struct rrt_attn_weights {
 typedef struct rrt_encoder_weights {
   rrt_attn_weights rmsa[RRT_MAX_RMSA_LAYERS];   /* layers.{i}.* */
   rrt_attn_weights crmsa;                         /* cr_msa.norm.*, cr_msa.attn.attn.* */
-  const float *phi;                               /* cr_msa.attn.phi [dim, crmsa_k] */
+  const float *phi;                               /* cr_msa.attn.phi [dim, crmsa_k]          (crmsa_mlp = 0) */
+  const float *phi0_w, *phi2_w;                   /* cr_msa.attn.phi.0.weight [dim/4, dim],
+                                                     cr_msa.attn.phi.2.weight [crmsa_k, dim/4] (crmsa_mlp = 1) */
   const float *norm_w, *norm_b;                   /* final norm.* (modules/rrt.py:139,195) */
 } rrt_encoder_weights;
 
@@ -145,6 +147,8 @@ int rrt_region_attention_f32(const float *qkv, const float *pe_w, float *o,
  *            (zero rows for pad tokens);
  *  combine : per region the combine softmax over its P tokens -> rep [k, R8, dim], and the
  *            per-token dispatch weights wdisp [Np8, k] = minmax_p(logit) * softmax_k(logit);
+ *            with mean_rstd == NULL, x1 must already hold LN(x1) in region-major order
+ *            [Np8, dim] (the crmsa_mlp path) and gamma/beta are ignored;
  *  dispatch: y = LN(x1 + sum_n wdisp[.,n] * rep2[n, region] (+ x0)), the final norm fused. */
 int rrt_crmsa_logits_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
                          float *mean_rstd, float *logits, int64_t L, int32_t dim, int32_t k,
@@ -156,6 +160,9 @@ int rrt_crmsa_dispatch_ln_f32(const float *x1, const float *x0, const float *wdi
                               const float *rep2, const float *gamma,
                               const float *beta, float *y, int64_t L, int32_t dim, int32_t k,
                               const rrt_grid *g8, void *stream);
+/* crmsa_mlp logits (rmsa.py:248-252, :305): logits[r, n] = sum_j tanh(hid[r, j]) * w2[n, j] */
+int rrt_crmsa_mlp_logits_f32(const float *hid, const float *w2, float *logits, int64_t rows,
+                             int32_t hdim, int32_t k, void *stream);
 /* final LayerNorm only (cr_msa=False path): y = LN(x1 (+ x0)) */
 int rrt_layernorm_f32(const float *x1, const float *x0, const float *gamma, const float *beta,
                       float *y, int64_t L, int32_t dim, void *stream);

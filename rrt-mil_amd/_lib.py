@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _f32p = C.POINTER(C.c_float)
 
@@ -36,7 +36,8 @@ class AttnWeights(C.Structure):
 
 class EncoderWeights(C.Structure):
     _fields_ = [("rmsa", AttnWeights * RRT_MAX_RMSA_LAYERS), ("crmsa", AttnWeights),
-                ("phi", C.c_void_p), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p)]
+                ("phi", C.c_void_p), ("phi0_w", C.c_void_p), ("phi2_w", C.c_void_p),
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/rrt_hip.h declares
@@ -65,6 +66,7 @@ SIGNATURES = {
                                                           C.POINTER(Grid), C.c_void_p]),
     "rrt_crmsa_dispatch_ln_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32,
                                                               C.POINTER(Grid), C.c_void_p]),
+    "rrt_crmsa_mlp_logits_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "rrt_layernorm_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p]),
 }
 

@@ -25,7 +25,7 @@ int64_t ceil_sqrt(int64_t n) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
-  float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2;
+  float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *v8, *hid;
   size_t bytes;
 };
 
@@ -56,6 +56,10 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     w.rep_qkv = take(k * R8 * 3 * D);
     w.rep_o = take(k * R8 * D);
     w.rep2 = take(k * R8 * D);
+    if (d.crmsa_mlp) {
+      w.v8 = take(Np8 * D);
+      w.hid = take(Np8 * (D / 4));
+    }
   }
   w.bytes = off ? off : 256;
   return w;
@@ -72,7 +76,7 @@ int check_desc(const rrt_encoder_desc* d, int64_t N) {
     if (d->region_size <= 0 && d->region_num <= 0) return unsupported("region_num must be positive");
   }
   if (d->cr_msa) {
-    if (d->crmsa_mlp) return unsupported("crmsa_mlp=True (MLP phi) is not on the HIP path yet");
+    if (d->crmsa_mlp && d->dim % 128 != 0) return unsupported("crmsa_mlp needs dim % 128 == 0 (hidden dim/4 is a GEMM K)");
     if (d->crmsa_k <= 0 || d->crmsa_k > RRT_MAX_CRMSA_K) return unsupported("crmsa_k must be in [1,8]");
     if (d->crmsa_heads <= 0 || d->dim % d->crmsa_heads != 0) return unsupported("crmsa_heads must divide dim");
   }
@@ -243,12 +247,23 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
   }
   // ---- CR-MSA TransLayer (rmsa.py:290-337) + all_shortcut + final LayerNorm (rrt.py:190-195)
   const rrt_attn_weights& cw = w->crmsa;
-  if (!cw.norm_w || !cw.norm_b || !cw.qkv_w || !cw.proj_w || !cw.proj_b || !w->phi) return RRT_E_INVALID;
+  if (!cw.norm_w || !cw.norm_b || !cw.qkv_w || !cw.proj_w || !cw.proj_b) return RRT_E_INVALID;
+  if (desc->crmsa_mlp ? (!w->phi0_w || !w->phi2_w) : !w->phi) return RRT_E_INVALID;
   const GridDev gd8 = to_dev(g8);
   const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
-  RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, ws.mean_rstd, ws.logits, D, k, gd8, st));
-  RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, ws.mean_rstd, ws.logits, ws.wdisp, ws.rep, D, k,
-                               gd8, st));
+  if (desc->crmsa_mlp) {
+    // MLP phi (rmsa.py:248-252,305): v = LN(x1) materialised in region-major order, hidden = v W1^T on
+    // the matrix cores, logits = tanh(hidden) W2^T; the combine then runs on the normalised rows
+    RRT_TRY(launch_ln_partition(xin, cw.norm_w, cw.norm_b, ws.v8, D, gd8, st));
+    LinearEpilogue ep{};
+    RRT_TRY(launch_linear(ws.v8, w->phi0_w, ws.hid, gd8.Np, D / 4, D, ep, st));
+    RRT_TRY(launch_crmsa_mlp_logits(ws.hid, w->phi2_w, ws.logits, gd8.Np, D / 4, k, st));
+    RRT_TRY(launch_crmsa_combine(ws.v8, nullptr, nullptr, nullptr, ws.logits, ws.wdisp, ws.rep, D, k, gd8, st));
+  } else {
+    RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, ws.mean_rstd, ws.logits, D, k, gd8, st));
+    RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, ws.mean_rstd, ws.logits, ws.wdisp, ws.rep, D, k,
+                                 gd8, st));
+  }
   RRT_MARK(RRT_EV_CR_COMBINE);
   // inner MSA over the representatives: batch = k, sequence = R8 regions, no EPEG (rmsa.py:322)
   RRT_TRY(inner_attention(ws.rep, k, R8, cw, D, desc->crmsa_heads, 0, ws.rep_qkv, ws.rep_o, st));
@@ -328,7 +343,8 @@ int rrt_crmsa_logits_f32(const float* x1, const float* gamma, const float* beta,
 int rrt_crmsa_combine_f32(const float* x1, const float* gamma, const float* beta, const float* mean_rstd,
                           const float* logits, float* wdisp, float* rep, int64_t L, int32_t dim, int32_t k,
                           const rrt_grid* g8, void* stream) {
-  if (!x1 || !gamma || !beta || !mean_rstd || !logits || !wdisp || !rep || !g8 || L != g8->L) return RRT_E_INVALID;
+  if (!x1 || !logits || !wdisp || !rep || !g8 || L != g8->L) return RRT_E_INVALID;
+  if (mean_rstd && (!gamma || !beta)) return RRT_E_INVALID;
   if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4) return unsupported("crmsa: k in [1,8], dim%4==0");
   return (int)launch_crmsa_combine(x1, gamma, beta, mean_rstd, logits, wdisp, rep, dim, k, to_dev(*g8),
                                    (hipStream_t)stream);
@@ -341,6 +357,13 @@ int rrt_crmsa_dispatch_ln_f32(const float* x1, const float* x0, const float* wdi
   if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4 || dim > 2048) return unsupported("crmsa: k in [1,8], dim%4==0, dim<=2048");
   return (int)launch_crmsa_dispatch_ln(x1, x0, wdisp, rep2, gamma, beta, y, dim, k, to_dev(*g8),
                                        (hipStream_t)stream);
+}
+
+int rrt_crmsa_mlp_logits_f32(const float* hid, const float* w2, float* logits, int64_t rows, int32_t hdim,
+                             int32_t k, void* stream) {
+  if (!hid || !w2 || !logits || rows <= 0 || hdim <= 0) return RRT_E_INVALID;
+  if (k <= 0 || k > RRT_MAX_CRMSA_K) return unsupported("crmsa: k in [1,8]");
+  return (int)launch_crmsa_mlp_logits(hid, w2, logits, (int)rows, hdim, k, (hipStream_t)stream);
 }
 
 int rrt_layernorm_f32(const float* x1, const float* x0, const float* gamma, const float* beta, float* y,

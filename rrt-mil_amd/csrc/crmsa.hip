@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restri
 // in LDS; phase 2 is the [k x P] . [P x 64] contraction over raw x1 rows with 16 row groups x 16
 // float4 column lanes, every thread's row loads independent (deep memory-level parallelism);
 // LN's affine is applied once at the end:  rep = gamma * (W.X1 - c0) + beta * c1.
+template <bool VNORM>   // VNORM: x1 is already LN(x1) in region-major order [Np8, dim] (crmsa_mlp path)
 __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restrict__ x1,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -196,9 +197,9 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
       int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
       int t = (ri * g.s + pi) * g.H + rj * g.s + pj;
       const bool real = t < g.L;
-      tok[p] = real ? t : -1;
-      const float mean = real ? mean_rstd[2 * (size_t)t] : 0.f;
-      const float rstd = real ? mean_rstd[2 * (size_t)t + 1] : 0.f;
+      tok[p] = real ? (VNORM ? reg * g.P + p : t) : -1;
+      const float mean = (real && !VNORM) ? mean_rstd[2 * (size_t)t] : 0.f;
+      const float rstd = real ? (VNORM ? 1.0f : mean_rstd[2 * (size_t)t + 1]) : 0.f;
 #pragma unroll
       for (int n = 0; n < KMAX; ++n)
         if (n < k) {
@@ -262,7 +263,8 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
     }
     const float c0 = (s_c0[n][0] + s_c0[n][1]) + (s_c0[n][2] + s_c0[n][3]);
     const float c1 = (s_c1[n][0] + s_c1[n][1]) + (s_c1[n][2] + s_c1[n][3]);
-    const float4 gm = *(const float4*)(gamma + cc), bt = *(const float4*)(beta + cc);
+    float4 gm = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!VNORM) { gm = *(const float4*)(gamma + cc); bt = *(const float4*)(beta + cc); }
     float4 out;
     out.x = gm.x * (a.x - c0) + bt.x * c1;
     out.y = gm.y * (a.y - c0) + bt.y * c1;
@@ -361,6 +363,32 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
   }
 }
 
+// crmsa_mlp logits (rmsa.py:248-252, :305): logits[row][n] = sum_j tanh(hid[row][j]) * W2[n][j].
+// One wave per row of hid [rows, hdim]; zero pad rows give zero logits by themselves.
+__global__ __launch_bounds__(256) void crmsa_mlp_logits_kernel(const float* __restrict__ hid,
+                                                               const float* __restrict__ w2,
+                                                               float* __restrict__ logits, int rows,
+                                                               int hdim, int k) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float acc[KMAX];
+#pragma unroll
+  for (int n = 0; n < KMAX; ++n) acc[n] = 0.f;
+  for (int j = lane; j < hdim; j += 64) {
+    const float t = tanhf(hid[(size_t)row * hdim + j]);
+#pragma unroll
+    for (int n = 0; n < KMAX; ++n)
+      if (n < k) acc[n] += t * w2[(size_t)n * hdim + j];
+  }
+#pragma unroll
+  for (int n = 0; n < KMAX; ++n)
+    if (n < k) {
+      const float a = wave_sum(acc[n]);
+      if (lane == 0) logits[(size_t)row * k + n] = a;
+    }
+}
+
 template <bool CRMSA>
 hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
                            const float* rep2, const float* gamma, const float* beta, float* y, int L,
@@ -400,11 +428,17 @@ hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float
   dim3 grid(g8.rs * g8.rs, (dim + 63) / 64), block(256);
   const size_t lds = ((size_t)g8.P * KMAX + ((g8.P + 3) & ~3)) * 4 + (size_t)16 * KMAX * 16 * sizeof(float4);
   if (lds > 150 * 1024) return hipErrorInvalidValue;   // P8 > ~3500 tokens per region (N > 220k)
+  const bool vnorm = mean_rstd == nullptr;   // crmsa_mlp path: x1 holds LN(x1) rows in region-major order
+  auto kern = vnorm ? crmsa_combine_kernel<true> : crmsa_combine_kernel<false>;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)crmsa_combine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-  crmsa_combine_kernel<<<grid, block, lds, st>>>(x1, gamma, beta, mean_rstd, logits, wdisp, rep, dim,
-                                                 k, g8);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<grid, block, lds, st>>>(x1, gamma, beta, mean_rstd, logits, wdisp, rep, dim, k, g8);
+  return hipGetLastError();
+}
+
+hipError_t launch_crmsa_mlp_logits(const float* hid, const float* w2, float* logits, int rows, int hdim,
+                                   int k, hipStream_t st) {
+  crmsa_mlp_logits_kernel<<<dim3((rows + 3) / 4), 256, 0, st>>>(hid, w2, logits, rows, hdim, k);
   return hipGetLastError();
 }
 

@@ -29,6 +29,9 @@ hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float*
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
                                 const float* mean_rstd, const float* logits, float* wdisp,
                                 float* rep, int dim, int k, const GridDev& g8, hipStream_t st);
+// mean_rstd == nullptr: x1 is LN(x1) already, region-major [Np8, dim] (crmsa_mlp path)
+hipError_t launch_crmsa_mlp_logits(const float* hid, const float* w2, float* logits, int rows, int hdim,
+                                   int k, hipStream_t st);
 hipError_t launch_crmsa_dispatch_ln(const float* x1, const float* x0, const float* wdisp,
                                     const float* rep2, const float* gamma,
                                     const float* beta, float* y, int dim, int k, const GridDev& g8,

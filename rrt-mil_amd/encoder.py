@@ -188,7 +188,10 @@ class RRTEncoder(nn.Module):
             w.rmsa[i] = self._attn_weights(layer)
         if self._desc.cr_msa:
             w.crmsa = self._attn_weights(self.cr_msa)
-            if not self._desc.crmsa_mlp:
+            if self._desc.crmsa_mlp:
+                w.phi0_w = self._ptr(self.cr_msa.attn.phi[0].weight)
+                w.phi2_w = self._ptr(self.cr_msa.attn.phi[2].weight)
+            else:
                 w.phi = self._ptr(self.cr_msa.attn.phi)
         w.norm_w, w.norm_b = self._ptr(self.norm.weight), self._ptr(self.norm.bias)
         return w

@@ -48,7 +48,7 @@ def test_workspace_and_errors(lib):
     # u/o + qkv + x1 dominate: (9216*512*4 + 9000*512) floats
     assert n.value >= (9216 * 512 * 4 + 9000 * 512) * 4
     assert lib.rrt_encoder_workspace_size(C.byref(enc._desc), 0, C.byref(n)) == -1
-    bad = RRTEncoder(crmsa_mlp=True)
+    bad = RRTEncoder(mlp_dim=64, crmsa_mlp=True)
     rc = lib.rrt_encoder_workspace_size(C.byref(bad._desc), 100, C.byref(n))
     assert rc == -2 and b"crmsa_mlp" in lib.rrt_strerror(rc)
     with pytest.raises(NotImplementedError):

@@ -177,6 +177,16 @@ def main():
         x, y, _, _ = run_ref(700, cfg)
         save(f"G6_d64_n700_{name}", cfg=cfg_array(cfg), n=np.array(700), y=y)
 
+    # G7: MLP phi (crmsa_mlp=True) at dims the HIP path supports (dim % 128 == 0)
+    for D, N in ((512, 2000), (128, 700)):
+        cfg = dict(mlp_dim=D, epeg_k=15, crmsa_k=3, region_num=8, crmsa_mlp=True)
+        if D == 128:
+            cfg["n_heads"] = 2
+            cfg["crmsa_heads"] = 2
+        x, y, _, _ = run_ref(N, cfg)
+        ri = np.arange(0, N, 8)
+        save(f"G7_d{D}_n{N}_mlp", cfg=cfg_array(cfg), n=np.array(N), rows=ri, y_rows=y[ri], y_sums=checksums(y))
+
 
 if __name__ == "__main__":
     main()
