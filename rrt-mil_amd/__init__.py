@@ -4,8 +4,9 @@
 """
 from . import geometry, sharding, synth  # noqa: F401
 from . import _lib  # noqa: F401
+from .mil import Attention, AttentionGated, DAttention, RRTMIL  # noqa: F401
 from .encoder import (CrossRegionAttntion, InnerAttention, RegionAttntion, RRTEncoder,  # noqa: F401
                       TransLayer, initialize_weights)
 
-__all__ = ["RRTEncoder", "TransLayer", "RegionAttntion", "CrossRegionAttntion", "InnerAttention",
+__all__ = ["RRTEncoder", "RRTMIL", "DAttention", "TransLayer", "RegionAttntion", "CrossRegionAttntion", "InnerAttention",
            "initialize_weights", "geometry", "sharding", "synth"]

@@ -104,3 +104,22 @@ def bag(n_tokens: int, dim: int = 512, tag: str = "bag", nonneg: bool = False) -
     ResNet-50 features."""
     x = normal(f"{tag}/{n_tokens}x{dim}", (n_tokens, dim))
     return np.maximum(x, 0.0) if nonneg else x
+
+
+def mil_state(input_dim=1024, n_classes=2, da_bias=False, **enc_cfg):
+    """Closed-form parameters of RRTMIL (modules/rrt.py:204-225): encoder state under
+    ``online_encoder.`` plus patch_to_emb / pool_fn / predictor tensors."""
+    out = {"patch_to_emb.0.weight": uniform("mil/fc.w", (512, input_dim), -1, 1) / np.sqrt(input_dim),
+           "patch_to_emb.0.bias": uniform("mil/fc.b", (512,), -0.05, 0.05)}
+    out = {k: v.astype(np.float32) for k, v in out.items()}
+    for k, v in encoder_state(**enc_cfg).items():
+        out["online_encoder." + k] = v
+    D = enc_cfg.get("mlp_dim", 512)
+    out["pool_fn.attention.attention.0.weight"] = (uniform("mil/da0", (128, D), -1, 1) / np.sqrt(D)).astype(np.float32)
+    out["pool_fn.attention.attention.2.weight"] = (uniform("mil/da2", (1, 128), -1, 1) / np.sqrt(128) * 4).astype(np.float32)
+    if da_bias:
+        out["pool_fn.attention.attention.0.bias"] = uniform("mil/da0b", (128,), -0.05, 0.05)
+        out["pool_fn.attention.attention.2.bias"] = uniform("mil/da2b", (1,), -0.05, 0.05)
+    out["predictor.weight"] = (uniform("mil/pred.w", (n_classes, D), -1, 1) / np.sqrt(D)).astype(np.float32)
+    out["predictor.bias"] = uniform("mil/pred.b", (n_classes,), -0.05, 0.05)
+    return out

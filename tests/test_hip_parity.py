@@ -212,7 +212,7 @@ def test_crmsa_stages(L, D, k):
 
 
 # ------------------------------------------------------------------ whole path
-SMALL = [n for n in golden_names("G") if not n.startswith("G0") and "mlp" not in n]
+SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G7", "G8")) and "mlp" not in n]
 # crmsa_mlp needs dim % 128 == 0 on the HIP path (hidden = dim/4 is a GEMM K): D=64 golden is out of range
 
 
@@ -337,3 +337,24 @@ def test_full_size_properties():
     changed = np.nonzero(np.abs(ya - yb).max(-1) > 0)[0]
     ii, jj = changed // 96, changed % 96
     assert changed.size > 0 and set(ii // 12) == {3} and set(jj // 12) == {4}
+
+
+@pytest.mark.parametrize("name", ["G8_rrtmil_n1000", "G8_rrtmil_n9000"])
+def test_rrtmil_matches_reference(name):
+    """BASELINE configs[2] (C16-R50): fc 1024->512 + ReLU -> encoder (HIP) -> DAttention -> predictor,
+    against the real reference RRTMIL's logits and attention scores (modules/rrt.py:227-246)."""
+    from hip_util import DEV, dev
+    from rrt_mil_amd import RRTMIL
+    g = load_golden(name)
+    cfg, N = g["cfg"], int(g["n"])
+    st = synth.mil_state(input_dim=1024, n_classes=2, epeg_k=15, crmsa_k=1)
+    mil = RRTMIL(**cfg).eval()
+    mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    mil = mil.to(DEV)
+    feats = dev(synth.bag(N, 1024, tag="mil", nonneg=True)).unsqueeze(0)
+    logits, attn = mil(feats, return_attn=True)
+    torch.cuda.synchronize()
+    assert logits.shape == (1, 2) and attn.shape == (1, N)
+    _cmp(logits.cpu().numpy(), g["logits"], 1e-4, name + " logits")
+    _cmp(attn.cpu().numpy(), g["attn"], 1e-6, name + " attention")    # softmax weights ~1/N
+    assert torch.equal(mil(feats), logits)

@@ -187,6 +187,19 @@ def main():
         ri = np.arange(0, N, 8)
         save(f"G7_d{D}_n{N}_mlp", cfg=cfg_array(cfg), n=np.array(N), rows=ri, y_rows=y[ri], y_sums=checksums(y))
 
+    # G8: RRTMIL (BASELINE configs[2], C16-R50): fc 1024->512 + ReLU, epeg_k=15, crmsa_k=1, all_shortcut
+    from _ref import load_reference
+    _, RefMIL = load_reference()
+    for N in (1000, 9000):
+        cfg = dict(input_dim=1024, n_classes=2, epeg_k=15, crmsa_k=1, all_shortcut=True)
+        st = synth.mil_state(input_dim=1024, n_classes=2, epeg_k=15, crmsa_k=1)
+        mil = RefMIL(**cfg).eval()
+        mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+        feats = synth.bag(N, 1024, tag="mil", nonneg=True)        # pooled ResNet-50 features are >= 0
+        with torch.no_grad():
+            logits, attn = mil(torch.from_numpy(feats).unsqueeze(0), return_attn=True)
+        save(f"G8_rrtmil_n{N}", cfg=cfg_array(cfg), n=np.array(N), logits=logits.numpy(), attn=attn.numpy())
+
 
 if __name__ == "__main__":
     main()
