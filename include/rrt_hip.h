@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 2
+#define RRT_ABI_VERSION 3
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -32,6 +32,13 @@ enum {
   RRT_E_UNSUPPORTED = -2,   /* configuration outside the HIP path (see rrt_strerror) */
   RRT_E_WORKSPACE = -3      /* workspace too small */
 };
+
+/* Arithmetic of the nn.Linear layers (qkv / proj of R-MSA and CR-MSA, MLP phi).  F32 is exact
+ * fp32 on the fp32 matrix cores (the default; what the <=1e-3 fp32 parity claim is made on).
+ * BF16 / F16 round the two MFMA operands to bf16 / fp16 and accumulate in fp32 -- the
+ * autocast-class numerics of the reference's --amp path (main.py:101-102,439); LayerNorm,
+ * softmax, attention, residuals and all intermediates in HBM stay fp32 in every mode. */
+enum { RRT_COMPUTE_F32 = 0, RRT_COMPUTE_BF16 = 1, RRT_COMPUTE_F16 = 2 };
 
 /* Region-grid geometry: RegionAttntion.padding, modules/rmsa.py:175-202 (same body
  * CrossRegionAttntion.padding :261-288).  H = padded grid side, s = region side,
@@ -61,6 +68,7 @@ typedef struct rrt_encoder_desc {
   int32_t crmsa_heads;
   int32_t crmsa_mlp;       /* 1: phi is Linear(dim, dim/4) -> Tanh -> Linear(dim/4, k), rmsa.py:248-252 */
   int32_t all_shortcut;
+  int32_t compute;         /* RRT_COMPUTE_*: operand precision of the nn.Linear layers */
 } rrt_encoder_desc;
 
 /* InnerAttention parameters, modules/rmsa.py:57-89.  Row-major, fp32.
@@ -127,13 +135,14 @@ int rrt_ln_partition_f32(const float *x, const float *gamma, const float *beta, 
 /* nn.Linear (rmsa.py:100, :131): C[M,N] = A[M,K] . B[N,K]^T + bias[N] (bias may be NULL).
  * q_cols>0: columns [0,q_cols) are multiplied by q_scale after the bias (rmsa.py:103). */
 int rrt_linear_f32(const float *A, const float *B, const float *bias, float *C,
-                   int64_t M, int32_t N, int32_t K, int32_t q_cols, float q_scale, void *stream);
+                   int64_t M, int32_t N, int32_t K, int32_t q_cols, float q_scale,
+                   int32_t compute /* RRT_COMPUTE_* */, void *stream);
 
 /* nn.Linear + region_reverse + un-pad + residual (rmsa.py:131, :41-54, :227-228; rrt.py:125):
  * out[t] = resid[t] + (A . B^T + bias)[slot(t)] for the L real tokens. */
 int rrt_linear_unpartition_residual_f32(const float *A, const float *B, const float *bias,
                                         const float *resid, float *out, int32_t N, int32_t K,
-                                        const rrt_grid *g, void *stream);
+                                        const rrt_grid *g, int32_t compute, void *stream);
 
 /* Region attention core (rmsa.py:103-122): qkv [n_regions*P, 3*dim] (q already scaled),
  * EPEG taps pe_w [heads, epeg_k] (NULL/0 = none; pe bias is softmax-invariant and not needed)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _f32p = C.POINTER(C.c_float)
 
@@ -26,7 +26,7 @@ class EncoderDesc(C.Structure):
                 ("region_num", C.c_int32), ("region_size", C.c_int32), ("min_region_num", C.c_int32),
                 ("min_region_ratio", C.c_float), ("epeg", C.c_int32), ("epeg_k", C.c_int32),
                 ("cr_msa", C.c_int32), ("crmsa_k", C.c_int32), ("crmsa_heads", C.c_int32),
-                ("crmsa_mlp", C.c_int32), ("all_shortcut", C.c_int32)]
+                ("crmsa_mlp", C.c_int32), ("all_shortcut", C.c_int32), ("compute", C.c_int32)]
 
 
 class AttnWeights(C.Structure):
@@ -54,10 +54,10 @@ SIGNATURES = {
     "rrt_ln_partition_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_int32, C.POINTER(Grid), C.c_void_p]),
     "rrt_linear_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
-                                 C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+                                 C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "rrt_linear_unpartition_residual_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Grid),
-                                                      C.c_void_p]),
+                                                      C.c_int32, C.c_void_p]),
     "rrt_region_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "rrt_crmsa_logits_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32,
@@ -69,6 +69,8 @@ SIGNATURES = {
     "rrt_crmsa_mlp_logits_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "rrt_layernorm_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p]),
 }
+
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
 
 # stage-boundary event slots of rrt_encoder_forward_events_f32 (enum in include/rrt_hip.h)
 EV_START, EV_LN_PARTITION, EV_QKV, EV_ATTN, EV_PROJ, EV_CR_COMBINE, EV_CR_INNER, EV_END, EV_COUNT = range(9)

@@ -81,13 +81,15 @@ int check_desc(const rrt_encoder_desc* d, int64_t N) {
     if (d->crmsa_heads <= 0 || d->dim % d->crmsa_heads != 0) return unsupported("crmsa_heads must divide dim");
   }
   if (N > (int64_t)4000000) return unsupported("bag larger than 4e6 tokens");
+  if (d->compute < 0 || d->compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
   return RRT_OK;
 }
 
 hipError_t inner_attention(const float* u, int n_regions, int P, const rrt_attn_weights& w, int dim,
-                           int heads, int epeg_k, float* qkv, float* o, hipStream_t st) {
+                           int heads, int epeg_k, float* qkv, float* o, int prec, hipStream_t st) {
   const int M = n_regions * P;
   LinearEpilogue ep{};
+  ep.prec = prec;
   ep.bias = w.qkv_b;
   ep.q_cols = dim;
   ep.q_scale = 1.0f / sqrtf((float)(dim / heads));   // head_dim ** -0.5, modules/rmsa.py:65,103
@@ -221,6 +223,7 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
     if (li == 0) RRT_MARK(RRT_EV_LN_PARTITION);
     {
       LinearEpilogue ep{};
+      ep.prec = desc->compute;
       ep.bias = lw.qkv_b;
       ep.q_cols = D;
       ep.q_scale = 1.0f / sqrtf((float)(D / desc->n_heads));   // head_dim ** -0.5, rmsa.py:65,103
@@ -231,6 +234,7 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
                                     desc->n_heads, desc->epeg ? desc->epeg_k : 0, st));
     if (li == 0) RRT_MARK(RRT_EV_ATTN);
     LinearEpilogue ep{};
+    ep.prec = desc->compute;
     ep.bias = lw.proj_b;
     ep.resid = xin;
     ep.g = gd;
@@ -256,6 +260,7 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
     // the matrix cores, logits = tanh(hidden) W2^T; the combine then runs on the normalised rows
     RRT_TRY(launch_ln_partition(xin, cw.norm_w, cw.norm_b, ws.v8, D, gd8, st));
     LinearEpilogue ep{};
+    ep.prec = desc->compute;
     RRT_TRY(launch_linear(ws.v8, w->phi0_w, ws.hid, gd8.Np, D / 4, D, ep, st));
     RRT_TRY(launch_crmsa_mlp_logits(ws.hid, w->phi2_w, ws.logits, gd8.Np, D / 4, k, st));
     RRT_TRY(launch_crmsa_combine(ws.v8, nullptr, nullptr, nullptr, ws.logits, ws.wdisp, ws.rep, D, k, gd8, st));
@@ -266,9 +271,10 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
   }
   RRT_MARK(RRT_EV_CR_COMBINE);
   // inner MSA over the representatives: batch = k, sequence = R8 regions, no EPEG (rmsa.py:322)
-  RRT_TRY(inner_attention(ws.rep, k, R8, cw, D, desc->crmsa_heads, 0, ws.rep_qkv, ws.rep_o, st));
+  RRT_TRY(inner_attention(ws.rep, k, R8, cw, D, desc->crmsa_heads, 0, ws.rep_qkv, ws.rep_o, desc->compute, st));
   {
     LinearEpilogue ep{};
+    ep.prec = desc->compute;
     ep.bias = cw.proj_b;
     RRT_TRY(launch_linear(ws.rep_o, cw.proj_w, ws.rep2, k * R8, D, D, ep, st));
   }
@@ -302,10 +308,12 @@ int rrt_ln_partition_f32(const float* x, const float* gamma, const float* beta, 
 }
 
 int rrt_linear_f32(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N,
-                   int32_t K, int32_t q_cols, float q_scale, void* stream) {
+                   int32_t K, int32_t q_cols, float q_scale, int32_t compute, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return RRT_E_INVALID;
   if (K % 32) return unsupported("linear: K must be a multiple of 32");
+  if (compute < 0 || compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
   LinearEpilogue ep{};
+  ep.prec = compute;
   ep.bias = bias;
   ep.q_cols = q_cols;
   ep.q_scale = q_scale;
@@ -314,10 +322,12 @@ int rrt_linear_f32(const float* A, const float* B, const float* bias, float* C, 
 
 int rrt_linear_unpartition_residual_f32(const float* A, const float* B, const float* bias,
                                         const float* resid, float* out, int32_t N, int32_t K,
-                                        const rrt_grid* g, void* stream) {
+                                        const rrt_grid* g, int32_t compute, void* stream) {
   if (!A || !B || !resid || !out || !g || N <= 0 || K <= 0) return RRT_E_INVALID;
   if (K % 32) return unsupported("linear: K must be a multiple of 32");
+  if (compute < 0 || compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
   LinearEpilogue ep{};
+  ep.prec = compute;
   ep.bias = bias;
   ep.resid = resid;
   ep.g = to_dev(*g);

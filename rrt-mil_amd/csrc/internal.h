@@ -10,6 +10,7 @@ hipError_t launch_ln_partition(const float* x, const float* gamma, const float* 
                                int dim, const GridDev& g, hipStream_t st);
 
 struct LinearEpilogue {
+  int prec;              // MFMA operand precision: 0 f32 (exact), 1 bf16, 2 f16 (fp32 accumulate)
   const float* bias;     // [N] or null
   int q_cols;            // columns [0,q_cols) scaled by q_scale after bias
   float q_scale;

@@ -40,7 +40,42 @@ namespace {
 constexpr int BK = 32;
 constexpr int MAX_GRID = 512;   // 2 resident blocks per CU
 
-template <int MT, int NT, bool UNPART>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// operand precision of the MFMA (accumulation and everything around it stay fp32)
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
+
+template <int PREC>
+struct Frag8;
+template <>
+struct Frag8<PREC_BF16> {
+  using type = bf16x8;
+  static __device__ __forceinline__ type pack(float4 a, float4 b) {   // v_cvt_pk_bf16_f32 (RNE)
+    type r;
+    r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+    r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+    return r;
+  }
+  static __device__ __forceinline__ f32x4 mfma(type a, type b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Frag8<PREC_F16> {
+  using type = f16x8;
+  static __device__ __forceinline__ type pack(float4 a, float4 b) {   // v_cvt_pk_f16_f32 (RNE)
+    type r;
+    r[0] = (_Float16)a.x; r[1] = (_Float16)a.y; r[2] = (_Float16)a.z; r[3] = (_Float16)a.w;
+    r[4] = (_Float16)b.x; r[5] = (_Float16)b.y; r[6] = (_Float16)b.z; r[7] = (_Float16)b.w;
+    return r;
+  }
+  static __device__ __forceinline__ f32x4 mfma(type a, type b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <int MT, int NT, bool UNPART, int PREC>
 __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict__ A,
                                                         const float* __restrict__ B,
                                                         float* __restrict__ C, int M, int N, int K,
@@ -129,40 +164,64 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
         tile_offsets(ntm * BM, ntn * BN);
         stage(A + (size_t)ntm * BM * K, B + (size_t)ntn * BN * K, nxt);
       }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        float4 af[MT], bf[NT];
-        const int cslot = 4 * kk + lg;
+      if constexpr (PREC == PREC_F32) {
+  #pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          float4 af[MT], bf[NT];
+          const int cslot = 4 * kk + lg;
+  #pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            int row = wave * (16 * NT) + j * 16 + lr;
+            bf[j] = *(const float4*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+  #pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            int row = i * 16 + lr;
+            af[i] = *(const float4*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+  #pragma unroll
+          for (int i = 0; i < MT; ++i)
+  #pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+  #pragma unroll
+          for (int i = 0; i < MT; ++i)
+  #pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+  #pragma unroll
+          for (int i = 0; i < MT; ++i)
+  #pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+  #pragma unroll
+          for (int i = 0; i < MT; ++i)
+  #pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+      } else {
+        // autocast-class numerics: operands rounded to bf16 / fp16 (RNE) as they leave LDS, fp32
+        // accumulation.  One 16x16x32 MFMA covers the whole BK = 32 tile: lane group g holds
+        // k = 8g..8g+7 of its row (logical slots 2g, 2g+1).
+        using F = Frag8<PREC>;
+        typename F::type a8[MT], b8[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          int row = wave * (16 * NT) + j * 16 + lr;
-          bf[j] = *(const float4*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          const int row = wave * (16 * NT) + j * 16 + lr, f = (row >> 1) & 7;
+          b8[j] = F::pack(*(const float4*)(Bs + row * BK + (((2 * lg) ^ f) << 2)),
+                          *(const float4*)(Bs + row * BK + (((2 * lg + 1) ^ f) << 2)));
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          int row = i * 16 + lr;
-          af[i] = *(const float4*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          const int row = i * 16 + lr, f = (row >> 1) & 7;
+          a8[i] = F::pack(*(const float4*)(As + row * BK + (((2 * lg) ^ f) << 2)),
+                          *(const float4*)(As + row * BK + (((2 * lg + 1) ^ f) << 2)));
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(a8[i], b8[j], acc[i][j]);
       }
     }
 
@@ -217,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
   }
 }
 
-template <int MT, int NT, bool UNPART>
+template <int MT, int NT, bool UNPART, int PREC>
 hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, int K, int grid_cap,
                       const LinearEpilogue& ep, hipStream_t st) {
   constexpr int BM = 16 * MT, BN = 64 * NT;
@@ -226,7 +285,7 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
   const int grid = ntiles < grid_cap ? ntiles : grid_cap;
-  auto kern = linear_kernel<MT, NT, UNPART>;
+  auto kern = linear_kernel<MT, NT, UNPART, PREC>;
   if (LDS_BYTES > 64 * 1024) {
     static bool done = false;   // benign race: idempotent attribute
     if (!done) {
@@ -269,9 +328,16 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
   const bool u = ep.resid != nullptr;
   const Cfg c = choose(M, N);
 #define RRT_CASE(MT_, NT_)                                                                  \
-  if (c.mt == MT_ && c.nt == NT_)                                                           \
-    return u ? launch_cfg<MT_, NT_, true>(A, B, C, M, N, K, c.cap, ep, st)                  \
-             : launch_cfg<MT_, NT_, false>(A, B, C, M, N, K, c.cap, ep, st)
+  if (c.mt == MT_ && c.nt == NT_) {                                                         \
+    if (ep.prec == PREC_BF16)                                                               \
+      return u ? launch_cfg<MT_, NT_, true, PREC_BF16>(A, B, C, M, N, K, c.cap, ep, st)     \
+               : launch_cfg<MT_, NT_, false, PREC_BF16>(A, B, C, M, N, K, c.cap, ep, st);   \
+    if (ep.prec == PREC_F16)                                                                \
+      return u ? launch_cfg<MT_, NT_, true, PREC_F16>(A, B, C, M, N, K, c.cap, ep, st)      \
+               : launch_cfg<MT_, NT_, false, PREC_F16>(A, B, C, M, N, K, c.cap, ep, st);    \
+    return u ? launch_cfg<MT_, NT_, true, PREC_F32>(A, B, C, M, N, K, c.cap, ep, st)        \
+             : launch_cfg<MT_, NT_, false, PREC_F32>(A, B, C, M, N, K, c.cap, ep, st);      \
+  }
   RRT_CASE(9, 1);
   RRT_CASE(8, 1);
   RRT_CASE(9, 2);

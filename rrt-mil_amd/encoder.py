@@ -158,7 +158,11 @@ class RRTEncoder(nn.Module):
             dim=mlp_dim, n_heads=n_heads, n_rmsa_layers=n_layers - 1, region_num=region_num,
             region_size=region_size, min_region_num=min_region_num, min_region_ratio=min_region_ratio,
             epeg=int(bool(epeg)), epeg_k=epeg_k, cr_msa=int(bool(cr_msa)), crmsa_k=crmsa_k,
-            crmsa_heads=crmsa_heads, crmsa_mlp=int(bool(crmsa_mlp)), all_shortcut=int(bool(all_shortcut)))
+            crmsa_heads=crmsa_heads, crmsa_mlp=int(bool(crmsa_mlp)), all_shortcut=int(bool(all_shortcut)),
+            compute=_lib.COMPUTE_F32)
+        # None: exact fp32 unless the call runs under torch autocast (then bf16/fp16 MFMA operands in
+        # the Linear layers, like the reference's --amp path); or force torch.float32/bfloat16/float16
+        self.compute_dtype = None
         self._ws = None           # cached workspace tensor (grown on demand, per device)
         if need_init:
             self.apply(initialize_weights)
@@ -205,14 +209,23 @@ class RRTEncoder(nn.Module):
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
         return self._ws
 
+    def _compute_mode(self):
+        dt = self.compute_dtype
+        if dt is None and torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+        return {None: _lib.COMPUTE_F32, torch.float32: _lib.COMPUTE_F32, torch.bfloat16: _lib.COMPUTE_BF16,
+                torch.float16: _lib.COMPUTE_F16}[dt]
+
     def forward_bag(self, x2d, out=None):
         """One bag: x2d (N, D) fp32 device tensor -> (N, D).  Enqueued on the current stream."""
         lib = _lib.load()
         if not x2d.is_cuda:
             raise _lib.RRTHipError("rrt_mil_amd.RRTEncoder runs on MI355X only: move the bag to a "
                                    "'cuda' (HIP) device; there is no CPU fallback")
+        if x2d.dtype in (torch.bfloat16, torch.float16):
+            x2d = x2d.float()        # e.g. the bf16 output of an autocast patch_to_emb; HBM tensors stay fp32
         if x2d.dtype != torch.float32:
-            raise NotImplementedError("fp32 bags only (bf16/autocast configs are not built yet)")
+            raise NotImplementedError(f"unsupported bag dtype {x2d.dtype}")
         if self.training and self.drop_out > 0:
             raise NotImplementedError("training-mode forward (proj dropout p=%.2f + autograd) is not built; "
                                       "call .eval()" % self.drop_out)
@@ -227,6 +240,7 @@ class RRTEncoder(nn.Module):
         ws = self._workspace(n, x2d.device)
         w = self._weights()
         stream = torch.cuda.current_stream(x2d.device).cuda_stream
+        self._desc.compute = self._compute_mode()
         rc = lib.rrt_encoder_forward_f32(C.byref(self._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
                                          ws.data_ptr(), ws.numel(), stream)
         _lib.check(rc, "rrt_encoder_forward_f32")

@@ -35,12 +35,12 @@ def run_encoder(x, state, cfg):
     return y.cpu().numpy()
 
 
-def linear(A, B, bias=None, q_cols=0, q_scale=1.0):
+def linear(A, B, bias=None, q_cols=0, q_scale=1.0, compute=0):
     lib = _lib.load()
     M, K = A.shape
     N = B.shape[0]
     Cout = torch.full((M, N), float("nan"), device=DEV)
-    _lib.check(lib.rrt_linear_f32(p(A), p(B), p(bias), p(Cout), M, N, K, q_cols, q_scale, stream()), "linear")
+    _lib.check(lib.rrt_linear_f32(p(A), p(B), p(bias), p(Cout), M, N, K, q_cols, q_scale, compute, stream()), "linear")
     torch.cuda.synchronize()
     return Cout
 

@@ -102,7 +102,7 @@ def test_linear_unpartition_residual(L, rn):
     out = torch.full((L, D), float("nan"), device=DEV)
     dA, dB, db, dr = dev(A), dev(B), dev(bias), dev(res)
     _lib.check(lib.rrt_linear_unpartition_residual_f32(p(dA), p(dB), p(db), p(dr), p(out),
-                                                       D, D, C.byref(g), stream()), "unpart")
+                                                       D, D, C.byref(g), 0, stream()), "unpart")
     torch.cuda.synchronize()
     Z = A.astype(np.float64) @ B.astype(np.float64).T + bias
     z = np.empty((Np, D))
@@ -358,3 +358,78 @@ def test_rrtmil_matches_reference(name):
     _cmp(logits.cpu().numpy(), g["logits"], 1e-4, name + " logits")
     _cmp(attn.cpu().numpy(), g["attn"], 1e-6, name + " attention")    # softmax weights ~1/N
     assert torch.equal(mil(feats), logits)
+
+
+# ------------------------------------------------------------------ reduced-precision operand modes
+def _round_bf16(a):
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(9216, 1536, 512), (192, 512, 512), (1000, 130, 96), (9216, 512, 1024)])
+def test_linear_reduced_precision(M, N, K, compute):
+    """bf16 / fp16 MFMA operands, fp32 accumulate: must equal the float64 product of the ROUNDED
+    operands (the rounding itself is the only approximation the mode introduces)."""
+    from hip_util import dev, linear
+    A = synth.normal(f"linr/A{M}x{K}", (M, K))
+    B = synth.uniform(f"linr/B{N}x{K}", (N, K), -1, 1) / np.sqrt(K)
+    bias = synth.uniform(f"linr/b{N}", (N,), -0.5, 0.5)
+    dA, dB, db = dev(A), dev(B), dev(bias)
+    got = linear(dA, dB, db, 0, 1.0, compute).cpu().numpy()
+    rnd = _round_bf16 if compute == 1 else (lambda a: a.astype(np.float16).astype(np.float32))
+    ref = rnd(A).astype(np.float64) @ rnd(B).astype(np.float64).T + bias
+    # bf16: exact up to fp32 accumulation order.  fp16: mean error 3e-7, but rare elements whose
+    # weight operand is an fp16 SUBNORMAL (|w| < 6.1e-5) differ by up to ~1.4e-4 (hardware denormal
+    # handling vs numpy) -- far below the mode's own rounding error (~1e-3), hence the looser bound.
+    _cmp(got, ref, 2e-5 if compute == 1 else 5e-4, f"linear compute={compute}")
+    assert np.abs(got - ref).mean() < 2e-6
+    exact = A.astype(np.float64) @ B.astype(np.float64).T + bias
+    assert np.abs(got - exact).max() > 1e-4          # the mode really is reduced precision
+
+
+# BASELINE.json configs[2..4] ask for bf16: autocast-class numerics, compared with the fp32
+# reference at the bounds SURVEY.md §7.3 H2 proposes (2e-2 max, 2e-3 mean).
+TOL_AMP_MAX, TOL_AMP_MEAN = 2e-2, 2e-3
+
+
+@pytest.mark.parametrize("name,dt", [("G3_d512_n9000", torch.bfloat16), ("G3_d512_n9000", torch.float16),
+                                     ("G4_d512_n30000_rn16", torch.bfloat16),
+                                     ("G5_d512_n3000_k21_c5", torch.bfloat16),
+                                     ("G5_d512_n15000_k21_c5", torch.bfloat16),
+                                     ("G5_d512_n9000_c1_sc", torch.bfloat16)])
+def test_encoder_amp_modes(name, dt):
+    from hip_util import encoder_from_state, dev
+    g = load_golden(name)
+    x, st, cfg = synth_case(g)
+    enc = encoder_from_state(st, cfg)
+    xd = dev(x)
+    enc.compute_dtype = dt
+    y = enc(xd).cpu().numpy()
+    err = np.abs(y[g["rows"]] - g["y_rows"])
+    assert np.isfinite(y).all() and err.max() <= TOL_AMP_MAX and err.mean() <= TOL_AMP_MEAN, (err.max(), err.mean())
+    assert err.max() > 1e-5                      # not silently the exact path
+    # torch autocast selects the same mode
+    enc.compute_dtype = None
+    with torch.autocast("cuda", dtype=dt):
+        y2 = enc(xd).cpu().numpy()
+    y3 = enc(xd).cpu().numpy()                   # outside autocast: exact fp32 again
+    assert np.array_equal(y, y2)
+    _cmp(y3[g["rows"]], g["y_rows"], TOL_E2E, name + " fp32 after amp")
+
+
+def test_rrtmil_autocast_bf16():
+    """BASELINE configs[2]: C16-R50 RRTMIL under bf16 autocast (the reference's --amp path)."""
+    from hip_util import DEV, dev
+    from rrt_mil_amd import RRTMIL
+    g = load_golden("G8_rrtmil_n9000")
+    st = synth.mil_state(input_dim=1024, n_classes=2, epeg_k=15, crmsa_k=1)
+    mil = RRTMIL(**g["cfg"]).eval()
+    mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    mil = mil.to(DEV)
+    feats = dev(synth.bag(9000, 1024, tag="mil", nonneg=True)).unsqueeze(0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = mil(feats)
+    torch.cuda.synchronize()
+    assert np.abs(logits.float().cpu().numpy() - g["logits"]).max() <= 2e-2

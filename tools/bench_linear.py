@@ -32,7 +32,7 @@ def main():
             M, N, K = args[i:i + 3]
             A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev) / K ** 0.5
             bias = torch.randn(N, device=dev); C = torch.empty(M, N, device=dev)
-            f = lambda: _lib.check(lib.rrt_linear_f32(A.data_ptr(), B.data_ptr(), bias.data_ptr(), C.data_ptr(), M, N, K, 0, 1.0, st))
+            f = lambda: _lib.check(lib.rrt_linear_f32(A.data_ptr(), B.data_ptr(), bias.data_ptr(), C.data_ptr(), M, N, K, 0, 1.0, int(os.environ.get("RRT_COMPUTE", "0")), st))
             med, mn = timeit(f)
             print(f"linear M={M} N={N} K={K}: median {med:.1f} us  min {mn:.1f} us  {2.0 * M * N * K / med / 1e6:.1f} TFLOP/s (median)")
     elif kind == "attn":
