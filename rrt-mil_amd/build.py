@@ -13,8 +13,10 @@ LIB = os.path.join(HERE, "librrt_hip.so")
 STAMP = os.path.join(HERE, "csrc", ".build_stamp")
 SOURCES = ["ln_partition.hip", "linear_f32.hip", "region_attn.hip", "crmsa.hip", "api.hip"]
 HEADERS = ["common.h", "internal.h", os.path.join("..", "..", "include", "rrt_hip.h")]
+# -amdgpu-mfma-vgpr-form: gfx950 has one unified VGPR/AGPR file; keep MFMA accumulators in VGPRs so the
+# softmax / rescale VALU code does not shuttle them through v_accvgpr_read/write (hazard stalls).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
-         "-Wall", "-Wno-unused-function"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall", "-Wno-unused-function"]
 
 
 def _digest():

@@ -35,7 +35,10 @@ namespace {
 constexpr int HD = 64;
 constexpr float NEG_BIG = -3.0e38f;
 
-template <int TC>
+// DIRECT = true: no K/V ring in LDS -- every wave loads its K and V MFMA fragments straight from
+// global memory (L2-resident: the K/V of a (region, head) is P x 512 B and shared by P/16 waves).
+// The chunk loop then has no DMA, no barrier and no LDS traffic; LDS only stages the Q rows.
+template <int TC, bool DIRECT>
 __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restrict__ qkv,
                                                           const float* __restrict__ pe_w,
                                                           float* __restrict__ o, int P, int dim,
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
       dma16(vbase + (size_t)j * ld + (p << 2), buf + (KC * HD + q * 256) * 4);
     }
   };
-  stage(0, lds_b);
+  if (!DIRECT) stage(0, lds_b);
 
   // ---- Q~ fragments (B operand): bq[c] = log2(e) * Q~[qi][16c + 4*lg .. +3] -------------
   // Q~ = Q + EPEG stencil over the query axis (see header).  The Q rows the block needs
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
     const int r_lo = max(ib0 - half, 0);
     const int r_hi = min(ib0 + nw * 16 + half, P);          // exclusive
     const int nrows = r_hi - r_lo;                           // <= 2*KC (checked at launch)
-    const unsigned qbuf = lds_b + STAGE * 4;
+    const unsigned qbuf = DIRECT ? lds_b : lds_b + STAGE * 4;
     for (int q = wave; q * 4 < nrows; q += nw) {
       int S = q * 64 + lane;
       int row = S >> 4, p = S & 15;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
     wait_vm0();
     __syncthreads();
     if (active && qi < P) {
-      const float* Qs = lds + STAGE;
+      const float* Qs = DIRECT ? lds : lds + STAGE;
       const int lrow = qi - r_lo;                            // this lane's query row in the LDS image
 #pragma unroll
       for (int c = 0; c < 4; ++c)
@@ -142,14 +145,19 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
   for (int c = 0; c < 4; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nch = (P + KC - 1) / KC;
+  if (DIRECT && !active) return;
   for (int ch = 0; ch < nch; ++ch) {
-    wait_vm0();
-    __syncthreads();
-    float* cur = lds + (ch & 1) * STAGE;
-    if (ch + 1 < nch) stage(ch + 1, lds_b + ((ch + 1) & 1) * STAGE * 4);
-    if (!active) continue;
-    const float* Ks = cur;
-    const float* Vs = cur + KC * HD;
+    const float* Ks = nullptr;
+    const float* Vs = nullptr;
+    if (!DIRECT) {
+      wait_vm0();
+      __syncthreads();
+      float* cur = lds + (ch & 1) * STAGE;
+      if (ch + 1 < nch) stage(ch + 1, lds_b + ((ch + 1) & 1) * STAGE * 4);
+      if (!active) continue;
+      Ks = cur;
+      Vs = cur + KC * HD;
+    }
     const int j0 = ch * KC;
 
     // S^T tiles: s[jt][r] = log2e * score(query lane&15, key j0 + 16*jt + 4*lg + r).
@@ -163,7 +171,13 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
 #pragma unroll
       for (int jt = 0; jt < TC; ++jt) {
         const int row = jt * 16 + (lane & 15);
-        a[jt] = *(const float4*)(Ks + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+        if (DIRECT) {
+          int j = j0 + row;
+          j = j < P ? j : P - 1;                      // tail keys: masked below
+          a[jt] = *(const float4*)(kbase + (size_t)j * ld + 16 * c + 4 * lg);
+        } else {
+          a[jt] = *(const float4*)(Ks + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+        }
       }
 #pragma unroll
       for (int jt = 0; jt < TC; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].x, bq[c].x, s[jt], 0, 0, 0);
@@ -216,7 +230,14 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = jt * 16 + 4 * lg + r;
-        float4 v = *(const float4*)(Vs + row * HD + ((lane & 15) << 2));
+        float4 v;
+        if (DIRECT) {
+          int j = j0 + row;
+          j = j < P ? j : P - 1;                      // p = 0 for masked keys
+          v = *(const float4*)(vbase + (size_t)j * ld + ((lane & 15) << 2));
+        } else {
+          v = *(const float4*)(Vs + row * HD + ((lane & 15) << 2));
+        }
         const float p = s[jt][r];
         oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.x, oacc[0], 0, 0, 0);
         oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.y, oacc[1], 0, 0, 0);
@@ -328,16 +349,24 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
   }
   const int nqb = (ntiles + nw - 1) / nw;
   dim3 grid(nqb, heads, n_regions), block(nw * 64);
-  if (tc_force == 2) {
-    region_attn_kernel<2><<<grid, block, 2 * 2 * 32 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+  static const int direct = getenv("RRT_ATTN_DIRECT") ? atoi(getenv("RRT_ATTN_DIRECT")) : 0;
+  if (direct) {
+    // LDS = the Q staging rows only (16*nw queries + halo), 4-row granularity
+    const int qrows = epeg_k > 0 ? (((P < 16 * nw + epeg_k - 1 ? P : 16 * nw + epeg_k - 1) + 3) & ~3) : 4;
+    const size_t lds = (size_t)qrows * HD * 4;
+    if (direct == 1) region_attn_kernel<1, true><<<grid, block, lds, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+    else if (direct == 2) region_attn_kernel<2, true><<<grid, block, lds, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+    else region_attn_kernel<3, true><<<grid, block, lds, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+  } else if (tc_force == 2) {
+    region_attn_kernel<2, false><<<grid, block, 2 * 2 * 32 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
   } else if (tc_force == 1) {
-    region_attn_kernel<1><<<grid, block, 2 * 2 * 16 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+    region_attn_kernel<1, false><<<grid, block, 2 * 2 * 16 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
   } else if (P <= 16) {
-    region_attn_kernel<1><<<grid, block, 2 * 2 * 16 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+    region_attn_kernel<1, false><<<grid, block, 2 * 2 * 16 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
   } else if (P <= 32) {
-    region_attn_kernel<2><<<grid, block, 2 * 2 * 32 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+    region_attn_kernel<2, false><<<grid, block, 2 * 2 * 32 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
   } else {
-    region_attn_kernel<3><<<grid, block, 2 * 2 * 48 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+    region_attn_kernel<3, false><<<grid, block, 2 * 2 * 48 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
   }
   return hipGetLastError();
 }
