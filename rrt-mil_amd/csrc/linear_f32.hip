@@ -75,6 +75,56 @@ struct Frag8<PREC_F16> {
   }
 };
 
+
+// Epilogue shared by the kernels below.  The MFMAs are issued with the operand roles swapped
+// (A-slot = W fragment, B-slot = X fragment), i.e. each 16x16 accumulator holds the TRANSPOSED
+// output tile: reg r of lane (lr, lg) is C[m = m_tile + lr][n = n_tile + 4*lg + r].  A lane thus
+// owns 4 consecutive output columns of one row -> one 16-byte store per tile (9 per wave and output
+// tile instead of 36 dword stores; the dword form was store-issue bound), float4 bias / residual
+// loads, and one slot->token map per row.
+template <int MT, int NT, bool UNPART>
+__device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT][NT], float* __restrict__ C, int M, int N,
+                                           int m0, int n0, int wave, int lr, int lg,
+                                           const LinearEpilogue& ep) {
+  const bool vec = (N & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int nb = n0 + wave * (16 * NT) + j * 16 + 4 * lg;      // first of this lane's 4 columns
+    float bias[4], scale[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bias[r] = (ep.bias && nb + r < N) ? ep.bias[nb + r] : 0.f;
+      scale[r] = (nb + r < ep.q_cols) ? ep.q_scale : 1.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + i * 16 + lr;
+      if (m >= M) continue;
+      size_t row = (size_t)m;
+      if (UNPART) {
+        const int t = slot_to_token(m, ep.g);
+        if (t >= ep.g.L) continue;               // pad slot: nothing to write
+        row = (size_t)t;
+      }
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (acc[i][j][r] + bias[r]) * scale[r];
+      float* dst = C + row * N + nb;
+      if (vec && nb + 3 < N) {
+        if (UNPART) {
+          const float4 q = *(const float4*)(ep.resid + row * N + nb);
+          v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+        }
+        *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nb + r < N) dst[r] = v[r] + (UNPART ? ep.resid[row * N + nb + r] : 0.f);
+      }
+    }
+  }
+}
+
 template <int MT, int NT, bool UNPART, int PREC>
 __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict__ A,
                                                         const float* __restrict__ B,
@@ -183,22 +233,22 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
           for (int i = 0; i < MT; ++i)
   #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].x, af[i].x, acc[i][j], 0, 0, 0);
   #pragma unroll
           for (int i = 0; i < MT; ++i)
   #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].y, af[i].y, acc[i][j], 0, 0, 0);
   #pragma unroll
           for (int i = 0; i < MT; ++i)
   #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].z, af[i].z, acc[i][j], 0, 0, 0);
   #pragma unroll
           for (int i = 0; i < MT; ++i)
   #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].w, af[i].w, acc[i][j], 0, 0, 0);
         }
       } else {
         // autocast-class numerics: operands rounded to bf16 / fp16 (RNE) as they leave LDS, fp32
@@ -221,58 +271,169 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(a8[i], b8[j], acc[i][j]);
+          for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(b8[j], a8[i], acc[i][j]);
       }
     }
 
-    // epilogue.  16x16 C layout: col = lane&15, row = 4*(lane>>4) + reg
-    float bias[NT], scale[NT];
-    int ncol[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      ncol[j] = n0 + wave * (16 * NT) + j * 16 + lr;
-      bias[j] = (ep.bias && ncol[j] < N) ? ep.bias[ncol[j]] : 0.f;
-      scale[j] = (ncol[j] < ep.q_cols) ? ep.q_scale : 1.0f;
-    }
-    if (!UNPART) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + i * 16 + 4 * lg + r;
-          if (m < M) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              if (ncol[j] < N) C[(size_t)m * N + ncol[j]] = (acc[i][j][r] + bias[j]) * scale[j];
-          }
-        }
-    } else {
-      // rows are region-major slots: map each to its token once, batch the residual loads
-      // (clamped, branch-free) ahead of the stores
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        int tok[4];
-        float res[4][NT];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + i * 16 + 4 * lg + r;
-          int t = slot_to_token(m < M ? m : M - 1, ep.g);
-          tok[r] = (m < M && t < ep.g.L) ? t : -1;
-          const int tl = tok[r] < 0 ? 0 : tok[r];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) res[r][j] = ep.resid[(size_t)tl * N + (ncol[j] < N ? ncol[j] : 0)];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (tok[r] >= 0) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              if (ncol[j] < N) C[(size_t)tok[r] * N + ncol[j]] = res[r][j] + (acc[i][j][r] + bias[j]) * scale[j];
-          }
-      }
-    }
+    store_tile<MT, NT, UNPART>(acc, C, M, N, m0, n0, wave, lr, lg, ep);
     tm = ntm;
     tn = ntn;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Warp-specialised variant (large tiles): waves 0-3 compute, waves 4-5 load.
+// Why: in linear_kernel every wave both issues LDS-DMA and stores its epilogue, and the only
+// vector-memory counter (vmcnt) covers loads AND stores -- the first `s_waitcnt vmcnt(0)` of a
+// block's next tile therefore waits for the previous tile's 36 epilogue stores to reach L2
+// (measured: ~10 us per tile that two co-resident blocks hit in lockstep).  Here the loader waves
+// own every DMA and every vmcnt wait; the compute waves never wait on vector memory, so their
+// stores drain underneath the next tile's MFMAs.  One s_barrier per K tile, shared by all 6 waves.
+template <int MT, int NT, bool UNPART, int PREC>
+__global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restrict__ A,
+                                                           const float* __restrict__ B,
+                                                           float* __restrict__ C, int M, int N, int K,
+                                                           int tiles_n, int ntiles, LinearEpilogue ep) {
+  constexpr int BM = 16 * MT, BN = 64 * NT;
+  constexpr int STAGE = (BM + BN) * BK;
+  constexpr int NA = BM / 8, NB = BN / 8;                // DMA wave-instructions per A / B tile
+  constexpr int LA = (NA + 1) / 2, LB = NB / 2;          // per loader wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lds = (float*)smem;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lds_b = lds_addr_of(lds);
+
+  const int G = gridDim.x;
+  int first;
+  {
+    const int b = blockIdx.x, q = G >> 3, r = G & 7, xcd = b & 7, idx = b >> 3;
+    first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  if (first >= ntiles) return;
+  const int nk = K / BK;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = wave - 4;
+    unsigned aoff[LA], boff[LB];
+    auto tile_offsets = [&](int m0, int n0) {
+#pragma unroll
+      for (int qi = 0; qi < LA; ++qi) {
+        int S = (qi * 2 + lw) * 64 + lane;
+        int row = S >> 3, p = S & 7;
+        int gr = m0 + row;
+        gr = gr < M ? gr : M - 1;
+        aoff[qi] = (unsigned)(gr - m0) * (unsigned)K * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+      }
+#pragma unroll
+      for (int qi = 0; qi < LB; ++qi) {
+        int S = (qi * 2 + lw) * 64 + lane;
+        int row = S >> 3, p = S & 7;
+        int gr = n0 + row;
+        gr = gr < N ? gr : N - 1;
+        boff[qi] = (unsigned)(gr - n0) * (unsigned)K * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+      }
+    };
+    auto stage = [&](const float* abase, const float* bbase, unsigned buf) {
+#pragma unroll
+      for (int qi = 0; qi < LA; ++qi)
+        if (qi * 2 + lw < NA) dma16s(abase, aoff[qi], buf + (qi * 2 + lw) * 1024);
+#pragma unroll
+      for (int qi = 0; qi < LB; ++qi) dma16s(bbase, boff[qi], buf + BM * BK * 4 + (qi * 2 + lw) * 1024);
+    };
+    int tile = first;
+    int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    tile_offsets(tm * BM, tn * BN);
+    stage(A + (size_t)tm * BM * K, B + (size_t)tn * BN * K, lds_b);
+    int it = 0;
+    for (; tile < ntiles; tile += G) {
+      const int ntile = tile + G;
+      const int ntm = ntile / tiles_n, ntn = ntile - ntm * tiles_n;
+      for (int kt = 0; kt < nk; ++kt, ++it) {
+        wait_vm0();
+        __syncthreads();          // publishes K tile `it`; compute waves are done with the other buffer
+        const unsigned nxt = lds_b + ((it + 1) & 1) * STAGE * 4;
+        if (kt + 1 < nk) {
+          stage(A + (size_t)tm * BM * K + (kt + 1) * BK, B + (size_t)tn * BN * K + (kt + 1) * BK, nxt);
+        } else if (ntile < ntiles) {
+          tile_offsets(ntm * BM, ntn * BN);
+          stage(A + (size_t)ntm * BM * K, B + (size_t)ntn * BN * K, nxt);
+        }
+      }
+      tm = ntm;
+      tn = ntn;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves
+  const int lr = lane & 15, lg = lane >> 4;
+  int it = 0;
+  for (int tile = first; tile < ntiles; tile += G) {
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      __syncthreads();
+      const float* As = lds + (it & 1) * STAGE;
+      const float* Bs = As + BM * BK;
+      if constexpr (PREC == PREC_F32) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          float4 af[MT], bf[NT];
+          const int cslot = 4 * kk + lg;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            int row = wave * (16 * NT) + j * 16 + lr;
+            bf[j] = *(const float4*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            int row = i * 16 + lr;
+            af[i] = *(const float4*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+#pragma unroll
+          for (int comp = 0; comp < 4; ++comp)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                const float a = comp == 0 ? af[i].x : comp == 1 ? af[i].y : comp == 2 ? af[i].z : af[i].w;
+                const float b = comp == 0 ? bf[j].x : comp == 1 ? bf[j].y : comp == 2 ? bf[j].z : bf[j].w;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
+              }
+        }
+      } else {
+        using F = Frag8<PREC>;
+        typename F::type a8[MT], b8[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wave * (16 * NT) + j * 16 + lr, f = (row >> 1) & 7;
+          b8[j] = F::pack(*(const float4*)(Bs + row * BK + (((2 * lg) ^ f) << 2)),
+                          *(const float4*)(Bs + row * BK + (((2 * lg + 1) ^ f) << 2)));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = i * 16 + lr, f = (row >> 1) & 7;
+          a8[i] = F::pack(*(const float4*)(As + row * BK + (((2 * lg) ^ f) << 2)),
+                          *(const float4*)(As + row * BK + (((2 * lg + 1) ^ f) << 2)));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(b8[j], a8[i], acc[i][j]);
+      }
+    }
+
+    // stores are fire-and-forget: nothing in this wave waits on vmcnt for them
+    store_tile<MT, NT, UNPART>(acc, C, M, N, m0, n0, wave, lr, lg, ep);
   }
 }
 
@@ -285,6 +446,21 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
   const int grid = ntiles < grid_cap ? ntiles : grid_cap;
+  if constexpr (MT >= 8) {
+    static const bool use_ws = getenv("RRT_LINEAR_NO_WS") == nullptr;
+    if (use_ws) {
+      auto kws = linear_ws_kernel<MT, NT, UNPART, PREC>;
+      if (LDS_BYTES > 64 * 1024) {
+        static bool donew = false;
+        if (!donew) {
+          (void)hipFuncSetAttribute((const void*)kws, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+          donew = true;
+        }
+      }
+      kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
+      return hipGetLastError();
+    }
+  }
   auto kern = linear_kernel<MT, NT, UNPART, PREC>;
   if (LDS_BYTES > 64 * 1024) {
     static bool done = false;   // benign race: idempotent attribute
