@@ -77,16 +77,27 @@ def flops_total(n):
             + 6 * g8.Np * D * k + 8 * k * 64 * D * D + 4 * k * 64 * 64 * D)
 
 
-def cpu_baseline(budget_s=20.0):
-    """Reference-equivalent CPU path (oracle port) on this host: bounded sample."""
+def cpu_baseline(budget_s=22.0):
+    """Reference-equivalent CPU path (oracle port) on this host: bounded sample.  The eager op
+    sequence scales poorly past a few dozen threads (many small aten ops), so a short probe picks
+    the thread count at which the reference path is FASTEST before the timed sample."""
     from oracle import rrt_oracle  # the only place bench.py touches oracle/
     state = synth.encoder_state(**CFG)
     st = {k: torch.from_numpy(v) for k, v in state.items()}
     x = torch.from_numpy(synth.bag(N_TOKENS, DIM))
-    cores = torch.get_num_threads()
-    rrt_oracle.forward_eager(x, st, CFG)             # warm-up
+    ncpu = os.cpu_count() or torch.get_num_threads()
+    cands = sorted({c for c in (ncpu, ncpu // 2, ncpu // 4, 32, 16, 8) if 1 <= c <= ncpu}, reverse=True)
+    probe = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        rrt_oracle.forward_eager(x, st, CFG)         # warm-up at this thread count
+        t0 = time.perf_counter()
+        rrt_oracle.forward_eager(x, st, CFG)
+        probe[c] = time.perf_counter() - t0
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
     times = []
-    t_end = time.perf_counter() + budget_s
+    t_end = time.perf_counter() + budget_s * 0.6
     while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 200):
         t0 = time.perf_counter()
         rrt_oracle.forward_eager(x, st, CFG)
@@ -96,7 +107,8 @@ def cpu_baseline(budget_s=20.0):
             "sample": f"{len(times)} bags of N={N_TOKENS} D={DIM} (median {med * 1e3:.1f} ms/bag), "
                       f"oracle/rrt_oracle.py::forward_eager (same aten op sequence as the reference, "
                       f"bit-identical to it in the build container), torch {torch.__version__} CPU, "
-                      f"{cores} threads"}
+                      f"{cores} of {ncpu} hardware threads (fastest of "
+                      + ", ".join(f"{c}: {probe[c] * 1e3:.0f} ms" for c in cands) + ")"}
 
 
 def main():

@@ -200,6 +200,31 @@ def main():
             logits, attn = mil(torch.from_numpy(feats).unsqueeze(0), return_attn=True)
         save(f"G8_rrtmil_n{N}", cfg=cfg_array(cfg), n=np.array(N), logits=logits.numpy(), attn=attn.numpy())
 
+    # G9: awkward sizes / geometry escapes at D=64 (cheap): N around grid boundaries, the
+    # min_region_num / min_region_ratio "give up region attention" branch (rmsa.py:191-196),
+    # region_size override, region_num=3 (non power of two), epeg_k larger than P
+    g9 = {
+        "n2": (2, {}), "n63": (63, {}), "n64": (64, {}), "n65": (65, {}), "n257": (257, {}),
+        "n1000_rn3": (1000, dict(region_num=3)),
+        "n90_minnum": (90, dict(min_region_num=100)),            # L < min_region_num -> one region
+        "n300_minratio": (300, dict(min_region_ratio=2.0)),      # padding too large -> one region
+        "n500_rs5": (500, dict(region_size=5)),
+        "n130_k31": (130, dict(epeg_k=31)),                      # taps wider than the 4-token regions
+    }
+    for name, (N, extra) in g9.items():
+        cfg = dict(mlp_dim=64, epeg_k=15, crmsa_k=3, region_num=8)
+        cfg.update(extra)
+        x, y, _, _ = run_ref(N, cfg)
+        save(f"G9_d64_{name}", cfg=cfg_array(cfg), n=np.array(N), y=y)
+    # the same kind of cases at D=512 (head dim 64 -> the MFMA attention kernel)
+    for name in ("n2", "n65", "n1000_rn3", "n90_minnum", "n130_k31"):
+        N, extra = g9[name]
+        cfg = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)
+        cfg.update(extra)
+        x, y, _, _ = run_ref(N, cfg)
+        ri = np.arange(0, N, max(1, N // 64))
+        save(f"G9_d512_{name}", cfg=cfg_array(cfg), n=np.array(N), rows=ri, y_rows=y[ri], y_sums=checksums(y))
+
 
 if __name__ == "__main__":
     main()
