@@ -151,6 +151,15 @@ int rrt_region_attention_f32(const float *qkv, const float *pe_w, float *o,
                              int32_t n_regions, int32_t P, int32_t dim, int32_t heads,
                              int32_t epeg_k, void *stream);
 
+/* Fused R-MSA core (rmsa.py:100-122 in one kernel per (region, head)): u [n_regions*P, dim]
+ * region-major LayerNorm-ed tokens -> o [n_regions*P, dim]; qkv_w [3*dim, dim], qkv_b [3*dim] or NULL,
+ * pe_w [heads, epeg_k] or NULL.  The qkv tensor never exists in HBM.  Supported when head dim is 64
+ * and 112 < P <= 144 (one region fits a CU's LDS); otherwise RRT_E_UNSUPPORTED and the caller uses
+ * rrt_linear_f32 + rrt_region_attention_f32 (rrt_encoder_forward_f32 chooses by itself). */
+int rrt_rmsa_fused_f32(const float *u, const float *qkv_w, const float *qkv_b, const float *pe_w,
+                       float *o, int32_t n_regions, int32_t P, int32_t dim, int32_t heads,
+                       int32_t epeg_k, int32_t compute, void *stream);
+
 /* CR-MSA (rmsa.py:303-335), three kernels around the inner MSA (g8 = the 8x8 grid):
  *  logits  : LayerNorm statistics mean_rstd [L,2] and logits [Np8, k] in region-major order
  *            (zero rows for pad tokens);

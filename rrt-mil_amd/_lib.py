@@ -60,6 +60,7 @@ SIGNATURES = {
                                                       C.c_int32, C.c_void_p]),
     "rrt_region_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "rrt_rmsa_fused_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
     "rrt_crmsa_logits_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32,
                                                          C.POINTER(Grid), C.c_void_p]),
     "rrt_crmsa_combine_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32,

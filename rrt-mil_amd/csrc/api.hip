@@ -221,6 +221,23 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
     float* xout = (li & 1) ? ws.xb : ws.xa;
     RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, ws.uo, D, gd, st));
     if (li == 0) RRT_MARK(RRT_EV_LN_PARTITION);
+    const int ek = desc->epeg ? desc->epeg_k : 0;
+    if (rmsa_fused_supported(gd.P, D, desc->n_heads, ek) && rmsa_fused_supported_rows(gd.Np, D)) {
+      // qkv projection + EPEG + attention in one kernel per (region, head): qkv never reaches HBM.
+      // O goes to the qkv workspace (first Np*D floats), u stays in uo.
+      RRT_TRY(launch_rmsa_fused(ws.uo, lw.qkv_w, lw.qkv_b, desc->epeg ? lw.pe_w : nullptr, ws.qkv,
+                                gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, desc->compute, st));
+      if (li == 0) { RRT_MARK(RRT_EV_QKV); RRT_MARK(RRT_EV_ATTN); }
+      LinearEpilogue ep{};
+      ep.prec = desc->compute;
+      ep.bias = lw.proj_b;
+      ep.resid = xin;
+      ep.g = gd;
+      RRT_TRY(launch_linear(ws.qkv, lw.proj_w, xout, gd.Np, D, D, ep, st));
+      if (li == 0) RRT_MARK(RRT_EV_PROJ);
+      xin = xout;
+      continue;
+    }
     {
       LinearEpilogue ep{};
       ep.prec = desc->compute;
@@ -339,6 +356,18 @@ int rrt_region_attention_f32(const float* qkv, const float* pe_w, float* o, int3
   if (!qkv || !o || n_regions <= 0 || P <= 0 || dim <= 0 || heads <= 0 || dim % heads) return RRT_E_INVALID;
   if (pe_w && epeg_k > 0 && epeg_k % 2 == 0) return unsupported("epeg_k must be odd");
   return (int)launch_region_attention(qkv, pe_w, o, n_regions, P, dim, heads, epeg_k, (hipStream_t)stream);
+}
+
+int rrt_rmsa_fused_f32(const float* u, const float* qkv_w, const float* qkv_b, const float* pe_w, float* o,
+                       int32_t n_regions, int32_t P, int32_t dim, int32_t heads, int32_t epeg_k,
+                       int32_t compute, void* stream) {
+  if (!u || !qkv_w || !o || n_regions <= 0 || P <= 0 || dim <= 0 || heads <= 0) return RRT_E_INVALID;
+  if (compute < 0 || compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
+  const int ek = pe_w ? epeg_k : 0;
+  if (!rmsa_fused_supported(P, dim, heads, ek) || !rmsa_fused_supported_rows((long)n_regions * P, dim))
+    return unsupported("rmsa_fused: needs head dim 64, 112 < P <= 144, epeg_k <= 63 (use linear + region_attention)");
+  return (int)launch_rmsa_fused(u, qkv_w, qkv_b, pe_w, o, n_regions, P, dim, heads, ek, compute,
+                                (hipStream_t)stream);
 }
 
 int rrt_crmsa_logits_f32(const float* x1, const float* gamma, const float* beta, const float* phi,

@@ -96,3 +96,53 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 }
 
 #define LN_EPS 1e-5f
+
+// ---- optional in-kernel timeline tracing (tools/build_ablation.sh trace -DRRT_TRACE) ------------
+// Per wave: up to RRT_TRACE_EV 64-bit shader-clock stamps + HW_ID/XCC_ID, written to a device
+// symbol that tools/trace_attn.py reads back.  Compiled out of the product build.
+#ifdef RRT_TRACE
+#define RRT_TRACE_EV 32
+#define RRT_TRACE_WAVES 8192
+// one private copy per translation unit (no -fgpu-rdc); each traced file defines its own reader with
+// RRT_TRACE_DEFINE_READER(name) -> extern "C" int name(void* host, size_t bytes, int clear)
+static __device__ unsigned long long g_rrt_trace[RRT_TRACE_WAVES * RRT_TRACE_EV];
+#define RRT_TRACE_DEFINE_READER(NAME)                                                                  \
+  extern "C" int NAME(void* host, size_t bytes, int clear) {                                           \
+    size_t n = sizeof(unsigned long long) * RRT_TRACE_WAVES * RRT_TRACE_EV;                            \
+    if (bytes < n) n = bytes;                                                                          \
+    hipError_t e = hipDeviceSynchronize();                                                             \
+    if (e == hipSuccess && host)                                                                       \
+      e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rrt_trace), n, 0, hipMemcpyDeviceToHost);             \
+    if (e == hipSuccess && clear) {                                                                    \
+      void* d = nullptr;                                                                               \
+      e = hipGetSymbolAddress(&d, HIP_SYMBOL(g_rrt_trace));                                            \
+      if (e == hipSuccess) e = hipMemset(d, 0, sizeof(unsigned long long) * RRT_TRACE_WAVES * RRT_TRACE_EV); \
+    }                                                                                                  \
+    return (int)e;                                                                                     \
+  }
+struct WaveTrace {
+  unsigned long long* p;
+  int n;
+  __device__ __forceinline__ void init(int wave_linear) {
+    p = (wave_linear < RRT_TRACE_WAVES) ? g_rrt_trace + (size_t)wave_linear * RRT_TRACE_EV : nullptr;
+    n = 1;
+    if (p && (threadIdx.x & 63) == 0) {
+      unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+      unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));    // HW_REG_XCC_ID
+      p[0] = ((unsigned long long)xcc << 32) | hw;
+    }
+  }
+  __device__ __forceinline__ void mark() {
+    if (p && n < RRT_TRACE_EV) {
+      unsigned long long t = __builtin_amdgcn_s_memtime();
+      if ((threadIdx.x & 63) == 0) p[n] = t;
+    }
+    ++n;
+  }
+};
+#define RRT_TRACE_INIT(w) WaveTrace _tr; _tr.init(w)
+#define RRT_TRACE_MARK() _tr.mark()
+#else
+#define RRT_TRACE_INIT(w)
+#define RRT_TRACE_MARK()
+#endif

@@ -24,6 +24,13 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
 hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o, int n_regions,
                                    int P, int dim, int heads, int epeg_k, hipStream_t st);
 
+// fused qkv projection + EPEG + attention per (region, head) (rmsa_fused.hip); P in (112,144], head dim 64
+bool rmsa_fused_supported(int P, int D, int heads, int epeg_k);
+bool rmsa_fused_supported_rows(long n_rows, int D);
+hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w,
+                             float* O, int n_regions, int P, int D, int heads, int epeg_k, int prec,
+                             hipStream_t st);
+
 hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float* beta,
                                const float* phi, float* mean_rstd, float* logits, int dim, int k,
                                const GridDev& g8, hipStream_t st);

@@ -82,10 +82,17 @@ struct Frag8<PREC_F16> {
 // owns 4 consecutive output columns of one row -> one 16-byte store per tile (9 per wave and output
 // tile instead of 36 dword stores; the dword form was store-issue bound), float4 bias / residual
 // loads, and one slot->token map per row.
+#ifdef RRT_TRACE
+#define RRT_EPI_TRACE_ARG , WaveTrace& _tr
+#define RRT_EPI_TRACE_PASS , _tr
+#else
+#define RRT_EPI_TRACE_ARG
+#define RRT_EPI_TRACE_PASS
+#endif
 template <int MT, int NT, bool UNPART>
 __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT][NT], float* __restrict__ C, int M, int N,
                                            int m0, int n0, int wave, int lr, int lg,
-                                           const LinearEpilogue& ep) {
+                                           const LinearEpilogue& ep RRT_EPI_TRACE_ARG) {
   const bool vec = (N & 3) == 0;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -96,6 +103,10 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT][NT], float* __
       bias[r] = (ep.bias && nb + r < N) ? ep.bias[nb + r] : 0.f;
       scale[r] = (nb + r < ep.q_cols) ? ep.q_scale : 1.0f;
     }
+#ifdef RRT_TRACE
+    asm volatile("" :: "v"(bias[0]), "v"(bias[3]));
+    RRT_TRACE_MARK();                                 // epilogue: bias landed
+#endif
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0 + i * 16 + lr;
@@ -116,12 +127,63 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT][NT], float* __
           v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
         }
         *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+#ifdef RRT_TRACE
+        if (i == 2 || i == 5) RRT_TRACE_MARK();       // epilogue: 3 / 6 row-tiles stored
+#endif
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (nb + r < N) dst[r] = v[r] + (UNPART ? ep.resid[row * N + nb + r] : 0.f);
       }
     }
+  }
+}
+
+
+// One 16-row slice (row tile I) of an output tile: the deferred epilogue of linear_ws_kernel issues
+// these one per K iteration of the block's NEXT tile, so the chip never sees all blocks bursting
+// their whole tiles at once (measured: ~1.2K cycles to issue ONE store while HBM writes saturate).
+template <int MT, int NT, bool UNPART, int I>
+__device__ __forceinline__ void store_slice(const f32x4 (&acc)[MT][NT], const float (&bias)[NT][4],
+                                            float* __restrict__ C, int M, int N, int m0, int n0, int wave,
+                                            int lr, int lg, const LinearEpilogue& ep) {
+  const int m = m0 + I * 16 + lr;
+  if (m >= M) return;
+  size_t row = (size_t)m;
+  if (UNPART) {
+    const int t = slot_to_token(m, ep.g);
+    if (t >= ep.g.L) return;
+    row = (size_t)t;
+  }
+  const bool vec = (N & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int nb = n0 + wave * (16 * NT) + j * 16 + 4 * lg;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (acc[I][j][r] + bias[j][r]) * ((nb + r < ep.q_cols) ? ep.q_scale : 1.0f);
+    float* dst = C + row * N + nb;
+    if (vec && nb + 3 < N) {
+      if (UNPART) {
+        const float4 q = *(const float4*)(ep.resid + row * N + nb);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      }
+      *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < N) dst[r] = v[r] + (UNPART ? ep.resid[row * N + nb + r] : 0.f);
+    }
+  }
+}
+
+template <int MT, int NT, bool UNPART, int I = 0>
+__device__ __forceinline__ void store_all_slices(const f32x4 (&acc)[MT][NT], const float (&bias)[NT][4],
+                                                 float* __restrict__ C, int M, int N, int m0, int n0,
+                                                 int wave, int lr, int lg, const LinearEpilogue& ep) {
+  if constexpr (I < MT) {
+    store_slice<MT, NT, UNPART, I>(acc, bias, C, M, N, m0, n0, wave, lr, lg, ep);
+    store_all_slices<MT, NT, UNPART, I + 1>(acc, bias, C, M, N, m0, n0, wave, lr, lg, ep);
   }
 }
 
@@ -137,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = (float*)smem;              // [2][A: BM*BK | B: BN*BK]
 
+  RRT_TRACE_INIT(1 << 30);   // (untraced kernel: null tracer so the shared epilogue compiles)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lr = lane & 15, lg = lane >> 4;
@@ -275,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
       }
     }
 
-    store_tile<MT, NT, UNPART>(acc, C, M, N, m0, n0, wave, lr, lg, ep);
+    store_tile<MT, NT, UNPART>(acc, C, M, N, m0, n0, wave, lr, lg, ep RRT_EPI_TRACE_PASS);
     tm = ntm;
     tn = ntn;
   }
@@ -313,6 +376,8 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
   }
   if (first >= ntiles) return;
   const int nk = K / BK;
+  RRT_TRACE_INIT(blockIdx.x * 6 + wave);
+  RRT_TRACE_MARK();                                   // [1] entry
 
   if (wave >= 4) {
     // ------------------------------------------------------------------ loader waves
@@ -347,13 +412,16 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
     int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     tile_offsets(tm * BM, tn * BN);
     stage(A + (size_t)tm * BM * K, B + (size_t)tn * BN * K, lds_b);
+    RRT_TRACE_MARK();                                 // loader [2] first stage issued
     int it = 0;
     for (; tile < ntiles; tile += G) {
       const int ntile = tile + G;
       const int ntm = ntile / tiles_n, ntn = ntile - ntm * tiles_n;
       for (int kt = 0; kt < nk; ++kt, ++it) {
         wait_vm0();
+        if (kt == 0 || kt == 8) RRT_TRACE_MARK();     // loader: K tile 0 / 8 landed (before barrier)
         __syncthreads();          // publishes K tile `it`; compute waves are done with the other buffer
+        if (kt == 0 || kt == 8) RRT_TRACE_MARK();     // loader: barrier passed
         const unsigned nxt = lds_b + ((it + 1) & 1) * STAGE * 4;
         if (kt + 1 < nk) {
           stage(A + (size_t)tm * BM * K + (kt + 1) * BK, B + (size_t)tn * BN * K + (kt + 1) * BK, nxt);
@@ -371,9 +439,24 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
   // -------------------------------------------------------------------- compute waves
   const int lr = lane & 15, lg = lane >> 4;
   int it = 0;
+  // deferred epilogue state: the previous tile's accumulators, bias and origin
+  f32x4 prev[MT][NT];
+  float pbias[NT][4];
+  int pm0 = 0, pn0 = 0;
+  bool have_prev = false;
+  auto load_bias = [&](int n0_, float (&bz)[NT][4]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nb = n0_ + wave * (16 * NT) + j * 16 + 4 * lg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bz[j][r] = (ep.bias && nb + r < N) ? ep.bias[nb + r] : 0.f;
+    }
+  };
   for (int tile = first; tile < ntiles; tile += G) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    float cbias[NT][4];
+    load_bias(n0, cbias);                 // lands under the K loop
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -382,6 +465,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
 
     for (int kt = 0; kt < nk; ++kt, ++it) {
       __syncthreads();
+      if (kt == 0 || kt == 1 || kt == 8 || kt == 9) RRT_TRACE_MARK();   // compute: barrier kt passed
       const float* As = lds + (it & 1) * STAGE;
       const float* Bs = As + BM * BK;
       if constexpr (PREC == PREC_F32) {
@@ -430,11 +514,43 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(b8[j], a8[i], acc[i][j]);
       }
+      // one 16-row slice of the PREVIOUS tile per K iteration (behind this iteration's MFMAs)
+      // (static register indexing: always slice 0, then rotate the remaining slices down)
+      if (have_prev && kt < MT) {
+        store_slice<MT, NT, UNPART, 0>(prev, pbias, C, M, N, pm0 + kt * 16, pn0, wave, lr, lg, ep);
+#pragma unroll
+        for (int i = 0; i + 1 < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) prev[i][j] = prev[i + 1][j];
+      }
     }
+    if (have_prev)                        // K shorter than MT iterations: flush what is left
+      for (int i = nk; i < MT; ++i) {
+        store_slice<MT, NT, UNPART, 0>(prev, pbias, C, M, N, pm0 + i * 16, pn0, wave, lr, lg, ep);
+#pragma unroll
+        for (int q = 0; q + 1 < MT; ++q)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) prev[q][j] = prev[q + 1][j];
+      }
 
-    // stores are fire-and-forget: nothing in this wave waits on vmcnt for them
-    store_tile<MT, NT, UNPART>(acc, C, M, N, m0, n0, wave, lr, lg, ep);
+    RRT_TRACE_MARK();                                 // compute: last MFMA of the tile issued
+    // hand the tile over to the deferred epilogue (stores are fire-and-forget: nothing in this
+    // wave ever waits on vmcnt for them)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) prev[i][j] = acc[i][j];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pbias[j][r] = cbias[j][r];
+    pm0 = m0;
+    pn0 = n0;
+    have_prev = true;
+    RRT_TRACE_MARK();
   }
+  // the block's last tile has no successor to hide behind
+  if (have_prev) store_all_slices<MT, NT, UNPART>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
 }
 
 template <int MT, int NT, bool UNPART, int PREC>
@@ -498,6 +614,10 @@ Cfg choose(int M, int N) {
 }
 
 }  // namespace
+
+#ifdef RRT_TRACE
+RRT_TRACE_DEFINE_READER(rrt_debug_trace_linear)
+#endif
 
 hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
                          const LinearEpilogue& ep, hipStream_t st) {

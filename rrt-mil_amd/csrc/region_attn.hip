@@ -65,6 +65,8 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
   const int qi = i0 + (lane & 15);
   const int lg = lane >> 4;
 
+  RRT_TRACE_INIT(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * nw + wave);
+  RRT_TRACE_MARK();                                   // [1] kernel entry
   const unsigned lds_b = lds_addr_of(lds);
   auto stage = [&](int ch, unsigned buf) {
     const int j0 = ch * KC;
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
     }
     wait_vm0();
     __syncthreads();
+    RRT_TRACE_MARK();                                 // [2] Q rows (+chunk 0) landed
     if (active && qi < P) {
       const float* Qs = DIRECT ? lds : lds + STAGE;
       const int lrow = qi - r_lo;                            // this lane's query row in the LDS image
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
     // the barrier at the top of chunk 0 orders these reads before chunk 1 overwrites the buffer
   }
 
+  RRT_TRACE_MARK();                                   // [3] Q~ fragments built
   float m_run = NEG_BIG, l_run = 0.f;
   f32x4 oacc[4];
 #pragma unroll
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
       Vs = cur + KC * HD;
     }
     const int j0 = ch * KC;
+    RRT_TRACE_MARK();                                 // [4+5c] chunk barrier passed
 
     // S^T tiles: s[jt][r] = log2e * score(query lane&15, key j0 + 16*jt + 4*lg + r).
     // jt innermost: consecutive MFMAs hit different accumulators (40-cycle dependent latency)
@@ -188,6 +193,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
 #pragma unroll
       for (int jt = 0; jt < TC; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].w, bq[c].w, s[jt], 0, 0, 0);
     }
+    RRT_TRACE_MARK();                                 // [5+5c] S^T MFMAs issued
     if (j0 + KC > P) {   // tail chunk only: mask keys >= P
 #pragma unroll
       for (int jt = 0; jt < TC; ++jt)
@@ -202,6 +208,8 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
       for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[jt][r]);
     cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
     cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    asm volatile("" :: "v"(cmax));
+    RRT_TRACE_MARK();                                 // [6+5c] scores complete + row max reduced
     const float m_new = fmaxf(m_run, cmax);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
@@ -224,6 +232,8 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
         for (int c = 0; c < 4; ++c) oacc[c][r] *= ar;
       }
     }
+    asm volatile("" :: "v"(l_run), "v"(oacc[0][0]));
+    RRT_TRACE_MARK();                                 // [7+5c] softmax + rescale done
     // O += P V   (A = P^T regs, B = V rows; float4 of V = 4 head-dim tiles)
 #pragma unroll
     for (int jt = 0; jt < TC; ++jt)
@@ -244,8 +254,10 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
         oacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.z, oacc[2], 0, 0, 0);
         oacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.w, oacc[3], 0, 0, 0);
       }
+    RRT_TRACE_MARK();                                 // [8+5c] PV MFMAs issued
   }
   if (!active) return;
+  RRT_TRACE_MARK();                                   // last PV MFMAs issued
   float l_tot = l_run + __shfl_xor(l_run, 16);
   l_tot += __shfl_xor(l_tot, 32);
   const float inv = 1.0f / l_tot;
@@ -315,6 +327,10 @@ __global__ __launch_bounds__(256) void region_attn_generic_kernel(const float* _
 }
 
 }  // namespace
+
+#ifdef RRT_TRACE
+RRT_TRACE_DEFINE_READER(rrt_debug_trace_attn)
+#endif
 
 hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o, int n_regions,
                                    int P, int dim, int heads, int epeg_k, hipStream_t st) {

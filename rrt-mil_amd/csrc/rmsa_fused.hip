@@ -1,0 +1,375 @@
+// rmsa_fused.hip -- R-MSA in ONE kernel per (region, head): qkv projection + EPEG + attention.
+//
+// Replaces InnerAttention.forward up to (not including) proj, modules/rmsa.py:100-122:
+//     qkv = Linear(D, 3D)(U) ; q *= hd^-0.5 ; S = q k^T ; S += dwconv(S) ; softmax ; O = A v
+// The unfused path (linear_f32.hip -> region_attn.hip) writes the [Np, 3D] qkv tensor to HBM and
+// reads it back: 113 MB of traffic per bag at the north star, a store burst at the end of every
+// GEMM tile (measured ~1.2K cycles to issue one store while all blocks write at once), the
+// end-of-kernel L2 write-back of 56 MB, one more launch, and ~7K cycles per attention wave waiting
+// for its first K/V DMA.  Here a block owns one region x one head:
+//   phase 1  C[P x 192] = U_r[P x D] . W_h[192 x D]^T on the fp32 (or bf16/f16) matrix cores --
+//            the same 16x16x4 MFMA / LDS-DMA / XOR-swizzle machinery as linear_ws_kernel
+//            (2 loader waves + 4 compute waves, 144 x 192 tile, BK = 32, double buffered);
+//   phase 2  the accumulators (+bias, q*scale) go to LDS as Q, K (swizzled) and V (linear) tiles,
+//            aliasing the now dead staging buffers -- qkv never exists in HBM;
+//   phase 3  EPEG as a sliding-window stencil over the Q tile: thread = (16-byte column slot, run of
+//            6 consecutive query rows) reads 6 + k - 1 rows once instead of k rows per output
+//            (the per-lane version was LDS-bandwidth bound: 8.4K cycles per wave), x log2(e);
+//   phase 4  softmax(Q~ K^T) V per 16-query tile with every key tile of the region resident
+//            (single pass, no online-softmax rescale), scores transposed exactly as in
+//            region_attn.hip; only O [P x 64] is written.
+// LDS: max(2 x 43 KB staging, Q/K/V 3 x 36.9 KB) + Q~ 36.9 KB = 147.5 KB -> one block per CU;
+// 512 blocks at N = 9000 = 2 per CU.  Requires head dim 64 and P <= 16*MT <= 144.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "internal.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int HD = 64;
+constexpr int BN = 3 * HD;          // q | k | v columns of one head
+constexpr float NEG_BIG = -3.0e38f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
+
+template <int PREC>
+struct Frag8;
+template <>
+struct Frag8<PREC_BF16> {
+  using type = bf16x8;
+  static __device__ __forceinline__ type pack(float4 a, float4 b) {
+    type r;
+    r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+    r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+    return r;
+  }
+  static __device__ __forceinline__ f32x4 mfma(type a, type b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Frag8<PREC_F16> {
+  using type = f16x8;
+  static __device__ __forceinline__ type pack(float4 a, float4 b) {
+    type r;
+    r[0] = (_Float16)a.x; r[1] = (_Float16)a.y; r[2] = (_Float16)a.z; r[3] = (_Float16)a.w;
+    r[4] = (_Float16)b.x; r[5] = (_Float16)b.y; r[6] = (_Float16)b.z; r[7] = (_Float16)b.w;
+    return r;
+  }
+  static __device__ __forceinline__ f32x4 mfma(type a, type b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <int MT, int PREC>
+__global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restrict__ U,
+                                                            const float* __restrict__ Wqkv,
+                                                            const float* __restrict__ bqkv,
+                                                            const float* __restrict__ pe_w,
+                                                            float* __restrict__ O, int n_rows, int P,
+                                                            int D, int epeg_k, float q_scale) {
+  constexpr int BM = 16 * MT;
+  constexpr int STAGE = (BM + BN) * BK;            // floats per pipeline stage
+  constexpr int TILE = BM * HD;                    // floats of one Q / K / V tile
+  constexpr int NA = BM / 8, NB = BN / 8;          // DMA wave-instructions per A / B stage
+  constexpr int LA = (NA + 1) / 2, LB = NB / 2;    // per loader wave
+  constexpr int NT = 3;                            // 16-column tiles per compute wave (4 x 48 = 192)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lds = (float*)smem;
+  float* Qs = lds;                                 // after phase 1 (aliases the staging ring)
+  float* Ks = lds + TILE;
+  float* Vs = lds + 2 * TILE;
+  float* Qt = lds + 3 * TILE;                      // Q~ (own buffer)
+  float* wpad = lds + 4 * TILE;                    // EPEG taps, zero padded by RUN on both sides, +1 at the centre
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const unsigned lds_b = lds_addr_of(lds);
+  const int head = blockIdx.x, reg = blockIdx.y;
+  const int row0 = reg * P;                        // first token row of this region
+  const int nk = D / BK;
+
+  // ================================================================== phase 1: projection
+  if (wave >= 4) {
+    const int lw = wave - 4;
+    unsigned aoff[LA], boff[LB];
+#pragma unroll
+    for (int qi = 0; qi < LA; ++qi) {
+      int S = (qi * 2 + lw) * 64 + lane;
+      int row = S >> 3, p = S & 7;
+      int gr = row0 + row;
+      gr = gr < n_rows ? gr : n_rows - 1;          // rows past the last region: re-read (never used)
+      aoff[qi] = (unsigned)gr * (unsigned)D * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int qi = 0; qi < LB; ++qi) {
+      int S = (qi * 2 + lw) * 64 + lane;
+      int row = S >> 3, p = S & 7;                  // row in [0,192): c = row/64 picks q / k / v
+      int wr = (row >> 6) * D + head * HD + (row & 63);
+      boff[qi] = (unsigned)wr * (unsigned)D * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+    }
+    auto stage = [&](int kt, unsigned buf) {
+#pragma unroll
+      for (int qi = 0; qi < LA; ++qi)
+        if (qi * 2 + lw < NA) dma16s(U + kt * BK, aoff[qi], buf + (qi * 2 + lw) * 1024);
+#pragma unroll
+      for (int qi = 0; qi < LB; ++qi) dma16s(Wqkv + kt * BK, boff[qi], buf + BM * BK * 4 + (qi * 2 + lw) * 1024);
+    };
+    stage(0, lds_b);
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_vm0();
+      __syncthreads();                              // publishes K tile kt
+      if (kt + 1 < nk) stage(kt + 1, lds_b + ((kt + 1) & 1) * STAGE * 4);
+    }
+  } else {
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();
+      const float* As = lds + (kt & 1) * STAGE;
+      const float* Bs = As + BM * BK;
+      if constexpr (PREC == PREC_F32) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          float4 af[MT], bf[NT];
+          const int cslot = 4 * kk + lg;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            int row = wave * (16 * NT) + j * 16 + lr;
+            bf[j] = *(const float4*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            int row = i * 16 + lr;
+            af[i] = *(const float4*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+#pragma unroll
+          for (int comp = 0; comp < 4; ++comp)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                const float a = comp == 0 ? af[i].x : comp == 1 ? af[i].y : comp == 2 ? af[i].z : af[i].w;
+                const float b = comp == 0 ? bf[j].x : comp == 1 ? bf[j].y : comp == 2 ? bf[j].z : bf[j].w;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
+              }
+        }
+      } else {
+        using F = Frag8<PREC>;
+        typename F::type a8[MT], b8[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wave * (16 * NT) + j * 16 + lr, f = (row >> 1) & 7;
+          b8[j] = F::pack(*(const float4*)(Bs + row * BK + (((2 * lg) ^ f) << 2)),
+                          *(const float4*)(Bs + row * BK + (((2 * lg + 1) ^ f) << 2)));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = i * 16 + lr, f = (row >> 1) & 7;
+          a8[i] = F::pack(*(const float4*)(As + row * BK + (((2 * lg) ^ f) << 2)),
+                          *(const float4*)(As + row * BK + (((2 * lg + 1) ^ f) << 2)));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(b8[j], a8[i], acc[i][j]);
+      }
+    }
+    // ================================================================ phase 2: Q / K / V tiles -> LDS
+    __syncthreads();                                // every wave is done with the staging ring
+    // transposed accumulators: reg r of lane (lr, lg) is C[m = 16i + lr][n = 48*wave + 16j + 4lg + r]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = wave * (16 * NT) + j * 16 + 4 * lg;        // 0..191, multiple of 4
+      const int c = n >> 6, d = n & 63;                         // q / k / v and the head-dim column
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bqkv) b = *(const float4*)(bqkv + c * D + head * HD + d);
+      const float sc = c == 0 ? q_scale : 1.0f;
+      float* dstm = c == 0 ? Qs : (c == 1 ? Ks : Vs);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = i * 16 + lr;
+        const int slot = (c == 2) ? (d >> 2) : ((d >> 2) ^ (m & 15));   // V linear, Q/K XOR-swizzled
+        float4 v = make_float4((acc[i][j][0] + b.x) * sc, (acc[i][j][1] + b.y) * sc,
+                               (acc[i][j][2] + b.z) * sc, (acc[i][j][3] + b.w) * sc);
+        *(float4*)(dstm + m * HD + (slot << 2)) = v;
+      }
+    }
+  }
+  if (wave >= 4) __syncthreads();                   // loader side of the "staging ring is dead" barrier
+  __syncthreads();                                  // Q / K / V tiles complete
+
+  // ================================================================== phase 3: EPEG stencil -> Q~
+  // thread = (slot s of 16, run g of RUN consecutive query rows); all 6 waves take part
+  {
+    constexpr int RUN = (BM * 16 + 383) / 384;      // 6 for BM = 144
+    const int half = epeg_k >> 1;
+    // wpad[RUN + tap] = log2(e) * (w[tap] + [tap == half]); zeros elsewhere: no tap conditionals below
+    for (int i = tid; i < 2 * RUN + 64; i += 384) {
+      const int tap = i - RUN;
+      float wt = (tap >= 0 && tap < epeg_k) ? pe_w[head * epeg_k + tap] : 0.f;
+      if (tap == half) wt += 1.0f;
+      wpad[i] = wt * LOG2E;
+    }
+    __syncthreads();
+    const int s = tid & 15, g = tid >> 4;
+    const int r0 = g * RUN;
+    if (r0 < BM) {
+      float4 out[RUN];
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // source rows r0 - half .. r0 + RUN - 1 + half, clipped to the region [0, P) (zero padding)
+      const int lo = max(r0 - half, 0), hi = min(r0 + RUN - 1 + half, P - 1);
+      for (int rr = lo; rr <= hi; ++rr) {
+        const float4 v = *(const float4*)(Qs + rr * HD + ((s ^ (rr & 15)) << 2));
+        const float* wp = wpad + (rr - r0 + half + RUN);       // tap for output o is at wp[-o]
+#pragma unroll
+        for (int o = 0; o < RUN; ++o) {
+          const float wt = wp[-o];
+          out[o].x += wt * v.x; out[o].y += wt * v.y; out[o].z += wt * v.z; out[o].w += wt * v.w;
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) {
+        const int m = r0 + o;
+        if (m < BM) *(float4*)(Qt + m * HD + ((s ^ (m & 15)) << 2)) = out[o];
+      }
+    }
+  }
+  __syncthreads();
+  if (wave >= 4) return;
+
+  // ================================================================== phase 4: attention from LDS
+  for (int t = wave; t < MT; t += 4) {
+    const int i0 = t * 16;
+    if (i0 >= P) break;
+    float4 bq[4];
+    {
+      const int m = i0 + lr;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bq[c] = *(const float4*)(Qt + m * HD + (((4 * c + lg) ^ (m & 15)) << 2));
+    }
+    f32x4 s[MT];
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt) s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float4 a[MT];
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) {
+        const int row = jt * 16 + lr;
+        a[jt] = *(const float4*)(Ks + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+      }
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].x, bq[c].x, s[jt], 0, 0, 0);
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].y, bq[c].y, s[jt], 0, 0, 0);
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].z, bq[c].z, s[jt], 0, 0, 0);
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].w, bq[c].w, s[jt], 0, 0, 0);
+    }
+    float cmax = NEG_BIG;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;       // keys past the region
+        cmax = fmaxf(cmax, s[jt][r]);
+      }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    float psum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[jt][r] - cmax);
+        s[jt][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    const float inv = 1.0f / psum;
+    f32x4 oacc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = jt * 16 + 4 * lg + r;
+        const float4 v = *(const float4*)(Vs + row * HD + (lr << 2));
+        const float p = s[jt][r];
+        oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.x, oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.y, oacc[1], 0, 0, 0);
+        oacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.z, oacc[2], 0, 0, 0);
+        oacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.w, oacc[3], 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ir = __shfl(inv, 4 * lg + r);
+      const int i = i0 + 4 * lg + r;
+      if (i < P) {
+        float4 out = make_float4(oacc[0][r] * ir, oacc[1][r] * ir, oacc[2][r] * ir, oacc[3][r] * ir);
+        *(float4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)) = out;
+      }
+    }
+  }
+}
+
+template <int MT, int PREC>
+hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w, float* O,
+                     int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
+  constexpr int BM = 16 * MT;
+  constexpr size_t STG = (size_t)2 * (BM + BN) * BK * 4, QKV = (size_t)3 * BM * HD * 4;
+  constexpr size_t LDS = (STG > QKV ? STG : QKV) + (size_t)BM * HD * 4 + 512;   // + Q~ + padded taps
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  auto kern = rmsa_fused_kernel<MT, PREC>;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    done = true;
+  }
+  const float q_scale = 1.0f / sqrtf((float)HD);
+  kern<<<dim3(heads, n_regions), dim3(384), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D,
+                                                     pe_w ? epeg_k : 0, q_scale);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool rmsa_fused_supported(int P, int D, int heads, int epeg_k) {
+  static const bool off = getenv("RRT_NO_FUSED") != nullptr;
+  if (off) return false;
+  // one block holds a whole region: P <= 144; MT = 9 or 8 row tiles (smaller regions: unfused path)
+  return heads > 0 && D == heads * HD && D % BK == 0 && P > 112 && P <= 144 && epeg_k >= 0 && epeg_k <= 63;
+}
+
+bool rmsa_fused_supported_rows(long n_rows, int D) {   // 32-bit DMA byte offsets into U
+  return n_rows * (long)D * 4 < 4000000000L;
+}
+
+hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w,
+                             float* O, int n_regions, int P, int D, int heads, int epeg_k, int prec,
+                             hipStream_t st) {
+#define RRT_FUSED(MT_)                                                                              \
+  switch (prec) {                                                                                   \
+    case 1: return launch_mt<MT_, PREC_BF16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st); \
+    case 2: return launch_mt<MT_, PREC_F16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st);  \
+    default: return launch_mt<MT_, PREC_F32>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st); \
+  }
+  if (P > 128) { RRT_FUSED(9) }
+  RRT_FUSED(8)
+#undef RRT_FUSED
+}

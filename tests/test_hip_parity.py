@@ -433,3 +433,39 @@ def test_rrtmil_autocast_bf16():
         logits = mil(feats)
     torch.cuda.synchronize()
     assert np.abs(logits.float().cpu().numpy() - g["logits"]).max() <= 2e-2
+
+
+# ------------------------------------------------------------------ fused R-MSA core
+@pytest.mark.parametrize("R,P,D,heads,ek,compute", [(64, 144, 512, 8, 15, 0), (9, 121, 512, 8, 15, 0),
+                                                    (3, 130, 512, 8, 0, 0), (2, 144, 512, 8, 21, 0),
+                                                    (5, 113, 512, 8, 15, 0), (4, 128, 256, 4, 9, 0),
+                                                    (64, 144, 512, 8, 15, 1)])
+def test_rmsa_fused(R, P, D, heads, ek, compute):
+    """qkv projection + EPEG + attention in one kernel (qkv never in HBM) against the float64
+    restatement of rmsa.py:100-122 with the explicit [P,P] stencil."""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    u = synth.normal(f"fus/u{R}x{P}", (R * P, D))
+    W = synth.uniform(f"fus/w{D}", (3 * D, D), -1, 1) / np.sqrt(D)
+    b = synth.uniform(f"fus/b{D}", (3 * D,), -0.3, 0.3)
+    pe = synth.uniform("fus/pe", (heads, max(ek, 1)), -1, 1) / np.sqrt(max(ek, 1))
+    d_u, d_W, d_b, d_pe = dev(u), dev(W), dev(b), dev(pe)
+    o = torch.full((R * P, D), float("nan"), device=DEV)
+    _lib.check(lib.rrt_rmsa_fused_f32(p(d_u), p(d_W), p(d_b), p(d_pe) if ek else None, p(o), R, P, D, heads, ek,
+                                      compute, stream()), "rmsa_fused")
+    torch.cuda.synchronize()
+    if compute == 1:
+        qkv = _round_bf16(u).astype(np.float64) @ _round_bf16(W).astype(np.float64).T + b
+    else:
+        qkv = u.astype(np.float64) @ W.astype(np.float64).T + b
+    qkv[:, :D] *= (D // heads) ** -0.5
+    ref = _attn_ref(qkv, pe, R, P, D, heads, ek)
+    _cmp(o.cpu().numpy(), ref, 5e-5, f"rmsa_fused R{R} P{P} D{D} k{ek} c{compute}")
+
+
+def test_rmsa_fused_unsupported_shapes_report():
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    t = torch.zeros(64 * 3, 512 * 3, device=DEV)
+    rc = lib.rrt_rmsa_fused_f32(p(t), p(t), None, None, p(t), 3, 64, 512, 8, 0, 0, stream())
+    assert rc == -2 and b"rmsa_fused" in lib.rrt_strerror(rc)

@@ -5,7 +5,7 @@ name=$1; shift
 cd "$(dirname "$0")/.."
 mkdir -p tools/_abl
 objs=""
-for f in ln_partition linear_f32 region_attn crmsa api; do
+for f in ln_partition linear_f32 region_attn rmsa_fused crmsa api; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast "$@" -c rrt-mil_amd/csrc/$f.hip -o tools/_abl/${name}_$f.o &
   objs="$objs tools/_abl/${name}_$f.o"
 done
