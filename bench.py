@@ -41,9 +41,10 @@ from rrt_mil_amd.geometry import region_grid  # noqa: E402
 N_TOKENS, DIM = 9000, 512
 CFG = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
-# HBM-side bytes of the dominant kernel per launch from rocprofv3 --pmc (separate FETCH_SIZE and
-# WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_c_traffic_pmc.txt
-TRAFFIC_BYTES_PER_LAUNCH = 154.7e6
+# HBM-side bytes of the dominant kernel (rmsa_fused_kernel) per launch from rocprofv3 --pmc (separate
+# FETCH_SIZE and WRITE_SIZE passes; FETCH_SIZE doubled per the gfx950 correction):
+# 2 * 33965.7 KiB + 18432 KiB -- profiles/r01_e_fused_traffic_pmc.txt
+TRAFFIC_BYTES_PER_LAUNCH = 88.4e6
 
 
 class HipEvents:
@@ -161,7 +162,7 @@ def main():
         # one step = S independent bags, one per stream (bag-parallel inside the GPU as well)
         for s_ in range(S):
             x = bags[(i * S + s_) % len(bags)]
-            if timed and s_ == 0:   # mark the dominant kernel: [after LN+partition, after qkv linear]
+            if timed and s_ == 0:   # mark the dominant kernel: [after LN+partition, after the fused R-MSA core]
                 for j in range(_lib.EV_COUNT):
                     ev_arr[j] = None
                 ev_arr[_lib.EV_LN_PARTITION] = ev_pairs[i][0]
@@ -203,9 +204,10 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, device=dev)   # whole-job time = slowest rank
     assert torch.isfinite(out).all()
 
-    # dominant kernel: R-MSA qkv linear  [Np, D] x [3D, D]^T  (fp32 MFMA)
+    # dominant kernel: rmsa_fused_kernel = qkv projection [Np, D] x [3D, D]^T + region attention
+    # (Q K^T and A V) per (region, head), fp32 MFMA.  Algorithmic FLOPs per launch (SURVEY §8d terms):
     g = region_grid(N_TOKENS, CFG["region_num"])
-    qkv_flops = 2.0 * g.Np * (3 * DIM) * DIM
+    qkv_flops = 2.0 * g.Np * (3 * DIM) * DIM + 4.0 * g.Np * g.P * DIM
     qkv_ms = float(np.mean([hev.elapsed_ms(a, b) for a, b in ev_pairs]))
     achieved = qkv_flops / (qkv_ms * 1e-3) / 1e12
 
@@ -224,7 +226,8 @@ def main():
                        "parallelism": f"bag-parallel x{world} (no data-path collective)",
                        "gflop_per_bag": round(flops_total(N_TOKENS) / 1e9, 2),
                        "whole_path_tflops": round(S * flops_total(N_TOKENS) / (ms_per_step * 1e-3) / 1e12, 2)},
-            "roofline": {"bound": "mfma", "kernel": "linear_kernel<9,1,false> (R-MSA qkv linear: [9216,512] x [1536,512]^T, 144x64 tiles, persistent)",
+            "roofline": {"bound": "mfma", "kernel": "rmsa_fused_kernel<9,0> (R-MSA per (region, head): qkv projection 144x192x512 + EPEG + "
+                                   "softmax(QK^T)V from LDS; 14.50 + 2.72 GFLOP)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "flops_per_launch": qkv_flops, "avg_launch_ms": round(qkv_ms, 5),

@@ -10,7 +10,7 @@
 //   phase 1  C[P x 192] = U_r[P x D] . W_h[192 x D]^T on the fp32 (or bf16/f16) matrix cores --
 //            the same 16x16x4 MFMA / LDS-DMA / XOR-swizzle machinery as linear_ws_kernel
 //            (2 loader waves + 4 compute waves, 144 x 192 tile, BK = 32, double buffered);
-//   phase 2  the accumulators (+bias, q*scale) go to LDS as Q, K (swizzled) and V (linear) tiles,
+//   phase 2  the accumulators (+bias, q*scale) go to LDS as XOR-swizzled Q, K and V tiles,
 //            aliasing the now dead staging buffers -- qkv never exists in HBM;
 //   phase 3  EPEG as a sliding-window stencil over the Q tile: thread = (16-byte column slot, run of
 //            6 consecutive query rows) reads 6 + k - 1 rows once instead of k rows per output
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
                                                             const float* __restrict__ bqkv,
                                                             const float* __restrict__ pe_w,
                                                             float* __restrict__ O, int n_rows, int P,
-                                                            int D, int epeg_k, float q_scale) {
+                                                            int D, int heads_rt, int epeg_k, float q_scale) {
   constexpr int BM = 16 * MT;
   constexpr int STAGE = (BM + BN) * BK;            // floats per pipeline stage
   constexpr int TILE = BM * HD;                    // floats of one Q / K / V tile
@@ -92,9 +92,30 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const unsigned lds_b = lds_addr_of(lds);
-  const int head = blockIdx.x, reg = blockIdx.y;
+  // XCD-aware block -> (region, head) map.  Hardware places block b on XCD b % 8 (speed heuristic
+  // only): the 8 head-blocks of a region are given consecutive slots of ONE XCD, so the region's
+  // U panel (P x D fp32 = 295 KB) is fetched from HBM once and served to the other 7 heads from
+  // that XCD's L2 (the naive head-fastest order put the 8 heads on 8 different XCDs: 8x the reads).
+  int head, reg;
+  {
+    const int b = blockIdx.x;
+    const int n_regions = gridDim.x / heads_rt;
+    const int full = (n_regions >> 3) * 8 * heads_rt;       // blocks of complete 8-region groups
+    if (b < full) {
+      const int xcd = b & 7, idx = b >> 3;
+      const int grp = idx / heads_rt;                        // group of 8 regions, one per XCD
+      reg = grp * 8 + xcd;
+      head = idx - grp * heads_rt;
+    } else {                                                 // ragged tail: plain order (bijective)
+      const int rem = b - full;
+      reg = (n_regions >> 3) * 8 + rem / heads_rt;
+      head = rem % heads_rt;
+    }
+  }
   const int row0 = reg * P;                        // first token row of this region
   const int nk = D / BK;
+  RRT_TRACE_INIT(blockIdx.x * 6 + wave);
+  RRT_TRACE_MARK();                                 // [1] entry
 
   // ================================================================== phase 1: projection
   if (wave >= 4) {
@@ -136,6 +157,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();
+      if (kt == 0 || kt == 1 || kt == 8) RRT_TRACE_MARK();   // [2,3,4] barrier kt passed
       const float* As = lds + (kt & 1) * STAGE;
       const float* Bs = As + BM * BK;
       if constexpr (PREC == PREC_F32) {
@@ -185,6 +207,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
           for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(b8[j], a8[i], acc[i][j]);
       }
     }
+    RRT_TRACE_MARK();                               // [5] last projection MFMA issued
     // ================================================================ phase 2: Q / K / V tiles -> LDS
     __syncthreads();                                // every wave is done with the staging ring
     // transposed accumulators: reg r of lane (lr, lg) is C[m = 16i + lr][n = 48*wave + 16j + 4lg + r]
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int m = i * 16 + lr;
-        const int slot = (c == 2) ? (d >> 2) : ((d >> 2) ^ (m & 15));   // V linear, Q/K XOR-swizzled
+        const int slot = (d >> 2) ^ (m & 15);     // all three tiles XOR-swizzled: conflict-free row-per-lane writes
         float4 v = make_float4((acc[i][j][0] + b.x) * sc, (acc[i][j][1] + b.y) * sc,
                                (acc[i][j][2] + b.z) * sc, (acc[i][j][3] + b.w) * sc);
         *(float4*)(dstm + m * HD + (slot << 2)) = v;
@@ -208,6 +231,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   }
   if (wave >= 4) __syncthreads();                   // loader side of the "staging ring is dead" barrier
   __syncthreads();                                  // Q / K / V tiles complete
+  RRT_TRACE_MARK();                                 // [6] Q/K/V in LDS
 
   // ================================================================== phase 3: EPEG stencil -> Q~
   // thread = (slot s of 16, run g of RUN consecutive query rows); all 6 waves take part
@@ -215,7 +239,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     constexpr int RUN = (BM * 16 + 383) / 384;      // 6 for BM = 144
     const int half = epeg_k >> 1;
     // wpad[RUN + tap] = log2(e) * (w[tap] + [tap == half]); zeros elsewhere: no tap conditionals below
-    for (int i = tid; i < 2 * RUN + 64; i += 384) {
+    for (int i = tid; i < 2 * RUN + 66; i += 384) {
       const int tap = i - RUN;
       float wt = (tap >= 0 && tap < epeg_k) ? pe_w[head * epeg_k + tap] : 0.f;
       if (tap == half) wt += 1.0f;
@@ -230,14 +254,21 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
       for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
       // source rows r0 - half .. r0 + RUN - 1 + half, clipped to the region [0, P) (zero padding)
       const int lo = max(r0 - half, 0), hi = min(r0 + RUN - 1 + half, P - 1);
+      // wr[o] = weight of source row rr for output row r0+o = wpad[rr - r0 + half + RUN - o]; stepping rr
+      // shifts the window by one: one LDS read per source row instead of RUN
+      float wr[RUN];
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) wr[o] = wpad[lo - r0 + half + RUN - o];
       for (int rr = lo; rr <= hi; ++rr) {
         const float4 v = *(const float4*)(Qs + rr * HD + ((s ^ (rr & 15)) << 2));
-        const float* wp = wpad + (rr - r0 + half + RUN);       // tap for output o is at wp[-o]
+        const float wnext = wpad[rr + 1 - r0 + half + RUN];
 #pragma unroll
         for (int o = 0; o < RUN; ++o) {
-          const float wt = wp[-o];
-          out[o].x += wt * v.x; out[o].y += wt * v.y; out[o].z += wt * v.z; out[o].w += wt * v.w;
+          out[o].x += wr[o] * v.x; out[o].y += wr[o] * v.y; out[o].z += wr[o] * v.z; out[o].w += wr[o] * v.w;
         }
+#pragma unroll
+        for (int o = RUN - 1; o > 0; --o) wr[o] = wr[o - 1];
+        wr[0] = wnext;
       }
 #pragma unroll
       for (int o = 0; o < RUN; ++o) {
@@ -247,12 +278,15 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     }
   }
   __syncthreads();
-  if (wave >= 4) return;
+  RRT_TRACE_MARK();                                 // [7] Q~ built
 
   // ================================================================== phase 4: attention from LDS
-  for (int t = wave; t < MT; t += 4) {
+  // all six waves (the loaders are idle now): tiles 0..5 -> waves 0..5, tiles 6.. -> waves 2,3,4,...
+  // (waves 4,5 presumably share SIMDs with waves 0,1: the extra tiles go to the others first)
+  for (int pass = 0; pass < 2; ++pass) {
+    const int t = pass == 0 ? wave : ((wave >= 2 && wave <= 4) ? wave + 4 : MT);
     const int i0 = t * 16;
-    if (i0 >= P) break;
+    if (t >= MT || i0 >= P) break;
     float4 bq[4];
     {
       const int m = i0 + lr;
@@ -279,6 +313,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
 #pragma unroll
       for (int jt = 0; jt < MT; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].w, bq[c].w, s[jt], 0, 0, 0);
     }
+    RRT_TRACE_MARK();                               // tile: S^T issued
     float cmax = NEG_BIG;
 #pragma unroll
     for (int jt = 0; jt < MT; ++jt)
@@ -301,6 +336,8 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     psum += __shfl_xor(psum, 16);
     psum += __shfl_xor(psum, 32);
     const float inv = 1.0f / psum;
+    asm volatile("" :: "v"(inv));
+    RRT_TRACE_MARK();                               // tile: softmax done
     f32x4 oacc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -309,13 +346,14 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = jt * 16 + 4 * lg + r;
-        const float4 v = *(const float4*)(Vs + row * HD + (lr << 2));
+        const float4 v = *(const float4*)(Vs + row * HD + ((lr ^ (row & 15)) << 2));
         const float p = s[jt][r];
         oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.x, oacc[0], 0, 0, 0);
         oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.y, oacc[1], 0, 0, 0);
         oacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.z, oacc[2], 0, 0, 0);
         oacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.w, oacc[3], 0, 0, 0);
       }
+    RRT_TRACE_MARK();                               // tile: PV issued
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float ir = __shfl(inv, 4 * lg + r);
@@ -325,6 +363,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
         *(float4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)) = out;
       }
     }
+    RRT_TRACE_MARK();                               // tile: O stored
   }
 }
 
@@ -342,12 +381,16 @@ hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const
     done = true;
   }
   const float q_scale = 1.0f / sqrtf((float)HD);
-  kern<<<dim3(heads, n_regions), dim3(384), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D,
-                                                     pe_w ? epeg_k : 0, q_scale);
+  kern<<<dim3(heads * n_regions), dim3(384), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D, heads,
+                                                      pe_w ? epeg_k : 0, q_scale);
   return hipGetLastError();
 }
 
 }  // namespace
+
+#ifdef RRT_TRACE
+RRT_TRACE_DEFINE_READER(rrt_debug_trace_fused)
+#endif
 
 bool rmsa_fused_supported(int P, int D, int heads, int epeg_k) {
   static const bool off = getenv("RRT_NO_FUSED") != nullptr;
