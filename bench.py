@@ -204,6 +204,23 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, device=dev)   # whole-job time = slowest rank
     assert torch.isfinite(out).all()
 
+    # informational: the same workload with bf16 Linear operands (the reference's --amp / autocast
+    # path, BASELINE configs[2..4]); fp32 accumulate and fp32 tensors in HBM.  Not the headline value.
+    amp = None
+    if rank == 0:
+        enc._desc.compute = _lib.COMPUTE_BF16
+        for i in range(5):
+            step(i, False)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for i in range(30):
+            step(i, False)
+        torch.cuda.synchronize()
+        amp = {"value": round(S * 30 / (time.perf_counter() - ta), 2), "unit": "slides/s", "n_gpus": 1,
+               "note": "rank 0 only, 30 steps after the timed region; RRT_COMPUTE_BF16 (bf16 MFMA operands in "
+                       "the Linear layers / fused projection, fp32 accumulate)"}
+        enc._desc.compute = _lib.COMPUTE_F32
+
     # dominant kernel: rmsa_fused_kernel = qkv projection [Np, D] x [3D, D]^T + region attention
     # (Q K^T and A V) per (region, head), fp32 MFMA.  Algorithmic FLOPs per launch (SURVEY §8d terms):
     g = region_grid(N_TOKENS, CFG["region_num"])
@@ -240,6 +257,7 @@ def main():
                                   "avg_launch_ms": round(iso_ms, 5),
                                   "note": "same kernel, untimed pass with one bag in flight (median of 10)"},
         }
+        rec["amp_bf16"] = amp
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)

@@ -225,6 +225,12 @@ def main():
         ri = np.arange(0, N, max(1, N // 64))
         save(f"G9_d512_{name}", cfg=cfg_array(cfg), n=np.array(N), rows=ri, y_rows=y[ri], y_sums=checksums(y))
 
+    # G10: two R-MSA layers (n_layers=3) at D=512, N=8000 (P=144: the fused kernel on every layer)
+    cfg = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8, n_layers=3)
+    x, y, _, _ = run_ref(8000, cfg)
+    ri = np.arange(0, 8000, 80)
+    save("G10_d512_n8000_layers3", cfg=cfg_array(cfg), n=np.array(8000), rows=ri, y_rows=y[ri], y_sums=checksums(y))
+
 
 if __name__ == "__main__":
     main()
