@@ -469,3 +469,26 @@ def test_rmsa_fused_unsupported_shapes_report():
     t = torch.zeros(64 * 3, 512 * 3, device=DEV)
     rc = lib.rrt_rmsa_fused_f32(p(t), p(t), None, None, p(t), 3, 64, 512, 8, 0, 0, stream())
     assert rc == -2 and b"rmsa_fused" in lib.rrt_strerror(rc)
+
+
+def test_bag_feeder_matches_direct_copy(tmp_path):
+    """Row f3: pinned double-buffered H2D feed -- same bags, same order, same results as bag.to(device);
+    accepts tensors and .pt paths (dataloader.py:181)."""
+    from hip_util import encoder_from_state, DEV
+    from rrt_mil_amd import BagFeeder
+    cfg = dict(mlp_dim=64)
+    enc = encoder_from_state(synth.encoder_state(mlp_dim=64), cfg)
+    sizes = [300, 1000, 64, 777, 2000, 50, 1234]
+    bags = [torch.from_numpy(synth.bag(n, 64, tag=f"feed{i}")) for i, n in enumerate(sizes)]
+    path = str(tmp_path / "bag.pt")
+    torch.save(bags[3].unsqueeze(0), path)          # (1, N, D) on disk, like the reference's feature files
+    mixed = list(bags)
+    mixed[3] = path
+    want = [enc(b.to(DEV)).cpu() for b in bags]
+    got = []
+    for dev_bag in BagFeeder(mixed, device=DEV, depth=3):
+        assert dev_bag.is_cuda and dev_bag.dtype == torch.float32
+        got.append(enc(dev_bag).cpu())
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
