@@ -43,20 +43,34 @@ __device__ __forceinline__ int slot_to_token(int slot, const GridDev& g) {
   return (ri * g.s + pi) * g.H + rj * g.s + pj;
 }
 
+// Wave-wide reductions without LDS traffic: __shfl_xor lowers to ds_bpermute_b32 (an LDS-pipe round
+// trip per step, 6 dependent steps per reduction); here 4 DPP row rotations reduce each 16-lane row
+// in the VALU and 4 v_readlane + scalar-operand adds combine the rows.  Result is wave-uniform.
+#define RRT_DPP_ROR(x, n) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0x120 + (n), 0xF, 0xF, false))
+__device__ __forceinline__ float rrt_readlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += RRT_DPP_ROR(v, 8);
+  v += RRT_DPP_ROR(v, 4);
+  v += RRT_DPP_ROR(v, 2);
+  v += RRT_DPP_ROR(v, 1);
+  return (rrt_readlane(v, 0) + rrt_readlane(v, 16)) + (rrt_readlane(v, 32) + rrt_readlane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, RRT_DPP_ROR(v, 8));
+  v = fmaxf(v, RRT_DPP_ROR(v, 4));
+  v = fmaxf(v, RRT_DPP_ROR(v, 2));
+  v = fmaxf(v, RRT_DPP_ROR(v, 1));
+  return fmaxf(fmaxf(rrt_readlane(v, 0), rrt_readlane(v, 16)), fmaxf(rrt_readlane(v, 32), rrt_readlane(v, 48)));
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  return v;
+  v = fminf(v, RRT_DPP_ROR(v, 8));
+  v = fminf(v, RRT_DPP_ROR(v, 4));
+  v = fminf(v, RRT_DPP_ROR(v, 2));
+  v = fminf(v, RRT_DPP_ROR(v, 1));
+  return fminf(fminf(rrt_readlane(v, 0), rrt_readlane(v, 16)), fminf(rrt_readlane(v, 32), rrt_readlane(v, 48)));
 }
 
 // 16-byte global -> LDS DMA (global_load_lds_dwordx4): the LDS destination is the

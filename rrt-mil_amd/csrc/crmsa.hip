@@ -43,7 +43,10 @@ __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restri
     phi_t[n * dim + d] = phi[idx];
   }
   __syncthreads();
-  const int t0 = (blockIdx.x * 4 + wave) * RW;
+  // persistent: phi is staged once per block, then the block grid-strides over groups of 4*RW rows
+  const int ngroups = (g.Np + 4 * RW - 1) / (4 * RW);
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  const int t0 = (grp * 4 + wave) * RW;
   float4 r[RW][NV];
   float sum[RW];
 #pragma unroll
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restri
       mean_rstd[2 * (size_t)t] = m;
       mean_rstd[2 * (size_t)t + 1] = rs;
     }
+  }
   }
 }
 
@@ -410,7 +414,8 @@ hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
 hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float* beta,
                                const float* phi, float* mean_rstd, float* logits, int dim, int k,
                                const GridDev& g8, hipStream_t st) {
-  dim3 grid((g8.Np + 4 * RW - 1) / (4 * RW)), block(256);
+  const int ngroups = (g8.Np + 4 * RW - 1) / (4 * RW);
+  dim3 grid(ngroups < 1024 ? ngroups : 1024), block(256);     // <= 4 resident blocks per CU, grid-stride
   const size_t lds = (size_t)dim * k * sizeof(float);
 #define RRT_LOGITS(NV) \
   crmsa_logits_kernel<NV><<<grid, block, lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, dim, k, g8)
