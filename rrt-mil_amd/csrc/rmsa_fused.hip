@@ -18,8 +18,9 @@
 //   phase 4  softmax(Q~ K^T) V per 16-query tile with every key tile of the region resident
 //            (single pass, no online-softmax rescale), scores transposed exactly as in
 //            region_attn.hip; only O [P x 64] is written.
-// LDS: max(2 x 43 KB staging, Q/K/V 3 x 36.9 KB) + Q~ 36.9 KB = 147.5 KB -> one block per CU;
-// 512 blocks at N = 9000 = 2 per CU.  Requires head dim 64 and P <= 16*MT <= 144.
+// LDS: max(2 x 43 KB staging, Q/K/V 3 x 36.9 KB) = 108 KiB (Q~ overwrites Q) -> one block per CU, with
+// 52 KiB left for a co-resident kernel of another bag; 512 blocks at N = 9000 = 2 per CU.
+// Requires head dim 64 and P <= 16*MT <= 144.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -84,8 +85,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   float* Qs = lds;                                 // after phase 1 (aliases the staging ring)
   float* Ks = lds + TILE;
   float* Vs = lds + 2 * TILE;
-  float* Qt = lds + 3 * TILE;                      // Q~ (own buffer)
-  float* wpad = lds + 4 * TILE;                    // EPEG taps, zero padded by RUN on both sides, +1 at the centre
+  float* Qt = Qs;                                  // Q~ overwrites Q in place (phase 3)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -236,32 +236,33 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   // ================================================================== phase 3: EPEG stencil -> Q~
   // thread = (slot s of 16, run g of RUN consecutive query rows); all 6 waves take part
   {
+    // In place: every thread first gathers its outputs in registers, a barrier retires all reads of
+    // the Q tile, then Q~ is written over it.  (A separate Q~ buffer + tap table cost 37.4 KB more
+    // LDS; at 108 KiB a proj tile of another bag (52 KiB) can share the CU: 108 + 52 = 160 KiB.)
     constexpr int RUN = (BM * 16 + 383) / 384;      // 6 for BM = 144
     const int half = epeg_k >> 1;
-    // wpad[RUN + tap] = log2(e) * (w[tap] + [tap == half]); zeros elsewhere: no tap conditionals below
-    for (int i = tid; i < 2 * RUN + 66; i += 384) {
-      const int tap = i - RUN;
-      float wt = (tap >= 0 && tap < epeg_k) ? pe_w[head * epeg_k + tap] : 0.f;
-      if (tap == half) wt += 1.0f;
-      wpad[i] = wt * LOG2E;
-    }
-    __syncthreads();
+    const float* w = pe_w + head * epeg_k;          // taps come from global (L1-resident, <= 63 floats)
+    auto tap = [&](int t) {                         // log2(e) * (w[t] + [t == half]); 0 outside [0, k)
+      float wt = (t >= 0 && t < epeg_k) ? w[t] : 0.f;
+      if (t == half) wt += 1.0f;
+      return wt * LOG2E;
+    };
     const int s = tid & 15, g = tid >> 4;
     const int r0 = g * RUN;
-    if (r0 < BM) {
-      float4 out[RUN];
+    float4 out[RUN];
 #pragma unroll
-      for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < BM) {
       // source rows r0 - half .. r0 + RUN - 1 + half, clipped to the region [0, P) (zero padding)
       const int lo = max(r0 - half, 0), hi = min(r0 + RUN - 1 + half, P - 1);
-      // wr[o] = weight of source row rr for output row r0+o = wpad[rr - r0 + half + RUN - o]; stepping rr
-      // shifts the window by one: one LDS read per source row instead of RUN
+      // wr[o] = weight of source row rr for output row r0+o = tap(rr - r0 - o + half); stepping rr
+      // shifts the window by one: one tap fetch per source row instead of RUN
       float wr[RUN];
 #pragma unroll
-      for (int o = 0; o < RUN; ++o) wr[o] = wpad[lo - r0 + half + RUN - o];
+      for (int o = 0; o < RUN; ++o) wr[o] = tap(lo - r0 - o + half);
       for (int rr = lo; rr <= hi; ++rr) {
         const float4 v = *(const float4*)(Qs + rr * HD + ((s ^ (rr & 15)) << 2));
-        const float wnext = wpad[rr + 1 - r0 + half + RUN];
+        const float wnext = tap(rr + 1 - r0 + half);
 #pragma unroll
         for (int o = 0; o < RUN; ++o) {
           out[o].x += wr[o] * v.x; out[o].y += wr[o] * v.y; out[o].z += wr[o] * v.z; out[o].w += wr[o] * v.w;
@@ -270,6 +271,9 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
         for (int o = RUN - 1; o > 0; --o) wr[o] = wr[o - 1];
         wr[0] = wnext;
       }
+    }
+    __syncthreads();                                // all reads of Q done
+    if (r0 < BM) {
 #pragma unroll
       for (int o = 0; o < RUN; ++o) {
         const int m = r0 + o;
@@ -372,7 +376,7 @@ hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const
                      int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
   constexpr int BM = 16 * MT;
   constexpr size_t STG = (size_t)2 * (BM + BN) * BK * 4, QKV = (size_t)3 * BM * HD * 4;
-  constexpr size_t LDS = (STG > QKV ? STG : QKV) + (size_t)BM * HD * 4 + 512;   // + Q~ + padded taps
+  constexpr size_t LDS = (STG > QKV ? STG : QKV);   // staging ring, then the Q/K/V tiles (Q~ in place)
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = rmsa_fused_kernel<MT, PREC>;
   static bool done = false;
