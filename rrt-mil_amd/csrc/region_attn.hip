@@ -359,9 +359,12 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
     if ((P < 16 * nw + epeg_k - 1 ? P : 16 * nw + epeg_k - 1) > 2 * kc) return hipErrorInvalidValue;
   }
   int tc_force = 0;
-  if (const char* e = getenv("RRT_ATTN_CFG")) {   // tuning hook: "tc,nw"
+  if (const char* e = getenv("RRT_ATTN_CFG")) {   // tuning hook: "tc,nw" (rejected if the Q rows do not fit)
     int a = 0, b = 0;
-    if (sscanf(e, "%d,%d", &a, &b) == 2) { tc_force = a; nw = b; }
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= 3 && b >= 1 && b <= 4) {
+      const int need = P < 16 * b + epeg_k - 1 ? P : 16 * b + epeg_k - 1;
+      if (epeg_k <= 0 || need <= 2 * 16 * a) { tc_force = a; nw = b; }
+    }
   }
   const int nqb = (ntiles + nw - 1) / nw;
   dim3 grid(nqb, heads, n_regions), block(nw * 64);
