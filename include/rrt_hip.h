@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 3
+#define RRT_ABI_VERSION 4
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -39,6 +39,9 @@ enum {
  * autocast-class numerics of the reference's --amp path (main.py:101-102,439); LayerNorm,
  * softmax, attention, residuals and all intermediates in HBM stay fp32 in every mode. */
 enum { RRT_COMPUTE_F32 = 0, RRT_COMPUTE_BF16 = 1, RRT_COMPUTE_F16 = 2 };
+
+/* Elementwise activations of the caller-side layers (patch_to_emb, DAttention). */
+enum { RRT_ACT_NONE = 0, RRT_ACT_RELU = 1, RRT_ACT_GELU = 2, RRT_ACT_TANH = 3, RRT_ACT_SIGMOID = 4 };
 
 /* Region-grid geometry: RegionAttntion.padding, modules/rmsa.py:175-202 (same body
  * CrossRegionAttntion.padding :261-288).  H = padded grid side, s = region side,
@@ -184,6 +187,54 @@ int rrt_crmsa_mlp_logits_f32(const float *hid, const float *w2, float *logits, i
 /* final LayerNorm only (cr_msa=False path): y = LN(x1 (+ x0)) */
 int rrt_layernorm_f32(const float *x1, const float *x0, const float *gamma, const float *beta,
                       float *y, int64_t L, int32_t dim, void *stream);
+
+/* ---- row f1: the RRTMIL slide classifier around the encoder (modules/rrt.py:204-246) ----
+ * patch_to_emb Linear(input_dim, dim)+act (rrt.py:208-217; Dropout is identity in eval) ->
+ * RRTEncoder -> DAttention pooling (modules/datten.py) -> predictor Linear(dim, n_classes). */
+typedef struct rrt_mil_desc {
+  rrt_encoder_desc enc;
+  int32_t input_dim;       /* patch feature width (multiple of 32) */
+  int32_t emb_act;         /* RRT_ACT_RELU / RRT_ACT_GELU / RRT_ACT_NONE (RRTMIL act=) */
+  int32_t n_classes;
+  int32_t pool_hidden;     /* DAttention D = 128 (multiple of 4) */
+  int32_t pool_act;        /* RRT_ACT_RELU / GELU / TANH / NONE (da_act) */
+  int32_t pool_gated;      /* 1: AttentionGated (datten.py:40-83) */
+} rrt_mil_desc;
+
+/* Row-major fp32, state_dict layout.  Non-gated: pool_a = pool_fn.attention.attention.0,
+ * pool_c = its last Linear; gated: pool_a/pool_b/pool_c = attention_a.0 / attention_b.0 / attention_c.
+ * Biases may be NULL (da_bias=False). */
+typedef struct rrt_mil_weights {
+  rrt_encoder_weights enc;
+  const float *emb_w, *emb_b;         /* patch_to_emb.0  [dim, input_dim], [dim] */
+  const float *pool_a_w, *pool_a_b;   /* [pool_hidden, dim], [pool_hidden] */
+  const float *pool_b_w, *pool_b_b;   /* gated only */
+  const float *pool_c_w, *pool_c_b;   /* [1, pool_hidden], [1] */
+  const float *pred_w, *pred_b;       /* predictor [n_classes, dim], [n_classes] */
+} rrt_mil_weights;
+
+int rrt_mil_workspace_size(const rrt_mil_desc *desc, int64_t n_tokens, size_t *bytes);
+
+/* RRTMIL.forward (eval, one bag): x [n_tokens, input_dim] -> logits [n_classes].
+ * attn (optional, [n_tokens]): the attention row the reference returns with return_attn=True
+ * (softmax over the bag, or the raw scores when no_norm != 0).  feat (optional, [n_tokens, dim]):
+ * the encoder output. */
+int rrt_mil_forward_f32(const rrt_mil_desc *desc, const rrt_mil_weights *w, const float *x,
+                        float *logits, float *attn, int32_t no_norm, float *feat, int64_t n_tokens,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* DAttention + predictor alone on encoder features y [n_tokens, dim] (datten.py:28-38,69-83; rrt.py:241).
+ * pooled (optional, [dim]) receives the bag embedding.  workspace: rrt_pool_workspace_size bytes. */
+int rrt_pool_workspace_size(int64_t n_tokens, int32_t dim, int32_t hidden, int32_t gated, size_t *bytes);
+int rrt_pool_predict_f32(const float *y, const float *a_w, const float *a_b, const float *b_w,
+                         const float *b_b, const float *c_w, const float *c_b, const float *pred_w,
+                         const float *pred_b, float *pooled, float *logits, float *attn, int32_t no_norm,
+                         int64_t n_tokens, int32_t dim, int32_t hidden, int32_t act, int32_t n_classes,
+                         int32_t compute, void *workspace, size_t workspace_bytes, void *stream);
+
+/* nn.Linear with an activation epilogue: C = act(A . B^T + bias)   (patch_to_emb, rrt.py:208-217) */
+int rrt_linear_act_f32(const float *A, const float *B, const float *bias, float *C, int64_t M, int32_t N,
+                       int32_t K, int32_t act, int32_t compute, void *stream);
 
 #ifdef __cplusplus
 }

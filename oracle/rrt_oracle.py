@@ -242,6 +242,59 @@ def forward_eager(x, state, cfg=None):
     return x.squeeze(0)
 
 
+# --------------------------------------------------------------------------- RRTMIL (row f1) in float64
+def _act64(v, name):
+    """nn.ReLU / nn.GELU (exact erf form) / nn.Tanh; any other name = no activation layer
+    (modules/rrt.py:210-213, modules/datten.py:14-19,51-56)."""
+    if name == "relu":
+        return np.maximum(v, 0.0)
+    if name == "gelu":
+        from scipy.special import erf
+        return 0.5 * v * (1.0 + erf(v / np.sqrt(2.0)))
+    if name == "tanh":
+        return np.tanh(v)
+    return v
+
+
+def pool_predict_f64(y, state, da_act="relu", gated=False):
+    """DAttention pooling + predictor on encoder features y (N, D): modules/datten.py:28-38
+    (Attention.forward) / :69-83 (AttentionGated.forward), modules/rrt.py:241.
+    Returns (logits (n_classes,), attention (N,) softmax over the bag, raw scores (N,), pooled (D,))."""
+    st = {k: np.asarray(v, dtype=np.float64) for k, v in state.items() if k.startswith(("pool_fn.", "predictor."))}
+    y = np.asarray(y, dtype=np.float64)
+    pf = "pool_fn.attention."
+
+    def lin(v, name):
+        o = v @ st[name + ".weight"].T
+        return o + st[name + ".bias"] if name + ".bias" in st else o
+
+    if gated:
+        a = _act64(lin(y, pf + "attention_a.0"), da_act)
+        b = 1.0 / (1.0 + np.exp(-lin(y, pf + "attention_b.0")))
+        raw = lin(a * b, pf + "attention_c")[:, 0]
+    else:
+        last = 2 if da_act in ("relu", "gelu", "tanh") else 1
+        raw = lin(_act64(lin(y, pf + "attention.0"), da_act), pf + f"attention.{last}")[:, 0]
+    attn = _softmax64(raw, 0)                       # softmax over the N patches (datten.py:32)
+    pooled = attn @ y
+    logits = pooled @ st["predictor.weight"].T + st["predictor.bias"]
+    return logits, attn, raw, pooled
+
+
+def mil_forward_f64(feats, state, cfg=None):
+    """RRTMIL.forward (eval), modules/rrt.py:227-246: patch_to_emb (+act) -> RRTEncoder -> DAttention ->
+    predictor.  ``cfg``: the RRTMIL constructor kwargs; ``state``: its state_dict as arrays."""
+    cfg = dict(cfg or {})
+    f = np.asarray(feats, dtype=np.float64)
+    emb = f @ np.asarray(state["patch_to_emb.0.weight"], np.float64).T + np.asarray(state["patch_to_emb.0.bias"], np.float64)
+    emb = _act64(emb, str(cfg.get("act", "relu")).lower())
+    enc_state = {k[len("online_encoder."):]: v for k, v in state.items() if k.startswith("online_encoder.")}
+    enc_cfg = {k: v for k, v in cfg.items() if k in _DEFAULTS}
+    y = forward_f64(emb, enc_state, enc_cfg)
+    logits, attn, raw, _ = pool_predict_f64(y, state, cfg.get("da_act", "relu"), bool(cfg.get("da_gated", False)))
+    return logits, attn, raw
+
+
 def flops_per_bag(N, D=512, region_num=8, heads=8, epeg_k=15, crmsa_k=3):
     """Algorithmic FLOPs per bag, SURVEY.md §8(d) / BASELINE.md §3."""
     H, s, _ = grid(N, region_num)

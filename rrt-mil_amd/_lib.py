@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _f32p = C.POINTER(C.c_float)
 
@@ -39,6 +39,21 @@ class EncoderWeights(C.Structure):
                 ("phi", C.c_void_p), ("phi0_w", C.c_void_p), ("phi2_w", C.c_void_p),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p)]
 
+
+class MilDesc(C.Structure):
+    _fields_ = [("enc", EncoderDesc), ("input_dim", C.c_int32), ("emb_act", C.c_int32),
+                ("n_classes", C.c_int32), ("pool_hidden", C.c_int32), ("pool_act", C.c_int32),
+                ("pool_gated", C.c_int32)]
+
+
+class MilWeights(C.Structure):
+    _fields_ = [("enc", EncoderWeights)] + [(n, C.c_void_p) for n in (
+        "emb_w", "emb_b", "pool_a_w", "pool_a_b", "pool_b_w", "pool_b_b", "pool_c_w", "pool_c_b",
+        "pred_w", "pred_b")]
+
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_BY_NAME = {"relu": ACT_RELU, "gelu": ACT_GELU, "tanh": ACT_TANH}   # anything else: no activation
 
 # name -> (restype, argtypes); every symbol include/rrt_hip.h declares
 SIGNATURES = {
@@ -69,6 +84,15 @@ SIGNATURES = {
                                                               C.POINTER(Grid), C.c_void_p]),
     "rrt_crmsa_mlp_logits_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "rrt_layernorm_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p]),
+    "rrt_mil_workspace_size": (C.c_int, [C.POINTER(MilDesc), C.c_int64, C.POINTER(C.c_size_t)]),
+    "rrt_mil_forward_f32": (C.c_int, [C.POINTER(MilDesc), C.POINTER(MilWeights), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,
+                                      C.c_void_p]),
+    "rrt_pool_workspace_size": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "rrt_pool_predict_f32": (C.c_int, [C.c_void_p] * 12 + [C.c_int32, C.c_int64] + [C.c_int32] * 5 +
+                             [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rrt_linear_act_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                        C.c_void_p]),
 }
 
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2

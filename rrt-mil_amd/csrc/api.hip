@@ -413,3 +413,163 @@ int rrt_layernorm_f32(const float* x1, const float* x0, const float* gamma, cons
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ row f1: RRTMIL around the encoder
+namespace {
+
+struct PoolWs {
+  float *hid_a, *hid_b, *a_raw, *part;
+  size_t bytes;
+};
+PoolWs carve_pool(int64_t N, int dim, int hidden, int gated, char* base) {
+  PoolWs w{};
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off = align_up(off + nfloat * sizeof(float), 256);
+    return p;
+  };
+  const size_t nb = (size_t)(N + POOL_CHUNK - 1) / POOL_CHUNK;
+  w.hid_a = take((size_t)N * hidden);
+  if (gated) w.hid_b = take((size_t)N * hidden);
+  w.a_raw = take((size_t)N);
+  w.part = take(nb * ((size_t)dim + 4));
+  w.bytes = off;
+  return w;
+}
+
+int check_pool(int64_t N, int dim, int hidden, int act, int n_classes) {
+  if (N <= 0 || dim <= 0 || hidden <= 0 || n_classes <= 0) return RRT_E_INVALID;
+  if (dim % 32) return unsupported("pool: dim must be a multiple of 32");
+  if (hidden % 4) return unsupported("pool: hidden width must be a multiple of 4");
+  if (act < RRT_ACT_NONE || act > RRT_ACT_TANH) return unsupported("pool: act must be none/relu/gelu/tanh");
+  if (N > (int64_t)1000000) return unsupported("pool: bag larger than 1e6 tokens");
+  return RRT_OK;
+}
+
+int pool_predict(const float* y, const float* a_w, const float* a_b, const float* b_w, const float* b_b,
+                 const float* c_w, const float* c_b, const float* pred_w, const float* pred_b, float* pooled,
+                 float* logits, float* attn, int no_norm, int64_t N, int dim, int hidden, int act,
+                 int n_classes, int compute, const PoolWs& ws, hipStream_t st) {
+  hipError_t e;
+  LinearEpilogue ep{};
+  ep.prec = compute;
+  ep.bias = a_b;
+  ep.act = act;
+  e = launch_linear(y, a_w, ws.hid_a, (int)N, hidden, dim, ep, st);
+  if (e != hipSuccess) return (int)e;
+  if (b_w) {
+    ep.bias = b_b;
+    ep.act = RRT_ACT_SIGMOID;
+    e = launch_linear(y, b_w, ws.hid_b, (int)N, hidden, dim, ep, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  e = launch_pool_partial(y, ws.hid_a, b_w ? ws.hid_b : nullptr, c_w, c_b, ws.a_raw, ws.part, (int)N, dim,
+                          hidden, st);
+  if (e != hipSuccess) return (int)e;
+  e = launch_pool_merge(ws.part, ws.a_raw, pred_w, pred_b, pooled, logits, attn, no_norm, (int)N, dim,
+                        n_classes, st);
+  return (int)e;
+}
+
+int check_mil(const rrt_mil_desc* d, int64_t N) {
+  if (!d) return RRT_E_INVALID;
+  int rc = check_desc(&d->enc, N);
+  if (rc) return rc;
+  if (d->input_dim <= 0 || d->input_dim % 32) return unsupported("input_dim must be a positive multiple of 32");
+  if (d->emb_act != RRT_ACT_NONE && d->emb_act != RRT_ACT_RELU && d->emb_act != RRT_ACT_GELU)
+    return unsupported("emb_act must be none/relu/gelu");
+  return check_pool(N, d->enc.dim, d->pool_hidden, d->pool_act, d->n_classes);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rrt_linear_act_f32(const float* A, const float* B, const float* bias, float* C, int64_t M, int32_t N,
+                       int32_t K, int32_t act, int32_t compute, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return RRT_E_INVALID;
+  if (K % 32) return unsupported("linear: K must be a multiple of 32");
+  if (compute < 0 || compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
+  if (act < RRT_ACT_NONE || act > RRT_ACT_SIGMOID) return unsupported("unknown activation");
+  LinearEpilogue ep{};
+  ep.prec = compute;
+  ep.bias = bias;
+  ep.act = act;
+  return (int)launch_linear(A, B, C, (int)M, N, K, ep, (hipStream_t)stream);
+}
+
+int rrt_pool_workspace_size(int64_t n_tokens, int32_t dim, int32_t hidden, int32_t gated, size_t* bytes) {
+  if (!bytes) return RRT_E_INVALID;
+  int rc = check_pool(n_tokens, dim, hidden, RRT_ACT_NONE, 1);
+  if (rc) return rc;
+  *bytes = carve_pool(n_tokens, dim, hidden, gated, nullptr).bytes;
+  return RRT_OK;
+}
+
+int rrt_pool_predict_f32(const float* y, const float* a_w, const float* a_b, const float* b_w, const float* b_b,
+                         const float* c_w, const float* c_b, const float* pred_w, const float* pred_b,
+                         float* pooled, float* logits, float* attn, int32_t no_norm, int64_t n_tokens,
+                         int32_t dim, int32_t hidden, int32_t act, int32_t n_classes, int32_t compute,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!y || !a_w || !c_w || !pred_w || !logits) return RRT_E_INVALID;
+  int rc = check_pool(n_tokens, dim, hidden, act, n_classes);
+  if (rc) return rc;
+  if (compute < 0 || compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
+  const int gated = b_w != nullptr;
+  if (!workspace || workspace_bytes < carve_pool(n_tokens, dim, hidden, gated, nullptr).bytes) return RRT_E_WORKSPACE;
+  PoolWs ws = carve_pool(n_tokens, dim, hidden, gated, (char*)workspace);
+  return pool_predict(y, a_w, a_b, b_w, b_b, c_w, c_b, pred_w, pred_b, pooled, logits, attn, no_norm, n_tokens,
+                      dim, hidden, act, n_classes, compute, ws, (hipStream_t)stream);
+}
+
+int rrt_mil_workspace_size(const rrt_mil_desc* desc, int64_t n_tokens, size_t* bytes) {
+  if (!bytes) return RRT_E_INVALID;
+  int rc = check_mil(desc, n_tokens);
+  if (rc) return rc;
+  size_t enc = 0;
+  rc = rrt_encoder_workspace_size(&desc->enc, n_tokens, &enc);
+  if (rc) return rc;
+  const size_t act = align_up((size_t)n_tokens * desc->enc.dim * sizeof(float), 256);
+  *bytes = 2 * act + align_up(enc, 256) +
+           carve_pool(n_tokens, desc->enc.dim, desc->pool_hidden, desc->pool_gated, nullptr).bytes;
+  return RRT_OK;
+}
+
+int rrt_mil_forward_f32(const rrt_mil_desc* desc, const rrt_mil_weights* w, const float* x, float* logits,
+                        float* attn, int32_t no_norm, float* feat, int64_t n_tokens, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  if (!desc || !w || !x || !logits) return RRT_E_INVALID;
+  int rc = check_mil(desc, n_tokens);
+  if (rc) return rc;
+  if (!w->emb_w || !w->pool_a_w || !w->pool_c_w || !w->pred_w || (desc->pool_gated && !w->pool_b_w))
+    return RRT_E_INVALID;
+  size_t need = 0, enc_bytes = 0;
+  rc = rrt_mil_workspace_size(desc, n_tokens, &need);
+  if (rc) return rc;
+  if (!workspace || workspace_bytes < need) return RRT_E_WORKSPACE;
+  rc = rrt_encoder_workspace_size(&desc->enc, n_tokens, &enc_bytes);
+  if (rc) return rc;
+  const int D = desc->enc.dim;
+  const size_t act = align_up((size_t)n_tokens * D * sizeof(float), 256);
+  char* base = (char*)workspace;
+  float* emb = (float*)base;
+  float* y = feat ? feat : (float*)(base + act);
+  char* enc_ws = base + 2 * act;
+  PoolWs pws = carve_pool(n_tokens, D, desc->pool_hidden, desc->pool_gated, enc_ws + align_up(enc_bytes, 256));
+  hipStream_t st = (hipStream_t)stream;
+
+  LinearEpilogue ep{};
+  ep.prec = desc->enc.compute;
+  ep.bias = w->emb_b;
+  ep.act = desc->emb_act;
+  hipError_t e = launch_linear(x, w->emb_w, emb, (int)n_tokens, D, desc->input_dim, ep, st);
+  if (e != hipSuccess) return (int)e;
+  rc = rrt_encoder_forward_f32(&desc->enc, &w->enc, emb, y, n_tokens, enc_ws, enc_bytes, stream);
+  if (rc) return rc;
+  return pool_predict(y, w->pool_a_w, w->pool_a_b, desc->pool_gated ? w->pool_b_w : nullptr, w->pool_b_b,
+                      w->pool_c_w, w->pool_c_b, w->pred_w, w->pred_b, nullptr, logits, attn, no_norm, n_tokens,
+                      D, desc->pool_hidden, desc->pool_act, desc->n_classes, desc->enc.compute, pws, st);
+}
+
+}  // extern "C"

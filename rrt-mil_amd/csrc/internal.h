@@ -14,6 +14,7 @@ struct LinearEpilogue {
   const float* bias;     // [N] or null
   int q_cols;            // columns [0,q_cols) scaled by q_scale after bias
   float q_scale;
+  int act;               // RRT_ACT_* applied last (0 = none)
   // un-partition + residual (used when resid != null): C row = token, A row = slot
   const float* resid;
   GridDev g;
@@ -46,3 +47,13 @@ hipError_t launch_crmsa_dispatch_ln(const float* x1, const float* x0, const floa
                                     hipStream_t st);
 hipError_t launch_layernorm(const float* x1, const float* x0, const float* gamma,
                             const float* beta, float* y, int L, int dim, hipStream_t st);
+
+// ABMIL attention pooling behind the encoder (modules/datten.py:28-38,69-83) + predictor (rrt.py:241):
+// per-chunk scores and online-softmax partials, then one merge block
+constexpr int POOL_CHUNK = 32;   // tokens per partial
+hipError_t launch_pool_partial(const float* y, const float* hid_a, const float* hid_b, const float* wc,
+                               const float* bc, float* a_raw, float* part, int N, int dim, int hid,
+                               hipStream_t st);
+hipError_t launch_pool_merge(const float* part, const float* a_raw, const float* pred_w, const float* pred_b,
+                             float* pooled, float* logits, float* attn, int no_norm, int N, int dim,
+                             int n_classes, hipStream_t st);

@@ -89,10 +89,26 @@ struct Frag8<PREC_F16> {
 #define RRT_EPI_TRACE_ARG
 #define RRT_EPI_TRACE_PASS
 #endif
-template <int MT, int NT, bool UNPART>
+// Epilogue flavours (template MODE): plain store; un-partition + residual; activation.
+constexpr int MODE_PLAIN = 0, MODE_UNPART = 1, MODE_ACT = 2;
+
+// Elementwise activation of the epilogue (RRT_ACT_*; callers of the hot path: patch_to_emb's ReLU/GELU
+// modules/rrt.py:208-217, DAttention's hidden activation / gate modules/datten.py:14-22,52-62).
+__device__ __forceinline__ float activate(float v, int act) {
+  switch (act) {
+    case RRT_ACT_RELU: return v > 0.f ? v : 0.f;
+    case RRT_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    case RRT_ACT_TANH: return tanhf(v);
+    case RRT_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+template <int MT, int NT, int MODE>
 __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT][NT], float* __restrict__ C, int M, int N,
                                            int m0, int n0, int wave, int lr, int lg,
                                            const LinearEpilogue& ep RRT_EPI_TRACE_ARG) {
+  constexpr bool UNPART = MODE == MODE_UNPART, ACT = MODE == MODE_ACT;
   const bool vec = (N & 3) == 0;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -120,6 +136,10 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT][NT], float* __
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (acc[i][j][r] + bias[r]) * scale[r];
+      if constexpr (ACT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = activate(v[r], ep.act);
+      }
       float* dst = C + row * N + nb;
       if (vec && nb + 3 < N) {
         if (UNPART) {
@@ -143,10 +163,11 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT][NT], float* __
 // One 16-row slice (row tile I) of an output tile: the deferred epilogue of linear_ws_kernel issues
 // these one per K iteration of the block's NEXT tile, so the chip never sees all blocks bursting
 // their whole tiles at once (measured: ~1.2K cycles to issue ONE store while HBM writes saturate).
-template <int MT, int NT, bool UNPART, int I>
+template <int MT, int NT, int MODE, int I>
 __device__ __forceinline__ void store_slice(const f32x4 (&acc)[MT][NT], const float (&bias)[NT][4],
                                             float* __restrict__ C, int M, int N, int m0, int n0, int wave,
                                             int lr, int lg, const LinearEpilogue& ep) {
+  constexpr bool UNPART = MODE == MODE_UNPART, ACT = MODE == MODE_ACT;
   const int m = m0 + I * 16 + lr;
   if (m >= M) return;
   size_t row = (size_t)m;
@@ -162,6 +183,10 @@ __device__ __forceinline__ void store_slice(const f32x4 (&acc)[MT][NT], const fl
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = (acc[I][j][r] + bias[j][r]) * ((nb + r < ep.q_cols) ? ep.q_scale : 1.0f);
+    if constexpr (ACT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = activate(v[r], ep.act);
+    }
     float* dst = C + row * N + nb;
     if (vec && nb + 3 < N) {
       if (UNPART) {
@@ -177,17 +202,17 @@ __device__ __forceinline__ void store_slice(const f32x4 (&acc)[MT][NT], const fl
   }
 }
 
-template <int MT, int NT, bool UNPART, int I = 0>
+template <int MT, int NT, int MODE, int I = 0>
 __device__ __forceinline__ void store_all_slices(const f32x4 (&acc)[MT][NT], const float (&bias)[NT][4],
                                                  float* __restrict__ C, int M, int N, int m0, int n0,
                                                  int wave, int lr, int lg, const LinearEpilogue& ep) {
   if constexpr (I < MT) {
-    store_slice<MT, NT, UNPART, I>(acc, bias, C, M, N, m0, n0, wave, lr, lg, ep);
-    store_all_slices<MT, NT, UNPART, I + 1>(acc, bias, C, M, N, m0, n0, wave, lr, lg, ep);
+    store_slice<MT, NT, MODE, I>(acc, bias, C, M, N, m0, n0, wave, lr, lg, ep);
+    store_all_slices<MT, NT, MODE, I + 1>(acc, bias, C, M, N, m0, n0, wave, lr, lg, ep);
   }
 }
 
-template <int MT, int NT, bool UNPART, int PREC>
+template <int MT, int NT, int MODE, int PREC>
 __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict__ A,
                                                         const float* __restrict__ B,
                                                         float* __restrict__ C, int M, int N, int K,
@@ -338,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
       }
     }
 
-    store_tile<MT, NT, UNPART>(acc, C, M, N, m0, n0, wave, lr, lg, ep RRT_EPI_TRACE_PASS);
+    store_tile<MT, NT, MODE>(acc, C, M, N, m0, n0, wave, lr, lg, ep RRT_EPI_TRACE_PASS);
     tm = ntm;
     tn = ntn;
   }
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
 // (measured: ~10 us per tile that two co-resident blocks hit in lockstep).  Here the loader waves
 // own every DMA and every vmcnt wait; the compute waves never wait on vector memory, so their
 // stores drain underneath the next tile's MFMAs.  One s_barrier per K tile, shared by all 6 waves.
-template <int MT, int NT, bool UNPART, int PREC>
+template <int MT, int NT, int MODE, int PREC>
 __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restrict__ A,
                                                            const float* __restrict__ B,
                                                            float* __restrict__ C, int M, int N, int K,
@@ -517,7 +542,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
       // one 16-row slice of the PREVIOUS tile per K iteration (behind this iteration's MFMAs)
       // (static register indexing: always slice 0, then rotate the remaining slices down)
       if (have_prev && kt < MT) {
-        store_slice<MT, NT, UNPART, 0>(prev, pbias, C, M, N, pm0 + kt * 16, pn0, wave, lr, lg, ep);
+        store_slice<MT, NT, MODE, 0>(prev, pbias, C, M, N, pm0 + kt * 16, pn0, wave, lr, lg, ep);
 #pragma unroll
         for (int i = 0; i + 1 < MT; ++i)
 #pragma unroll
@@ -526,7 +551,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
     }
     if (have_prev)                        // K shorter than MT iterations: flush what is left
       for (int i = nk; i < MT; ++i) {
-        store_slice<MT, NT, UNPART, 0>(prev, pbias, C, M, N, pm0 + i * 16, pn0, wave, lr, lg, ep);
+        store_slice<MT, NT, MODE, 0>(prev, pbias, C, M, N, pm0 + i * 16, pn0, wave, lr, lg, ep);
 #pragma unroll
         for (int q = 0; q + 1 < MT; ++q)
 #pragma unroll
@@ -550,10 +575,10 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
     RRT_TRACE_MARK();
   }
   // the block's last tile has no successor to hide behind
-  if (have_prev) store_all_slices<MT, NT, UNPART>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
+  if (have_prev) store_all_slices<MT, NT, MODE>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
 }
 
-template <int MT, int NT, bool UNPART, int PREC>
+template <int MT, int NT, int MODE, int PREC>
 hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, int K, int grid_cap,
                       const LinearEpilogue& ep, hipStream_t st) {
   constexpr int BM = 16 * MT, BN = 64 * NT;
@@ -565,7 +590,7 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
   if constexpr (MT >= 8) {
     static const bool use_ws = getenv("RRT_LINEAR_NO_WS") == nullptr;
     if (use_ws) {
-      auto kws = linear_ws_kernel<MT, NT, UNPART, PREC>;
+      auto kws = linear_ws_kernel<MT, NT, MODE, PREC>;
       if (LDS_BYTES > 64 * 1024) {
         static bool donew = false;
         if (!donew) {
@@ -577,7 +602,7 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
       return hipGetLastError();
     }
   }
-  auto kern = linear_kernel<MT, NT, UNPART, PREC>;
+  auto kern = linear_kernel<MT, NT, MODE, PREC>;
   if (LDS_BYTES > 64 * 1024) {
     static bool done = false;   // benign race: idempotent attribute
     if (!done) {
@@ -623,17 +648,16 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
                          const LinearEpilogue& ep, hipStream_t st) {
   const bool u = ep.resid != nullptr;
   const Cfg c = choose(M, N);
-#define RRT_CASE(MT_, NT_)                                                                  \
-  if (c.mt == MT_ && c.nt == NT_) {                                                         \
-    if (ep.prec == PREC_BF16)                                                               \
-      return u ? launch_cfg<MT_, NT_, true, PREC_BF16>(A, B, C, M, N, K, c.cap, ep, st)     \
-               : launch_cfg<MT_, NT_, false, PREC_BF16>(A, B, C, M, N, K, c.cap, ep, st);   \
-    if (ep.prec == PREC_F16)                                                                \
-      return u ? launch_cfg<MT_, NT_, true, PREC_F16>(A, B, C, M, N, K, c.cap, ep, st)      \
-               : launch_cfg<MT_, NT_, false, PREC_F16>(A, B, C, M, N, K, c.cap, ep, st);    \
-    return u ? launch_cfg<MT_, NT_, true, PREC_F32>(A, B, C, M, N, K, c.cap, ep, st)        \
-             : launch_cfg<MT_, NT_, false, PREC_F32>(A, B, C, M, N, K, c.cap, ep, st);      \
+#define RRT_CASE(MT_, NT_)                                                                          \
+  if (c.mt == MT_ && c.nt == NT_) {                                                                 \
+    if (ep.prec == PREC_BF16) return RRT_MODES(MT_, NT_, PREC_BF16);                                \
+    if (ep.prec == PREC_F16) return RRT_MODES(MT_, NT_, PREC_F16);                                  \
+    return RRT_MODES(MT_, NT_, PREC_F32);                                                           \
   }
+#define RRT_MODES(MT_, NT_, P_)                                                                     \
+  (u ? launch_cfg<MT_, NT_, MODE_UNPART, P_>(A, B, C, M, N, K, c.cap, ep, st)                       \
+     : ep.act ? launch_cfg<MT_, NT_, MODE_ACT, P_>(A, B, C, M, N, K, c.cap, ep, st)                 \
+              : launch_cfg<MT_, NT_, MODE_PLAIN, P_>(A, B, C, M, N, K, c.cap, ep, st))
   RRT_CASE(9, 1);
   RRT_CASE(8, 1);
   RRT_CASE(9, 2);
@@ -641,5 +665,6 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
   RRT_CASE(4, 1);
   RRT_CASE(2, 1);
 #undef RRT_CASE
+#undef RRT_MODES
   return hipErrorInvalidValue;
 }

@@ -6,13 +6,19 @@ path) -> DAttention pooling -> predictor.  Same constructor, parameter names and
 forward signature, so reference checkpoints load with strict=True.
 
 Row f1 of SURVEY.md §8: the prologue / pooling / predictor are the *callers* of the hot
-path; here they are plain PyTorch-ROCm ops (a [N,in]x[in,512] GEMM and an N x 128 GEMV
-chain), not yet fused into the HIP kernels.
+path.  For the form every reference trainer uses -- one bag (1, N, input_dim), eval -- the whole
+classifier is ONE C-ABI call (`rrt_mil_forward_f32`): patch_to_emb on the fp32 matrix cores with
+the activation in the GEMM epilogue, the encoder, and DAttention pooling + predictor as an online
+softmax over token chunks (csrc/mil_pool.hip).  The nn.Module tree below is the parameter store
+(reference names) and the composite path for other input ranks.
 """
+import ctypes as C
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib
 from .encoder import RRTEncoder, initialize_weights
 
 
@@ -106,8 +112,81 @@ class RRTMIL(nn.Module):
         self.predictor = nn.Linear(self.online_encoder.final_dim, n_classes)
         self.apply(initialize_weights)
 
+        self._act_name = act.lower() if act.lower() in ("relu", "gelu") else "none"
+        self._da_act = da_act
+        self._ws = None
+
+    # ------------------------------------------------------------------ the one-call HIP path
+    def _mil_desc(self, input_dim):
+        enc = self.online_encoder
+        d = _lib.MilDesc()
+        C.memmove(C.byref(d.enc), C.byref(enc._desc), C.sizeof(_lib.EncoderDesc))
+        d.enc.compute = enc._compute_mode()
+        d.input_dim = input_dim
+        d.emb_act = _lib.ACT_BY_NAME.get(self._act_name, _lib.ACT_NONE)
+        d.n_classes = self.predictor.out_features
+        att = self.pool_fn.attention
+        d.pool_hidden = att.D
+        d.pool_act = _lib.ACT_BY_NAME.get(self._da_act, _lib.ACT_NONE)
+        d.pool_gated = int(self.pool_fn.gated)
+        return d
+
+    def _mil_weights(self):
+        enc, p = self.online_encoder, RRTEncoder._ptr
+        w = _lib.MilWeights()
+        w.enc = enc._weights()
+        lin = self.patch_to_emb[0]
+        w.emb_w, w.emb_b = p(lin.weight), p(lin.bias)
+        att = self.pool_fn.attention
+        if self.pool_fn.gated:
+            a, b, c = att.attention_a[0], att.attention_b[0], att.attention_c
+            w.pool_b_w, w.pool_b_b = p(b.weight), p(b.bias)
+        else:
+            a, c = att.attention[0], att.attention[-1]
+        w.pool_a_w, w.pool_a_b = p(a.weight), p(a.bias)
+        w.pool_c_w, w.pool_c_b = p(c.weight), p(c.bias)
+        w.pred_w, w.pred_b = p(self.predictor.weight), p(self.predictor.bias)
+        return w
+
+    def forward_bag(self, x2d, return_attn=False, no_norm=False):
+        """One bag: x2d (N, input_dim) fp32 device tensor -> logits (n_classes,) [, attention (N,)]."""
+        lib = _lib.load()
+        if not x2d.is_cuda:
+            raise _lib.RRTHipError("rrt_mil_amd.RRTMIL runs on MI355X only: move the bag to a 'cuda' (HIP) "
+                                   "device; there is no CPU fallback")
+        if self.training and (self.online_encoder.drop_out > 0 or isinstance(self.dp, nn.Dropout)):
+            raise NotImplementedError("training-mode forward (dropout + autograd) is not built; call .eval()")
+        if x2d.dtype in (torch.bfloat16, torch.float16):
+            x2d = x2d.float()
+        if x2d.dtype != torch.float32:
+            raise NotImplementedError(f"unsupported bag dtype {x2d.dtype}")
+        x2d = x2d.contiguous()
+        n, in_dim = x2d.shape
+        if in_dim != self.patch_to_emb[0].in_features:
+            raise ValueError(f"expected feature dim {self.patch_to_emb[0].in_features}, got {in_dim}")
+        d, w = self._mil_desc(in_dim), self._mil_weights()
+        need = C.c_size_t()
+        _lib.check(lib.rrt_mil_workspace_size(C.byref(d), n, C.byref(need)), "rrt_mil_workspace_size")
+        if self._ws is None or self._ws.device != x2d.device or self._ws.numel() < need.value:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=x2d.device)
+        logits = torch.empty(d.n_classes, dtype=torch.float32, device=x2d.device)
+        attn = torch.empty(n, dtype=torch.float32, device=x2d.device) if return_attn else None
+        rc = lib.rrt_mil_forward_f32(C.byref(d), C.byref(w), x2d.data_ptr(), logits.data_ptr(),
+                                     attn.data_ptr() if return_attn else None, int(bool(no_norm)), None, n,
+                                     self._ws.data_ptr(), self._ws.numel(),
+                                     torch.cuda.current_stream(x2d.device).cuda_stream)
+        _lib.check(rc, "rrt_mil_forward_f32")
+        return (logits, attn) if return_attn else logits
+
     @torch.no_grad()
     def forward(self, x, return_attn=False, no_norm=False):
+        if x.dim() == 3 and x.size(0) == 1 and x.is_cuda:
+            # (1, N, input_dim): the form of every reference trainer -> one library call
+            out = self.forward_bag(x[0], return_attn=return_attn, no_norm=no_norm)
+            if return_attn:
+                return out[0].unsqueeze(0), out[1].unsqueeze(0)
+            return out.unsqueeze(0)
+        # other ranks: the reference's op sequence around the HIP encoder
         x = self.dp(self.patch_to_emb(x))                 # (1, N, 512)
         x = self.online_encoder(x)                        # feature re-embedding: the HIP path
         if return_attn:

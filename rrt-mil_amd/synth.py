@@ -106,20 +106,31 @@ def bag(n_tokens: int, dim: int = 512, tag: str = "bag", nonneg: bool = False) -
     return np.maximum(x, 0.0) if nonneg else x
 
 
-def mil_state(input_dim=1024, n_classes=2, da_bias=False, **enc_cfg):
+def mil_state(input_dim=1024, n_classes=2, da_bias=False, da_gated=False, da_act="relu", **enc_cfg):
     """Closed-form parameters of RRTMIL (modules/rrt.py:204-225): encoder state under
-    ``online_encoder.`` plus patch_to_emb / pool_fn / predictor tensors."""
+    ``online_encoder.`` plus patch_to_emb / pool_fn / predictor tensors (state_dict names of
+    modules/datten.py: ``attention.{0,2}`` -- ``{0,1}`` without an activation -- or the gated
+    ``attention_a.0 / attention_b.0 / attention_c``)."""
     out = {"patch_to_emb.0.weight": uniform("mil/fc.w", (512, input_dim), -1, 1) / np.sqrt(input_dim),
            "patch_to_emb.0.bias": uniform("mil/fc.b", (512,), -0.05, 0.05)}
     out = {k: v.astype(np.float32) for k, v in out.items()}
     for k, v in encoder_state(**enc_cfg).items():
         out["online_encoder." + k] = v
     D = enc_cfg.get("mlp_dim", 512)
-    out["pool_fn.attention.attention.0.weight"] = (uniform("mil/da0", (128, D), -1, 1) / np.sqrt(D)).astype(np.float32)
-    out["pool_fn.attention.attention.2.weight"] = (uniform("mil/da2", (1, 128), -1, 1) / np.sqrt(128) * 4).astype(np.float32)
+    w0 = (uniform("mil/da0", (128, D), -1, 1) / np.sqrt(D)).astype(np.float32)
+    w2 = (uniform("mil/da2", (1, 128), -1, 1) / np.sqrt(128) * 4).astype(np.float32)
+    if da_gated:
+        names = ("pool_fn.attention.attention_a.0", "pool_fn.attention.attention_c")
+        out["pool_fn.attention.attention_b.0.weight"] = (uniform("mil/dab", (128, D), -1, 1) / np.sqrt(D)).astype(np.float32)
+        if da_bias:
+            out["pool_fn.attention.attention_b.0.bias"] = uniform("mil/dabb", (128,), -0.05, 0.05)
+    else:
+        last = 2 if da_act in ("relu", "gelu", "tanh") else 1
+        names = ("pool_fn.attention.attention.0", f"pool_fn.attention.attention.{last}")
+    out[names[0] + ".weight"], out[names[1] + ".weight"] = w0, w2
     if da_bias:
-        out["pool_fn.attention.attention.0.bias"] = uniform("mil/da0b", (128,), -0.05, 0.05)
-        out["pool_fn.attention.attention.2.bias"] = uniform("mil/da2b", (1,), -0.05, 0.05)
+        out[names[0] + ".bias"] = uniform("mil/da0b", (128,), -0.05, 0.05)
+        out[names[1] + ".bias"] = uniform("mil/da2b", (1,), -0.05, 0.05)
     out["predictor.weight"] = (uniform("mil/pred.w", (n_classes, D), -1, 1) / np.sqrt(D)).astype(np.float32)
     out["predictor.bias"] = uniform("mil/pred.b", (n_classes,), -0.05, 0.05)
     return out

@@ -212,7 +212,7 @@ def test_crmsa_stages(L, D, k):
 
 
 # ------------------------------------------------------------------ whole path
-SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G7", "G8")) and "mlp" not in n]
+SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G7", "G8", "G11")) and "mlp" not in n]
 # crmsa_mlp needs dim % 128 == 0 on the HIP path (hidden = dim/4 is a GEMM K): D=64 golden is out of range
 
 
@@ -358,6 +358,118 @@ def test_rrtmil_matches_reference(name):
     _cmp(logits.cpu().numpy(), g["logits"], 1e-4, name + " logits")
     _cmp(attn.cpu().numpy(), g["attn"], 1e-6, name + " attention")    # softmax weights ~1/N
     assert torch.equal(mil(feats), logits)
+
+
+# ------------------------------------------------------------------ row f1: RRTMIL around the encoder
+@pytest.mark.parametrize("act", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(9000, 512, 1024), (1000, 130, 96), (9000, 128, 512)])
+def test_linear_act(M, N, K, act):
+    """nn.Linear + activation in the GEMM epilogue (patch_to_emb rrt.py:208-217, DAttention datten.py:14-22)."""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    A = synth.normal(f"act/A{M}x{K}", (M, K))
+    B = synth.uniform(f"act/B{N}x{K}", (N, K), -1, 1) / np.sqrt(K) * 2
+    bias = synth.uniform(f"act/b{N}", (N,), -0.5, 0.5)
+    dA, dB, db = dev(A), dev(B), dev(bias)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    _lib.check(lib.rrt_linear_act_f32(p(dA), p(dB), p(db), p(out), M, N, K, act, 0, stream()), "linear_act")
+    torch.cuda.synchronize()
+    z = A.astype(np.float64) @ B.astype(np.float64).T + bias
+    name = {1: "relu", 2: "gelu", 3: "tanh"}.get(act)
+    ref = O._act64(z, name) if name else 1.0 / (1.0 + np.exp(-z))
+    _cmp(out.cpu().numpy(), ref, 2e-5, f"linear+act{act} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("N,D,gated,bias,act,ncls", [(9000, 512, False, False, "relu", 2), (9000, 512, True, True, "tanh", 4),
+                                                     (1, 512, False, True, "gelu", 2), (31, 64, True, False, "relu", 3),
+                                                     (33, 512, False, False, "none", 1), (30000, 512, False, True, "tanh", 2),
+                                                     (1000, 1024, True, True, "gelu", 5)])
+def test_pool_predict(N, D, gated, bias, act, ncls):
+    """DAttention pooling + predictor (online softmax over token chunks) against the float64 restatement of
+    datten.py:28-38 / :69-83 and rrt.py:241; both forms of the returned attention row."""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    st = synth.mil_state(input_dim=64, n_classes=ncls, da_bias=bias, da_gated=gated, da_act=act, mlp_dim=D)
+    st = {k: v for k, v in st.items() if k.startswith(("pool_fn.", "predictor."))}
+    y = synth.normal(f"pool/y{N}x{D}", (N, D)) * 1.5
+    # a few dominant tokens: the softmax over the bag must be far from uniform somewhere
+    y[:: max(1, N // 7)] *= 4.0
+    logits_ref, attn_ref, raw_ref, pooled_ref = O.pool_predict_f64(y, st, act, gated)
+    pf = "pool_fn.attention."
+    if gated:
+        na, nb_, nc = pf + "attention_a.0", pf + "attention_b.0", pf + "attention_c"
+    else:
+        na, nb_, nc = pf + "attention.0", None, pf + ("attention.2" if act in ("relu", "gelu", "tanh") else "attention.1")
+    d = {k: dev(v) for k, v in st.items()}
+    g = lambda n: d.get(n) if n else None
+    need = C.c_size_t()
+    _lib.check(lib.rrt_pool_workspace_size(N, D, 128, int(gated), C.byref(need)), "pool ws")
+    ws = torch.full((need.value,), 0xFF, dtype=torch.uint8, device=DEV)       # NaN-poisoned workspace
+    dy = dev(y)
+    for no_norm in (0, 1):
+        pooled = torch.full((D,), float("nan"), device=DEV)
+        logits = torch.full((ncls,), float("nan"), device=DEV)
+        attn = torch.full((N,), float("nan"), device=DEV)
+        rc = lib.rrt_pool_predict_f32(p(dy), p(g(na + ".weight")), p(g(na + ".bias")),
+                                      p(g(nb_ + ".weight")) if nb_ else None, p(g(nb_ + ".bias")) if nb_ else None,
+                                      p(g(nc + ".weight")), p(g(nc + ".bias")), p(d["predictor.weight"]),
+                                      p(d["predictor.bias"]), p(pooled), p(logits), p(attn), no_norm, N, D, 128,
+                                      _lib.ACT_BY_NAME.get(act, 0), ncls, 0, p(ws), ws.numel(), stream())
+        _lib.check(rc, "pool_predict")
+        torch.cuda.synchronize()
+        # peaked softmax: an fp32 score error d moves every weight by a factor e^d -> tolerance relative
+        # to the magnitude of the result
+        scale = max(1.0, float(np.abs(pooled_ref).max()))
+        _cmp(pooled.cpu().numpy(), pooled_ref, 2e-5 * scale, "pooled")
+        _cmp(logits.cpu().numpy(), logits_ref, 2e-5 * scale, "logits")
+        if no_norm:
+            _cmp(attn.cpu().numpy(), raw_ref, 2e-5, "raw scores")
+        else:
+            got = attn.cpu().numpy()
+            assert abs(got.astype(np.float64).sum() - 1.0) < 1e-5
+            assert np.abs(got - attn_ref).max() <= 1e-6 + 1e-5 * attn_ref.max()
+
+
+@pytest.mark.parametrize("name", golden_names("G11"))
+def test_rrtmil_variants_match_reference(name):
+    """RRTMIL constructor variants (gated / bias / activations / n_classes / input_dim) through the one-call
+    HIP path (rrt_mil_forward_f32) against the real reference's logits, attention and raw scores."""
+    from hip_util import DEV, dev
+    from rrt_mil_amd import RRTMIL
+    g = load_golden(name)
+    cfg, N = g["cfg"], int(g["n"])
+    enc_keys = {k: v for k, v in cfg.items() if k in ("epeg_k", "crmsa_k")}
+    st = synth.mil_state(input_dim=cfg["input_dim"], n_classes=cfg["n_classes"], da_bias=cfg.get("da_bias", False),
+                         da_gated=cfg.get("da_gated", False), da_act=cfg.get("da_act", "relu"), **enc_keys)
+    mil = RRTMIL(**cfg).eval()
+    mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    mil = mil.to(DEV)
+    feats = dev(synth.bag(N, cfg["input_dim"], tag="mil/" + name[len("G11_rrtmil_"):], nonneg=True)).unsqueeze(0)
+    logits, attn = mil(feats, return_attn=True)
+    _, raw = mil(feats, return_attn=True, no_norm=True)
+    torch.cuda.synchronize()
+    assert logits.shape == (1, cfg["n_classes"]) and attn.shape == (1, N) and raw.shape == (1, N)
+    _cmp(logits.cpu().numpy(), g["logits"], 1e-4, name + " logits")
+    _cmp(attn.cpu().numpy(), g["attn"], 1e-6, name + " attention")
+    _cmp(raw.cpu().numpy(), g["attn_raw"], 1e-4, name + " raw scores")
+    # the composite path (other input ranks: reference op sequence in torch around the HIP encoder) agrees
+    with torch.no_grad():
+        x2 = mil.dp(mil.patch_to_emb(feats))
+        y2 = mil.online_encoder(x2)
+        l2 = mil.predictor(mil.pool_fn(y2))
+    _cmp(l2.cpu().numpy(), logits.cpu().numpy(), 1e-4, name + " composite vs one-call")
+
+
+def test_rrtmil_fails_loudly():
+    from rrt_mil_amd import RRTMIL
+    mil = RRTMIL(input_dim=64, n_classes=2).eval()
+    with pytest.raises(_lib.RRTHipError):
+        mil.forward_bag(torch.zeros(10, 64))                 # CPU tensor: no fallback
+    mil = mil.to("cuda:0")
+    with pytest.raises(ValueError):
+        mil.forward_bag(torch.zeros(10, 96, device="cuda:0"))
+    with pytest.raises(NotImplementedError):
+        mil.train()(torch.zeros(1, 10, 64, device="cuda:0"))
 
 
 # ------------------------------------------------------------------ reduced-precision operand modes

@@ -79,7 +79,13 @@ def checksums(y):
     return np.array([y64.sum(), np.abs(y64).sum(), np.abs(y64).max()])
 
 
+ONLY = os.environ.get("GOLDEN_ONLY")    # e.g. GOLDEN_ONLY=G11: rewrite only fixtures with this prefix
+
+
 def save(name, **arrs):
+    if ONLY and not name.startswith(ONLY):
+        print(f"{name}: kept (GOLDEN_ONLY={ONLY})")
+        return
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrs)
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB", {k: getattr(v, 'shape', None) for k, v in arrs.items()})
@@ -199,6 +205,31 @@ def main():
         with torch.no_grad():
             logits, attn = mil(torch.from_numpy(feats).unsqueeze(0), return_attn=True)
         save(f"G8_rrtmil_n{N}", cfg=cfg_array(cfg), n=np.array(N), logits=logits.numpy(), attn=attn.numpy())
+
+    # G11: RRTMIL caller variants (modules/datten.py gated / bias / activations, rrt.py act=, n_classes,
+    # input_dim), with both forms of the returned attention row (normalised / no_norm raw scores)
+    mil_variants = {
+        "gated_tanh_bias": (1500, dict(input_dim=1024, n_classes=4, act="gelu", da_gated=True, da_act="tanh",
+                                       da_bias=True, epeg_k=15, crmsa_k=3)),
+        "gelu_bias": (700, dict(input_dim=512, n_classes=2, act="relu", da_act="gelu", da_bias=True,
+                                epeg_k=9, crmsa_k=1, all_shortcut=True)),
+        "noact": (300, dict(input_dim=96, n_classes=3, act="none", da_act="none", epeg_k=15, crmsa_k=3)),
+        "gated_relu": (2500, dict(input_dim=1024, n_classes=2, act="relu", da_gated=True, da_act="relu",
+                                  epeg_k=15, crmsa_k=3)),
+    }
+    for tag, (N, cfg) in mil_variants.items():
+        enc_keys = {k: v for k, v in cfg.items() if k in ("epeg_k", "crmsa_k")}
+        st = synth.mil_state(input_dim=cfg["input_dim"], n_classes=cfg["n_classes"],
+                             da_bias=cfg.get("da_bias", False), da_gated=cfg.get("da_gated", False),
+                             da_act=cfg["da_act"], **enc_keys)
+        mil = RefMIL(**cfg).eval()
+        mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+        feats = synth.bag(N, cfg["input_dim"], tag="mil/" + tag, nonneg=True)
+        with torch.no_grad():
+            logits, attn = mil(torch.from_numpy(feats).unsqueeze(0), return_attn=True)
+            _, raw = mil(torch.from_numpy(feats).unsqueeze(0), return_attn=True, no_norm=True)
+        save(f"G11_rrtmil_{tag}", cfg=cfg_array(cfg), n=np.array(N), logits=logits.numpy(), attn=attn.numpy(),
+             attn_raw=raw.numpy())
 
     # G9: awkward sizes / geometry escapes at D=64 (cheap): N around grid boundaries, the
     # min_region_num / min_region_ratio "give up region attention" branch (rmsa.py:191-196),
