@@ -228,6 +228,33 @@ def main():
                        "the Linear layers / fused projection, fp32 accumulate)"}
         enc._desc.compute = _lib.COMPUTE_F32
 
+    # informational: the whole slide classifier of BASELINE configs[2] (C16-R50 shape) through the one-call
+    # path (row f1): N=9000 x 1024 features -> fc 512 + ReLU -> encoder(crmsa_k=1, all_shortcut) ->
+    # DAttention -> predictor; one bag in flight, fp32.  Not the headline value.
+    mil_rec = None
+    if rank == 0:
+        from rrt_mil_amd import RRTMIL
+        mcfg = dict(input_dim=1024, n_classes=2, epeg_k=15, crmsa_k=1, all_shortcut=True)
+        mil = RRTMIL(**mcfg).eval()
+        mst = synth.mil_state(input_dim=1024, n_classes=2, epeg_k=15, crmsa_k=1)
+        mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in mst.items()}, strict=True)
+        mil = mil.to(dev)
+        feats = torch.from_numpy(synth.bag(N_TOKENS, 1024, tag="mil", nonneg=True)).to(dev).unsqueeze(0)
+        for _ in range(5):
+            lg = mil(feats)
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        for _ in range(50):
+            lg = mil(feats)
+        torch.cuda.synchronize()
+        tm = (time.perf_counter() - tm) / 50
+        assert torch.isfinite(lg).all()
+        mil_rec = {"value": round(1.0 / tm, 2), "unit": "slides/s", "ms_per_slide": round(tm * 1e3, 4), "n_gpus": 1,
+                   "note": "RRTMIL(input_dim=1024, epeg_k=15, crmsa_k=1, all_shortcut=True).eval() forward, "
+                           "N=9000 x 1024 -> logits, fp32, one bag in flight, rank 0 after the timed region "
+                           "(rrt_mil_forward_f32: patch_to_emb GEMM+ReLU, encoder, DAttention pooling, predictor)"}
+        del mil, feats
+
     # dominant kernel: rmsa_fused_kernel = qkv projection [Np, D] x [3D, D]^T + region attention
     # (Q K^T and A V) per (region, head), fp32 MFMA.  Algorithmic FLOPs per launch (SURVEY §8d terms):
     g = region_grid(N_TOKENS, CFG["region_num"])
@@ -265,6 +292,7 @@ def main():
                                   "note": "same kernel, untimed pass with one bag in flight (median of 10)"},
         }
         rec["amp_bf16"] = amp
+        rec["rrtmil_c16"] = mil_rec
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)
