@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 4
+#define RRT_ABI_VERSION 5
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -157,7 +157,7 @@ int rrt_region_attention_f32(const float *qkv, const float *pe_w, float *o,
 /* Fused R-MSA core (rmsa.py:100-122 in one kernel per (region, head)): u [n_regions*P, dim]
  * region-major LayerNorm-ed tokens -> o [n_regions*P, dim]; qkv_w [3*dim, dim], qkv_b [3*dim] or NULL,
  * pe_w [heads, epeg_k] or NULL.  The qkv tensor never exists in HBM.  Supported when head dim is 64
- * and 112 < P <= 144 (one region fits a CU's LDS); otherwise RRT_E_UNSUPPORTED and the caller uses
+ * and 48 < P <= 208 (one region's Q, K, V tiles fit a CU's LDS); otherwise RRT_E_UNSUPPORTED and the caller uses
  * rrt_linear_f32 + rrt_region_attention_f32 (rrt_encoder_forward_f32 chooses by itself). */
 int rrt_rmsa_fused_f32(const float *u, const float *qkv_w, const float *qkv_b, const float *pe_w,
                        float *o, int32_t n_regions, int32_t P, int32_t dim, int32_t heads,
@@ -235,6 +235,27 @@ int rrt_pool_predict_f32(const float *y, const float *a_w, const float *a_b, con
 /* nn.Linear with an activation epilogue: C = act(A . B^T + bias)   (patch_to_emb, rrt.py:208-217) */
 int rrt_linear_act_f32(const float *A, const float *B, const float *bias, float *C, int64_t M, int32_t N,
                        int32_t K, int32_t act, int32_t compute, void *stream);
+
+/* ---- batch-of-bags executor (BASELINE configs[4]: mixed-size bags, every bag an independent B=1 forward;
+ * the reference loops `for bag in loader: model(bag)`, main.py:466-467 / :558-560) ----
+ * Bags are independent units, and one bag's forward is a dependent chain of ~10 kernels that leaves
+ * launch ramps, tails and store phases idle; the executor keeps `n_streams` bags in flight on its own HIP
+ * streams (one workspace each, owned by the executor) so those gaps are filled by another bag's kernels.
+ * rrt_executor_forward is ordered on the caller's `stream` like any other call here (fork: the internal
+ * streams wait for `stream`; join: `stream` waits for them); it never synchronises the host unless a
+ * workspace has to grow.  One executor per host thread and device.  Set GPU_MAX_HW_QUEUES >= 8 in the
+ * process environment so every stream gets its own hardware queue. */
+typedef struct rrt_executor rrt_executor;
+typedef struct rrt_bag {
+  const float *x;      /* [n_tokens, dim] device */
+  float *y;            /* [n_tokens, dim] device, != x */
+  int64_t n_tokens;
+} rrt_bag;
+int rrt_executor_create(const rrt_encoder_desc *desc, int32_t n_streams, int64_t max_tokens,
+                        rrt_executor **out);
+int rrt_executor_forward(rrt_executor *ex, const rrt_encoder_weights *w, const rrt_bag *bags,
+                         int32_t n_bags, void *stream);
+int rrt_executor_destroy(rrt_executor *ex);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _f32p = C.POINTER(C.c_float)
 
@@ -50,6 +50,10 @@ class MilWeights(C.Structure):
     _fields_ = [("enc", EncoderWeights)] + [(n, C.c_void_p) for n in (
         "emb_w", "emb_b", "pool_a_w", "pool_a_b", "pool_b_w", "pool_b_b", "pool_c_w", "pool_c_b",
         "pred_w", "pred_b")]
+
+
+class Bag(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("n_tokens", C.c_int64)]
 
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
@@ -91,6 +95,10 @@ SIGNATURES = {
     "rrt_pool_workspace_size": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "rrt_pool_predict_f32": (C.c_int, [C.c_void_p] * 12 + [C.c_int32, C.c_int64] + [C.c_int32] * 5 +
                              [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rrt_executor_create": (C.c_int, [C.POINTER(EncoderDesc), C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "rrt_executor_forward": (C.c_int, [C.c_void_p, C.POINTER(EncoderWeights), C.POINTER(Bag), C.c_int32,
+                                       C.c_void_p]),
+    "rrt_executor_destroy": (C.c_int, [C.c_void_p]),
     "rrt_linear_act_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                         C.c_void_p]),
 }

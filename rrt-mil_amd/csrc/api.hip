@@ -365,7 +365,7 @@ int rrt_rmsa_fused_f32(const float* u, const float* qkv_w, const float* qkv_b, c
   if (compute < 0 || compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
   const int ek = pe_w ? epeg_k : 0;
   if (!rmsa_fused_supported(P, dim, heads, ek) || !rmsa_fused_supported_rows((long)n_regions * P, dim))
-    return unsupported("rmsa_fused: needs head dim 64, 112 < P <= 144, epeg_k <= 63 (use linear + region_attention)");
+    return unsupported("rmsa_fused: needs head dim 64, 48 < P <= 208, epeg_k <= 63 (use linear + region_attention)");
   return (int)launch_rmsa_fused(u, qkv_w, qkv_b, pe_w, o, n_regions, P, dim, heads, ek, compute,
                                 (hipStream_t)stream);
 }
@@ -570,6 +570,118 @@ int rrt_mil_forward_f32(const rrt_mil_desc* desc, const rrt_mil_weights* w, cons
   return pool_predict(y, w->pool_a_w, w->pool_a_b, desc->pool_gated ? w->pool_b_w : nullptr, w->pool_b_b,
                       w->pool_c_w, w->pool_c_b, w->pred_w, w->pred_b, nullptr, logits, attn, no_norm, n_tokens,
                       D, desc->pool_hidden, desc->pool_act, desc->n_classes, desc->enc.compute, pws, st);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ batch-of-bags executor
+#define RRT_EXEC_MAX_STREAMS 8
+struct rrt_executor {
+  rrt_encoder_desc desc;
+  int n_streams;
+  int device;
+  hipStream_t streams[RRT_EXEC_MAX_STREAMS];
+  void* ws[RRT_EXEC_MAX_STREAMS];
+  size_t ws_bytes[RRT_EXEC_MAX_STREAMS];
+  hipEvent_t fork, join[RRT_EXEC_MAX_STREAMS];
+};
+
+extern "C" {
+
+int rrt_executor_destroy(rrt_executor* ex) {
+  if (!ex) return RRT_OK;
+  for (int s = 0; s < ex->n_streams; ++s) {
+    if (ex->streams[s]) (void)hipStreamSynchronize(ex->streams[s]);
+    if (ex->ws[s]) (void)hipFree(ex->ws[s]);
+    if (ex->join[s]) (void)hipEventDestroy(ex->join[s]);
+    if (ex->streams[s]) (void)hipStreamDestroy(ex->streams[s]);
+  }
+  if (ex->fork) (void)hipEventDestroy(ex->fork);
+  delete ex;
+  return RRT_OK;
+}
+
+int rrt_executor_create(const rrt_encoder_desc* desc, int32_t n_streams, int64_t max_tokens, rrt_executor** out) {
+  if (!desc || !out || max_tokens <= 0) return RRT_E_INVALID;
+  if (n_streams < 1 || n_streams > RRT_EXEC_MAX_STREAMS) return unsupported("executor: n_streams must be in [1,8]");
+  size_t need = 0;
+  int rc = rrt_encoder_workspace_size(desc, max_tokens, &need);
+  if (rc) return rc;
+  rrt_executor* ex = new rrt_executor();
+  memset(ex, 0, sizeof(*ex));
+  ex->desc = *desc;
+  ex->n_streams = n_streams;
+  hipError_t e = hipGetDevice(&ex->device);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->fork, hipEventDisableTiming);
+  for (int s = 0; s < n_streams && e == hipSuccess; ++s) {
+    e = hipStreamCreateWithFlags(&ex->streams[s], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->join[s], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&ex->ws[s], need);
+    if (e == hipSuccess) ex->ws_bytes[s] = need;
+  }
+  if (e != hipSuccess) {
+    rrt_executor_destroy(ex);
+    return (int)e;
+  }
+  *out = ex;
+  return RRT_OK;
+}
+
+int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const rrt_bag* bags, int32_t n_bags,
+                         void* stream) {
+  if (!ex || !w || (n_bags > 0 && !bags) || n_bags < 0) return RRT_E_INVALID;
+  if (n_bags == 0) return RRT_OK;
+  if (n_bags > 65536) return unsupported("executor: more than 65536 bags in one call");
+  // validate everything before the first launch: nothing runs if any bag is unsupported
+  for (int i = 0; i < n_bags; ++i) {
+    if (!bags[i].x || !bags[i].y || bags[i].x == bags[i].y) return RRT_E_INVALID;
+    int rc = check_desc(&ex->desc, bags[i].n_tokens);
+    if (rc) return rc;
+  }
+  // longest-processing-time-first onto the least loaded stream (cost ~ tokens); submission order within
+  // a stream follows that order, so the big bags start first and the small ones fill the tail
+  const int S = ex->n_streams < n_bags ? ex->n_streams : n_bags;
+  int order_buf[256];
+  int* order = n_bags <= 256 ? order_buf : new int[n_bags];
+  for (int i = 0; i < n_bags; ++i) order[i] = i;
+  for (int i = 1; i < n_bags; ++i) {        // insertion sort, stable, descending n_tokens (n_bags is small)
+    int v = order[i], j = i - 1;
+    while (j >= 0 && bags[order[j]].n_tokens < bags[v].n_tokens) { order[j + 1] = order[j]; --j; }
+    order[j + 1] = v;
+  }
+  hipStream_t caller = (hipStream_t)stream;
+  hipError_t e = hipEventRecord(ex->fork, caller);
+  for (int s = 0; s < S && e == hipSuccess; ++s) e = hipStreamWaitEvent(ex->streams[s], ex->fork, 0);
+  int rc = (int)e;
+  int64_t load[RRT_EXEC_MAX_STREAMS] = {0};
+  for (int k = 0; k < n_bags && rc == RRT_OK; ++k) {
+    const rrt_bag& b = bags[order[k]];
+    int s = 0;
+    for (int t = 1; t < S; ++t)
+      if (load[t] < load[s]) s = t;
+    load[s] += b.n_tokens;
+    size_t need = 0;
+    rc = rrt_encoder_workspace_size(&ex->desc, b.n_tokens, &need);
+    if (rc) break;
+    if (need > ex->ws_bytes[s]) {            // grow: the only host synchronisation in this call
+      e = hipStreamSynchronize(ex->streams[s]);
+      if (e == hipSuccess) e = hipFree(ex->ws[s]);
+      ex->ws[s] = nullptr;
+      ex->ws_bytes[s] = 0;
+      if (e == hipSuccess) e = hipMalloc(&ex->ws[s], need);
+      if (e != hipSuccess) { rc = (int)e; break; }
+      ex->ws_bytes[s] = need;
+    }
+    rc = encoder_forward(&ex->desc, w, b.x, b.y, b.n_tokens, ex->ws[s], ex->ws_bytes[s], ex->streams[s], nullptr);
+  }
+  // join even after an error so the caller's stream stays ordered after whatever was enqueued
+  for (int s = 0; s < S; ++s) {
+    hipError_t j = hipEventRecord(ex->join[s], ex->streams[s]);
+    if (j == hipSuccess) j = hipStreamWaitEvent(caller, ex->join[s], 0);
+    if (rc == RRT_OK && j != hipSuccess) rc = (int)j;
+  }
+  if (order != order_buf) delete[] order;
+  return rc;
 }
 
 }  // extern "C"

@@ -20,7 +20,7 @@
 //            region_attn.hip; only O [P x 64] is written.
 // LDS: max(2 x 43 KB staging, Q/K/V 3 x 36.9 KB) = 108 KiB (Q~ overwrites Q) -> one block per CU, with
 // 52 KiB left for a co-resident kernel of another bag; 512 blocks at N = 9000 = 2 per CU.
-// Requires head dim 64 and P <= 16*MT <= 144.
+// Requires head dim 64 and P <= 16*MT <= 208 (MT = 13: 3 x 52 KB tiles = 156 KiB of the 160 KiB LDS).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -285,10 +285,13 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   RRT_TRACE_MARK();                                 // [7] Q~ built
 
   // ================================================================== phase 4: attention from LDS
-  // all six waves (the loaders are idle now): tiles 0..5 -> waves 0..5, tiles 6.. -> waves 2,3,4,...
-  // (waves 4,5 presumably share SIMDs with waves 0,1: the extra tiles go to the others first)
-  for (int pass = 0; pass < 2; ++pass) {
-    const int t = pass == 0 ? wave : ((wave >= 2 && wave <= 4) ? wave + 4 : MT);
+  // all six waves (the loaders are idle now).  Tile -> wave schedule balanced per SIMD (waves 4, 5 share
+  // SIMDs 0, 1 with waves 0, 1): tiles 0..5 -> waves 0..5; 6, 7 -> waves 2, 3; 8, 9 -> waves 4, 5;
+  // 10, 11 -> waves 2, 3 again; 12 -> wave 0.
+  for (int pass = 0; pass < 3; ++pass) {
+    int t = wave;
+    if (pass == 1) t = wave >= 2 ? wave + 4 : (wave == 0 ? 12 : MT);
+    if (pass == 2) t = (wave == 2 || wave == 3) ? wave + 8 : MT;
     const int i0 = t * 16;
     if (t >= MT || i0 >= P) break;
     float4 bq[4];
@@ -399,8 +402,10 @@ RRT_TRACE_DEFINE_READER(rrt_debug_trace_fused)
 bool rmsa_fused_supported(int P, int D, int heads, int epeg_k) {
   static const bool off = getenv("RRT_NO_FUSED") != nullptr;
   if (off) return false;
-  // one block holds a whole region: P <= 144; MT = 9 or 8 row tiles (smaller regions: unfused path)
-  return heads > 0 && D == heads * HD && D % BK == 0 && P > 112 && P <= 144 && epeg_k >= 0 && epeg_k <= 63;
+  // one block holds a whole region: Q, K and V tiles of 16*MT rows in LDS -> P <= 208; MT in
+  // {4, 6, 7, 8, 9, 11, 13} covers the region sizes s*s, s = 7..14, of bags of ~2.3k..12.5k tokens at
+  // region_num = 8 (4x that at 16); smaller / larger regions take the unfused kernels
+  return heads > 0 && D == heads * HD && D % BK == 0 && P > 48 && P <= 208 && epeg_k >= 0 && epeg_k <= 63;
 }
 
 bool rmsa_fused_supported_rows(long n_rows, int D) {   // 32-bit DMA byte offsets into U
@@ -416,7 +421,12 @@ hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqk
     case 2: return launch_mt<MT_, PREC_F16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st);  \
     default: return launch_mt<MT_, PREC_F32>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st); \
   }
+  if (P > 176) { RRT_FUSED(13) }
+  if (P > 144) { RRT_FUSED(11) }
   if (P > 128) { RRT_FUSED(9) }
-  RRT_FUSED(8)
+  if (P > 112) { RRT_FUSED(8) }
+  if (P > 96) { RRT_FUSED(7) }
+  if (P > 64) { RRT_FUSED(6) }
+  RRT_FUSED(4)
 #undef RRT_FUSED
 }

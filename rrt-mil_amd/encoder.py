@@ -246,6 +246,72 @@ class RRTEncoder(nn.Module):
         _lib.check(rc, "rrt_encoder_forward_f32")
         return y
 
+    # ------------------------------------------------------------------ batch of independent bags
+    def _executor(self, n_streams, max_tokens, device):
+        key = (n_streams, device)
+        ex = getattr(self, "_ex", None)
+        if ex is not None and self._ex_key == key and bytes(self._ex_desc) == bytes(self._desc):
+            return ex
+        self._drop_executor()
+        lib = _lib.load()
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.rrt_executor_create(C.byref(self._desc), n_streams, max_tokens, C.byref(h)),
+                       "rrt_executor_create")
+        self._ex, self._ex_key, self._ex_desc = h, key, _lib.EncoderDesc.from_buffer_copy(self._desc)
+        return h
+
+    def _drop_executor(self):
+        ex = getattr(self, "_ex", None)
+        if ex is not None:
+            _lib.load().rrt_executor_destroy(ex)
+            self._ex = None
+
+    def __del__(self):
+        try:
+            self._drop_executor()
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def forward_bags(self, bags, streams=2, outs=None):
+        """A batch of independent bags (each (N_i, D) or (1, N_i, D), any mix of sizes) -> list of outputs of
+        the same shapes.  What the reference does with ``for bag in loader: model(bag)`` (main.py:466-467),
+        with ``streams`` bags in flight on the library's own HIP streams (rrt_executor_forward); ordered on
+        the current stream like a normal op.  Bags are never mixed."""
+        lib = _lib.load()
+        if not bags:
+            return []
+        if self.training and self.drop_out > 0:
+            raise NotImplementedError("training-mode forward is not built; call .eval()")
+        dev = bags[0].device
+        xs = []
+        for b in bags:
+            if not b.is_cuda or b.device != dev:
+                raise _lib.RRTHipError("forward_bags: every bag must be on the same HIP device (no CPU fallback)")
+            x2 = b[0] if b.dim() == 3 and b.size(0) == 1 else b
+            if x2.dim() != 2 or x2.size(1) != self.final_dim:
+                raise ValueError(f"forward_bags: expected (N, {self.final_dim}) or (1, N, {self.final_dim}) bags, "
+                                 f"got {tuple(b.shape)}")
+            if x2.dtype in (torch.bfloat16, torch.float16):
+                x2 = x2.float()
+            if x2.dtype != torch.float32:
+                raise NotImplementedError(f"unsupported bag dtype {x2.dtype}")
+            xs.append(x2.contiguous())
+        ys = [torch.empty_like(x) for x in xs] if outs is None else outs
+        self._desc.compute = self._compute_mode()
+        ex = self._executor(int(streams), max(x.size(0) for x in xs), dev)
+        arr = (_lib.Bag * len(xs))()
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            arr[i].x, arr[i].y, arr[i].n_tokens = x.data_ptr(), y.data_ptr(), x.size(0)
+        w = self._weights()
+        with torch.cuda.device(dev):
+            rc = lib.rrt_executor_forward(ex, C.byref(w), arr, len(xs), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "rrt_executor_forward")
+        # xs / ys are touched on the executor's streams, but the call joins the current stream before it
+        # returns, so the caching allocator's stream-ordered reuse of these buffers stays correct
+        return [y.unsqueeze(0) if b.dim() == 3 else y for b, y in zip(bags, ys)]
+
     @torch.no_grad()
     def forward(self, x):
         # rank handling: modules/rrt.py:166-175 and :197-201
