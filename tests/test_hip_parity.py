@@ -339,6 +339,41 @@ def test_full_size_properties():
     assert changed.size > 0 and set(ii // 12) == {3} and set(jj // 12) == {4}
 
 
+@pytest.mark.parametrize("N,rn", [(100000, 8), (120000, 16)])
+def test_huge_bag(N, rn):
+    """Far beyond the golden sizes (regions of 1600 / 484 tokens: the streaming online-softmax attention, 64-bit
+    row offsets, a 1 GB workspace).  R-MSA is region-local, so with cr_msa=False one whole region can be
+    checked against the float64 restatement without running the oracle on the full bag; the full encoder
+    (with CR-MSA) is checked through the LayerNorm property."""
+    from hip_util import encoder_from_state, dev
+    D = 512
+    x = synth.bag(N, D, tag=f"huge{N}")
+    H, s, add = O.grid(N, rn)
+    P = s * s
+    st = synth.encoder_state(cr_msa=False)
+    enc = encoder_from_state(st, dict(cr_msa=False, region_num=rn))
+    xd = dev(x)
+    y = enc(xd).cpu().numpy()
+    assert np.isfinite(y).all()
+    for ri, rj in ((0, 0), (3, rn - 2), (rn - 1, rn - 1)):        # first, interior and last (padded) region
+        ii, jj = np.meshgrid(ri * s + np.arange(s), rj * s + np.arange(s), indexing="ij")
+        t = (ii * H + jj).reshape(-1)                             # token ids of the region, region order
+        real = t < N
+        u = np.zeros((P, D))
+        u[real] = O._ln64(x[t[real]].astype(np.float64), st["layers.0.norm.weight"].astype(np.float64),
+                          st["layers.0.norm.bias"].astype(np.float64))
+        z = O._inner_attention64(u[None], st, "layers.0.attn.attn.", 8, 15)[0]
+        ref = O._ln64(x[t[real]].astype(np.float64) + z[real], st["norm.weight"].astype(np.float64),
+                      st["norm.bias"].astype(np.float64))
+        _cmp(y[t[real]], ref, 2e-4, f"huge bag N={N} region ({ri},{rj})")
+    del enc
+    st = synth.encoder_state()
+    enc = encoder_from_state(st, dict(region_num=rn))
+    y = enc(xd).cpu().numpy().astype(np.float64)
+    zn = (y - st["norm.bias"].astype(np.float64)) / st["norm.weight"].astype(np.float64)
+    assert np.abs(zn.mean(-1)).max() < 1e-4 and np.abs(zn.var(-1) - 1.0).max() < 1e-3
+
+
 @pytest.mark.parametrize("name", ["G8_rrtmil_n1000", "G8_rrtmil_n9000"])
 def test_rrtmil_matches_reference(name):
     """BASELINE configs[2] (C16-R50): fc 1024->512 + ReLU -> encoder (HIP) -> DAttention -> predictor,
