@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 5
+#define RRT_ABI_VERSION 6
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -72,9 +72,12 @@ typedef struct rrt_encoder_desc {
   int32_t crmsa_mlp;       /* 1: phi is Linear(dim, dim/4) -> Tanh -> Linear(dim/4, k), rmsa.py:248-252 */
   int32_t all_shortcut;
   int32_t compute;         /* RRT_COMPUTE_*: operand precision of the nn.Linear layers */
+  int32_t ffn;             /* 1: every TransLayer (CR-MSA's too) ends with x + Mlp(LN2(x)), rrt.py:105-106,127-129 */
+  int32_t ffn_act;         /* RRT_ACT_GELU (ffn_act='gelu') or RRT_ACT_RELU (anything else), rrt.py:105 */
+  int32_t ffn_hidden;      /* int(dim * mlp_ratio), a multiple of 32 */
 } rrt_encoder_desc;
 
-/* InnerAttention parameters, modules/rmsa.py:57-89.  Row-major, fp32.
+/* One TransLayer's parameters: InnerAttention, modules/rmsa.py:57-89 (+ the optional FFN).  Row-major, fp32.
  * qkv_w [3*dim, dim], qkv_b [3*dim] or NULL, proj_w [dim, dim], proj_b [dim],
  * pe_w [heads, epeg_k] or NULL, pe_b [heads] or NULL. */
 typedef struct rrt_attn_weights {
@@ -82,6 +85,11 @@ typedef struct rrt_attn_weights {
   const float *qkv_w, *qkv_b;
   const float *proj_w, *proj_b;
   const float *pe_w, *pe_b;
+  /* ffn = 1 only (Mlp, modules/rrt.py:25-41): norm2 [dim]; fc1 [ffn_hidden, dim] + [ffn_hidden];
+   * fc2 [dim, ffn_hidden] + [dim] */
+  const float *norm2_w, *norm2_b;
+  const float *fc1_w, *fc1_b;
+  const float *fc2_w, *fc2_b;
 } rrt_attn_weights;
 
 typedef struct rrt_encoder_weights {

@@ -58,7 +58,7 @@ def partition_index(H, s):
 _DEFAULTS = dict(mlp_dim=512, region_num=8, n_layers=2, n_heads=8, epeg=True, epeg_k=15,
                  region_size=0, min_region_num=0, min_region_ratio=0.0, qkv_bias=True,
                  cr_msa=True, crmsa_k=3, all_shortcut=False, crmsa_mlp=False, crmsa_heads=8,
-                 epeg_bias=True)
+                 epeg_bias=True, ffn=False, ffn_act="gelu", mlp_ratio=4.0)
 
 
 def _cfg(cfg):
@@ -110,6 +110,14 @@ def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None):
     return out
 
 
+def _ffn64(x, st, pfx, act):
+    """TransLayer's optional FFN (ffn=True): x + fc2(act(fc1(LN2(x)))), modules/rrt.py:25-41,127-129."""
+    g = lambda k: st[pfx + k].astype(np.float64)
+    u = _ln64(x, g("norm2.weight"), g("norm2.bias"))
+    h = _act64(u @ g("mlp.fc1.weight").T + g("mlp.fc1.bias"), "gelu" if act == "gelu" else "relu")
+    return x + h @ g("mlp.fc2.weight").T + g("mlp.fc2.bias")
+
+
 def forward_f64(x, state, cfg=None, taps=None):
     """x: (N, D) array -> (N, D) float64.  ``state``: {reference state_dict key: array}."""
     c = _cfg(cfg)
@@ -128,6 +136,8 @@ def forward_f64(x, state, cfg=None, taps=None):
         z = np.empty((H * H, D))
         z[perm] = Z.reshape(-1, D)
         x = x + z[:N]
+        if c["ffn"]:
+            x = _ffn64(x, st, p, c["ffn_act"])
         if taps is not None:
             taps[p + "out"] = x
     if c["cr_msa"]:
@@ -154,6 +164,8 @@ def forward_f64(x, state, cfg=None, taps=None):
         z = np.empty((H * H, D))
         z[perm] = out.reshape(-1, D)
         x = x + z[:N]
+        if c["ffn"]:
+            x = _ffn64(x, st, p, c["ffn_act"])
         if taps is not None:
             taps["cr_msa.rep"] = rep
             taps["cr_msa.out"] = x
@@ -200,6 +212,12 @@ def forward_eager(x, state, cfg=None):
         o = (attn @ v).transpose(1, 2).reshape(B_, P, D)
         return F.linear(o, st[pfx + "proj.weight"], st[pfx + "proj.bias"])
 
+    def ffn(t, pfx):                                                         # modules/rrt.py:25-41,127-129
+        u = F.layer_norm(t, (D,), st[pfx + "norm2.weight"], st[pfx + "norm2.bias"], 1e-5)
+        h = F.linear(u, st[pfx + "mlp.fc1.weight"], st[pfx + "mlp.fc1.bias"])
+        h = F.gelu(h) if c["ffn_act"] == "gelu" else F.relu(h)
+        return t + F.linear(h, st[pfx + "mlp.fc2.weight"], st[pfx + "mlp.fc2.bias"])
+
     with torch.no_grad():
         for li in range(c["n_layers"] - 1):
             p = f"layers.{li}."
@@ -211,6 +229,8 @@ def forward_eager(x, state, cfg=None):
             if add > 0:
                 z = z[:, :-add]
             x = x + z
+            if c["ffn"]:
+                x = ffn(x, p)
         if c["cr_msa"]:
             p = "cr_msa."
             v = F.layer_norm(x, (D,), st[p + "norm.weight"], st[p + "norm.bias"], 1e-5)
@@ -236,6 +256,8 @@ def forward_eager(x, state, cfg=None):
             if add > 0:
                 z = z[:, :-add]
             x = x + z
+            if c["ffn"]:
+                x = ffn(x, p)
         if c["all_shortcut"]:
             x = x + x0
         x = F.layer_norm(x, (D,), st["norm.weight"], st["norm.bias"], 1e-5)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _f32p = C.POINTER(C.c_float)
 
@@ -26,12 +26,14 @@ class EncoderDesc(C.Structure):
                 ("region_num", C.c_int32), ("region_size", C.c_int32), ("min_region_num", C.c_int32),
                 ("min_region_ratio", C.c_float), ("epeg", C.c_int32), ("epeg_k", C.c_int32),
                 ("cr_msa", C.c_int32), ("crmsa_k", C.c_int32), ("crmsa_heads", C.c_int32),
-                ("crmsa_mlp", C.c_int32), ("all_shortcut", C.c_int32), ("compute", C.c_int32)]
+                ("crmsa_mlp", C.c_int32), ("all_shortcut", C.c_int32), ("compute", C.c_int32),
+                ("ffn", C.c_int32), ("ffn_act", C.c_int32), ("ffn_hidden", C.c_int32)]
 
 
 class AttnWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("norm_w", "norm_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
-                                          "pe_w", "pe_b")]
+                                          "pe_w", "pe_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b",
+                                          "fc2_w", "fc2_b")]
 
 
 class EncoderWeights(C.Structure):

@@ -26,6 +26,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
   float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *v8, *hid;
+  float *ffn_ln, *ffn_hid;
   size_t bytes;
 };
 
@@ -45,7 +46,13 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     w.uo = take(Np * D);
     w.qkv = take(Np * 3 * D);
     w.xa = take((size_t)N * D);
-    if (d.n_rmsa_layers > 1) w.xb = take((size_t)N * D);
+    if (d.n_rmsa_layers > 1 || d.ffn) w.xb = take((size_t)N * D);
+  }
+  if (d.ffn) {
+    if (!w.xa) w.xa = take((size_t)N * D);
+    if (!w.xb) w.xb = take((size_t)N * D);
+    w.ffn_ln = take((size_t)N * D);
+    w.ffn_hid = take((size_t)N * d.ffn_hidden);
   }
   if (d.cr_msa) {
     const size_t k = d.crmsa_k;
@@ -79,6 +86,11 @@ int check_desc(const rrt_encoder_desc* d, int64_t N) {
     if (d->crmsa_mlp && d->dim % 128 != 0) return unsupported("crmsa_mlp needs dim % 128 == 0 (hidden dim/4 is a GEMM K)");
     if (d->crmsa_k <= 0 || d->crmsa_k > RRT_MAX_CRMSA_K) return unsupported("crmsa_k must be in [1,8]");
     if (d->crmsa_heads <= 0 || d->dim % d->crmsa_heads != 0) return unsupported("crmsa_heads must divide dim");
+  }
+  if (d->ffn) {
+    if (d->ffn_hidden <= 0 || d->ffn_hidden % 32 != 0)
+      return unsupported("ffn: hidden width int(dim * mlp_ratio) must be a positive multiple of 32");
+    if (d->ffn_act != RRT_ACT_GELU && d->ffn_act != RRT_ACT_RELU) return unsupported("ffn_act must be gelu or relu");
   }
   if (N > (int64_t)4000000) return unsupported("bag larger than 4e6 tokens");
   if (d->compute < 0 || d->compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
@@ -211,6 +223,37 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
   } while (0)
   RRT_MARK(RRT_EV_START);
 
+  // TransLayer's optional FFN (rrt.py:127-129): xo = xi + fc2(act(fc1(LN2(xi)))).  LN2 -> GEMM with the
+  // activation in its epilogue -> GEMM with the residual in its epilogue (identity slot->token map).
+  GridDev gid{};
+  {
+    const int Hs = (int)ceil_sqrt(N);
+    gid.L = (int)N;
+    gid.H = gid.s = Hs;
+    gid.rs = 1;
+    gid.P = gid.Np = Hs * Hs;
+    gid.inv_H = gid.inv_s = 1.0f / (float)Hs;
+    gid.inv_rs = 1.0f;
+    gid.inv_P = 1.0f / (float)gid.P;
+  }
+  auto ffn_block = [&](const rrt_attn_weights& lw, const float* xi, float* xo) -> int {
+    if (!lw.norm2_w || !lw.norm2_b || !lw.fc1_w || !lw.fc1_b || !lw.fc2_w || !lw.fc2_b) return RRT_E_INVALID;
+    hipError_t fe = launch_layernorm(xi, nullptr, lw.norm2_w, lw.norm2_b, ws.ffn_ln, (int)N, D, st);
+    if (fe != hipSuccess) return (int)fe;
+    LinearEpilogue e1{};
+    e1.prec = desc->compute;
+    e1.bias = lw.fc1_b;
+    e1.act = desc->ffn_act;
+    fe = launch_linear(ws.ffn_ln, lw.fc1_w, ws.ffn_hid, (int)N, desc->ffn_hidden, D, e1, st);
+    if (fe != hipSuccess) return (int)fe;
+    LinearEpilogue e2{};
+    e2.prec = desc->compute;
+    e2.bias = lw.fc2_b;
+    e2.resid = xi;
+    e2.g = gid;
+    return (int)launch_linear(ws.ffn_hid, lw.fc2_w, xo, (int)N, D, desc->ffn_hidden, e2, st);
+  };
+
   const float* xin = x;   // current activations [N, D]
   // ---- R-MSA TransLayers: x = x + unpart(InnerAttention(part(pad(LN(x)))))  (rrt.py:117-125)
   for (int li = 0; li < desc->n_rmsa_layers; ++li) {
@@ -218,7 +261,8 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
     if (!lw.norm_w || !lw.norm_b || !lw.qkv_w || !lw.proj_w || !lw.proj_b) return RRT_E_INVALID;
     if (desc->epeg && !lw.pe_w) return RRT_E_INVALID;
     const GridDev gd = to_dev(g);
-    float* xout = (li & 1) ? ws.xb : ws.xa;
+    // without FFN the layers ping-pong xa / xb; with it attention writes xa and the FFN writes xb
+    float* xout = desc->ffn ? ws.xa : ((li & 1) ? ws.xb : ws.xa);
     RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, ws.uo, D, gd, st));
     if (li == 0) RRT_MARK(RRT_EV_LN_PARTITION);
     const int ek = desc->epeg ? desc->epeg_k : 0;
@@ -236,6 +280,11 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
       RRT_TRY(launch_linear(ws.qkv, lw.proj_w, xout, gd.Np, D, D, ep, st));
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;
+      if (desc->ffn) {
+        rc = ffn_block(lw, xout, ws.xb);
+        if (rc) return rc;
+        xin = ws.xb;
+      }
       continue;
     }
     {
@@ -258,6 +307,11 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
     RRT_TRY(launch_linear(ws.uo, lw.proj_w, xout, gd.Np, D, D, ep, st));
     if (li == 0) RRT_MARK(RRT_EV_PROJ);
     xin = xout;
+    if (desc->ffn) {
+      rc = ffn_block(lw, xout, ws.xb);
+      if (rc) return rc;
+      xin = ws.xb;
+    }
   }
   const float* x0 = desc->all_shortcut ? x : nullptr;
   if (!w->norm_w || !w->norm_b) return RRT_E_INVALID;
@@ -296,6 +350,16 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
     RRT_TRY(launch_linear(ws.rep_o, cw.proj_w, ws.rep2, k * R8, D, D, ep, st));
   }
   RRT_MARK(RRT_EV_CR_INNER);
+  if (desc->ffn) {
+    // x2 = x1 + dispatch (no LayerNorm yet) -> FFN -> (+ shortcut) -> final LayerNorm.  xin is xb or the
+    // caller's x: xa is free for x2, and xin is dead once the dispatch has read it.
+    RRT_TRY(launch_crmsa_dispatch_ln(xin, nullptr, ws.wdisp, ws.rep2, nullptr, nullptr, ws.xa, D, k, gd8, st));
+    rc = ffn_block(cw, ws.xa, ws.xb);
+    if (rc) return rc;
+    RRT_TRY(launch_layernorm(ws.xb, x0, w->norm_w, w->norm_b, y, (int)N, D, st));
+    RRT_MARK(RRT_EV_END);
+    return RRT_OK;
+  }
   RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, ws.wdisp, ws.rep2, w->norm_w, w->norm_b, y, D, k,
                                    gd8, st));
   RRT_MARK(RRT_EV_END);

@@ -326,6 +326,18 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
         }
     }
   }
+  if (gamma == nullptr) {              // no LayerNorm: an FFN follows (ffn = 1), rows go out as they are
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      if (t0 + i >= L) break;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        int c = (v * 64 + lane) * 4;
+        if (c < dim) *(float4*)(y + (size_t)(t0 + i) * dim + c) = r[i][v];
+      }
+    }
+    return;
+  }
   const float inv_d = 1.0f / (float)dim;
   float mean[RW], rstd[RW];
 #pragma unroll

@@ -95,20 +95,31 @@ class CrossRegionAttntion(nn.Module):
             nn.init.kaiming_uniform_(self.phi, a=math.sqrt(5))
 
 
+class Mlp(nn.Module):
+    """Holder mirroring modules/rrt.py:25-41 (TransLayer's FFN when ffn=True)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.ReLU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
 class TransLayer(nn.Module):
-    """Holder mirroring modules/rrt.py:43-110: pre-norm residual attention block."""
+    """Holder mirroring modules/rrt.py:43-110: pre-norm residual attention block (+ optional FFN)."""
 
     def __init__(self, norm_layer=nn.LayerNorm, dim=512, head=8, drop_out=0.1, drop_path=0., ffn=False,
                  ffn_act='gelu', mlp_ratio=4., trans_dim=64, attn='rmsa', n_region=8, epeg=False,
                  region_size=0, min_region_num=0, min_region_ratio=0, qkv_bias=True, crmsa_k=3,
                  epeg_k=15, **kwargs):
         super().__init__()
-        if ffn:
-            raise NotImplementedError("ffn=True (ablation MLP block) is not on the HIP path")
         if drop_path > 0.:
             raise NotImplementedError("drop_path > 0 (training-only stochastic depth) is not on the HIP path")
         self.norm = norm_layer(dim)
-        self.norm2 = nn.Identity()
+        self.norm2 = norm_layer(dim) if ffn else nn.Identity()
         common = dict(dim=dim, num_heads=head, drop=drop_out, region_num=n_region, head_dim=dim // head,
                       epeg=epeg, region_size=region_size, min_region_num=min_region_num,
                       min_region_ratio=min_region_ratio, qkv_bias=qkv_bias)
@@ -122,7 +133,9 @@ class TransLayer(nn.Module):
             raise NotImplementedError
         self.drop_path = nn.Identity()
         self.ffn = ffn
-        self.mlp = nn.Identity()
+        act_layer = nn.GELU if ffn_act == 'gelu' else nn.ReLU
+        self.mlp = (Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop_out)
+                    if ffn else nn.Identity())
 
 
 class RRTEncoder(nn.Module):
@@ -159,7 +172,8 @@ class RRTEncoder(nn.Module):
             region_size=region_size, min_region_num=min_region_num, min_region_ratio=min_region_ratio,
             epeg=int(bool(epeg)), epeg_k=epeg_k, cr_msa=int(bool(cr_msa)), crmsa_k=crmsa_k,
             crmsa_heads=crmsa_heads, crmsa_mlp=int(bool(crmsa_mlp)), all_shortcut=int(bool(all_shortcut)),
-            compute=_lib.COMPUTE_F32)
+            compute=_lib.COMPUTE_F32, ffn=int(bool(ffn)),
+            ffn_act=_lib.ACT_GELU if ffn_act == 'gelu' else _lib.ACT_RELU, ffn_hidden=int(mlp_dim * mlp_ratio))
         # None: exact fp32 unless the call runs under torch autocast (then bf16/fp16 MFMA operands in
         # the Linear layers, like the reference's --amp path); or force torch.float32/bfloat16/float16
         self.compute_dtype = None
@@ -184,6 +198,10 @@ class RRTEncoder(nn.Module):
         w.proj_w, w.proj_b = self._ptr(ia.proj.weight), self._ptr(ia.proj.bias)
         if ia.pe is not None:
             w.pe_w, w.pe_b = self._ptr(ia.pe.weight), self._ptr(ia.pe.bias)   # [h,1,k,1] == [h,k]
+        if layer.ffn:
+            w.norm2_w, w.norm2_b = self._ptr(layer.norm2.weight), self._ptr(layer.norm2.bias)
+            w.fc1_w, w.fc1_b = self._ptr(layer.mlp.fc1.weight), self._ptr(layer.mlp.fc1.bias)
+            w.fc2_w, w.fc2_b = self._ptr(layer.mlp.fc2.weight), self._ptr(layer.mlp.fc2.bias)
         return w
 
     def _weights(self):

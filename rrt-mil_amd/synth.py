@@ -41,7 +41,7 @@ def normal(name: str, shape, dtype=np.float32) -> np.ndarray:
 
 def encoder_state_shapes(mlp_dim=512, n_layers=2, n_heads=8, epeg=True, epeg_k=15,
                          cr_msa=True, crmsa_k=3, crmsa_mlp=False, qkv_bias=True,
-                         epeg_bias=True, **_unused):
+                         epeg_bias=True, ffn=False, mlp_ratio=4., **_unused):
     """Ordered {state_dict key: shape} of the default-path RRTEncoder."""
     D = mlp_dim
     sh = {"norm.weight": (D,), "norm.bias": (D,)}
@@ -57,10 +57,21 @@ def encoder_state_shapes(mlp_dim=512, n_layers=2, n_heads=8, epeg=True, epeg_k=1
             if epeg_bias:
                 sh[prefix + "pe.bias"] = (n_heads,)
 
+    def mlp(prefix):                       # TransLayer(ffn=True): norm2 + Mlp, modules/rrt.py:25-41,48,106
+        if ffn:
+            hid = int(D * mlp_ratio)
+            sh[prefix + "norm2.weight"] = (D,)
+            sh[prefix + "norm2.bias"] = (D,)
+            sh[prefix + "mlp.fc1.weight"] = (hid, D)
+            sh[prefix + "mlp.fc1.bias"] = (hid,)
+            sh[prefix + "mlp.fc2.weight"] = (D, hid)
+            sh[prefix + "mlp.fc2.bias"] = (D,)
+
     for i in range(n_layers - 1):
         sh[f"layers.{i}.norm.weight"] = (D,)
         sh[f"layers.{i}.norm.bias"] = (D,)
         inner(f"layers.{i}.attn.attn.", epeg)
+        mlp(f"layers.{i}.")
     if cr_msa:
         sh["cr_msa.norm.weight"] = (D,)
         sh["cr_msa.norm.bias"] = (D,)
@@ -70,6 +81,7 @@ def encoder_state_shapes(mlp_dim=512, n_layers=2, n_heads=8, epeg=True, epeg_k=1
             sh["cr_msa.attn.phi.2.weight"] = (crmsa_k, D // 4)
         else:
             sh["cr_msa.attn.phi"] = (D, crmsa_k)
+        mlp("cr_msa.")
     return sh
 
 
@@ -79,9 +91,9 @@ def encoder_state(**cfg):
     so that gamma/beta mistakes show up in parity tests)."""
     out = {}
     for k, shape in encoder_state_shapes(**cfg).items():
-        if k.endswith("norm.weight"):
+        if k.endswith(("norm.weight", "norm2.weight")):
             out[k] = 1.0 + uniform(k, shape, -0.25, 0.25)
-        elif k.endswith("norm.bias"):
+        elif k.endswith(("norm.bias", "norm2.bias")):
             out[k] = uniform(k, shape, -0.1, 0.1)
         elif k.endswith("pe.weight"):
             b = 1.0 / np.sqrt(shape[2])

@@ -106,10 +106,21 @@ def test_cpu_tensor_and_ablations_raise():
     enc = RRTEncoder(mlp_dim=64).eval()
     with pytest.raises(_lib.RRTHipError):
         enc(torch.zeros(1, 10, 64))
-    for kw in (dict(pos='ppeg'), dict(ffn=True), dict(attn='ntrans'), dict(epeg_2d=True),
+    for kw in (dict(pos='ppeg'), dict(attn='ntrans'), dict(epeg_2d=True),
                dict(epeg_type='value_bf'), dict(region_attn='ntrans')):
         with pytest.raises(NotImplementedError):
             RRTEncoder(mlp_dim=64, **kw)
+
+
+def test_ffn_state_dict_surface():
+    """ffn=True (modules/rrt.py:25-41,48,105-106): norm2 + mlp.fc1/fc2 under every TransLayer, CR-MSA's too."""
+    cfg = dict(mlp_dim=64, ffn=True, mlp_ratio=2.0, n_layers=3)
+    enc = RRTEncoder(**cfg)
+    st = synth.encoder_state(**cfg)
+    enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    assert enc.cr_msa.mlp.fc1.weight.shape == (128, 64) and enc.layers[1].mlp.fc2.weight.shape == (64, 128)
+    assert enc._desc.ffn == 1 and enc._desc.ffn_hidden == 128 and enc._desc.ffn_act == _lib.ACT_GELU
+    assert RRTEncoder(mlp_dim=64, ffn=True, ffn_act='relu')._desc.ffn_act == _lib.ACT_RELU
 
 
 def test_rrtmil_state_dict_surface():

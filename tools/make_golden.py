@@ -24,7 +24,7 @@ os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(8)
 
 STATE_KEYS = ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k", "cr_msa", "crmsa_k",
-              "crmsa_mlp", "qkv_bias", "epeg_bias")
+              "crmsa_mlp", "qkv_bias", "epeg_bias", "ffn", "mlp_ratio")
 
 
 def run_ref(N, cfg, hooks=False, tag="bag"):
@@ -205,6 +205,24 @@ def main():
         with torch.no_grad():
             logits, attn = mil(torch.from_numpy(feats).unsqueeze(0), return_attn=True)
         save(f"G8_rrtmil_n{N}", cfg=cfg_array(cfg), n=np.array(N), logits=logits.numpy(), attn=attn.numpy())
+
+    # G12: ffn=True (row f4): every TransLayer, CR-MSA's included, gets x + Mlp(LN2(x)) (modules/rrt.py:25-41,
+    # 105-106,127-129); GELU / ReLU, mlp_ratio, with all_shortcut and without CR-MSA
+    ffn_variants = {
+        "d64_n300_gelu": (300, dict(mlp_dim=64, ffn=True)),
+        "d512_n1000_relu_r2": (1000, dict(mlp_dim=512, ffn=True, ffn_act="relu", mlp_ratio=2.0, all_shortcut=True)),
+        "d512_n3000_gelu": (3000, dict(mlp_dim=512, ffn=True, n_layers=3)),
+        "d512_n700_nocr": (700, dict(mlp_dim=512, ffn=True, cr_msa=False)),
+    }
+    for tag, (N, extra) in ffn_variants.items():
+        cfg = dict(epeg_k=15, crmsa_k=3, region_num=8)
+        cfg.update(extra)
+        x, y, _, _ = run_ref(N, cfg)
+        if N <= 300:
+            save(f"G12_ffn_{tag}", cfg=cfg_array(cfg), n=np.array(N), y=y)
+        else:
+            ri = np.arange(0, N, 8)
+            save(f"G12_ffn_{tag}", cfg=cfg_array(cfg), n=np.array(N), rows=ri, y_rows=y[ri], y_sums=checksums(y))
 
     # G11: RRTMIL caller variants (modules/datten.py gated / bias / activations, rrt.py act=, n_classes,
     # input_dim), with both forms of the returned attention row (normalised / no_norm raw scores)
