@@ -165,21 +165,26 @@ def main():
     ev_pairs = [(hev.create(), hev.create()) for _ in range(args.steps)]
     ev_arr = (C.c_void_p * _lib.EV_COUNT)()
 
+    # bags in flight on different streams share a phase gate: their MFMA-bound R-MSA cores take turns
+    # instead of time-slicing the matrix pipes, and the other bag's memory-bound kernels fill the gaps
+    gate = C.c_void_p()
+    if S > 1 and os.environ.get("RRT_BENCH_GATE", "1") != "0":
+        _lib.check(lib.rrt_phase_gate_create(C.byref(gate)), "phase gate")
+
     def step(i, timed):
         # one step = S independent bags, one per stream (bag-parallel inside the GPU as well)
         for s_ in range(S):
             x = bags[(i * S + s_) % len(bags)]
+            evs = None
             if timed and s_ == 0:   # mark the dominant kernel: [after LN+partition, after the fused R-MSA core]
                 for j in range(_lib.EV_COUNT):
                     ev_arr[j] = None
                 ev_arr[_lib.EV_LN_PARTITION] = ev_pairs[i][0]
                 ev_arr[_lib.EV_QKV] = ev_pairs[i][1]
-                rc = lib.rrt_encoder_forward_events_f32(C.byref(enc._desc), C.byref(w), x.data_ptr(),
-                                                        outs[s_].data_ptr(), N_TOKENS, wss[s_].data_ptr(),
-                                                        wss[s_].numel(), streams[s_], ev_arr)
-            else:
-                rc = lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), x.data_ptr(), outs[s_].data_ptr(),
-                                                 N_TOKENS, wss[s_].data_ptr(), wss[s_].numel(), streams[s_])
+                evs = ev_arr
+            rc = lib.rrt_encoder_forward_gated_f32(C.byref(enc._desc), C.byref(w), x.data_ptr(),
+                                                   outs[s_].data_ptr(), N_TOKENS, wss[s_].data_ptr(),
+                                                   wss[s_].numel(), streams[s_], gate, evs)
             _lib.check(rc, "forward")
 
     for i in range(args.warmup):

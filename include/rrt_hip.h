@@ -136,6 +136,18 @@ int rrt_encoder_forward_events_f32(const rrt_encoder_desc *desc, const rrt_encod
                                    void *workspace, size_t workspace_bytes, void *stream,
                                    void **events);
 
+/* Concurrent forwards on several streams (one bag each): a phase gate shared by those calls keeps their
+ * MFMA-bound R-MSA cores from co-running (two of them only time-slice the matrix pipes; one of them next to
+ * another bag's memory-bound kernels overlaps well).  Host-side object, one host thread; the executor
+ * below owns one.  events may be NULL (else as in rrt_encoder_forward_events_f32). */
+typedef struct rrt_phase_gate rrt_phase_gate;
+int rrt_phase_gate_create(rrt_phase_gate **out);
+int rrt_phase_gate_destroy(rrt_phase_gate *gate);
+int rrt_encoder_forward_gated_f32(const rrt_encoder_desc *desc, const rrt_encoder_weights *w,
+                                  const float *x, float *y, int64_t n_tokens,
+                                  void *workspace, size_t workspace_bytes, void *stream,
+                                  rrt_phase_gate *gate, void **events);
+
 /* ---- stage entry points (what the fused path is built from; used by the parity tests) ---- */
 
 /* LayerNorm (modules/rrt.py:121-123) + zero-pad (rmsa.py:199-200) + region_partition

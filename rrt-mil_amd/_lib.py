@@ -72,6 +72,11 @@ SIGNATURES = {
     "rrt_encoder_forward_events_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p,
                                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p,
                                                  C.POINTER(C.c_void_p)]),
+    "rrt_phase_gate_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "rrt_phase_gate_destroy": (C.c_int, [C.c_void_p]),
+    "rrt_encoder_forward_gated_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p,
+                                                C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                C.c_void_p, C.POINTER(C.c_void_p)]),
     "rrt_ln_partition_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_int32, C.POINTER(Grid), C.c_void_p]),
     "rrt_linear_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
