@@ -43,3 +43,20 @@ def synth_case(g):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def mil_case(name):
+    """(golden, cfg, state, feats) of an RRTMIL golden (G8 / G11 / G13), regenerated from the closed-form recipe."""
+    from rrt_mil_amd import synth
+    g = load_golden(name)
+    cfg, N = g["cfg"], int(g["n"])
+    enc_keys = {k: v for k, v in cfg.items() if k in ("epeg_k", "crmsa_k", "crmsa_mlp")}
+    st = synth.mil_state(input_dim=cfg["input_dim"], n_classes=cfg["n_classes"], da_bias=cfg.get("da_bias", False),
+                         da_gated=cfg.get("da_gated", False), da_act=cfg.get("da_act", "relu"), **enc_keys)
+    if name.startswith("G8"):
+        tag = "mil"
+    elif name.startswith("G11"):
+        tag = "mil/" + name[len("G11_rrtmil_"):]
+    else:
+        tag = "readme/" + name[len("G13_readme_"):]
+    return g, cfg, st, synth.bag(N, cfg["input_dim"], tag=tag, nonneg=True)

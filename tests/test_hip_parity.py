@@ -212,7 +212,7 @@ def test_crmsa_stages(L, D, k):
 
 
 # ------------------------------------------------------------------ whole path
-SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G7", "G8", "G11")) and "mlp" not in n]
+SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G7", "G8", "G11", "G13")) and "mlp" not in n]
 # crmsa_mlp needs dim % 128 == 0 on the HIP path (hidden = dim/4 is a GEMM K): D=64 golden is out of range
 
 
@@ -493,6 +493,24 @@ def test_rrtmil_variants_match_reference(name):
         y2 = mil.online_encoder(x2)
         l2 = mil.predictor(mil.pool_fn(y2))
     _cmp(l2.cpu().numpy(), logits.cpu().numpy(), 1e-4, name + " composite vs one-call")
+
+
+@pytest.mark.parametrize("name", golden_names("G13"))
+def test_rrtmil_readme_configs(name):
+    """The six published training configs of the reference README (C16 / TCGA-BRCA / TCGA-NSCLC x R50 / PLIP:
+    epeg_k 9..21, crmsa_k 1..5, crmsa_heads=1, crmsa_mlp, all_shortcut, da_act=tanh) as whole classifiers
+    through rrt_mil_forward_f32, against the real reference's logits and attention."""
+    from conftest import mil_case
+    from hip_util import DEV, dev
+    from rrt_mil_amd import RRTMIL
+    g, cfg, st, feats = mil_case(name)
+    mil = RRTMIL(**cfg).eval()
+    mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    mil = mil.to(DEV)
+    logits, attn = mil(dev(feats).unsqueeze(0), return_attn=True)
+    torch.cuda.synchronize()
+    _cmp(logits.cpu().numpy(), g["logits"], 1e-4, name + " logits")
+    _cmp(attn.cpu().numpy(), g["attn"], 1e-6, name + " attention")
 
 
 def test_rrtmil_fails_loudly():

@@ -7,7 +7,7 @@ import pytest
 from conftest import golden_names, load_golden, synth_case
 from oracle import rrt_oracle as O
 
-SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G8", "G11"))   # G8/G11 = RRTMIL goldens
+SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G8", "G11", "G13"))   # G8/G11/G13 = RRTMIL goldens
          and int(load_golden(n)["n"]) <= 4096]
 LARGE = ["G3_d512_n9000", "G5_d512_n9000_c1_sc"]
 
@@ -65,21 +65,16 @@ def test_flops_formula():
     assert abs(O.flops_per_bag(30000, region_num=16) / 1e9 - 74.25) < 0.01
 
 
-MIL = ["G8_rrtmil_n1000"] + golden_names("G11")
+MIL = ["G8_rrtmil_n1000"] + golden_names("G11") + golden_names("G13")
 
 
 @pytest.mark.parametrize("name", MIL)
 def test_mil_f64_truth_matches_reference(name):
     """Row f1: the oracle's float64 RRTMIL (patch_to_emb -> encoder -> DAttention -> predictor) against
-    the real reference RRTMIL's logits / attention / raw scores (tools/make_golden.py G8, G11)."""
-    from rrt_mil_amd import synth
-    g = load_golden(name)
-    cfg, N = g["cfg"], int(g["n"])
-    enc_keys = {k: v for k, v in cfg.items() if k in ("epeg_k", "crmsa_k")}
-    st = synth.mil_state(input_dim=cfg["input_dim"], n_classes=cfg["n_classes"], da_bias=cfg.get("da_bias", False),
-                         da_gated=cfg.get("da_gated", False), da_act=cfg.get("da_act", "relu"), **enc_keys)
-    tag = "mil" if name.startswith("G8") else "mil/" + name[len("G11_rrtmil_"):]
-    feats = synth.bag(N, cfg["input_dim"], tag=tag, nonneg=True)
+    the real reference RRTMIL's logits / attention / raw scores (tools/make_golden.py G8, G11, and G13 =
+    the six published configs of the reference README)."""
+    from conftest import mil_case
+    g, cfg, st, feats = mil_case(name)
     logits, attn, raw = O.mil_forward_f64(feats, st, cfg)
     assert np.abs(logits - g["logits"][0]).max() <= 2e-5
     assert np.abs(attn - g["attn"][0]).max() <= 1e-7          # softmax weights ~ 1/N

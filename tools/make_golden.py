@@ -249,6 +249,29 @@ def main():
         save(f"G11_rrtmil_{tag}", cfg=cfg_array(cfg), n=np.array(N), logits=logits.numpy(), attn=attn.numpy(),
              attn_raw=raw.numpy())
 
+    # G13: the six published training configs of the reference README (README.md:78-121) as RRTMIL classifiers
+    # (main.py:158-192 kwargs: --da_act=tanh everywhere; C16-R50 reads 1024-wide ResNet-50 features)
+    readme = {
+        "c16_r50": dict(input_dim=1024, epeg_k=15, crmsa_k=1, all_shortcut=True),
+        "c16_plip": dict(input_dim=512, epeg_k=9, crmsa_k=3, all_shortcut=True),
+        "brca_r50": dict(input_dim=512, epeg_k=17, crmsa_k=3, crmsa_heads=1),
+        "brca_plip": dict(input_dim=512, crmsa_k=1, all_shortcut=True),
+        "nsclc_r50": dict(input_dim=512, epeg_k=21, crmsa_k=5),
+        "nsclc_plip": dict(input_dim=512, epeg_k=13, crmsa_k=3, crmsa_heads=1, all_shortcut=True, crmsa_mlp=True),
+    }
+    for tag, extra in readme.items():
+        N = 2600
+        cfg = dict(n_classes=2, da_act="tanh", act="relu")
+        cfg.update(extra)
+        enc_keys = {k: v for k, v in cfg.items() if k in ("epeg_k", "crmsa_k", "crmsa_mlp")}
+        st = synth.mil_state(input_dim=cfg["input_dim"], n_classes=2, da_act="tanh", **enc_keys)
+        mil = RefMIL(**cfg).eval()
+        mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+        feats = synth.bag(N, cfg["input_dim"], tag="readme/" + tag, nonneg=True)
+        with torch.no_grad():
+            logits, attn = mil(torch.from_numpy(feats).unsqueeze(0), return_attn=True)
+        save(f"G13_readme_{tag}", cfg=cfg_array(cfg), n=np.array(N), logits=logits.numpy(), attn=attn.numpy())
+
     # G9: awkward sizes / geometry escapes at D=64 (cheap): N around grid boundaries, the
     # min_region_num / min_region_ratio "give up region attention" branch (rmsa.py:191-196),
     # region_size override, region_num=3 (non power of two), epeg_k larger than P
