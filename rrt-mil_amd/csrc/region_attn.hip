@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
 }
 
 // Generic head-dim fallback (hd != 64: e.g. crmsa_heads=1 -> hd=dim, or dim=64 -> hd=8).
-// One wave per query; VALU only.  Correctness path, not tuned.
+// One wave per query; VALU only (the published TCGA-BRCA-R50 / NSCLC-PLIP configs run CR-MSA's inner attention
+// with crmsa_heads=1: 3 x 64 queries of head dim 512).
 __global__ __launch_bounds__(256) void region_attn_generic_kernel(const float* __restrict__ qkv,
                                                                   const float* __restrict__ pe_w,
                                                                   float* __restrict__ o, int P,
@@ -302,14 +303,45 @@ __global__ __launch_bounds__(256) void region_attn_generic_kernel(const float* _
   }
   __builtin_amdgcn_wave_barrier();
   float mx = NEG_BIG;
-  for (int j = lane; j < P; j += 64) {
-    const float* kr = kbase + (size_t)j * ld;
-    float a = 0.f;
-    for (int d = 0; d < hd; ++d) a += qs[d] * kr[d];
-    ps[j] = a;
-    mx = fmaxf(mx, a);
+  if ((hd & 3) == 0) {
+    // keys serially, the head dim across the lanes in 16-byte pieces: every K row is read as contiguous
+    // 256-float runs (the lane-per-key form touched 64 rows per load instruction); 8 keys = up to 16
+    // independent 16-byte loads in flight per trip (the loop is a chain of L2 round trips otherwise)
+    for (int j0 = 0; j0 < P; j0 += 8) {
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = 0.f;
+      for (int d = lane * 4; d < hd; d += 256) {
+        const float4 q4 = *(const float4*)(qs + d);
+        float4 k4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u < P ? j0 + u : P - 1;
+          k4[u] = *(const float4*)(kbase + (size_t)j * ld + d);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += (q4.x * k4[u].x + q4.y * k4[u].y) + (q4.z * k4[u].z + q4.w * k4[u].w);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float v = wave_sum(a[u]);                  // wave-uniform
+        if (j0 + u < P) {
+          if (lane == 0) ps[j0 + u] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    for (int j = lane; j < P; j += 64) {
+      const float* kr = kbase + (size_t)j * ld;
+      float a = 0.f;
+      for (int d = 0; d < hd; ++d) a += qs[d] * kr[d];
+      ps[j] = a;
+      mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
   }
-  mx = wave_max(mx);
   float sum = 0.f;
   for (int j = lane; j < P; j += 64) {
     float p = __expf(ps[j] - mx);
@@ -319,6 +351,27 @@ __global__ __launch_bounds__(256) void region_attn_generic_kernel(const float* _
   sum = wave_sum(sum);
   const float inv = 1.0f / sum;
   __builtin_amdgcn_wave_barrier();
+  if ((hd & 3) == 0) {
+    // 4 head-dim columns per lane, 16 value rows in flight per trip
+    for (int d = lane * 4; d < hd; d += 256) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j0 = 0; j0 < P; j0 += 16) {
+        float4 v4[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = j0 + u < P ? j0 + u : P - 1;
+          v4[u] = *(const float4*)(vbase + (size_t)j * ld + d);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const float p = j0 + u < P ? ps[j0 + u] : 0.f;
+          acc.x += p * v4[u].x; acc.y += p * v4[u].y; acc.z += p * v4[u].z; acc.w += p * v4[u].w;
+        }
+      }
+      *(float4*)(o + (rbase + qi) * dim + head * hd + d) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+    return;
+  }
   for (int d = lane; d < hd; d += 64) {
     float a = 0.f;
     for (int j = 0; j < P; ++j) a += ps[j] * vbase[(size_t)j * ld + d];
