@@ -257,10 +257,11 @@ class RRTEncoder(nn.Module):
         y = out if out is not None else torch.empty_like(x2d)
         ws = self._workspace(n, x2d.device)
         w = self._weights()
-        stream = torch.cuda.current_stream(x2d.device).cuda_stream
         self._desc.compute = self._compute_mode()
-        rc = lib.rrt_encoder_forward_f32(C.byref(self._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
-                                         ws.data_ptr(), ws.numel(), stream)
+        with torch.cuda.device(x2d.device):      # kernels launch on the bag's device, whatever the current one is
+            stream = torch.cuda.current_stream(x2d.device).cuda_stream
+            rc = lib.rrt_encoder_forward_f32(C.byref(self._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
+                                             ws.data_ptr(), ws.numel(), stream)
         _lib.check(rc, "rrt_encoder_forward_f32")
         return y
 

@@ -171,10 +171,11 @@ class RRTMIL(nn.Module):
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=x2d.device)
         logits = torch.empty(d.n_classes, dtype=torch.float32, device=x2d.device)
         attn = torch.empty(n, dtype=torch.float32, device=x2d.device) if return_attn else None
-        rc = lib.rrt_mil_forward_f32(C.byref(d), C.byref(w), x2d.data_ptr(), logits.data_ptr(),
-                                     attn.data_ptr() if return_attn else None, int(bool(no_norm)), None, n,
-                                     self._ws.data_ptr(), self._ws.numel(),
-                                     torch.cuda.current_stream(x2d.device).cuda_stream)
+        with torch.cuda.device(x2d.device):      # kernels launch on the bag's device, whatever the current one is
+            rc = lib.rrt_mil_forward_f32(C.byref(d), C.byref(w), x2d.data_ptr(), logits.data_ptr(),
+                                         attn.data_ptr() if return_attn else None, int(bool(no_norm)), None, n,
+                                         self._ws.data_ptr(), self._ws.numel(),
+                                         torch.cuda.current_stream(x2d.device).cuda_stream)
         _lib.check(rc, "rrt_mil_forward_f32")
         return (logits, attn) if return_attn else logits
 
