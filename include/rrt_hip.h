@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 6
+#define RRT_ABI_VERSION 7
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -276,6 +276,16 @@ int rrt_executor_create(const rrt_encoder_desc *desc, int32_t n_streams, int64_t
 int rrt_executor_forward(rrt_executor *ex, const rrt_encoder_weights *w, const rrt_bag *bags,
                          int32_t n_bags, void *stream);
 int rrt_executor_destroy(rrt_executor *ex);
+
+/* ---- row f2 building blocks: backward stages (training is not assembled yet; these are parity-tested
+ * on their own) ----
+ * nn.Linear backward for Y[M,N] = X[M,K] . W[N,K]^T + b:  dX[M,K] = dY . W,  dW[N,K] = dY^T . X,
+ * db[N] = column sums of dY.  Any of dX / dW / db may be NULL.  N must be a multiple of 32 when dX is
+ * requested (it is the reduction length of that product). */
+int rrt_linear_backward_workspace_size(int64_t M, int32_t N, int32_t K, size_t *bytes);
+int rrt_linear_backward_f32(const float *dY, const float *X, const float *W, float *dX, float *dW,
+                            float *db, int64_t M, int32_t N, int32_t K, int32_t compute,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _f32p = C.POINTER(C.c_float)
 
@@ -106,6 +106,9 @@ SIGNATURES = {
     "rrt_executor_forward": (C.c_int, [C.c_void_p, C.POINTER(EncoderWeights), C.POINTER(Bag), C.c_int32,
                                        C.c_void_p]),
     "rrt_executor_destroy": (C.c_int, [C.c_void_p]),
+    "rrt_linear_backward_workspace_size": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "rrt_linear_backward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                                             C.c_void_p, C.c_size_t, C.c_void_p]),
     "rrt_linear_act_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                         C.c_void_p]),
 }

@@ -797,3 +797,26 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ row f2 building blocks (backward stages)
+extern "C" {
+
+int rrt_linear_backward_workspace_size(int64_t M, int32_t N, int32_t K, size_t* bytes) {
+  if (!bytes || M <= 0 || N <= 0 || K <= 0 || M > (int64_t)16000000) return RRT_E_INVALID;
+  *bytes = linear_bwd_workspace((int)M, N, K);
+  return RRT_OK;
+}
+
+int rrt_linear_backward_f32(const float* dY, const float* X, const float* W, float* dX, float* dW, float* db,
+                            int64_t M, int32_t N, int32_t K, int32_t compute, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!dY || M <= 0 || N <= 0 || K <= 0 || M > (int64_t)16000000) return RRT_E_INVALID;
+  if ((dX && !W) || (dW && !X)) return RRT_E_INVALID;
+  if (dX && N % 32) return unsupported("linear backward: N must be a multiple of 32 for dX");
+  if (compute < 0 || compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
+  if (!workspace || workspace_bytes < linear_bwd_workspace((int)M, N, K)) return RRT_E_WORKSPACE;
+  return (int)launch_linear_backward(dY, X, W, dX, dW, db, (int)M, N, K, compute, workspace, (hipStream_t)stream);
+}
+
+}  // extern "C"
+

@@ -57,3 +57,14 @@ hipError_t launch_pool_partial(const float* y, const float* hid_a, const float* 
 hipError_t launch_pool_merge(const float* part, const float* a_raw, const float* pred_w, const float* pred_b,
                              float* pooled, float* logits, float* attn, int no_norm, int N, int dim,
                              int n_classes, hipStream_t st);
+
+// ---- row f2 building blocks (backward)
+// nn.Linear backward: dX = dY W (forward GEMM on a transposed W), dW = dY^T X (split-K TN kernel), db = colsum(dY)
+size_t linear_bwd_workspace(int M, int N, int K);
+hipError_t launch_linear_backward(const float* dY, const float* X, const float* W, float* dX, float* dW, float* db,
+                                  int M, int N, int K, int prec, void* ws, hipStream_t st);
+hipError_t launch_transpose(const float* in, float* out, int R, int C, hipStream_t st);
+hipError_t launch_reduce_partials(const float* part, float* out, int S, size_t n, hipStream_t st);
+hipError_t launch_gemm_tn(const float* dY, const float* X, float* dW, float* scratch, int M, int N, int K,
+                          hipStream_t st);
+hipError_t launch_colsum(const float* Y, float* out, float* scratch, int M, int N, hipStream_t st);

@@ -1,0 +1,233 @@
+// linear_bwd.hip -- gradients of nn.Linear  Y[M,N] = X[M,K] . W[N,K]^T + b  (row f2 building block):
+//     dX[M,K] = dY . W            dW[N,K] = dY^T . X            db[N] = column sums of dY
+// dX reuses the forward GEMM (linear_f32.hip computes A.B^T with both operands reduction-contiguous) on a
+// transposed copy of W (<= 3 MB).  dW reduces over the ROWS of both operands, so it gets its own kernel:
+// a "TN" product on the fp32 matrix cores with split-K over row chunks (a 512 x 512 x 9216 product has only
+// 16 output tiles; the chunks make it >= 2 blocks per CU), partial products summed by a small reduce kernel
+// in a fixed order (bit-reproducible, no atomics).
+#include "internal.h"
+
+namespace {
+
+// ---- out[C,R] = in[R,C]^T, 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        int R, int C) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < C && r < R) out[(size_t)c * R + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+// ---- split-K TN product: part[s][n][k] = sum_{m in chunk s} A[m][n] * B[m][k]
+// block = 4 waves (2 x 2), tile 128 (n) x 128 (k), 32 rows of both operands per step.  Rows are staged in LDS
+// as they lie in memory (coalesced 16-byte loads); the MFMA fragments are read "down the columns":
+// lane (lr, lg) takes A_s[m = 4 kk + lg][n = .. + lr] -- 16 consecutive floats per lane group, and the row
+// pitch of 144 floats puts the four groups on disjoint bank ranges.
+constexpr int TN_BN = 128, TN_BK = 128, TN_BM = 32, TN_PITCH = 144;
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      float* __restrict__ part, int M, int N, int K,
+                                                      int rows_per_chunk) {
+  __shared__ __attribute__((aligned(16))) float As[TN_BM * TN_PITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[TN_BM * TN_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = blockIdx.x * TN_BN, k0 = blockIdx.y * TN_BK, s = blockIdx.z;
+  const int m_begin = s * rows_per_chunk;
+  const int m_end = min(M, m_begin + rows_per_chunk);
+  const bool vecA = (N & 3) == 0, vecB = (K & 3) == 0;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int m0 = m_begin; m0 < m_end; m0 += TN_BM) {
+    // stage 32 rows x 128 columns of each operand: 1024 float4 per operand, 4 per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 5, c4 = (idx & 31) * 4;
+      const int m = m0 + row;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (m < m_end) {
+        const int n = n0 + c4, k = k0 + c4;
+        if (vecA && n + 3 < N) va = *(const float4*)(A + (size_t)m * N + n);
+        else {
+          if (n < N) va.x = A[(size_t)m * N + n];
+          if (n + 1 < N) va.y = A[(size_t)m * N + n + 1];
+          if (n + 2 < N) va.z = A[(size_t)m * N + n + 2];
+          if (n + 3 < N) va.w = A[(size_t)m * N + n + 3];
+        }
+        if (vecB && k + 3 < K) vb = *(const float4*)(B + (size_t)m * K + k);
+        else {
+          if (k < K) vb.x = B[(size_t)m * K + k];
+          if (k + 1 < K) vb.y = B[(size_t)m * K + k + 1];
+          if (k + 2 < K) vb.z = B[(size_t)m * K + k + 2];
+          if (k + 3 < K) vb.w = B[(size_t)m * K + k + 3];
+        }
+      }
+      *(float4*)(As + row * TN_PITCH + c4) = va;
+      *(float4*)(Bs + row * TN_PITCH + c4) = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TN_BM / 4; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[(4 * kk + lg) * TN_PITCH + wn * 64 + i * 16 + lr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[(4 * kk + lg) * TN_PITCH + wk * 64 + j * 16 + lr];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[i = 4 lg + r][j = lr] of every 16 x 16 tile
+  float* out = part + (size_t)s * N * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * lg + r, k = k0 + wk * 64 + j * 16 + lr;
+        if (n < N && k < K) out[(size_t)n * K + k] = acc[i][j][r];
+      }
+}
+
+// ---- out[i] = sum_s part[s][i]  (fixed order)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int S, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n && (n & 3) == 0) {
+    float4 a = *(const float4*)(part + i);
+    for (int s = 1; s < S; ++s) {
+      const float4 b = *(const float4*)(part + (size_t)s * n + i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *(float4*)(out + i) = a;
+  } else {
+    for (size_t e = i; e < n && e < i + 4; ++e) {
+      float a = part[e];
+      for (int s = 1; s < S; ++s) a += part[(size_t)s * n + e];
+      out[e] = a;
+    }
+  }
+}
+
+// ---- column sums of Y[M,N] over row chunks: part[c][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y, float* __restrict__ part, int M,
+                                                     int N, int rows_per_chunk) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int m = m0;
+  for (; m + 3 < m1; m += 4) {
+    a0 += Y[(size_t)m * N + n];
+    a1 += Y[(size_t)(m + 1) * N + n];
+    a2 += Y[(size_t)(m + 2) * N + n];
+    a3 += Y[(size_t)(m + 3) * N + n];
+  }
+  for (; m < m1; ++m) a0 += Y[(size_t)m * N + n];
+  part[(size_t)blockIdx.y * N + n] = (a0 + a1) + (a2 + a3);
+}
+
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+int linear_bwd_chunks(int M, int N, int K, int* rows_per_chunk) {
+  const long tiles = (long)((N + TN_BN - 1) / TN_BN) * ((K + TN_BK - 1) / TN_BK);
+  int S = (int)((768 + tiles - 1) / tiles);                 // ~3 blocks per CU
+  const int max_s = (M + 4 * TN_BM - 1) / (4 * TN_BM);      // at least 128 rows per chunk
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  int rpc = (M + S - 1) / S;
+  rpc = (rpc + TN_BM - 1) / TN_BM * TN_BM;
+  S = (M + rpc - 1) / rpc;
+  *rows_per_chunk = rpc;
+  return S;
+}
+
+size_t linear_bwd_workspace(int M, int N, int K) {
+  int rpc;
+  const int S = linear_bwd_chunks(M, N, K, &rpc);
+  const int SB = (M + 127) / 128;
+  return align256((size_t)N * K * 4) + align256((size_t)S * N * K * 4) + align256((size_t)SB * N * 4);
+}
+
+hipError_t launch_transpose(const float* in, float* out, int R, int C, hipStream_t st) {
+  transpose_kernel<<<dim3((C + 31) / 32, (R + 31) / 32), 256, 0, st>>>(in, out, R, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(const float* part, float* out, int S, size_t n, hipStream_t st) {
+  reduce_partials_kernel<<<dim3((unsigned)((n + 1023) / 1024)), 256, 0, st>>>(part, out, S, n);
+  return hipGetLastError();
+}
+
+// dW[N,K] = dY[M,N]^T . X[M,K] ; scratch: S * N * K floats
+hipError_t launch_gemm_tn(const float* dY, const float* X, float* dW, float* scratch, int M, int N, int K,
+                          hipStream_t st) {
+  int rpc;
+  const int S = linear_bwd_chunks(M, N, K, &rpc);
+  dim3 grid((N + TN_BN - 1) / TN_BN, (K + TN_BK - 1) / TN_BK, S);
+  gemm_tn_kernel<<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, M, N, K, rpc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || S == 1) return e;
+  return launch_reduce_partials(scratch, dW, S, (size_t)N * K, st);
+}
+
+hipError_t launch_colsum(const float* Y, float* out, float* scratch, int M, int N, hipStream_t st) {
+  const int SB = (M + 127) / 128;
+  colsum_kernel<<<dim3((N + 255) / 256, SB), 256, 0, st>>>(Y, SB == 1 ? out : scratch, M, N, 128);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || SB == 1) return e;
+  return launch_reduce_partials(scratch, out, SB, (size_t)N, st);
+}
+
+// Full nn.Linear backward.  dX may be null (first layer).  ws: linear_bwd_workspace(M, N, K) bytes.
+hipError_t launch_linear_backward(const float* dY, const float* X, const float* W, float* dX, float* dW, float* db,
+                                  int M, int N, int K, int prec, void* ws, hipStream_t st) {
+  char* base = (char*)ws;
+  float* WT = (float*)base;
+  float* scratch = (float*)(base + align256((size_t)N * K * 4));
+  int rpc;
+  const int S = linear_bwd_chunks(M, N, K, &rpc);
+  float* cs = (float*)((char*)scratch + align256((size_t)S * N * K * 4));
+  hipError_t e;
+  if (dX) {
+    e = launch_transpose(W, WT, N, K, st);                    // WT [K, N]
+    if (e != hipSuccess) return e;
+    LinearEpilogue ep{};
+    ep.prec = prec;
+    e = launch_linear(dY, WT, dX, M, K, N, ep, st);           // dX[M,K] = dY[M,N] . WT[K,N]^T
+    if (e != hipSuccess) return e;
+  }
+  if (dW) {
+    e = launch_gemm_tn(dY, X, dW, scratch, M, N, K, st);
+    if (e != hipSuccess) return e;
+  }
+  if (db) {
+    e = launch_colsum(dY, db, cs, M, N, st);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}

@@ -709,3 +709,36 @@ def test_bag_feeder_matches_direct_copy(tmp_path):
     assert len(got) == len(want)
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ row f2 building blocks (backward stages)
+@pytest.mark.parametrize("M,N,K", [(9216, 1536, 512), (9216, 512, 512), (192, 1536, 512), (192, 512, 512),
+                                   (1000, 160, 96), (300, 192, 64), (3136, 512, 2048), (77, 32, 40)])
+def test_linear_backward(M, N, K):
+    """nn.Linear backward (dX = dY W, dW = dY^T X on the split-K TN kernel, db = colsum dY) against float64."""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    dY = synth.normal(f"lb/dy{M}x{N}", (M, N))
+    X = synth.normal(f"lb/x{M}x{K}", (M, K))
+    W = synth.uniform(f"lb/w{N}x{K}", (N, K), -1, 1) / np.sqrt(K)
+    d_dY, d_X, d_W = dev(dY), dev(X), dev(W)
+    dX = torch.full((M, K), float("nan"), device=DEV)
+    dW = torch.full((N, K), float("nan"), device=DEV)
+    db = torch.full((N,), float("nan"), device=DEV)
+    need = C.c_size_t()
+    _lib.check(lib.rrt_linear_backward_workspace_size(M, N, K, C.byref(need)), "ws")
+    ws = torch.full((need.value,), 0xFF, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.rrt_linear_backward_f32(p(d_dY), p(d_X), p(d_W), p(dX), p(dW), p(db), M, N, K, 0, p(ws),
+                                           ws.numel(), stream()), "linear_backward")
+    torch.cuda.synchronize()
+    dY64, X64, W64 = dY.astype(np.float64), X.astype(np.float64), W.astype(np.float64)
+    _cmp(dX.cpu().numpy(), dY64 @ W64, 3e-5, "dX")
+    scale = np.sqrt(M)                       # sums of M products of N(0,1) variables
+    _cmp(dW.cpu().numpy() / scale, dY64.T @ X64 / scale, 3e-5, "dW")
+    _cmp(db.cpu().numpy() / scale, dY64.sum(0) / scale, 3e-5, "db")
+    # optional outputs
+    _lib.check(lib.rrt_linear_backward_f32(p(d_dY), p(d_X), p(d_W), None, p(dW), None, M, N, K, 0, p(ws),
+                                           ws.numel(), stream()), "linear_backward dW only")
+    torch.cuda.synchronize()
+    _cmp(dW.cpu().numpy() / scale, dY64.T @ X64 / scale, 3e-5, "dW only")
+
