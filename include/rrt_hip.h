@@ -282,6 +282,12 @@ int rrt_executor_destroy(rrt_executor *ex);
  * nn.Linear backward for Y[M,N] = X[M,K] . W[N,K]^T + b:  dX[M,K] = dY . W,  dW[N,K] = dY^T . X,
  * db[N] = column sums of dY.  Any of dX / dW / db may be NULL.  N must be a multiple of 32 when dX is
  * requested (it is the reduction length of that product). */
+/* LayerNorm backward (eps 1e-5): dx [L, dim] = d/dx of LN(x) . dy (+ add, the residual branch's gradient,
+ * optional); dgamma_dbeta [2, dim].  g != NULL: dy is region-major padded [H*H, dim] (the qkv-linear backward's
+ * output) and token t reads its slot -- the adjoint of zero-pad + region_partition.  workspace: 512*2*dim floats. */
+int rrt_layernorm_backward_f32(const float *dy, const float *x, const float *gamma, const float *add,
+                               float *dx, float *dgamma_dbeta, int64_t L, int32_t dim, const rrt_grid *g,
+                               void *workspace, size_t workspace_bytes, void *stream);
 int rrt_linear_backward_workspace_size(int64_t M, int32_t N, int32_t K, size_t *bytes);
 int rrt_linear_backward_f32(const float *dY, const float *X, const float *W, float *dX, float *dW,
                             float *db, int64_t M, int32_t N, int32_t K, int32_t compute,

@@ -801,6 +801,19 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
 // ------------------------------------------------------------------ row f2 building blocks (backward stages)
 extern "C" {
 
+int rrt_layernorm_backward_f32(const float* dy, const float* x, const float* gamma, const float* add, float* dx,
+                               float* dgamma_dbeta, int64_t L, int32_t dim, const rrt_grid* g, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (!dy || !x || !gamma || !dx || !dgamma_dbeta || L <= 0 || dim <= 0 || dim % 4) return RRT_E_INVALID;
+  if (dim > 2048) return unsupported("dim > 2048");
+  if (g && g->L != L) return RRT_E_INVALID;
+  if (!workspace || workspace_bytes < ln_bwd_workspace(dim)) return RRT_E_WORKSPACE;
+  GridDev gd{};
+  if (g) gd = to_dev(*g);
+  return (int)launch_ln_backward(dy, x, gamma, add, dx, dgamma_dbeta, (float*)workspace, (int)L, dim,
+                                 g ? &gd : nullptr, (hipStream_t)stream);
+}
+
 int rrt_linear_backward_workspace_size(int64_t M, int32_t N, int32_t K, size_t* bytes) {
   if (!bytes || M <= 0 || N <= 0 || K <= 0 || M > (int64_t)16000000) return RRT_E_INVALID;
   *bytes = linear_bwd_workspace((int)M, N, K);

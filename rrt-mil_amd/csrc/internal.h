@@ -68,3 +68,7 @@ hipError_t launch_reduce_partials(const float* part, float* out, int S, size_t n
 hipError_t launch_gemm_tn(const float* dY, const float* X, float* dW, float* scratch, int M, int N, int K,
                           hipStream_t st);
 hipError_t launch_colsum(const float* Y, float* out, float* scratch, int M, int N, hipStream_t st);
+// LayerNorm backward; dgb = [2, dim] (dgamma, dbeta); g != null: dy rows are region-major slots; add: residual grad
+size_t ln_bwd_workspace(int dim);
+hipError_t launch_ln_backward(const float* dy, const float* x, const float* gamma, const float* add, float* dx,
+                              float* dgb, float* part, int L, int dim, const GridDev* g, hipStream_t st);

@@ -742,3 +742,50 @@ def test_linear_backward(M, N, K):
     torch.cuda.synchronize()
     _cmp(dW.cpu().numpy() / scale, dY64.T @ X64 / scale, 3e-5, "dW only")
 
+
+def _ln_bwd64(dy, x, gamma, eps=1e-5):
+    mu = x.mean(-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(((x - mu) ** 2).mean(-1, keepdims=True) + eps)
+    xh = (x - mu) * rstd
+    g = dy * gamma
+    dx = rstd * (g - g.mean(-1, keepdims=True) - xh * (g * xh).mean(-1, keepdims=True))
+    return dx, (dy * xh).sum(0), dy.sum(0)
+
+
+@pytest.mark.parametrize("L,D,rn", [(9000, 512, 8), (300, 64, 8), (1, 512, 8), (4096, 1024, 8), (30000, 512, 16)])
+def test_layernorm_backward(L, D, rn):
+    """LayerNorm backward, plain and with the upstream gradient in region-major padded order + residual."""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    x = synth.normal(f"lnb/x{L}x{D}", (L, D)) * 1.7 + 0.3
+    dy = synth.normal(f"lnb/dy{L}x{D}", (L, D))
+    gamma = (1.0 + synth.uniform(f"lnb/g{D}", (D,), -0.25, 0.25)).astype(np.float32)
+    add = synth.normal(f"lnb/add{L}x{D}", (L, D))
+    dx64, dg64, db64 = _ln_bwd64(dy.astype(np.float64), x.astype(np.float64), gamma.astype(np.float64))
+    d_x, d_dy, d_g, d_add = dev(x), dev(dy), dev(gamma), dev(add)
+    ws = torch.full((512 * 2 * D * 4,), 0xFF, dtype=torch.uint8, device=DEV)
+    dx = torch.full((L, D), float("nan"), device=DEV)
+    dgb = torch.full((2, D), float("nan"), device=DEV)
+    _lib.check(lib.rrt_layernorm_backward_f32(p(d_dy), p(d_x), p(d_g), None, p(dx), p(dgb), L, D, None, p(ws),
+                                              ws.numel(), stream()), "ln_backward")
+    torch.cuda.synchronize()
+    scale = max(1.0, np.sqrt(L))
+    _cmp(dx.cpu().numpy(), dx64, 2e-5, "dx")
+    _cmp(dgb[0].cpu().numpy() / scale, dg64 / scale, 2e-5, "dgamma")
+    _cmp(dgb[1].cpu().numpy() / scale, db64 / scale, 2e-5, "dbeta")
+    # region-major upstream gradient (adjoint of zero-pad + partition) + residual gradient
+    g = _lib.region_grid(L, rn)
+    Np = g.H * g.H
+    dU = synth.normal(f"lnb/du{Np}x{D}", (Np, D))               # pad slots hold garbage that must be ignored
+    perm = O.partition_index(g.H, g.s)                          # perm[slot] = token
+    dy_tok = np.empty((Np, D), np.float32)
+    dy_tok[perm] = dU
+    dx64, dg64, db64 = _ln_bwd64(dy_tok[:L].astype(np.float64), x.astype(np.float64), gamma.astype(np.float64))
+    d_dU = dev(dU)
+    _lib.check(lib.rrt_layernorm_backward_f32(p(d_dU), p(d_x), p(d_g), p(d_add), p(dx), p(dgb), L, D, C.byref(g),
+                                              p(ws), ws.numel(), stream()), "ln_backward mapped")
+    torch.cuda.synchronize()
+    _cmp(dx.cpu().numpy(), dx64 + add, 2e-5, "dx mapped + residual")
+    _cmp(dgb[0].cpu().numpy() / scale, dg64 / scale, 2e-5, "dgamma mapped")
+    _cmp(dgb[1].cpu().numpy() / scale, db64 / scale, 2e-5, "dbeta mapped")
+
