@@ -282,6 +282,14 @@ int rrt_executor_destroy(rrt_executor *ex);
  * nn.Linear backward for Y[M,N] = X[M,K] . W[N,K]^T + b:  dX[M,K] = dY . W,  dW[N,K] = dY^T . X,
  * db[N] = column sums of dY.  Any of dX / dW / db may be NULL.  N must be a multiple of 32 when dX is
  * requested (it is the reduction length of that product). */
+/* Region attention backward (rmsa.py:103-122): qkv [n_regions*P, 3*dim] as the forward stage wrote it (q scaled),
+ * o = the forward output, d_o its gradient  ->  d_qkv (gradient w.r.t. the qkv linear's raw output, same layout)
+ * and d_pe_w [heads, epeg_k] (NULL allowed; the conv bias gradient is exactly zero).  Head dim 64, P <= 144.
+ * workspace: n_regions * heads * max(epeg_k, 1) floats. */
+int rrt_region_attention_backward_f32(const float *qkv, const float *pe_w, const float *o, const float *d_o,
+                                      float *d_qkv, float *d_pe_w, int32_t n_regions, int32_t P, int32_t dim,
+                                      int32_t heads, int32_t epeg_k, void *workspace, size_t workspace_bytes,
+                                      void *stream);
 /* LayerNorm backward (eps 1e-5): dx [L, dim] = d/dx of LN(x) . dy (+ add, the residual branch's gradient,
  * optional); dgamma_dbeta [2, dim].  g != NULL: dy is region-major padded [H*H, dim] (the qkv-linear backward's
  * output) and token t reads its slot -- the adjoint of zero-pad + region_partition.  workspace: 512*2*dim floats. */

@@ -801,6 +801,20 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
 // ------------------------------------------------------------------ row f2 building blocks (backward stages)
 extern "C" {
 
+int rrt_region_attention_backward_f32(const float* qkv, const float* pe_w, const float* o, const float* d_o,
+                                      float* d_qkv, float* d_pe_w, int32_t n_regions, int32_t P, int32_t dim,
+                                      int32_t heads, int32_t epeg_k, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  if (!qkv || !o || !d_o || !d_qkv || n_regions <= 0 || P <= 0 || dim <= 0 || heads <= 0) return RRT_E_INVALID;
+  const int ek = pe_w ? epeg_k : 0;
+  if (ek > 0 && ek % 2 == 0) return unsupported("epeg_k must be odd");
+  if (!attn_bwd_supported(P, dim, heads, ek))
+    return unsupported("attention backward: needs head dim 64, P <= 144, epeg_k <= 63");
+  if (!workspace || workspace_bytes < attn_bwd_workspace(n_regions, heads, ek)) return RRT_E_WORKSPACE;
+  return (int)launch_attention_backward(qkv, pe_w, o, d_o, d_qkv, d_pe_w, (float*)workspace, n_regions, P, dim,
+                                        heads, ek, (hipStream_t)stream);
+}
+
 int rrt_layernorm_backward_f32(const float* dy, const float* x, const float* gamma, const float* add, float* dx,
                                float* dgamma_dbeta, int64_t L, int32_t dim, const rrt_grid* g, void* workspace,
                                size_t workspace_bytes, void* stream) {

@@ -1,0 +1,383 @@
+// attn_bwd.hip -- backward of the region attention core (row f2 building block).
+//
+// Forward (modules/rmsa.py:103-122, per region and head, Identity 1 of DESIGN.md):
+//     Q~ = (I + T_w) q ,  S = Q~ K^T ,  A = softmax_rows(S) ,  O = A V          q = scale * q_raw (as stashed)
+// Backward, one block per (region, head) with Q~, K, V and dO resident in LDS (4 x 36.9 KB at P = 144), the
+// probabilities recomputed from them (nothing of size P x P is ever stored, forward or backward):
+//     D_i  = <dO_i, O_i>                       (= rowsum(dA o A))
+//     dV   = A^T dO        dA = dO V^T        dS = A o (dA - D)
+//     dQ~  = dS K          dK = dS^T Q~
+//     dq_raw = scale * (I + T_w)^T dQ~         (the same sliding-window stencil with the taps flipped)
+//     dw_h[t] = sum_i <dQ~_i, q_{i + t - k/2}>  ;  the conv bias has an exactly-zero gradient (Identity 2)
+// Pass A (a wave owns 16-query tiles, scores transposed exactly as in the forward kernels) produces the row
+// statistics, D and dQ~ (kept in registers); pass B (a wave owns 16-key tiles; the same two MFMA helpers with
+// the roles of Q~ and K exchanged) produces dK and dV.  Scores are in base-2 units (log2(e) folded into Q~).
+// Requires head dim 64 and P <= 144.
+#include "internal.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr float NEG_BIG = -3.0e38f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// rows of a swizzled [BM][64] tile as MFMA fragments: lane (lr, lg) <- tile[row0 + lr][4*(4c + lg) .. +3]
+__device__ __forceinline__ void load_frags(const float* tile, int row, int lg, float4 (&f)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) f[c] = *(const float4*)(tile + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+}
+
+// s[t][r] = sum_d X[16 t + 4 lg + r][d] * f[d]  for the fragment rows f (lane lr = one row of the other operand)
+template <int MT>
+__device__ __forceinline__ void tile_scores(const float* X, const float4 (&f)[4], int lr, int lg, f32x4 (&s)[MT]) {
+#pragma unroll
+  for (int t = 0; t < MT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float4 a[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int row = t * 16 + lr;
+      a[t] = *(const float4*)(X + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, f[c].x, s[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, f[c].y, s[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, f[c].z, s[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, f[c].w, s[t], 0, 0, 0);
+  }
+}
+
+// o[c][r] = sum_{t, rows} p[t][r'] * X[16 t + 4 lg + r'][4 lr + c]   ->  o[c][r] belongs to (row 4 lg + r of the
+// p-operand's lane index, column 4 lr + c)
+template <int MT>
+__device__ __forceinline__ void tile_apply(const float* X, const f32x4 (&p)[MT], int lr, int lg, f32x4 (&o)[4]) {
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = t * 16 + 4 * lg + r;
+      const float4 v = *(const float4*)(X + row * HD + ((lr ^ (row & 15)) << 2));
+      const float w = p[t][r];
+      o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v.x, o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v.y, o[1], 0, 0, 0);
+      o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v.z, o[2], 0, 0, 0);
+      o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v.w, o[3], 0, 0, 0);
+    }
+}
+
+template <int MT>
+__global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restrict__ qkv,
+                                                          const float* __restrict__ pe_w,
+                                                          const float* __restrict__ O,
+                                                          const float* __restrict__ dO,
+                                                          float* __restrict__ dqkv, float* __restrict__ dpe_part,
+                                                          int P, int D, int heads, int epeg_k, float q_scale) {
+  constexpr int BM = 16 * MT;
+  constexpr int TILE = BM * HD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Qt = (float*)smem;             // q, then Q~ (x log2 e) in place
+  float* Ks = Qt + TILE;
+  float* Vs = Ks + TILE;
+  float* Gs = Vs + TILE;                // dO, later dQ~
+  float* lse = Gs + TILE;               // [BM] row log-sum-exp, base 2
+  float* dd = lse + BM;                 // [BM] D_i
+  float* wred = dd + BM;                // [6][64] wave partials of the tap gradients
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int reg = blockIdx.x / heads, head = blockIdx.x - reg * heads;
+  const size_t row0 = (size_t)reg * P;
+  const int ld = 3 * D;
+
+  // ---- phase 0: q, k, v, dO tiles -> LDS (XOR-swizzled 16-byte slots, rows >= P are zeros)
+  for (int idx = tid; idx < BM * 16; idx += 384) {
+    const int m = idx >> 4, s = idx & 15;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, g4 = q4;
+    if (m < P) {
+      const float* src = qkv + (row0 + m) * ld + head * HD + 4 * s;
+      q4 = *(const float4*)src;
+      k4 = *(const float4*)(src + D);
+      v4 = *(const float4*)(src + 2 * D);
+      g4 = *(const float4*)(dO + (row0 + m) * D + head * HD + 4 * s);
+    }
+    const int off = m * HD + ((s ^ (m & 15)) << 2);
+    *(float4*)(Qt + off) = q4;
+    *(float4*)(Ks + off) = k4;
+    *(float4*)(Vs + off) = v4;
+    *(float4*)(Gs + off) = g4;
+  }
+  __syncthreads();
+
+  // ---- phase 1: Q~ = log2(e) * (I + T_w) q, in place (the forward's sliding-window stencil)
+  constexpr int RUN = (BM * 16 + 383) / 384;
+  const int half = epeg_k >> 1;
+  const float* w = pe_w + head * epeg_k;
+  {
+    auto tap = [&](int t) {
+      float wt = (t >= 0 && t < epeg_k) ? w[t] : 0.f;
+      if (t == half) wt += 1.0f;
+      return wt * LOG2E;
+    };
+    const int s = tid & 15, g = tid >> 4;
+    const int r0 = g * RUN;
+    float4 out[RUN];
+#pragma unroll
+    for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < BM) {
+      const int lo = max(r0 - half, 0), hi = min(r0 + RUN - 1 + half, P - 1);
+      float wr[RUN];
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) wr[o] = tap(lo - r0 - o + half);
+      for (int rr = lo; rr <= hi; ++rr) {
+        const float4 v = *(const float4*)(Qt + rr * HD + ((s ^ (rr & 15)) << 2));
+        const float wnext = tap(rr + 1 - r0 + half);
+#pragma unroll
+        for (int o = 0; o < RUN; ++o) {
+          out[o].x += wr[o] * v.x; out[o].y += wr[o] * v.y; out[o].z += wr[o] * v.z; out[o].w += wr[o] * v.w;
+        }
+#pragma unroll
+        for (int o = RUN - 1; o > 0; --o) wr[o] = wr[o - 1];
+        wr[0] = wnext;
+      }
+    }
+    __syncthreads();
+    if (r0 < BM) {
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) {
+        const int m = r0 + o;
+        if (m < BM) *(float4*)(Qt + m * HD + ((s ^ (m & 15)) << 2)) = (m < P) ? out[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  __syncthreads();
+
+  // tile -> wave schedule of the forward fused kernel (MT <= 9: at most two tiles per wave)
+  auto tile_of = [&](int pass) { return pass == 0 ? wave : (wave >= 2 ? wave + 4 : MT); };
+
+  // ---- pass A: query tiles.  Row statistics, D, dQ~ (kept in registers until the tiles are dead)
+  f32x4 keep[2][4];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) keep[ps][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int t = tile_of(ps);
+    const int i0 = t * 16;
+    if (t >= MT || i0 >= P) break;
+    const int m = i0 + lr;
+    float4 fq[4], fg[4];
+    load_frags(Qt, m, lg, fq);
+    load_frags(Gs, m, lg, fg);
+    // D_i = <dO_i, O_i>: this lane's 16 of the 64 dims, then across the 4 lane groups
+    float dsum = 0.f;
+    if (m < P) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 o4 = *(const float4*)(O + (row0 + m) * D + head * HD + 4 * (4 * c + lg));
+        dsum += (fg[c].x * o4.x + fg[c].y * o4.y) + (fg[c].z * o4.z + fg[c].w * o4.w);
+      }
+    }
+    dsum += __shfl_xor(dsum, 16);
+    dsum += __shfl_xor(dsum, 32);
+    f32x4 s[MT];
+    tile_scores<MT>(Ks, fq, lr, lg, s);            // s[jt][r] = S2[query lr][key 16 jt + 4 lg + r]
+    float cmax = NEG_BIG;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;
+        cmax = fmaxf(cmax, s[jt][r]);
+      }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    float psum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[jt][r] - cmax);
+        s[jt][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    const float inv = 1.0f / psum;
+    if (lg == 0) {
+      lse[m] = cmax + __builtin_amdgcn_logf(psum);   // v_log_f32 = log2
+      dd[m] = dsum;
+    }
+    f32x4 da[MT];
+    tile_scores<MT>(Vs, fg, lr, lg, da);            // dA[query lr][key]
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[jt][r] = s[jt][r] * inv * (da[jt][r] - dsum);   // dS (masked keys: A = 0)
+    tile_apply<MT>(Ks, s, lr, lg, keep[ps]);        // dQ~[query 4 lg + r][d = 4 lr + c]
+  }
+  __syncthreads();
+
+  // ---- pass B: key tiles.  dV = A^T dO, dK = dS^T Q~ (Q~ carries log2 e: x ln 2)
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int t = tile_of(ps);
+    const int j0 = t * 16;
+    if (t >= MT || j0 >= P) break;
+    const int m = j0 + lr;
+    float4 fk[4], fv[4];
+    load_frags(Ks, m, lg, fk);
+    load_frags(Vs, m, lg, fv);
+    f32x4 a[MT], ds[MT];
+    tile_scores<MT>(Qt, fk, lr, lg, a);             // a[it][r] = S2[query 16 it + 4 lg + r][key lr]
+    tile_scores<MT>(Gs, fv, lr, lg, ds);            // dA[query][key lr]
+#pragma unroll
+    for (int it = 0; it < MT; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = it * 16 + 4 * lg + r;
+        const float p = q < P ? __builtin_amdgcn_exp2f(a[it][r] - lse[q]) : 0.f;
+        a[it][r] = p;
+        ds[it][r] = p * (ds[it][r] - dd[q]);
+      }
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dv[c] = dk[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile_apply<MT>(Gs, a, lr, lg, dv);              // dV[key 4 lg + r][d = 4 lr + c]
+    tile_apply<MT>(Qt, ds, lr, lg, dk);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = j0 + 4 * lg + r;
+      if (key < P) {
+        float* dst = dqkv + (row0 + key) * ld + head * HD + (lr << 2);
+        *(float4*)(dst + D) = make_float4(dk[0][r] * LN2, dk[1][r] * LN2, dk[2][r] * LN2, dk[3][r] * LN2);
+        *(float4*)(dst + 2 * D) = make_float4(dv[0][r], dv[1][r], dv[2][r], dv[3][r]);
+      }
+    }
+  }
+  __syncthreads();                                  // every read of Q~ / dO tiles is done
+
+  // ---- dQ~ tiles -> LDS over the dead dO tile (rows >= P and untouched tiles: zeros)
+  for (int idx = tid; idx < BM * 16; idx += 384) *(float4*)(Gs + idx * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int t = tile_of(ps);
+    const int i0 = t * 16;
+    if (t >= MT || i0 >= P) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * lg + r;
+      if (i < P)
+        *(float4*)(Gs + i * HD + ((lr ^ (i & 15)) << 2)) =
+            make_float4(keep[ps][0][r], keep[ps][1][r], keep[ps][2][r], keep[ps][3][r]);
+    }
+  }
+  __syncthreads();
+
+  // ---- dq_raw = q_scale * (I + T_w)^T dQ~ : the stencil with flipped taps; rows stay inside the region
+  {
+    auto tapf = [&](int t) {                        // weight of source row j for output row i, t = j - i + half
+      const int tt = epeg_k - 1 - t;                // flipped
+      float wt = (t >= 0 && t < epeg_k && tt >= 0) ? w[tt] : 0.f;
+      if (t == half) wt += 1.0f;
+      return wt * q_scale;
+    };
+    const int s = tid & 15, g = tid >> 4;
+    const int r0 = g * RUN;
+    if (r0 < P) {
+      float4 out[RUN];
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int lo = max(r0 - half, 0), hi = min(r0 + RUN - 1 + half, P - 1);
+      float wr[RUN];
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) wr[o] = tapf(lo - r0 - o + half);
+      for (int rr = lo; rr <= hi; ++rr) {
+        const float4 v = *(const float4*)(Gs + rr * HD + ((s ^ (rr & 15)) << 2));
+        const float wnext = tapf(rr + 1 - r0 + half);
+#pragma unroll
+        for (int o = 0; o < RUN; ++o) {
+          out[o].x += wr[o] * v.x; out[o].y += wr[o] * v.y; out[o].z += wr[o] * v.z; out[o].w += wr[o] * v.w;
+        }
+#pragma unroll
+        for (int o = RUN - 1; o > 0; --o) wr[o] = wr[o - 1];
+        wr[0] = wnext;
+      }
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) {
+        const int i = r0 + o;
+        if (i < P) *(float4*)(dqkv + (row0 + i) * ld + head * HD + 4 * s) = out[o];
+      }
+    }
+  }
+
+  // ---- tap gradients: dw[t] = sum_i <dQ~_i, q_{i + t - half}>   (q as stashed, read back from global / L2)
+  if (epeg_k > 0) {
+    const int s = tid & 15;
+    for (int t = 0; t < epeg_k; ++t) {
+      float acc = 0.f;
+      for (int i = tid >> 4; i < P; i += 24) {
+        const int j = i + t - half;
+        if (j >= 0 && j < P) {
+          const float4 g4 = *(const float4*)(Gs + i * HD + ((s ^ (i & 15)) << 2));
+          const float4 q4 = *(const float4*)(qkv + (row0 + j) * ld + head * HD + 4 * s);
+          acc += (g4.x * q4.x + g4.y * q4.y) + (g4.z * q4.z + g4.w * q4.w);
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) wred[wave * 64 + t] = acc;
+    }
+    __syncthreads();
+    if (tid < epeg_k) {
+      float a = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 6; ++wv) a += wred[wv * 64 + tid];
+      dpe_part[((size_t)reg * heads + head) * epeg_k + tid] = a;
+    }
+  }
+}
+
+template <int MT>
+hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, const float* dO, float* dqkv,
+                         float* dpe_part, int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
+  constexpr size_t LDS = ((size_t)4 * 16 * MT * HD + 2 * 16 * MT + 6 * 64) * sizeof(float);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  auto kern = attn_bwd_kernel<MT>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+  const float q_scale = 1.0f / sqrtf((float)HD);
+  kern<<<dim3(n_regions * heads), dim3(384), LDS, st>>>(qkv, pe_w, O, dO, dqkv, dpe_part, P, D, heads,
+                                                       pe_w ? epeg_k : 0, q_scale);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool attn_bwd_supported(int P, int D, int heads, int epeg_k) {
+  return heads > 0 && D == heads * HD && P > 0 && P <= 144 && epeg_k >= 0 && epeg_k <= 63;
+}
+
+size_t attn_bwd_workspace(int n_regions, int heads, int epeg_k) {
+  return (size_t)n_regions * heads * (epeg_k > 0 ? epeg_k : 1) * sizeof(float);
+}
+
+// dqkv [n_regions*P, 3D] (gradient w.r.t. the qkv linear's raw output); dpe [heads, epeg_k] or null
+hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const float* O, const float* dO,
+                                     float* dqkv, float* dpe, float* dpe_part, int n_regions, int P, int D,
+                                     int heads, int epeg_k, hipStream_t st) {
+  if (pe_w == nullptr) epeg_k = 0;
+  hipError_t e;
+  if (P > 128) e = launch_bwd_mt<9>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
+  else if (P > 112) e = launch_bwd_mt<8>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
+  else if (P > 96) e = launch_bwd_mt<7>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
+  else if (P > 64) e = launch_bwd_mt<6>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
+  else e = launch_bwd_mt<4>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
+  if (e != hipSuccess || epeg_k == 0 || dpe == nullptr) return e;
+  return launch_reduce_partials(dpe_part, dpe, n_regions, (size_t)heads * epeg_k, st);
+}

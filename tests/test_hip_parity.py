@@ -789,3 +789,50 @@ def test_layernorm_backward(L, D, rn):
     _cmp(dgb[0].cpu().numpy() / scale, dg64 / scale, 2e-5, "dgamma mapped")
     _cmp(dgb[1].cpu().numpy() / scale, db64 / scale, 2e-5, "dbeta mapped")
 
+
+@pytest.mark.parametrize("R,P,D,heads,ek", [(3, 144, 512, 8, 15), (2, 121, 512, 8, 21), (4, 64, 512, 8, 0),
+                                            (5, 49, 512, 8, 15), (2, 100, 256, 4, 9), (3, 130, 512, 8, 0),
+                                            (64, 144, 512, 8, 15), (2, 7, 128, 2, 15), (3, 81, 512, 8, 31)])
+def test_region_attention_backward(R, P, D, heads, ek):
+    """Attention backward (recomputed probabilities, EPEG adjoint, tap gradients) against float64 autograd of the
+    explicit formulation (scores [P,P], depth-wise conv along the query axis WITH a bias, softmax, A V)."""
+    from hip_util import dev, p, stream, DEV, region_attention
+    lib = _lib.load()
+    hd = D // heads
+    raw = synth.normal(f"ab/qkv{R}x{P}x{D}", (R * P, 3 * D)) * 0.6
+    pe = synth.uniform("ab/pe", (heads, max(ek, 1)), -1, 1) / np.sqrt(max(ek, 1))
+    pb = synth.uniform("ab/pb", (heads,), -0.3, 0.3)
+    dO = synth.normal(f"ab/do{R}x{P}x{D}", (R * P, D))
+    stash = raw.copy()
+    stash[:, :D] *= hd ** -0.5                       # the forward stage stores q already scaled
+    # float64 autograd oracle
+    tq = torch.tensor(raw, dtype=torch.float64, requires_grad=True)
+    tw = torch.tensor(pe, dtype=torch.float64, requires_grad=True)
+    tb = torch.tensor(pb, dtype=torch.float64, requires_grad=True)
+    t = tq.reshape(R, P, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0] * hd ** -0.5, t[1], t[2]
+    S = q @ k.transpose(-2, -1)
+    if ek:
+        S = S + torch.nn.functional.conv2d(S, tw.reshape(heads, 1, ek, 1), tb, padding=(ek // 2, 0), groups=heads)
+    Oref = (S.softmax(-1) @ v).transpose(1, 2).reshape(R * P, D)
+    (Oref * torch.tensor(dO, dtype=torch.float64)).sum().backward()
+    # HIP: forward output from the forward stage, then the backward stage
+    d_stash, d_pe, d_dO = dev(stash), dev(pe), dev(dO)
+    o = region_attention(d_stash, d_pe if ek else None, R, P, D, heads, ek)
+    _cmp(o.cpu().numpy(), Oref.detach().numpy(), 5e-5, "forward O")
+    dqkv = torch.full((R * P, 3 * D), float("nan"), device=DEV)
+    dpe = torch.full((heads, max(ek, 1)), float("nan"), device=DEV)
+    ws = torch.full((R * heads * max(ek, 1) * 4,), 0xFF, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.rrt_region_attention_backward_f32(p(d_stash), p(d_pe) if ek else None, p(o), p(d_dO), p(dqkv),
+                                                     p(dpe) if ek else None, R, P, D, heads, ek, p(ws), ws.numel(),
+                                                     stream()), "attention_backward")
+    torch.cuda.synchronize()
+    got, ref = dqkv.cpu().numpy(), tq.grad.numpy()
+    _cmp(got[:, :D], ref[:, :D], 1e-4, "dq")
+    _cmp(got[:, D:2 * D], ref[:, D:2 * D], 1e-4, "dk")
+    _cmp(got[:, 2 * D:], ref[:, 2 * D:], 1e-4, "dv")
+    if ek:
+        scale = max(1.0, np.sqrt(R * P))
+        _cmp(dpe.cpu().numpy() / scale, tw.grad.numpy() / scale, 1e-4, "d taps")
+        assert np.abs(tb.grad.numpy()).max() < 1e-9 * R * P          # Identity 2: the bias gradient is zero
+
