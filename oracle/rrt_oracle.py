@@ -175,15 +175,22 @@ def forward_f64(x, state, cfg=None, taps=None):
 
 
 # --------------------------------------------------------------------------- eager-equivalent torch/CPU port
-def forward_eager(x, state, cfg=None):
+def forward_eager(x, state, cfg=None, grad=False):
     """torch fp32 CPU port issuing the reference's aten op sequence; x: (N, D)
-    torch tensor or array -> torch (N, D).  Used as the timed CPU baseline."""
+    torch tensor or array -> torch (N, D).  Used as the timed CPU baseline.
+    grad=True: float64 leaves with requires_grad (x and every parameter) and a recorded graph -- torch autograd
+    then yields the reference's gradients (the oracle of the backward, row f2); returns (y, x_leaf, params)."""
+    import contextlib
     import torch
     import torch.nn.functional as F
     c = _cfg(cfg)
     st = {k_: (v_ if isinstance(v_, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v_)))
           for k_, v_ in state.items()}
     x = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+    if grad:
+        st = {k_: v_.double().requires_grad_(True) for k_, v_ in st.items()}
+        x = x.double().requires_grad_(True)
+        x_leaf = x
     x = x.unsqueeze(0)                                                       # (1,N,D), modules/rrt.py:166-175
     B, N, D = x.shape
     x0 = x
@@ -218,13 +225,13 @@ def forward_eager(x, state, cfg=None):
         h = F.gelu(h) if c["ffn_act"] == "gelu" else F.relu(h)
         return t + F.linear(h, st[pfx + "mlp.fc2.weight"], st[pfx + "mlp.fc2.bias"])
 
-    with torch.no_grad():
+    with (contextlib.nullcontext() if grad else torch.no_grad()):
         for li in range(c["n_layers"] - 1):
             p = f"layers.{li}."
             u = F.layer_norm(x, (D,), st[p + "norm.weight"], st[p + "norm.bias"], 1e-5)
             H, s, add = grid(N, c["region_num"], c["region_size"], c["min_region_num"], c["min_region_ratio"])
             if add > 0:
-                u = torch.cat([u, torch.zeros((B, add, D))], dim=1)
+                u = torch.cat([u, torch.zeros((B, add, D), dtype=u.dtype)], dim=1)
             z = unpart(inner(part(u, H, s), p + "attn.attn.", c["n_heads"], c["epeg_k"]), H, s)
             if add > 0:
                 z = z[:, :-add]
@@ -236,7 +243,7 @@ def forward_eager(x, state, cfg=None):
             v = F.layer_norm(x, (D,), st[p + "norm.weight"], st[p + "norm.bias"], 1e-5)
             H, s, add = grid(N, 8, 0, 0, 0.0)
             if add > 0:
-                v = torch.cat([v, torch.zeros((B, add, D))], dim=1)
+                v = torch.cat([v, torch.zeros((B, add, D), dtype=v.dtype)], dim=1)
             xr = part(v, H, s)
             if c["crmsa_mlp"]:
                 lg = F.linear(torch.tanh(F.linear(xr, st[p + "attn.phi.0.weight"])),
@@ -261,6 +268,8 @@ def forward_eager(x, state, cfg=None):
         if c["all_shortcut"]:
             x = x + x0
         x = F.layer_norm(x, (D,), st["norm.weight"], st["norm.bias"], 1e-5)
+    if grad:
+        return x.squeeze(0), x_leaf, st
     return x.squeeze(0)
 
 

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _f32p = C.POINTER(C.c_float)
 
@@ -40,6 +40,15 @@ class EncoderWeights(C.Structure):
     _fields_ = [("rmsa", AttnWeights * RRT_MAX_RMSA_LAYERS), ("crmsa", AttnWeights),
                 ("phi", C.c_void_p), ("phi0_w", C.c_void_p), ("phi2_w", C.c_void_p),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p)]
+
+
+class AttnGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm", "qkv_w", "qkv_b", "proj_w", "proj_b", "pe_w")]
+
+
+class EncoderGrads(C.Structure):
+    _fields_ = [("rmsa", AttnGrads * RRT_MAX_RMSA_LAYERS), ("crmsa", AttnGrads), ("phi", C.c_void_p),
+                ("norm", C.c_void_p)]
 
 
 class MilDesc(C.Structure):
@@ -113,6 +122,13 @@ SIGNATURES = {
     "rrt_linear_backward_workspace_size": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "rrt_linear_backward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                              C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rrt_encoder_train_sizes": (C.c_int, [C.POINTER(EncoderDesc), C.c_int64, C.POINTER(C.c_size_t),
+                                          C.POINTER(C.c_size_t)]),
+    "rrt_encoder_forward_train_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p,
+                                                C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rrt_encoder_backward_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.POINTER(EncoderGrads), C.c_void_p, C.c_int64,
+                                           C.c_void_p, C.c_size_t, C.c_void_p]),
     "rrt_linear_act_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                         C.c_void_p]),
 }

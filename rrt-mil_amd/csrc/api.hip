@@ -847,3 +847,274 @@ int rrt_linear_backward_f32(const float* dY, const float* X, const float* W, flo
 
 }  // extern "C"
 
+// ------------------------------------------------------------------ row f2: training forward + backward
+namespace {
+
+struct Stash {
+  float *u[RRT_MAX_RMSA_LAYERS], *qkv[RRT_MAX_RMSA_LAYERS], *o[RRT_MAX_RMSA_LAYERS], *xout[RRT_MAX_RMSA_LAYERS];
+  float *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *x2;
+  size_t bytes;
+};
+
+Stash carve_stash(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const rrt_grid& g8, char* base) {
+  Stash s{};
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off = align_up(off + nfloat * sizeof(float), 256);
+    return p;
+  };
+  const size_t D = d.dim, Np = (size_t)g.H * g.H, Np8 = (size_t)g8.H * g8.H;
+  const size_t R8 = (size_t)g8.regions_side * g8.regions_side, k = d.crmsa_k;
+  for (int l = 0; l < d.n_rmsa_layers; ++l) {
+    s.u[l] = take(Np * D);
+    s.qkv[l] = take(Np * 3 * D);
+    s.o[l] = take(Np * D);
+    s.xout[l] = take((size_t)N * D);
+  }
+  if (d.cr_msa) {
+    s.mean_rstd = take((size_t)N * 2);
+    s.logits = take(Np8 * k);
+    s.wdisp = take(Np8 * k);
+    s.rep = take(k * R8 * D);
+    s.rep_qkv = take(k * R8 * 3 * D);
+    s.rep_o = take(k * R8 * D);
+    s.rep2 = take(k * R8 * D);
+  }
+  s.x2 = take((size_t)N * D);
+  s.bytes = off;
+  return s;
+}
+
+struct BwdWs {
+  float *dx2, *dxa, *dxb, *dz, *dO, *dqkv, *lnpart, *attnpart, *dWd, *dC, *dlg, *Cw, *d_rep2, *d_rep_o,
+      *d_rep_qkv, *d_rep, *rows, *dxpart;
+  char* lin;
+  size_t bytes;
+};
+
+BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const rrt_grid& g8, char* base) {
+  BwdWs w{};
+  size_t off = 0;
+  auto takeb = [&](size_t nbytes) {
+    char* p = base ? base + off : nullptr;
+    off = align_up(off + nbytes, 256);
+    return p;
+  };
+  auto take = [&](size_t nfloat) { return (float*)takeb(nfloat * sizeof(float)); };
+  const size_t D = d.dim, Np = (size_t)g.H * g.H, Np8 = (size_t)g8.H * g8.H;
+  const size_t R8 = (size_t)g8.regions_side * g8.regions_side, k = d.crmsa_k;
+  w.dx2 = take((size_t)N * D);
+  w.dxa = take((size_t)N * D);
+  w.dxb = take((size_t)N * D);
+  w.lnpart = take(ln_bwd_workspace((int)D) / sizeof(float));
+  size_t lin = 0;
+  if (d.n_rmsa_layers > 0) {
+    w.dz = take(Np * D);
+    w.dO = take(Np * D);
+    w.dqkv = take(Np * 3 * D);
+    const int R = g.regions_side * g.regions_side;
+    w.attnpart = take(attn_bwd_workspace(R, d.n_heads, d.epeg ? d.epeg_k : 0) / sizeof(float));
+    lin = linear_bwd_workspace((int)Np, 3 * (int)D, (int)D);
+    const size_t l2 = linear_bwd_workspace((int)Np, (int)D, (int)D);
+    if (l2 > lin) lin = l2;
+  }
+  if (d.cr_msa) {
+    w.dWd = take(Np8 * k);
+    w.dC = take(Np8 * k);
+    w.dlg = take(Np8 * k);
+    w.Cw = take(Np8 * k);
+    w.d_rep2 = take(k * R8 * D);
+    w.d_rep_o = take(k * R8 * D);
+    w.d_rep_qkv = take(k * R8 * 3 * D);
+    w.d_rep = take(k * R8 * D);
+    w.rows = take((2 + k) * D);
+    w.dxpart = take(crmsa_bwd_dx_workspace((int)D, (int)k) / sizeof(float));
+    if (!w.attnpart) w.attnpart = take(attn_bwd_workspace((int)k, d.crmsa_heads, 0) / sizeof(float));
+    const size_t l3 = linear_bwd_workspace((int)(k * R8), 3 * (int)D, (int)D);
+    if (l3 > lin) lin = l3;
+  }
+  w.lin = takeb(lin ? lin : 256);
+  w.bytes = off;
+  return w;
+}
+
+int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8) {
+  int rc = check_desc(d, N);
+  if (rc) return rc;
+  if (d->ffn) return unsupported("training: ffn=True is not built");
+  if (d->crmsa_mlp) return unsupported("training: crmsa_mlp=True is not built");
+  if (d->compute != RRT_COMPUTE_F32) return unsupported("training: fp32 only");
+  if (d->dim > 1024) return unsupported("training: dim > 1024");
+  memset(g, 0, sizeof(*g));
+  if (d->n_rmsa_layers > 0) {
+    rc = rrt_region_grid(N, d->region_num, d->region_size, d->min_region_num, d->min_region_ratio, g);
+    if (rc) return rc;
+    if (!attn_bwd_supported(g->s * g->s, d->dim, d->n_heads, d->epeg ? d->epeg_k : 0))
+      return unsupported("training: R-MSA needs head dim 64 and regions of <= 144 tokens (N <= 9216 at region_num=8)");
+  }
+  rc = rrt_region_grid(N, 8, 0, 0, 0.f, g8);
+  if (rc) return rc;
+  if (d->cr_msa) {
+    const int R8 = g8->regions_side * g8->regions_side;
+    if (!attn_bwd_supported(R8, d->dim, d->crmsa_heads, 0))
+      return unsupported("training: CR-MSA needs head dim 64 (crmsa_heads = dim / 64)");
+  }
+  return RRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rrt_encoder_train_sizes(const rrt_encoder_desc* desc, int64_t n_tokens, size_t* stash_bytes,
+                            size_t* backward_workspace_bytes) {
+  if (!desc || !stash_bytes || !backward_workspace_bytes) return RRT_E_INVALID;
+  rrt_grid g{}, g8{};
+  int rc = check_train(desc, n_tokens, &g, &g8);
+  if (rc) return rc;
+  *stash_bytes = carve_stash(*desc, n_tokens, g, g8, nullptr).bytes;
+  *backward_workspace_bytes = carve_bwd(*desc, n_tokens, g, g8, nullptr).bytes;
+  return RRT_OK;
+}
+
+int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encoder_weights* w, const float* x,
+                                  float* y, int64_t n_tokens, void* stash, size_t stash_bytes, void* stream) {
+  if (!desc || !w || !x || !y || x == y) return RRT_E_INVALID;
+  rrt_grid g{}, g8{};
+  int rc = check_train(desc, n_tokens, &g, &g8);
+  if (rc) return rc;
+  Stash s = carve_stash(*desc, n_tokens, g, g8, nullptr);
+  if (!stash || stash_bytes < s.bytes) return RRT_E_WORKSPACE;
+  s = carve_stash(*desc, n_tokens, g, g8, (char*)stash);
+  hipStream_t st = (hipStream_t)stream;
+  const int D = desc->dim;
+  const int64_t N = n_tokens;
+  hipError_t e = hipSuccess;
+#define RRT_TRY(call)                   \
+  do {                                  \
+    e = (call);                         \
+    if (e != hipSuccess) return (int)e; \
+  } while (0)
+  const float* xin = x;
+  for (int li = 0; li < desc->n_rmsa_layers; ++li) {
+    const rrt_attn_weights& lw = w->rmsa[li];
+    if (!lw.norm_w || !lw.norm_b || !lw.qkv_w || !lw.proj_w || !lw.proj_b) return RRT_E_INVALID;
+    if (desc->epeg && !lw.pe_w) return RRT_E_INVALID;
+    const GridDev gd = to_dev(g);
+    RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, s.u[li], D, gd, st));
+    LinearEpilogue ep{};
+    ep.bias = lw.qkv_b;
+    ep.q_cols = D;
+    ep.q_scale = 1.0f / sqrtf((float)(D / desc->n_heads));
+    RRT_TRY(launch_linear(s.u[li], lw.qkv_w, s.qkv[li], gd.Np, 3 * D, D, ep, st));
+    RRT_TRY(launch_region_attention(s.qkv[li], desc->epeg ? lw.pe_w : nullptr, s.o[li], gd.rs * gd.rs, gd.P, D,
+                                    desc->n_heads, desc->epeg ? desc->epeg_k : 0, st));
+    LinearEpilogue ep2{};
+    ep2.bias = lw.proj_b;
+    ep2.resid = xin;
+    ep2.g = gd;
+    RRT_TRY(launch_linear(s.o[li], lw.proj_w, s.xout[li], gd.Np, D, D, ep2, st));
+    xin = s.xout[li];
+  }
+  const float* x0 = desc->all_shortcut ? x : nullptr;
+  if (!w->norm_w || !w->norm_b) return RRT_E_INVALID;
+  if (desc->cr_msa) {
+    const rrt_attn_weights& cw = w->crmsa;
+    if (!cw.norm_w || !cw.norm_b || !cw.qkv_w || !cw.proj_w || !cw.proj_b || !w->phi) return RRT_E_INVALID;
+    const GridDev gd8 = to_dev(g8);
+    const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
+    RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, s.mean_rstd, s.logits, D, k, gd8, st));
+    RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, s.mean_rstd, s.logits, s.wdisp, s.rep, D, k, gd8, st));
+    LinearEpilogue ep{};
+    ep.bias = cw.qkv_b;
+    ep.q_cols = D;
+    ep.q_scale = 1.0f / sqrtf((float)(D / desc->crmsa_heads));
+    RRT_TRY(launch_linear(s.rep, cw.qkv_w, s.rep_qkv, k * R8, 3 * D, D, ep, st));
+    RRT_TRY(launch_region_attention(s.rep_qkv, nullptr, s.rep_o, k, R8, D, desc->crmsa_heads, 0, st));
+    LinearEpilogue ep2{};
+    ep2.bias = cw.proj_b;
+    RRT_TRY(launch_linear(s.rep_o, cw.proj_w, s.rep2, k * R8, D, D, ep2, st));
+    RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, s.wdisp, s.rep2, nullptr, nullptr, s.x2, D, k, gd8, st));   // x2, no LN
+  } else {
+    RRT_TRY(launch_layernorm(xin, x0, nullptr, nullptr, s.x2, (int)N, D, st));                            // x2 = x1 (+ x)
+  }
+  RRT_TRY(launch_layernorm(s.x2, nullptr, w->norm_w, w->norm_b, y, (int)N, D, st));
+#undef RRT_TRY
+  return RRT_OK;
+}
+
+int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_weights* w, const float* x,
+                             const float* dy, const void* stash, size_t stash_bytes, const rrt_encoder_grads* gr,
+                             float* dx, int64_t n_tokens, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!desc || !w || !x || !dy || !gr) return RRT_E_INVALID;
+  rrt_grid g{}, g8{};
+  int rc = check_train(desc, n_tokens, &g, &g8);
+  if (rc) return rc;
+  Stash s = carve_stash(*desc, n_tokens, g, g8, nullptr);
+  if (!stash || stash_bytes < s.bytes) return RRT_E_WORKSPACE;
+  s = carve_stash(*desc, n_tokens, g, g8, (char*)stash);
+  BwdWs b = carve_bwd(*desc, n_tokens, g, g8, nullptr);
+  if (!workspace || workspace_bytes < b.bytes) return RRT_E_WORKSPACE;
+  b = carve_bwd(*desc, n_tokens, g, g8, (char*)workspace);
+  hipStream_t st = (hipStream_t)stream;
+  const int D = desc->dim, L = desc->n_rmsa_layers;
+  const int N = (int)n_tokens;
+  hipError_t e = hipSuccess;
+#define RRT_TRY(call)                   \
+  do {                                  \
+    e = (call);                         \
+    if (e != hipSuccess) return (int)e; \
+  } while (0)
+  if (!gr->norm) return RRT_E_INVALID;
+  // final LayerNorm
+  RRT_TRY(launch_ln_backward(dy, s.x2, w->norm_w, nullptr, b.dx2, gr->norm, b.lnpart, N, D, nullptr, st));
+  const float* cur = b.dx2;   // gradient w.r.t. the activations entering the stage being undone
+  if (desc->cr_msa) {
+    const rrt_attn_weights& cw = w->crmsa;
+    const rrt_attn_grads& cg = gr->crmsa;
+    if (!cg.norm || !cg.qkv_w || !cg.proj_w || !cg.proj_b || !gr->phi || (cw.qkv_b && !cg.qkv_b)) return RRT_E_INVALID;
+    const GridDev gd8 = to_dev(g8);
+    const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
+    const float* x1 = L > 0 ? s.xout[L - 1] : x;
+    RRT_TRY(launch_crmsa_tokdot(b.dx2, nullptr, nullptr, nullptr, s.rep2, b.dWd, D, k, gd8, st));
+    RRT_TRY(launch_crmsa_wsum(b.dx2, s.wdisp, b.d_rep2, D, k, gd8, st));
+    RRT_TRY(launch_linear_backward(b.d_rep2, s.rep_o, cw.proj_w, b.d_rep_o, cg.proj_w, cg.proj_b, k * R8, D, D, 0,
+                                   b.lin, st));
+    RRT_TRY(launch_attention_backward(s.rep_qkv, nullptr, s.rep_o, b.d_rep_o, b.d_rep_qkv, nullptr, b.attnpart, k,
+                                      R8, D, desc->crmsa_heads, 0, st));
+    RRT_TRY(launch_linear_backward(b.d_rep_qkv, s.rep, cw.qkv_w, b.d_rep, cg.qkv_w, cg.qkv_b, k * R8, 3 * D, D, 0,
+                                   b.lin, st));
+    RRT_TRY(launch_crmsa_tokdot(x1, s.mean_rstd, cw.norm_w, cw.norm_b, b.d_rep, b.dC, D, k, gd8, st));
+    RRT_TRY(launch_crmsa_bwd_region(s.logits, b.dC, b.dWd, b.dlg, b.Cw, k, gd8, st));
+    RRT_TRY(launch_crmsa_bwd_dx(x1, b.dx2, s.mean_rstd, cw.norm_w, cw.norm_b, w->phi, b.Cw, b.dlg, b.d_rep, b.dxa,
+                                b.rows, b.dxpart, D, k, gd8, st));
+    RRT_TRY(hipMemcpyAsync(cg.norm, b.rows, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    RRT_TRY(launch_transpose(b.rows + 2 * (size_t)D, gr->phi, k, D, st));      // [k, D] -> phi's [D, k]
+    cur = b.dxa;
+  }
+  for (int li = L - 1; li >= 0; --li) {
+    const rrt_attn_weights& lw = w->rmsa[li];
+    const rrt_attn_grads& lg = gr->rmsa[li];
+    if (!lg.norm || !lg.qkv_w || !lg.proj_w || !lg.proj_b || (lw.qkv_b && !lg.qkv_b) || (desc->epeg && !lg.pe_w))
+      return RRT_E_INVALID;
+    const GridDev gd = to_dev(g);
+    const float* xin = li > 0 ? s.xout[li - 1] : x;
+    RRT_TRY(launch_partition_rows(cur, b.dz, D, gd, st));
+    RRT_TRY(launch_linear_backward(b.dz, s.o[li], lw.proj_w, b.dO, lg.proj_w, lg.proj_b, gd.Np, D, D, 0, b.lin, st));
+    RRT_TRY(launch_attention_backward(s.qkv[li], desc->epeg ? lw.pe_w : nullptr, s.o[li], b.dO, b.dqkv,
+                                      desc->epeg ? lg.pe_w : nullptr, b.attnpart, gd.rs * gd.rs, gd.P, D,
+                                      desc->n_heads, desc->epeg ? desc->epeg_k : 0, st));
+    RRT_TRY(launch_linear_backward(b.dqkv, s.u[li], lw.qkv_w, b.dz, lg.qkv_w, lg.qkv_b, gd.Np, 3 * D, D, 0, b.lin,
+                                   st));                                       // dU -> dz (dead)
+    float* nxt = (cur == b.dxa) ? b.dxb : b.dxa;
+    RRT_TRY(launch_ln_backward(b.dz, xin, lw.norm_w, cur, nxt, lg.norm, b.lnpart, N, D, &gd, st));
+    cur = nxt;
+  }
+  if (dx) RRT_TRY(launch_layernorm(cur, desc->all_shortcut ? b.dx2 : nullptr, nullptr, nullptr, dx, N, D, st));
+#undef RRT_TRY
+  return RRT_OK;
+}
+
+}  // extern "C"
+

@@ -242,9 +242,10 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int q = it * 16 + 4 * lg + r;
+        // rows past the region: lse / dd were never written there (0 x garbage would be NaN)
         const float p = q < P ? __builtin_amdgcn_exp2f(a[it][r] - lse[q]) : 0.f;
         a[it][r] = p;
-        ds[it][r] = p * (ds[it][r] - dd[q]);
+        ds[it][r] = q < P ? p * (ds[it][r] - dd[q]) : 0.f;
       }
     f32x4 dv[4], dk[4];
 #pragma unroll

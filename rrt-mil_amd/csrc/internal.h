@@ -79,3 +79,16 @@ size_t attn_bwd_workspace(int n_regions, int heads, int epeg_k);
 hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const float* O, const float* dO,
                                      float* dqkv, float* dpe, float* dpe_part, int n_regions, int P, int D,
                                      int heads, int epeg_k, hipStream_t st);
+hipError_t launch_partition_rows(const float* src, float* dst, int dim, const GridDev& g, hipStream_t st);
+// CR-MSA backward stages (crmsa_bwd.hip)
+hipError_t launch_crmsa_tokdot(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                               const float* vec, float* out, int dim, int k, const GridDev& g, hipStream_t st);
+hipError_t launch_crmsa_wsum(const float* X, const float* W, float* out, int dim, int k, const GridDev& g,
+                             hipStream_t st);
+hipError_t launch_crmsa_bwd_region(const float* lg, const float* dC, const float* dWd, float* dlg, float* Cw, int k,
+                                   const GridDev& g, hipStream_t st);
+size_t crmsa_bwd_dx_workspace(int dim, int k);
+hipError_t launch_crmsa_bwd_dx(const float* x1, const float* dx2, const float* mean_rstd, const float* gamma,
+                               const float* beta, const float* phi, const float* Cw, const float* dlg,
+                               const float* drep, float* dx1, float* out_rows, float* part, int dim, int k,
+                               const GridDev& g, hipStream_t st);

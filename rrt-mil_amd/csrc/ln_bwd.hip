@@ -113,7 +113,26 @@ __global__ __launch_bounds__(256) void ln_backward_kernel(const float* __restric
   }
 }
 
+// dst [Np, dim] region-major <- src [L, dim] token order, pad slots = 0 (region_partition of a gradient)
+__global__ __launch_bounds__(256) void partition_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             int dim, GridDev g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int slot = blockIdx.x * 4 + wave; slot < g.Np; slot += gridDim.x * 4) {
+    const int t = slot_to_token(slot, g);
+    for (int c = lane * 4; c < dim; c += 256) {
+      const float4 v = t < g.L ? *(const float4*)(src + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(dst + (size_t)slot * dim + c) = v;
+    }
+  }
+}
+
 }  // namespace
+
+hipError_t launch_partition_rows(const float* src, float* dst, int dim, const GridDev& g, hipStream_t st) {
+  const int need = (g.Np + 3) / 4;
+  partition_rows_kernel<<<dim3(need < 4096 ? need : 4096), 256, 0, st>>>(src, dst, dim, g);
+  return hipGetLastError();
+}
 
 size_t ln_bwd_workspace(int dim) { return (size_t)LNB_BLOCKS * 2 * dim * sizeof(float); }
 

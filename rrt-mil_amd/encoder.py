@@ -138,6 +138,52 @@ class TransLayer(nn.Module):
                     if ffn else nn.Identity())
 
 
+class _EncoderFunction(torch.autograd.Function):
+    """One bag through rrt_encoder_forward_train_f32 / rrt_encoder_backward_f32 (row f2).  The parameters are
+    passed as inputs so that autograd routes their gradients; the stash (intermediates the backward needs)
+    lives in a tensor owned by the graph node."""
+
+    @staticmethod
+    def forward(ctx, enc, x2d, *params):
+        lib = _lib.load()
+        n = x2d.shape[0]
+        enc._desc.compute = _lib.COMPUTE_F32
+        stash_b, ws_b = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.rrt_encoder_train_sizes(C.byref(enc._desc), n, C.byref(stash_b), C.byref(ws_b)),
+                   "rrt_encoder_train_sizes")
+        stash = torch.empty(stash_b.value, dtype=torch.uint8, device=x2d.device)
+        y = torch.empty_like(x2d)
+        w = enc._weights()
+        with torch.cuda.device(x2d.device):
+            rc = lib.rrt_encoder_forward_train_f32(C.byref(enc._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
+                                                   stash.data_ptr(), stash.numel(),
+                                                   torch.cuda.current_stream(x2d.device).cuda_stream)
+        _lib.check(rc, "rrt_encoder_forward_train_f32")
+        ctx.enc, ctx.stash, ctx.ws_bytes = enc, stash, ws_b.value
+        ctx.save_for_backward(x2d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        enc = ctx.enc
+        (x2d,) = ctx.saved_tensors
+        n, dev = x2d.shape[0], x2d.device
+        dy = dy.contiguous().float()
+        grads, gstruct = enc._grad_buffers(dev)
+        dx = torch.empty_like(x2d) if ctx.needs_input_grad[1] else None
+        ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=dev)
+        w = enc._weights()
+        with torch.cuda.device(dev):
+            rc = lib.rrt_encoder_backward_f32(C.byref(enc._desc), C.byref(w), x2d.data_ptr(), dy.data_ptr(),
+                                              ctx.stash.data_ptr(), ctx.stash.numel(), C.byref(gstruct),
+                                              dx.data_ptr() if dx is not None else None, n, ws.data_ptr(), ws.numel(),
+                                              torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "rrt_encoder_backward_f32")
+        ctx.stash = None
+        return (None, dx) + tuple(grads)
+
+
 class RRTEncoder(nn.Module):
     def __init__(self, mlp_dim=512, pos_pos=0, pos='none', peg_k=7, attn='rmsa', region_num=8,
                  drop_out=0.1, n_layers=2, n_heads=8, drop_path=0., ffn=False, ffn_act='gelu',
@@ -217,6 +263,49 @@ class RRTEncoder(nn.Module):
                 w.phi = self._ptr(self.cr_msa.attn.phi)
         w.norm_w, w.norm_b = self._ptr(self.norm.weight), self._ptr(self.norm.bias)
         return w
+
+    def _grad_buffers(self, device):
+        """Fresh gradient tensors in the order of self.parameters() and the C struct pointing into them.
+        LayerNorm pairs share one [2, dim] buffer (d gamma, d beta); pe.bias gets zeros (its gradient is
+        exactly zero: a per-head constant added to every score cancels in the softmax)."""
+        D = self.final_dim
+        gs = _lib.EncoderGrads()
+        by_name = {}
+
+        def ln(prefix):
+            t = torch.empty((2, D), dtype=torch.float32, device=device)
+            by_name[prefix + ".weight"], by_name[prefix + ".bias"] = t[0], t[1]
+            return t.data_ptr()
+
+        def attn(prefix, layer, ag):
+            ia = layer.attn.attn
+            ag.norm = ln(prefix + "norm")
+            for nm, mod in (("qkv", ia.qkv), ("proj", ia.proj)):
+                gw = torch.empty_like(mod.weight)
+                by_name[f"{prefix}attn.attn.{nm}.weight"] = gw
+                setattr(ag, nm + "_w", gw.data_ptr())
+                if mod.bias is not None:
+                    gb = torch.empty_like(mod.bias)
+                    by_name[f"{prefix}attn.attn.{nm}.bias"] = gb
+                    setattr(ag, nm + "_b", gb.data_ptr())
+            if ia.pe is not None:
+                gw = torch.empty_like(ia.pe.weight)
+                by_name[prefix + "attn.attn.pe.weight"] = gw
+                ag.pe_w = gw.data_ptr()
+                if ia.pe.bias is not None:
+                    by_name[prefix + "attn.attn.pe.bias"] = torch.zeros_like(ia.pe.bias)
+
+        gs.norm = ln("norm")
+        for i, layer in enumerate(self.layers.children()):
+            attn(f"layers.{i}.", layer, gs.rmsa[i])
+        if self._desc.cr_msa:
+            attn("cr_msa.", self.cr_msa, gs.crmsa)
+            gphi = torch.empty_like(self.cr_msa.attn.phi)
+            by_name["cr_msa.attn.phi"] = gphi
+            gs.phi = gphi.data_ptr()
+        grads = [by_name[name] for name, _ in self.named_parameters()]
+        self._keep_grads = by_name          # the struct holds raw pointers: keep the tensors alive through the call
+        return grads, gs
 
     def _workspace(self, n_tokens, device):
         lib = _lib.load()
@@ -331,8 +420,34 @@ class RRTEncoder(nn.Module):
         # returns, so the caching allocator's stream-ordered reuse of these buffers stays correct
         return [y.unsqueeze(0) if b.dim() == 3 else y for b, y in zip(bags, ys)]
 
-    @torch.no_grad()
+    def _wants_grad(self, x):
+        """Training path (stash + autograd node) only in train() mode with gradients enabled and something to
+        differentiate; eval() forwards never record a graph (the reference's validation loops run under
+        torch.no_grad() anyway)."""
+        return (self.training and torch.is_grad_enabled()
+                and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
+
     def forward(self, x):
+        if self._wants_grad(x):
+            return self._forward_impl(x, True)
+        with torch.no_grad():
+            return self._forward_impl(x, False)
+
+    def forward_bag_train(self, x2d):
+        """One bag with an autograd graph (rrt_encoder_forward_train_f32 / rrt_encoder_backward_f32)."""
+        if not x2d.is_cuda:
+            raise _lib.RRTHipError("rrt_mil_amd.RRTEncoder runs on MI355X only; there is no CPU fallback")
+        if self.drop_out > 0:
+            raise NotImplementedError("training with proj dropout p=%.2f is not built yet; construct the encoder "
+                                      "with drop_out=0 (RRTMIL: trans_dropout=0)" % self.drop_out)
+        if self._compute_mode() != _lib.COMPUTE_F32:
+            raise NotImplementedError("training under autocast / reduced-precision operands is not built")
+        x2d = x2d.float().contiguous()
+        if x2d.shape[1] != self.final_dim:
+            raise ValueError(f"expected feature dim {self.final_dim}, got {x2d.shape[1]}")
+        return _EncoderFunction.apply(self, x2d, *self.parameters())
+
+    def _forward_impl(self, x, train):
         # rank handling: modules/rrt.py:166-175 and :197-201
         shape_len = 3
         if x.dim() == 2:
@@ -347,7 +462,7 @@ class RRTEncoder(nn.Module):
             # attention sequence, modules/rmsa.py:316-322); every reference trainer uses batch_size=1
             raise NotImplementedError("batch > 1: pass bags one at a time (reference semantics at B>1 "
                                       "couple the bags inside CR-MSA)")
-        y = self.forward_bag(x[0]).unsqueeze(0)
+        y = (self.forward_bag_train(x[0]) if train else self.forward_bag(x[0])).unsqueeze(0)
         if shape_len == 2:
             y = y.squeeze(0)
         elif shape_len == 4:

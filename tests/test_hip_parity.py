@@ -836,3 +836,63 @@ def test_region_attention_backward(R, P, D, heads, ek):
         _cmp(dpe.cpu().numpy() / scale, tw.grad.numpy() / scale, 1e-4, "d taps")
         assert np.abs(tb.grad.numpy()).max() < 1e-9 * R * P          # Identity 2: the bias gradient is zero
 
+
+# ------------------------------------------------------------------ row f2: training (forward + backward end to end)
+TRAIN_CASES = {
+    "crmsa_only_n700": (700, dict(mlp_dim=512, n_layers=1, crmsa_k=3)),
+    "rmsa_only_n1000": (1000, dict(mlp_dim=512, cr_msa=False, epeg_k=15)),
+    "default_n1500": (1500, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),
+    "c16_n2600": (2600, dict(mlp_dim=512, epeg_k=15, crmsa_k=1, all_shortcut=True)),
+    "nsclc_layers3_n900": (900, dict(mlp_dim=512, epeg_k=21, crmsa_k=5, n_layers=3)),
+    "noepeg_nobias_n500": (500, dict(mlp_dim=512, epeg=False, qkv_bias=False)),
+    "d256_n333": (333, dict(mlp_dim=256, n_heads=4, crmsa_heads=4, epeg_k=9)),
+}
+
+
+@pytest.mark.parametrize("case", list(TRAIN_CASES))
+def test_encoder_backward_matches_autograd(case):
+    """loss = <y, G>: every parameter gradient and dL/dx from rrt_encoder_backward_f32 (through the autograd
+    Function of RRTEncoder in train() mode) against torch autograd of the reference's op sequence in float64."""
+    from hip_util import DEV, dev
+    from rrt_mil_amd import RRTEncoder
+    N, cfg = TRAIN_CASES[case]
+    D = cfg["mlp_dim"]
+    st = synth.encoder_state(**{k: v for k, v in cfg.items() if k in ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k",
+                                                                      "cr_msa", "crmsa_k", "qkv_bias")})
+    x = synth.bag(N, D, tag="train/" + case)
+    G = synth.normal("train/G/" + case, (N, D))
+    # oracle
+    y64, x_leaf, params = O.forward_eager(x, st, cfg, grad=True)
+    (y64 * torch.from_numpy(G).double()).sum().backward()
+    # HIP
+    enc = RRTEncoder(drop_out=0., **cfg)
+    enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    enc = enc.to(DEV).train()
+    xd = dev(x).requires_grad_(True)
+    y = enc(xd.unsqueeze(0)).squeeze(0)
+    assert y.grad_fn is not None
+    _cmp(y.detach().cpu().numpy(), y64.detach().numpy(), 2e-4, case + " train forward")
+    (y * dev(G)).sum().backward()
+    torch.cuda.synchronize()
+
+    def rel(got, ref, what):
+        ref = ref.astype(np.float64)
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(got.astype(np.float64) - ref).max() / scale
+        assert np.isfinite(got).all(), what
+        assert err <= 2e-3, f"{case} {what}: max error {err:.2e} of the largest gradient entry"
+        return err
+
+    rel(xd.grad.cpu().numpy(), x_leaf.grad.numpy(), "dx")
+    for name, prm in enc.named_parameters():
+        ref = params[name].grad
+        assert prm.grad is not None, name
+        if name.endswith("pe.bias"):
+            assert float(prm.grad.abs().max()) == 0.0 and float(ref.abs().max()) < 1e-6     # Identity 2
+            continue
+        rel(prm.grad.cpu().numpy(), ref.numpy().reshape(prm.shape), name)
+    # eval() never records a graph; train() with dropout is refused
+    assert enc.eval()(xd.unsqueeze(0)).grad_fn is None
+    with pytest.raises(NotImplementedError):
+        RRTEncoder(**cfg).to(DEV).train()(xd.unsqueeze(0))
+
