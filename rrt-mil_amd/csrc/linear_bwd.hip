@@ -110,22 +110,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
       }
 }
 
-// ---- out[i] = sum_s part[s][i]  (fixed order)
+// ---- out[i] = sum_s part[s][i]  (fixed order; 8 independent 16-byte loads in flight per thread -- the plain
+//      dependent loop was a chain of S memory round trips: 131 us for 16 x 3 MB)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               int S, size_t n) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   if (i + 3 < n && (n & 3) == 0) {
-    float4 a = *(const float4*)(part + i);
-    for (int s = 1; s < S; ++s) {
-      const float4 b = *(const float4*)(part + (size_t)s * n + i);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < S; s0 += 8) {
+      float4 b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        b[u] = s0 + u < S ? *(const float4*)(part + (size_t)(s0 + u) * n + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
     }
     *(float4*)(out + i) = a;
   } else {
     for (size_t e = i; e < n && e < i + 4; ++e) {
-      float a = part[e];
-      for (int s = 1; s < S; ++s) a += part[(size_t)s * n + e];
+      float a = 0.f;
+      for (int s = 0; s < S; ++s) a += part[(size_t)s * n + e];
       out[e] = a;
     }
   }

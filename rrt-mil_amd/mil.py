@@ -179,8 +179,16 @@ class RRTMIL(nn.Module):
         _lib.check(rc, "rrt_mil_forward_f32")
         return (logits, attn) if return_attn else logits
 
-    @torch.no_grad()
     def forward(self, x, return_attn=False, no_norm=False):
+        if (self.training and torch.is_grad_enabled()
+                and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            # training: the encoder is the HIP autograd Function (forward with stash + backward kernels); the
+            # thin layers around it (patch_to_emb, Dropout, DAttention, predictor) are torch ops under autograd
+            return self._forward_layers(x, return_attn, no_norm)
+        with torch.no_grad():
+            return self._forward_infer(x, return_attn, no_norm)
+
+    def _forward_infer(self, x, return_attn=False, no_norm=False):
         if x.dim() == 3 and x.size(0) == 1 and x.is_cuda:
             # (1, N, input_dim): the form of every reference trainer -> one library call
             out = self.forward_bag(x[0], return_attn=return_attn, no_norm=no_norm)
@@ -188,6 +196,9 @@ class RRTMIL(nn.Module):
                 return out[0].unsqueeze(0), out[1].unsqueeze(0)
             return out.unsqueeze(0)
         # other ranks: the reference's op sequence around the HIP encoder
+        return self._forward_layers(x, return_attn, no_norm)
+
+    def _forward_layers(self, x, return_attn=False, no_norm=False):
         x = self.dp(self.patch_to_emb(x))                 # (1, N, 512)
         x = self.online_encoder(x)                        # feature re-embedding: the HIP path
         if return_attn:
