@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 8
+#define RRT_ABI_VERSION 9
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -304,7 +304,10 @@ int rrt_linear_backward_f32(const float *dY, const float *X, const float *W, flo
 /* ---- row f2: training.  Forward that stashes what the backward needs, and the backward itself ----
  * Supported: the default path (1-D 'attn' EPEG R-MSA layers, CR-MSA with the phi matrix, all_shortcut), head dim 64
  * in R-MSA and in CR-MSA's inner attention, regions of <= 144 tokens (N <= 9216 at region_num = 8), dim <= 1024,
- * ffn = 0, crmsa_mlp = 0, F32 compute; dropout is not applied (proj_drop must be 0).  Anything else: RRT_E_UNSUPPORTED.
+ * ffn = 0, crmsa_mlp = 0, F32 compute.  Anything else: RRT_E_UNSUPPORTED.
+ * drop_p / drop_seed: the train-mode proj_drop of every InnerAttention (rmsa.py:70,132; p = drop_out): a stateless
+ * mask, element kept iff hash(seed, layer, index) >= p * 2^32, kept values scaled by 1/(1-p); the backward call
+ * must receive the same (drop_p, drop_seed) as its forward.  drop_p = 0: no dropout.
  * Gradients mirror the parameters: norm = [2, dim] (d gamma then d beta); pe bias gradients are exactly zero and
  * are not written.  NULL gradient pointers are not allowed for parameters the model has. */
 typedef struct rrt_attn_grads {
@@ -324,12 +327,13 @@ int rrt_encoder_train_sizes(const rrt_encoder_desc *desc, int64_t n_tokens, size
                             size_t *backward_workspace_bytes);
 /* y = RRTEncoder(x) (eval-equivalent arithmetic), intermediates kept in the caller-owned stash */
 int rrt_encoder_forward_train_f32(const rrt_encoder_desc *desc, const rrt_encoder_weights *w, const float *x,
-                                  float *y, int64_t n_tokens, void *stash, size_t stash_bytes, void *stream);
+                                  float *y, int64_t n_tokens, void *stash, size_t stash_bytes,
+                                  float drop_p, uint64_t drop_seed, void *stream);
 /* given dy = dL/dy: every parameter gradient and (optional) dx = dL/dx.  x and the stash are those of the forward. */
 int rrt_encoder_backward_f32(const rrt_encoder_desc *desc, const rrt_encoder_weights *w, const float *x,
                              const float *dy, const void *stash, size_t stash_bytes,
                              const rrt_encoder_grads *grads, float *dx, int64_t n_tokens, void *workspace,
-                             size_t workspace_bytes, void *stream);
+                             size_t workspace_bytes, float drop_p, uint64_t drop_seed, void *stream);
 
 #ifdef __cplusplus
 }

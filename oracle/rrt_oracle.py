@@ -175,11 +175,13 @@ def forward_f64(x, state, cfg=None, taps=None):
 
 
 # --------------------------------------------------------------------------- eager-equivalent torch/CPU port
-def forward_eager(x, state, cfg=None, grad=False):
+def forward_eager(x, state, cfg=None, grad=False, drop=None):
     """torch fp32 CPU port issuing the reference's aten op sequence; x: (N, D)
     torch tensor or array -> torch (N, D).  Used as the timed CPU baseline.
     grad=True: float64 leaves with requires_grad (x and every parameter) and a recorded graph -- torch autograd
-    then yields the reference's gradients (the oracle of the backward, row f2); returns (y, x_leaf, params)."""
+    then yields the reference's gradients (the oracle of the backward, row f2); returns (y, x_leaf, params).
+    drop = (p, {layer: keep mask [rows, D]}): train-mode proj_drop (rmsa.py:132) with GIVEN masks (layer index, or
+    "cr_msa"), i.e. nn.Dropout's arithmetic x * keep / (1 - p) without its random number generator."""
     import contextlib
     import torch
     import torch.nn.functional as F
@@ -203,7 +205,13 @@ def forward_eager(x, state, cfg=None, grad=False):
         t = t.view(B, H // s, H // s, s, s, D)
         return t.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H * H, D)
 
-    def inner(t, pfx, heads, epeg_k):                                        # modules/rmsa.py:91-134
+    def proj_drop(z, key):                                                   # modules/rmsa.py:132
+        if drop is None:
+            return z
+        keep = torch.from_numpy(np.ascontiguousarray(drop[1][key])).to(z.dtype).reshape(z.shape)
+        return z * keep / (1.0 - drop[0])
+
+    def inner(t, pfx, heads, epeg_k, key=None):                              # modules/rmsa.py:91-134
         B_, P, _ = t.shape
         hd = D // heads
         qkv = F.linear(t, st[pfx + "qkv.weight"], st.get(pfx + "qkv.bias"))
@@ -217,7 +225,7 @@ def forward_eager(x, state, cfg=None, grad=False):
             attn = attn + pe
         attn = attn.softmax(dim=-1)
         o = (attn @ v).transpose(1, 2).reshape(B_, P, D)
-        return F.linear(o, st[pfx + "proj.weight"], st[pfx + "proj.bias"])
+        return proj_drop(F.linear(o, st[pfx + "proj.weight"], st[pfx + "proj.bias"]), key)
 
     def ffn(t, pfx):                                                         # modules/rrt.py:25-41,127-129
         u = F.layer_norm(t, (D,), st[pfx + "norm2.weight"], st[pfx + "norm2.bias"], 1e-5)
@@ -232,7 +240,7 @@ def forward_eager(x, state, cfg=None, grad=False):
             H, s, add = grid(N, c["region_num"], c["region_size"], c["min_region_num"], c["min_region_ratio"])
             if add > 0:
                 u = torch.cat([u, torch.zeros((B, add, D), dtype=u.dtype)], dim=1)
-            z = unpart(inner(part(u, H, s), p + "attn.attn.", c["n_heads"], c["epeg_k"]), H, s)
+            z = unpart(inner(part(u, H, s), p + "attn.attn.", c["n_heads"], c["epeg_k"], li), H, s)
             if add > 0:
                 z = z[:, :-add]
             x = x + z
@@ -256,7 +264,7 @@ def forward_eager(x, state, cfg=None, grad=False):
             mx = lg.max(dim=-1)[0].unsqueeze(-1)
             mm = (lg - mn) / (mx - mn + 1e-8)
             rep = torch.einsum("wpc,wnp->wnpc", xr, cw).sum(dim=-2).transpose(0, 1)
-            rep = inner(rep, p + "attn.attn.", c["crmsa_heads"], 0).transpose(0, 1)
+            rep = inner(rep, p + "attn.attn.", c["crmsa_heads"], 0, "cr_msa").transpose(0, 1)
             o = torch.einsum("wnc,wnp->wnpc", rep, mm)
             o = torch.einsum("wnpc,wnp->wnpc", o, dw).sum(dim=1)
             z = unpart(o, H, s)

@@ -978,9 +978,28 @@ int rrt_encoder_train_sizes(const rrt_encoder_desc* desc, int64_t n_tokens, size
   return RRT_OK;
 }
 
+namespace {
+struct DropCfg {
+  unsigned thresh;
+  float scale;
+  unsigned seed(uint64_t base, int layer) const { return (unsigned)(base ^ (base >> 32)) + 0x9E3779B9u * (unsigned)(layer + 1); }
+};
+int make_drop(float p, DropCfg* d) {
+  if (!(p >= 0.f) || p >= 1.f) return RRT_E_INVALID;
+  d->thresh = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;
+  if (p > 0.f && d->thresh == 0) d->thresh = 1;
+  d->scale = 1.0f / (1.0f - p);
+  return RRT_OK;
+}
+constexpr int DROP_LAYER_CRMSA = 100;
+}  // namespace
+
 int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encoder_weights* w, const float* x,
-                                  float* y, int64_t n_tokens, void* stash, size_t stash_bytes, void* stream) {
+                                  float* y, int64_t n_tokens, void* stash, size_t stash_bytes, float drop_p,
+                                  uint64_t drop_seed, void* stream) {
   if (!desc || !w || !x || !y || x == y) return RRT_E_INVALID;
+  DropCfg dc{};
+  if (make_drop(drop_p, &dc)) return RRT_E_INVALID;
   rrt_grid g{}, g8{};
   int rc = check_train(desc, n_tokens, &g, &g8);
   if (rc) return rc;
@@ -1014,6 +1033,9 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     ep2.bias = lw.proj_b;
     ep2.resid = xin;
     ep2.g = gd;
+    ep2.drop_thresh = dc.thresh;
+    ep2.drop_scale = dc.scale;
+    ep2.drop_seed = dc.seed(drop_seed, li);
     RRT_TRY(launch_linear(s.o[li], lw.proj_w, s.xout[li], gd.Np, D, D, ep2, st));
     xin = s.xout[li];
   }
@@ -1034,6 +1056,9 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     RRT_TRY(launch_region_attention(s.rep_qkv, nullptr, s.rep_o, k, R8, D, desc->crmsa_heads, 0, st));
     LinearEpilogue ep2{};
     ep2.bias = cw.proj_b;
+    ep2.drop_thresh = dc.thresh;
+    ep2.drop_scale = dc.scale;
+    ep2.drop_seed = dc.seed(drop_seed, DROP_LAYER_CRMSA);
     RRT_TRY(launch_linear(s.rep_o, cw.proj_w, s.rep2, k * R8, D, D, ep2, st));
     RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, s.wdisp, s.rep2, nullptr, nullptr, s.x2, D, k, gd8, st));   // x2, no LN
   } else {
@@ -1046,8 +1071,11 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
 
 int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_weights* w, const float* x,
                              const float* dy, const void* stash, size_t stash_bytes, const rrt_encoder_grads* gr,
-                             float* dx, int64_t n_tokens, void* workspace, size_t workspace_bytes, void* stream) {
+                             float* dx, int64_t n_tokens, void* workspace, size_t workspace_bytes, float drop_p,
+                             uint64_t drop_seed, void* stream) {
   if (!desc || !w || !x || !dy || !gr) return RRT_E_INVALID;
+  DropCfg dc{};
+  if (make_drop(drop_p, &dc)) return RRT_E_INVALID;
   rrt_grid g{}, g8{};
   int rc = check_train(desc, n_tokens, &g, &g8);
   if (rc) return rc;
@@ -1079,6 +1107,7 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     const float* x1 = L > 0 ? s.xout[L - 1] : x;
     RRT_TRY(launch_crmsa_tokdot(b.dx2, nullptr, nullptr, nullptr, s.rep2, b.dWd, D, k, gd8, st));
     RRT_TRY(launch_crmsa_wsum(b.dx2, s.wdisp, b.d_rep2, D, k, gd8, st));
+    RRT_TRY(launch_apply_drop_mask(b.d_rep2, k * R8, D, dc.thresh, dc.seed(drop_seed, DROP_LAYER_CRMSA), dc.scale, st));
     RRT_TRY(launch_linear_backward(b.d_rep2, s.rep_o, cw.proj_w, b.d_rep_o, cg.proj_w, cg.proj_b, k * R8, D, D, 0,
                                    b.lin, st));
     RRT_TRY(launch_attention_backward(s.rep_qkv, nullptr, s.rep_o, b.d_rep_o, b.d_rep_qkv, nullptr, b.attnpart, k,
@@ -1100,7 +1129,7 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
       return RRT_E_INVALID;
     const GridDev gd = to_dev(g);
     const float* xin = li > 0 ? s.xout[li - 1] : x;
-    RRT_TRY(launch_partition_rows(cur, b.dz, D, gd, st));
+    RRT_TRY(launch_partition_rows(cur, b.dz, D, gd, dc.thresh, dc.seed(drop_seed, li), dc.scale, st));
     RRT_TRY(launch_linear_backward(b.dz, s.o[li], lw.proj_w, b.dO, lg.proj_w, lg.proj_b, gd.Np, D, D, 0, b.lin, st));
     RRT_TRY(launch_attention_backward(s.qkv[li], desc->epeg ? lw.pe_w : nullptr, s.o[li], b.dO, b.dqkv,
                                       desc->epeg ? lg.pe_w : nullptr, b.attnpart, gd.rs * gd.rs, gd.P, D,

@@ -43,6 +43,20 @@ __device__ __forceinline__ int slot_to_token(int slot, const GridDev& g) {
   return (ri * g.s + pi) * g.H + rj * g.s + pj;
 }
 
+// Stateless dropout mask (training, proj_drop): element (row, col) of a layer's proj output is kept iff
+// hash(seed, row * ncols + col) >= p * 2^32.  Forward epilogue and backward regenerate the same mask from
+// (seed, index): nothing is stored.  murmur3's 32-bit finaliser over a Weyl-scrambled index; the parity tests
+// rebuild the mask in numpy (tests/hip_util.py::dropout_keep) and hand it to the oracle.
+__device__ __forceinline__ bool rrt_drop_keep(unsigned seed, unsigned long long idx, unsigned thresh) {
+  unsigned h = (unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0x85EBCA77u + seed;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h >= thresh;
+}
+
 // Wave-wide reductions without LDS traffic: __shfl_xor lowers to ds_bpermute_b32 (an LDS-pipe round
 // trip per step, 6 dependent steps per reduction); here 4 DPP row rotations reduce each 16-lane row
 // in the VALU and 4 v_readlane + scalar-operand adds combine the rows.  Result is wave-uniform.

@@ -15,6 +15,10 @@ struct LinearEpilogue {
   int q_cols;            // columns [0,q_cols) scaled by q_scale after bias
   float q_scale;
   int act;               // RRT_ACT_* applied last (0 = none)
+  // training only (fp32): dropout on (acc + bias) before the residual; thresh = p * 2^32 (0 = off), the kept
+  // values are scaled by drop_scale = 1 / (1 - p); mask index = A-row * N + column (common.h rrt_drop_keep)
+  unsigned drop_thresh, drop_seed;
+  float drop_scale;
   // un-partition + residual (used when resid != null): C row = token, A row = slot
   const float* resid;
   GridDev g;
@@ -79,7 +83,11 @@ size_t attn_bwd_workspace(int n_regions, int heads, int epeg_k);
 hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const float* O, const float* dO,
                                      float* dqkv, float* dpe, float* dpe_part, int n_regions, int P, int D,
                                      int heads, int epeg_k, hipStream_t st);
-hipError_t launch_partition_rows(const float* src, float* dst, int dim, const GridDev& g, hipStream_t st);
+// dst [Np, dim] region-major <- src [L, dim]; pads 0; optional dropout mask (thresh != 0) regenerated per element
+hipError_t launch_partition_rows(const float* src, float* dst, int dim, const GridDev& g, unsigned drop_thresh,
+                                 unsigned drop_seed, float drop_scale, hipStream_t st);
+hipError_t launch_apply_drop_mask(float* buf, int rows, int cols, unsigned drop_thresh, unsigned drop_seed,
+                                  float drop_scale, hipStream_t st);
 // CR-MSA backward stages (crmsa_bwd.hip)
 hipError_t launch_crmsa_tokdot(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
                                const float* vec, float* out, int dim, int k, const GridDev& g, hipStream_t st);

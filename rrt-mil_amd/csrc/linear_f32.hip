@@ -90,7 +90,7 @@ struct Frag8<PREC_F16> {
 #define RRT_EPI_TRACE_PASS
 #endif
 // Epilogue flavours (template MODE): plain store; un-partition + residual; activation.
-constexpr int MODE_PLAIN = 0, MODE_UNPART = 1, MODE_ACT = 2;
+constexpr int MODE_PLAIN = 0, MODE_UNPART = 1, MODE_ACT = 2, MODE_UNPART_DROP = 3, MODE_DROP = 4;   // 3, 4: training
 
 // Elementwise activation of the epilogue (RRT_ACT_*; callers of the hot path: patch_to_emb's ReLU/GELU
 // modules/rrt.py:208-217, DAttention's hidden activation / gate modules/datten.py:14-22,52-62).
@@ -108,7 +108,7 @@ template <int MT, int NT, int MODE>
 __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT][NT], float* __restrict__ C, int M, int N,
                                            int m0, int n0, int wave, int lr, int lg,
                                            const LinearEpilogue& ep RRT_EPI_TRACE_ARG) {
-  constexpr bool UNPART = MODE == MODE_UNPART, ACT = MODE == MODE_ACT;
+  constexpr bool UNPART = MODE == MODE_UNPART || MODE == MODE_UNPART_DROP, ACT = MODE == MODE_ACT, DROP = MODE >= MODE_UNPART_DROP;
   const bool vec = (N & 3) == 0;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -140,6 +140,11 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT][NT], float* __
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = activate(v[r], ep.act);
       }
+      if constexpr (DROP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] = rrt_drop_keep(ep.drop_seed, (unsigned long long)m * N + nb + r, ep.drop_thresh) ? v[r] * ep.drop_scale : 0.f;
+      }
       float* dst = C + row * N + nb;
       if (vec && nb + 3 < N) {
         if (UNPART) {
@@ -167,7 +172,7 @@ template <int MT, int NT, int MODE, int I>
 __device__ __forceinline__ void store_slice(const f32x4 (&acc)[MT][NT], const float (&bias)[NT][4],
                                             float* __restrict__ C, int M, int N, int m0, int n0, int wave,
                                             int lr, int lg, const LinearEpilogue& ep) {
-  constexpr bool UNPART = MODE == MODE_UNPART, ACT = MODE == MODE_ACT;
+  constexpr bool UNPART = MODE == MODE_UNPART || MODE == MODE_UNPART_DROP, ACT = MODE == MODE_ACT, DROP = MODE >= MODE_UNPART_DROP;
   const int m = m0 + I * 16 + lr;
   if (m >= M) return;
   size_t row = (size_t)m;
@@ -186,6 +191,11 @@ __device__ __forceinline__ void store_slice(const f32x4 (&acc)[MT][NT], const fl
     if constexpr (ACT) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = activate(v[r], ep.act);
+    }
+    if constexpr (DROP) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        v[r] = rrt_drop_keep(ep.drop_seed, (unsigned long long)m * N + nb + r, ep.drop_thresh) ? v[r] * ep.drop_scale : 0.f;
     }
     float* dst = C + row * N + nb;
     if (vec && nb + 3 < N) {
@@ -647,6 +657,7 @@ RRT_TRACE_DEFINE_READER(rrt_debug_trace_linear)
 hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
                          const LinearEpilogue& ep, hipStream_t st) {
   const bool u = ep.resid != nullptr;
+  if (ep.drop_thresh && (ep.prec != PREC_F32 || ep.act)) return hipErrorInvalidValue;   // dropout: fp32 training only
   const Cfg c = choose(M, N);
 #define RRT_CASE(MT_, NT_)                                                                          \
   if (c.mt == MT_ && c.nt == NT_) {                                                                 \
@@ -655,7 +666,9 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
     return RRT_MODES(MT_, NT_, PREC_F32);                                                           \
   }
 #define RRT_MODES(MT_, NT_, P_)                                                                     \
-  (u ? launch_cfg<MT_, NT_, MODE_UNPART, P_>(A, B, C, M, N, K, c.cap, ep, st)                       \
+  (ep.drop_thresh ? (u ? launch_cfg<MT_, NT_, MODE_UNPART_DROP, PREC_F32>(A, B, C, M, N, K, c.cap, ep, st)  \
+                       : launch_cfg<MT_, NT_, MODE_DROP, PREC_F32>(A, B, C, M, N, K, c.cap, ep, st))        \
+   : u ? launch_cfg<MT_, NT_, MODE_UNPART, P_>(A, B, C, M, N, K, c.cap, ep, st)                      \
      : ep.act ? launch_cfg<MT_, NT_, MODE_ACT, P_>(A, B, C, M, N, K, c.cap, ep, st)                 \
               : launch_cfg<MT_, NT_, MODE_PLAIN, P_>(A, B, C, M, N, K, c.cap, ep, st))
   RRT_CASE(9, 1);

@@ -115,22 +115,46 @@ __global__ __launch_bounds__(256) void ln_backward_kernel(const float* __restric
 
 // dst [Np, dim] region-major <- src [L, dim] token order, pad slots = 0 (region_partition of a gradient)
 __global__ __launch_bounds__(256) void partition_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                             int dim, GridDev g) {
+                                                             int dim, GridDev g, unsigned thresh, unsigned seed,
+                                                             float scale) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int slot = blockIdx.x * 4 + wave; slot < g.Np; slot += gridDim.x * 4) {
     const int t = slot_to_token(slot, g);
     for (int c = lane * 4; c < dim; c += 256) {
-      const float4 v = t < g.L ? *(const float4*)(src + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = t < g.L ? *(const float4*)(src + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (thresh) {       // adjoint of the forward's dropout on this layer's proj output (same mask)
+        const unsigned long long i = (unsigned long long)slot * dim + c;
+        v.x = rrt_drop_keep(seed, i, thresh) ? v.x * scale : 0.f;
+        v.y = rrt_drop_keep(seed, i + 1, thresh) ? v.y * scale : 0.f;
+        v.z = rrt_drop_keep(seed, i + 2, thresh) ? v.z * scale : 0.f;
+        v.w = rrt_drop_keep(seed, i + 3, thresh) ? v.w * scale : 0.f;
+      }
       *(float4*)(dst + (size_t)slot * dim + c) = v;
     }
   }
 }
 
+__global__ __launch_bounds__(256) void apply_drop_mask_kernel(float* __restrict__ buf, size_t n, unsigned thresh,
+                                                              unsigned seed, float scale) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) buf[i] = rrt_drop_keep(seed, i, thresh) ? buf[i] * scale : 0.f;
+}
+
 }  // namespace
 
-hipError_t launch_partition_rows(const float* src, float* dst, int dim, const GridDev& g, hipStream_t st) {
+hipError_t launch_partition_rows(const float* src, float* dst, int dim, const GridDev& g, unsigned drop_thresh,
+                                 unsigned drop_seed, float drop_scale, hipStream_t st) {
   const int need = (g.Np + 3) / 4;
-  partition_rows_kernel<<<dim3(need < 4096 ? need : 4096), 256, 0, st>>>(src, dst, dim, g);
+  partition_rows_kernel<<<dim3(need < 4096 ? need : 4096), 256, 0, st>>>(src, dst, dim, g, drop_thresh, drop_seed,
+                                                                      drop_scale);
+  return hipGetLastError();
+}
+
+hipError_t launch_apply_drop_mask(float* buf, int rows, int cols, unsigned drop_thresh, unsigned drop_seed,
+                                  float drop_scale, hipStream_t st) {
+  if (!drop_thresh) return hipSuccess;
+  const size_t n = (size_t)rows * cols;
+  apply_drop_mask_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(buf, n, drop_thresh, drop_seed, drop_scale);
   return hipGetLastError();
 }
 

@@ -154,12 +154,16 @@ class _EncoderFunction(torch.autograd.Function):
         stash = torch.empty(stash_b.value, dtype=torch.uint8, device=x2d.device)
         y = torch.empty_like(x2d)
         w = enc._weights()
+        # train-mode proj_drop: a stateless mask keyed by a seed drawn from torch's CPU generator (so
+        # torch.manual_seed reproduces a run); the backward regenerates the same mask from (p, seed)
+        drop_p = float(enc.drop_out) if enc.training else 0.0
+        seed = enc._next_drop_seed() if drop_p > 0 else 0
         with torch.cuda.device(x2d.device):
             rc = lib.rrt_encoder_forward_train_f32(C.byref(enc._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
-                                                   stash.data_ptr(), stash.numel(),
+                                                   stash.data_ptr(), stash.numel(), drop_p, seed,
                                                    torch.cuda.current_stream(x2d.device).cuda_stream)
         _lib.check(rc, "rrt_encoder_forward_train_f32")
-        ctx.enc, ctx.stash, ctx.ws_bytes = enc, stash, ws_b.value
+        ctx.enc, ctx.stash, ctx.ws_bytes, ctx.drop = enc, stash, ws_b.value, (drop_p, seed)
         ctx.save_for_backward(x2d)
         return y
 
@@ -178,7 +182,7 @@ class _EncoderFunction(torch.autograd.Function):
             rc = lib.rrt_encoder_backward_f32(C.byref(enc._desc), C.byref(w), x2d.data_ptr(), dy.data_ptr(),
                                               ctx.stash.data_ptr(), ctx.stash.numel(), C.byref(gstruct),
                                               dx.data_ptr() if dx is not None else None, n, ws.data_ptr(), ws.numel(),
-                                              torch.cuda.current_stream(dev).cuda_stream)
+                                              ctx.drop[0], ctx.drop[1], torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "rrt_encoder_backward_f32")
         ctx.stash = None
         return (None, dx) + tuple(grads)
@@ -420,6 +424,14 @@ class RRTEncoder(nn.Module):
         # returns, so the caching allocator's stream-ordered reuse of these buffers stays correct
         return [y.unsqueeze(0) if b.dim() == 3 else y for b, y in zip(bags, ys)]
 
+    def _next_drop_seed(self):
+        """63-bit seed for this call's dropout masks.  ``drop_seed`` (int) pins it (tests); otherwise it comes from
+        torch's default CPU generator."""
+        fixed = getattr(self, "drop_seed", None)
+        if fixed is not None:
+            return int(fixed)
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
     def _wants_grad(self, x):
         """Training path (stash + autograd node) only in train() mode with gradients enabled and something to
         differentiate; eval() forwards never record a graph (the reference's validation loops run under
@@ -437,9 +449,6 @@ class RRTEncoder(nn.Module):
         """One bag with an autograd graph (rrt_encoder_forward_train_f32 / rrt_encoder_backward_f32)."""
         if not x2d.is_cuda:
             raise _lib.RRTHipError("rrt_mil_amd.RRTEncoder runs on MI355X only; there is no CPU fallback")
-        if self.drop_out > 0:
-            raise NotImplementedError("training with proj dropout p=%.2f is not built yet; construct the encoder "
-                                      "with drop_out=0 (RRTMIL: trans_dropout=0)" % self.drop_out)
         if self._compute_mode() != _lib.COMPUTE_F32:
             raise NotImplementedError("training under autocast / reduced-precision operands is not built")
         x2d = x2d.float().contiguous()

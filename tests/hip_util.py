@@ -52,3 +52,21 @@ def region_attention(qkv, pe_w, n_regions, P, dim, heads, epeg_k):
                "region_attention")
     torch.cuda.synchronize()
     return o
+
+
+def dropout_keep(seed, layer, rows, cols, p):
+    """numpy replica of csrc/common.h::rrt_drop_keep for one layer's proj output [rows, cols]: the boolean keep
+    mask that rrt_encoder_forward_train_f32 applies for (drop_p = p, drop_seed = seed); layer = index of the R-MSA
+    layer, 100 for CR-MSA's inner attention (api.hip DropCfg::seed)."""
+    M32 = np.uint64(0xFFFFFFFF)
+    base = np.uint64(seed)
+    lseed = ((base ^ (base >> np.uint64(32))) + np.uint64(0x9E3779B9) * np.uint64(layer + 1)) & M32
+    idx = np.arange(rows * cols, dtype=np.uint64)
+    h = ((idx & M32) * np.uint64(0x9E3779B1) + (idx >> np.uint64(32)) * np.uint64(0x85EBCA77) + lseed) & M32
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & M32
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & M32
+    h ^= h >> np.uint64(16)
+    thresh = np.uint64(max(1, int(p * 4294967296.0)))
+    return (h >= thresh).reshape(rows, cols)

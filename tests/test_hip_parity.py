@@ -891,8 +891,53 @@ def test_encoder_backward_matches_autograd(case):
             assert float(prm.grad.abs().max()) == 0.0 and float(ref.abs().max()) < 1e-6     # Identity 2
             continue
         rel(prm.grad.cpu().numpy(), ref.numpy().reshape(prm.shape), name)
-    # eval() never records a graph; train() with dropout is refused
+    # eval() never records a graph
     assert enc.eval()(xd.unsqueeze(0)).grad_fn is None
-    with pytest.raises(NotImplementedError):
-        RRTEncoder(**cfg).to(DEV).train()(xd.unsqueeze(0))
+
+
+@pytest.mark.parametrize("case,p", [("default_n1500", 0.1), ("c16_n2600", 0.25), ("nsclc_layers3_n900", 0.1)])
+def test_encoder_backward_with_dropout(case, p):
+    """Train-mode proj_drop (the reference's default drop_out=0.1): the kernels' stateless mask is rebuilt in
+    numpy and handed to the float64 oracle, so forward and every gradient can be compared exactly; the masks
+    themselves are checked for rate and for independence between layers."""
+    from hip_util import DEV, dev, dropout_keep
+    from rrt_mil_amd import RRTEncoder
+    N, cfg = TRAIN_CASES[case]
+    D = cfg["mlp_dim"]
+    st = synth.encoder_state(**{k: v for k, v in cfg.items() if k in ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k",
+                                                                      "cr_msa", "crmsa_k", "qkv_bias")})
+    x = synth.bag(N, D, tag="train/" + case)
+    G = synth.normal("train/G/" + case, (N, D))
+    seed = 0x1234_5678_9ABC_DEF
+    H, s_, _ = O.grid(N, cfg.get("region_num", 8))
+    n_layers = cfg.get("n_layers", 2) - 1
+    masks = {li: dropout_keep(seed, li, H * H, D, p) for li in range(n_layers)}
+    masks["cr_msa"] = dropout_keep(seed, 100, cfg.get("crmsa_k", 3) * 64, D, p)
+    for m in masks.values():
+        assert abs(1.0 - m.mean() - p) < 0.01
+    if n_layers > 1:
+        assert 0.7 < (masks[0] == masks[1]).mean() < 0.9          # independent masks agree on p^2 + (1-p)^2
+    y64, x_leaf, params = O.forward_eager(x, st, cfg, grad=True, drop=(p, masks))
+    (y64 * torch.from_numpy(G).double()).sum().backward()
+    enc = RRTEncoder(drop_out=p, **cfg)
+    enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    enc = enc.to(DEV).train()
+    enc.drop_seed = seed
+    xd = dev(x).requires_grad_(True)
+    y = enc(xd.unsqueeze(0)).squeeze(0)
+    _cmp(y.detach().cpu().numpy(), y64.detach().numpy(), 2e-4, case + " train forward with dropout")
+    (y * dev(G)).sum().backward()
+    torch.cuda.synchronize()
+    for name, got, ref in [("dx", xd.grad, x_leaf.grad)] + [(n_, p_.grad, params[n_].grad.reshape(p_.shape))
+                                                            for n_, p_ in enc.named_parameters()
+                                                            if not n_.endswith("pe.bias")]:
+        ref = ref.numpy().astype(np.float64)
+        err = np.abs(got.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-6)
+        assert err <= 2e-3, f"{case} {name}: {err:.2e}"
+    # a fresh seed per call by default: two training forwards differ, eval does not
+    enc.drop_seed = None
+    y1, y2 = enc(xd.unsqueeze(0)), enc(xd.unsqueeze(0))
+    assert not torch.equal(y1, y2)
+    enc.eval()
+    assert torch.equal(enc(xd.unsqueeze(0)), enc(xd.unsqueeze(0)))
 
