@@ -521,8 +521,10 @@ def test_rrtmil_fails_loudly():
     mil = mil.to("cuda:0")
     with pytest.raises(ValueError):
         mil.forward_bag(torch.zeros(10, 96, device="cuda:0"))
-    with pytest.raises(NotImplementedError):
-        mil.train()(torch.zeros(1, 10, 64, device="cuda:0"))
+    out = mil.train()(torch.randn(1, 10, 64, device="cuda:0"))          # training records a graph (row f2)
+    assert out.grad_fn is not None and out.shape == (1, 2)
+    with pytest.raises(NotImplementedError):                            # the one-call inference path refuses train mode
+        mil.forward_bag(torch.zeros(10, 64, device="cuda:0"))
 
 
 # ------------------------------------------------------------------ batch-of-bags executor
