@@ -260,6 +260,33 @@ def main():
                            "(rrt_mil_forward_f32: patch_to_emb GEMM+ReLU, encoder, DAttention pooling, predictor)"}
         del mil, feats
 
+    # informational: one training step of the same encoder (row f2): forward with stash + full backward, fp32,
+    # default proj dropout 0.1, one bag per step, rank 0 after the timed region.  Not the headline value.
+    train_rec = None
+    if rank == 0:
+        tenc = RRTEncoder(**CFG).to(dev).train()
+        tenc.load_state_dict(enc.state_dict())
+        xg = bags[0].unsqueeze(0)
+        gy = torch.randn_like(xg)
+        torch.cuda.reset_peak_memory_stats(dev)
+
+        def tstep():
+            tenc.zero_grad(set_to_none=True)
+            (tenc(xg) * gy).sum().backward()
+        for _ in range(3):
+            tstep()
+        torch.cuda.synchronize()
+        tt = time.perf_counter()
+        for _ in range(20):
+            tstep()
+        torch.cuda.synchronize()
+        tt = (time.perf_counter() - tt) / 20
+        train_rec = {"ms_per_step": round(tt * 1e3, 4), "steps_per_s": round(1.0 / tt, 2),
+                     "peak_mem_mb": round(torch.cuda.max_memory_allocated(dev) / 1e6, 1),
+                     "note": "RRTEncoder.train() forward (stash) + backward of every parameter, N=9000 D=512, fp32, "
+                             "drop_out=0.1, one bag per step (rrt_encoder_forward_train_f32 / rrt_encoder_backward_f32)"}
+        del tenc
+
     # dominant kernel: rmsa_fused_kernel = qkv projection [Np, D] x [3D, D]^T + region attention
     # (Q K^T and A V) per (region, head), fp32 MFMA.  Algorithmic FLOPs per launch (SURVEY §8d terms):
     g = region_grid(N_TOKENS, CFG["region_num"])
@@ -298,6 +325,7 @@ def main():
         }
         rec["amp_bf16"] = amp
         rec["rrtmil_c16"] = mil_rec
+        rec["train_step"] = train_rec
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)
