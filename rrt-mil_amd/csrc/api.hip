@@ -809,7 +809,7 @@ int rrt_region_attention_backward_f32(const float* qkv, const float* pe_w, const
   const int ek = pe_w ? epeg_k : 0;
   if (ek > 0 && ek % 2 == 0) return unsupported("epeg_k must be odd");
   if (!attn_bwd_supported(P, dim, heads, ek))
-    return unsupported("attention backward: needs head dim 64, P <= 144, epeg_k <= 63");
+    return unsupported("attention backward: needs head dim 64, P <= 208, epeg_k <= 63");
   if (!workspace || workspace_bytes < attn_bwd_workspace(n_regions, heads, ek)) return RRT_E_WORKSPACE;
   return (int)launch_attention_backward(qkv, pe_w, o, d_o, d_qkv, d_pe_w, (float*)workspace, n_regions, P, dim,
                                         heads, ek, (hipStream_t)stream);
@@ -951,7 +951,7 @@ int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8)
     rc = rrt_region_grid(N, d->region_num, d->region_size, d->min_region_num, d->min_region_ratio, g);
     if (rc) return rc;
     if (!attn_bwd_supported(g->s * g->s, d->dim, d->n_heads, d->epeg ? d->epeg_k : 0))
-      return unsupported("training: R-MSA needs head dim 64 and regions of <= 144 tokens (N <= 9216 at region_num=8)");
+      return unsupported("training: R-MSA needs head dim 64 and regions of <= 208 tokens (N <= 12544 at region_num=8)");
   }
   rc = rrt_region_grid(N, 8, 0, 0, 0.f, g8);
   if (rc) return rc;

@@ -2,17 +2,18 @@
 //
 // Forward (modules/rmsa.py:103-122, per region and head, Identity 1 of DESIGN.md):
 //     Q~ = (I + T_w) q ,  S = Q~ K^T ,  A = softmax_rows(S) ,  O = A V          q = scale * q_raw (as stashed)
-// Backward, one block per (region, head) with Q~, K, V and dO resident in LDS (4 x 36.9 KB at P = 144), the
-// probabilities recomputed from them (nothing of size P x P is ever stored, forward or backward):
+// Backward, one block per (region, head) with three tiles resident in LDS -- Q~, K and a third one that holds V
+// during pass A and dO during pass B (3 x 53 KB at P = 208; the fragments a wave needs from the absent tile come
+// from global / L2) --, the probabilities recomputed (nothing of size P x P is ever stored, forward or backward):
 //     D_i  = <dO_i, O_i>                       (= rowsum(dA o A))
 //     dV   = A^T dO        dA = dO V^T        dS = A o (dA - D)
 //     dQ~  = dS K          dK = dS^T Q~
 //     dq_raw = scale * (I + T_w)^T dQ~         (the same sliding-window stencil with the taps flipped)
 //     dw_h[t] = sum_i <dQ~_i, q_{i + t - k/2}>  ;  the conv bias has an exactly-zero gradient (Identity 2)
 // Pass A (a wave owns 16-query tiles, scores transposed exactly as in the forward kernels) produces the row
-// statistics, D and dQ~ (kept in registers); pass B (a wave owns 16-key tiles; the same two MFMA helpers with
-// the roles of Q~ and K exchanged) produces dK and dV.  Scores are in base-2 units (log2(e) folded into Q~).
-// Requires head dim 64 and P <= 144.
+// statistics, D and dQ~ (parked in the dq columns of the output); pass B (a wave owns 16-key tiles; the same two
+// MFMA helpers with the roles of Q~ and K exchanged) produces dK and dV.  Scores are in base-2 units (log2(e)
+// folded into Q~).  Requires head dim 64 and P <= 208.
 #include "internal.h"
 
 namespace {
@@ -31,24 +32,32 @@ __device__ __forceinline__ void load_frags(const float* tile, int row, int lg, f
 // s[t][r] = sum_d X[16 t + 4 lg + r][d] * f[d]  for the fragment rows f (lane lr = one row of the other operand)
 template <int MT>
 __device__ __forceinline__ void tile_scores(const float* X, const float4 (&f)[4], int lr, int lg, f32x4 (&s)[MT]) {
+  constexpr int CH = MT > 7 ? (MT + 1) / 2 : MT;     // row fragments in flight: at most 7 tiles (28 VGPRs)
 #pragma unroll
   for (int t = 0; t < MT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    float4 a[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int row = t * 16 + lr;
-      a[t] = *(const float4*)(X + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+    for (int t0 = 0; t0 < MT; t0 += CH) {
+      float4 a[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int row = (t0 + u < MT ? t0 + u : MT - 1) * 16 + lr;
+        a[u] = *(const float4*)(X + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (t0 + u < MT) s[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, f[c].x, s[t0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (t0 + u < MT) s[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, f[c].y, s[t0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (t0 + u < MT) s[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, f[c].z, s[t0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (t0 + u < MT) s[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, f[c].w, s[t0 + u], 0, 0, 0);
     }
-#pragma unroll
-    for (int t = 0; t < MT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, f[c].x, s[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, f[c].y, s[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, f[c].z, s[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, f[c].w, s[t], 0, 0, 0);
   }
 }
 
@@ -56,7 +65,8 @@ __device__ __forceinline__ void tile_scores(const float* X, const float4 (&f)[4]
 // p-operand's lane index, column 4 lr + c)
 template <int MT>
 __device__ __forceinline__ void tile_apply(const float* X, const f32x4 (&p)[MT], int lr, int lg, f32x4 (&o)[4]) {
-#pragma unroll
+  // two tiles' rows in flight (32 VGPRs): fully unrolled, the scheduler hoists all 4 MT row loads and spills
+#pragma unroll 2
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -82,9 +92,8 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Qt = (float*)smem;             // q, then Q~ (x log2 e) in place
   float* Ks = Qt + TILE;
-  float* Vs = Ks + TILE;
-  float* Gs = Vs + TILE;                // dO, later dQ~
-  float* lse = Gs + TILE;               // [BM] row log-sum-exp, base 2
+  float* Xs = Ks + TILE;                // V (pass A), dO (pass B), dQ~ (stencil adjoint)
+  float* lse = Xs + TILE;               // [BM] row log-sum-exp, base 2
   float* dd = lse + BM;                 // [BM] D_i
   float* wred = dd + BM;                // [6][64] wave partials of the tap gradients
 
@@ -95,22 +104,20 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
   const size_t row0 = (size_t)reg * P;
   const int ld = 3 * D;
 
-  // ---- phase 0: q, k, v, dO tiles -> LDS (XOR-swizzled 16-byte slots, rows >= P are zeros)
+  // ---- phase 0: q, k, v tiles -> LDS (XOR-swizzled 16-byte slots, rows >= P are zeros)
   for (int idx = tid; idx < BM * 16; idx += 384) {
     const int m = idx >> 4, s = idx & 15;
-    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, g4 = q4;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
     if (m < P) {
       const float* src = qkv + (row0 + m) * ld + head * HD + 4 * s;
       q4 = *(const float4*)src;
       k4 = *(const float4*)(src + D);
       v4 = *(const float4*)(src + 2 * D);
-      g4 = *(const float4*)(dO + (row0 + m) * D + head * HD + 4 * s);
     }
     const int off = m * HD + ((s ^ (m & 15)) << 2);
     *(float4*)(Qt + off) = q4;
     *(float4*)(Ks + off) = k4;
-    *(float4*)(Vs + off) = v4;
-    *(float4*)(Gs + off) = g4;
+    *(float4*)(Xs + off) = v4;
   }
   __syncthreads();
 
@@ -157,32 +164,39 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
   }
   __syncthreads();
 
-  // tile -> wave schedule of the forward fused kernel (MT <= 9: at most two tiles per wave)
-  auto tile_of = [&](int pass) { return pass == 0 ? wave : (wave >= 2 ? wave + 4 : MT); };
+  // tile -> wave schedule of the forward fused kernel (balanced per SIMD; at most three tiles per wave)
+  auto tile_of = [&](int pass) {
+    if (pass == 0) return wave;
+    if (pass == 1) return wave >= 2 ? wave + 4 : (wave == 0 ? 12 : MT);
+    return (wave == 2 || wave == 3) ? wave + 8 : MT;
+  };
+  // fragment rows of a [rows, D]-strided global tensor: lane (lr, lg) <- row[4*(4c + lg) .. +3]
+  auto global_frags = [&](const float* base, size_t stride, int m, float4 (&f)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      f[c] = m < P ? *(const float4*)(base + (row0 + m) * stride + head * HD + 4 * (4 * c + lg))
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  float* dq_park = dqkv + head * HD;    // dQ~ rows are parked in the dq columns until the stencil adjoint
 
-  // ---- pass A: query tiles.  Row statistics, D, dQ~ (kept in registers until the tiles are dead)
-  f32x4 keep[2][4];
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) keep[ps][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
+  // ---- pass A: query tiles.  Row statistics, D, dQ~
+#pragma unroll 1
+  for (int ps = 0; ps < 3; ++ps) {
     const int t = tile_of(ps);
     const int i0 = t * 16;
     if (t >= MT || i0 >= P) break;
     const int m = i0 + lr;
     float4 fq[4], fg[4];
     load_frags(Qt, m, lg, fq);
-    load_frags(Gs, m, lg, fg);
+    global_frags(dO, (size_t)D, m, fg);
     // D_i = <dO_i, O_i>: this lane's 16 of the 64 dims, then across the 4 lane groups
     float dsum = 0.f;
-    if (m < P) {
+    {
+      float4 fo[4];
+      global_frags(O, (size_t)D, m, fo);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 o4 = *(const float4*)(O + (row0 + m) * D + head * HD + 4 * (4 * c + lg));
-        dsum += (fg[c].x * o4.x + fg[c].y * o4.y) + (fg[c].z * o4.z + fg[c].w * o4.w);
-      }
+      for (int c = 0; c < 4; ++c)
+        dsum += (fg[c].x * fo[c].x + fg[c].y * fo[c].y) + (fg[c].z * fo[c].z + fg[c].w * fo[c].w);
     }
     dsum += __shfl_xor(dsum, 16);
     dsum += __shfl_xor(dsum, 32);
@@ -214,29 +228,45 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
       lse[m] = cmax + __builtin_amdgcn_logf(psum);   // v_log_f32 = log2
       dd[m] = dsum;
     }
-    f32x4 da[MT];
-    tile_scores<MT>(Vs, fg, lr, lg, da);            // dA[query lr][key]
+    {
+      f32x4 da[MT];
+      tile_scores<MT>(Xs, fg, lr, lg, da);          // dA[query lr][key]  (Xs = V)
 #pragma unroll
-    for (int jt = 0; jt < MT; ++jt)
+      for (int jt = 0; jt < MT; ++jt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[jt][r] = s[jt][r] * inv * (da[jt][r] - dsum);   // dS (masked keys: A = 0)
-    tile_apply<MT>(Ks, s, lr, lg, keep[ps]);        // dQ~[query 4 lg + r][d = 4 lr + c]
+        for (int r = 0; r < 4; ++r) s[jt][r] = s[jt][r] * inv * (da[jt][r] - dsum);   // dS (masked keys: A = 0)
+    }
+    f32x4 dqt[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dqt[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile_apply<MT>(Ks, s, lr, lg, dqt);             // dQ~[query 4 lg + r][d = 4 lr + c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * lg + r;
+      if (i < P) *(float4*)(dq_park + (row0 + i) * ld + (lr << 2)) = make_float4(dqt[0][r], dqt[1][r], dqt[2][r], dqt[3][r]);
+    }
+  }
+  __syncthreads();                                  // V is dead: the third tile becomes dO
+  for (int idx = tid; idx < BM * 16; idx += 384) {
+    const int m = idx >> 4, s = idx & 15;
+    const float4 g4 = m < P ? *(const float4*)(dO + (row0 + m) * D + head * HD + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(Xs + m * HD + ((s ^ (m & 15)) << 2)) = g4;
   }
   __syncthreads();
 
   // ---- pass B: key tiles.  dV = A^T dO, dK = dS^T Q~ (Q~ carries log2 e: x ln 2)
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll 1
+  for (int ps = 0; ps < 3; ++ps) {
     const int t = tile_of(ps);
     const int j0 = t * 16;
     if (t >= MT || j0 >= P) break;
     const int m = j0 + lr;
     float4 fk[4], fv[4];
     load_frags(Ks, m, lg, fk);
-    load_frags(Vs, m, lg, fv);
+    global_frags(qkv + 2 * D, (size_t)ld, m, fv);
     f32x4 a[MT], ds[MT];
     tile_scores<MT>(Qt, fk, lr, lg, a);             // a[it][r] = S2[query 16 it + 4 lg + r][key lr]
-    tile_scores<MT>(Gs, fv, lr, lg, ds);            // dA[query][key lr]
+    tile_scores<MT>(Xs, fv, lr, lg, ds);            // dA[query][key lr]  (Xs = dO)
 #pragma unroll
     for (int it = 0; it < MT; ++it)
 #pragma unroll
@@ -250,7 +280,7 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
     f32x4 dv[4], dk[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) dv[c] = dk[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tile_apply<MT>(Gs, a, lr, lg, dv);              // dV[key 4 lg + r][d = 4 lr + c]
+    tile_apply<MT>(Xs, a, lr, lg, dv);              // dV[key 4 lg + r][d = 4 lr + c]
     tile_apply<MT>(Qt, ds, lr, lg, dk);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -262,23 +292,14 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
       }
     }
   }
-  __syncthreads();                                  // every read of Q~ / dO tiles is done
+  __syncthreads();                                  // every read of the dO tile is done; parked dQ~ rows are visible
 
-  // ---- dQ~ tiles -> LDS over the dead dO tile (rows >= P and untouched tiles: zeros)
-  for (int idx = tid; idx < BM * 16; idx += 384) *(float4*)(Gs + idx * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int t = tile_of(ps);
-    const int i0 = t * 16;
-    if (t >= MT || i0 >= P) break;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = i0 + 4 * lg + r;
-      if (i < P)
-        *(float4*)(Gs + i * HD + ((lr ^ (i & 15)) << 2)) =
-            make_float4(keep[ps][0][r], keep[ps][1][r], keep[ps][2][r], keep[ps][3][r]);
-    }
+  // ---- parked dQ~ rows -> LDS over the dead dO tile (rows >= P: zeros)
+  float* Gs = Xs;
+  for (int idx = tid; idx < BM * 16; idx += 384) {
+    const int m = idx >> 4, s = idx & 15;
+    const float4 g4 = m < P ? *(const float4*)(dq_park + (row0 + m) * ld + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(Gs + m * HD + ((s ^ (m & 15)) << 2)) = g4;
   }
   __syncthreads();
 
@@ -348,7 +369,7 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
 template <int MT>
 hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, const float* dO, float* dqkv,
                          float* dpe_part, int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
-  constexpr size_t LDS = ((size_t)4 * 16 * MT * HD + 2 * 16 * MT + 6 * 64) * sizeof(float);
+  constexpr size_t LDS = ((size_t)3 * 16 * MT * HD + 2 * 16 * MT + 6 * 64) * sizeof(float);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = attn_bwd_kernel<MT>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -361,7 +382,7 @@ hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, co
 }  // namespace
 
 bool attn_bwd_supported(int P, int D, int heads, int epeg_k) {
-  return heads > 0 && D == heads * HD && P > 0 && P <= 144 && epeg_k >= 0 && epeg_k <= 63;
+  return heads > 0 && D == heads * HD && P > 0 && P <= 208 && epeg_k >= 0 && epeg_k <= 63;
 }
 
 size_t attn_bwd_workspace(int n_regions, int heads, int epeg_k) {
@@ -374,7 +395,9 @@ hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const 
                                      int heads, int epeg_k, hipStream_t st) {
   if (pe_w == nullptr) epeg_k = 0;
   hipError_t e;
-  if (P > 128) e = launch_bwd_mt<9>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
+  if (P > 176) e = launch_bwd_mt<13>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
+  else if (P > 144) e = launch_bwd_mt<11>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
+  else if (P > 128) e = launch_bwd_mt<9>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   else if (P > 112) e = launch_bwd_mt<8>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   else if (P > 96) e = launch_bwd_mt<7>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   else if (P > 64) e = launch_bwd_mt<6>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);

@@ -794,7 +794,9 @@ def test_layernorm_backward(L, D, rn):
 
 @pytest.mark.parametrize("R,P,D,heads,ek", [(3, 144, 512, 8, 15), (2, 121, 512, 8, 21), (4, 64, 512, 8, 0),
                                             (5, 49, 512, 8, 15), (2, 100, 256, 4, 9), (3, 130, 512, 8, 0),
-                                            (64, 144, 512, 8, 15), (2, 7, 128, 2, 15), (3, 81, 512, 8, 31)])
+                                            (64, 144, 512, 8, 15), (2, 7, 128, 2, 15), (3, 81, 512, 8, 31),
+                                            (3, 169, 512, 8, 15), (2, 196, 512, 8, 21), (2, 208, 512, 8, 0),
+                                            (3, 177, 256, 4, 9)])
 def test_region_attention_backward(R, P, D, heads, ek):
     """Attention backward (recomputed probabilities, EPEG adjoint, tap gradients) against float64 autograd of the
     explicit formulation (scores [P,P], depth-wise conv along the query axis WITH a bias, softmax, A V)."""
@@ -848,6 +850,7 @@ TRAIN_CASES = {
     "nsclc_layers3_n900": (900, dict(mlp_dim=512, epeg_k=21, crmsa_k=5, n_layers=3)),
     "noepeg_nobias_n500": (500, dict(mlp_dim=512, epeg=False, qkv_bias=False)),
     "d256_n333": (333, dict(mlp_dim=256, n_heads=4, crmsa_heads=4, epeg_k=9)),
+    "p169_n10000": (10000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 169 tokens (MT = 11)
 }
 
 
