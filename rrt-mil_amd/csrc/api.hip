@@ -809,7 +809,7 @@ int rrt_region_attention_backward_f32(const float* qkv, const float* pe_w, const
   const int ek = pe_w ? epeg_k : 0;
   if (ek > 0 && ek % 2 == 0) return unsupported("epeg_k must be odd");
   if (!attn_bwd_supported(P, dim, heads, ek))
-    return unsupported("attention backward: needs head dim 64, P <= 208, epeg_k <= 63");
+    return unsupported("attention backward: needs head dim 64 with P <= 208, or (no EPEG, P <= 128, head dim % 4 == 0)");
   if (!workspace || workspace_bytes < attn_bwd_workspace(n_regions, heads, ek)) return RRT_E_WORKSPACE;
   return (int)launch_attention_backward(qkv, pe_w, o, d_o, d_qkv, d_pe_w, (float*)workspace, n_regions, P, dim,
                                         heads, ek, (hipStream_t)stream);
@@ -958,7 +958,7 @@ int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8)
   if (d->cr_msa) {
     const int R8 = g8->regions_side * g8->regions_side;
     if (!attn_bwd_supported(R8, d->dim, d->crmsa_heads, 0))
-      return unsupported("training: CR-MSA needs head dim 64 (crmsa_heads = dim / 64)");
+      return unsupported("training: CR-MSA's inner attention needs a head dim that is a multiple of 4");
   }
   return RRT_OK;
 }

@@ -379,10 +379,110 @@ hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, co
   return hipGetLastError();
 }
 
+// ---- any head dim (crmsa_heads = 1 -> head dim = dim), no EPEG, short sequences: CR-MSA's inner attention over
+// the k x 64 representatives.  VALU only: one block per (sequence, head), a wave per query / key row, the head dim
+// across the lanes; A and dS [P, P] in LDS.  (Published TCGA-BRCA-R50 / NSCLC-PLIP configs: 3 x 64 rows.)
+__global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const float* __restrict__ qkv,
+                                                               const float* __restrict__ O,
+                                                               const float* __restrict__ dO,
+                                                               float* __restrict__ dqkv, int P, int D, int hd,
+                                                               float q_scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* A = (float*)smem;              // [P][P] probabilities
+  float* dS = A + (size_t)P * P;        // [P][P]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int head = blockIdx.x, reg = blockIdx.y;
+  const int ld = 3 * D;
+  const size_t row0 = (size_t)reg * P;
+  const float* qb = qkv + row0 * ld + head * hd;
+  const float* kb = qb + D;
+  const float* vb = qb + 2 * D;
+  const float* ob = O + row0 * D + head * hd;
+  const float* gb = dO + row0 * D + head * hd;
+  // rows of S, softmax, D_i, rows of dA -> A, dS
+  for (int i = wave; i < P; i += 4) {
+    float dsum = 0.f;
+    for (int d = lane * 4; d < hd; d += 256) {
+      const float4 g = *(const float4*)(gb + (size_t)i * D + d), o = *(const float4*)(ob + (size_t)i * D + d);
+      dsum += (g.x * o.x + g.y * o.y) + (g.z * o.z + g.w * o.w);
+    }
+    dsum = wave_sum(dsum);
+    float mx = NEG_BIG;
+    for (int j0 = 0; j0 < P; j0 += 4) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f}, da[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int d = lane * 4; d < hd; d += 256) {
+        const float4 q4 = *(const float4*)(qb + (size_t)i * ld + d), g4 = *(const float4*)(gb + (size_t)i * D + d);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + u < P ? j0 + u : P - 1;
+          const float4 k4 = *(const float4*)(kb + (size_t)j * ld + d), v4 = *(const float4*)(vb + (size_t)j * ld + d);
+          s[u] += (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
+          da[u] += (g4.x * v4.x + g4.y * v4.y) + (g4.z * v4.z + g4.w * v4.w);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float sv = wave_sum(s[u]), dv = wave_sum(da[u]);
+        if (j0 + u < P) {
+          if (lane == 0) { A[i * P + j0 + u] = sv; dS[i * P + j0 + u] = dv; }
+          mx = fmaxf(mx, sv);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float sum = 0.f;
+    for (int j = lane; j < P; j += 64) {
+      const float p = __expf(A[i * P + j] - mx);
+      A[i * P + j] = p;
+      sum += p;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < P; j += 64) {
+      const float p = A[i * P + j] * inv;
+      A[i * P + j] = p;
+      dS[i * P + j] = p * (dS[i * P + j] - dsum);
+    }
+  }
+  __syncthreads();
+  // dq_i = scale * sum_j dS[i,j] k_j ; dk_j = sum_i dS[i,j] q_i ; dv_j = sum_i A[i,j] dO_i
+  for (int r = wave; r < P; r += 4) {
+    for (int d = lane * 4; d < hd; d += 256) {
+      float4 aq = make_float4(0.f, 0.f, 0.f, 0.f), ak = aq, av = aq;
+      for (int j0 = 0; j0 < P; j0 += 4) {
+        float4 k4[4], q4[4], g4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + u < P ? j0 + u : P - 1;
+          k4[u] = *(const float4*)(kb + (size_t)j * ld + d);
+          q4[u] = *(const float4*)(qb + (size_t)j * ld + d);
+          g4[u] = *(const float4*)(gb + (size_t)j * D + d);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j0 + u >= P) break;
+          const float w1 = dS[r * P + j0 + u], w2 = dS[(j0 + u) * P + r], w3 = A[(j0 + u) * P + r];
+          aq.x += w1 * k4[u].x; aq.y += w1 * k4[u].y; aq.z += w1 * k4[u].z; aq.w += w1 * k4[u].w;
+          ak.x += w2 * q4[u].x; ak.y += w2 * q4[u].y; ak.z += w2 * q4[u].z; ak.w += w2 * q4[u].w;
+          av.x += w3 * g4[u].x; av.y += w3 * g4[u].y; av.z += w3 * g4[u].z; av.w += w3 * g4[u].w;
+        }
+      }
+      float* dst = dqkv + (row0 + r) * ld + head * hd + d;
+      *(float4*)dst = make_float4(aq.x * q_scale, aq.y * q_scale, aq.z * q_scale, aq.w * q_scale);
+      *(float4*)(dst + D) = ak;
+      *(float4*)(dst + 2 * D) = av;
+    }
+  }
+}
+
 }  // namespace
 
+// MFMA path: head dim 64, P <= 208.  Generic path: any head dim that is a multiple of 4, no EPEG, P <= 128.
 bool attn_bwd_supported(int P, int D, int heads, int epeg_k) {
-  return heads > 0 && D == heads * HD && P > 0 && P <= 208 && epeg_k >= 0 && epeg_k <= 63;
+  if (heads <= 0 || P <= 0 || D % heads) return false;
+  const int hd = D / heads;
+  if (hd == HD) return P <= 208 && epeg_k >= 0 && epeg_k <= 63;
+  return epeg_k == 0 && P <= 128 && hd % 4 == 0;
 }
 
 size_t attn_bwd_workspace(int n_regions, int heads, int epeg_k) {
@@ -395,6 +495,14 @@ hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const 
                                      int heads, int epeg_k, hipStream_t st) {
   if (pe_w == nullptr) epeg_k = 0;
   hipError_t e;
+  if (D / heads != HD) {
+    const size_t lds = (size_t)2 * P * P * sizeof(float);
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_bwd_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attn_bwd_generic_kernel<<<dim3(heads, n_regions), 256, lds, st>>>(qkv, O, dO, dqkv, P, D, D / heads,
+                                                                      1.0f / sqrtf((float)(D / heads)));
+    return hipGetLastError();
+  }
   if (P > 176) e = launch_bwd_mt<13>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   else if (P > 144) e = launch_bwd_mt<11>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   else if (P > 128) e = launch_bwd_mt<9>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);

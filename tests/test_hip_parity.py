@@ -796,7 +796,9 @@ def test_layernorm_backward(L, D, rn):
                                             (5, 49, 512, 8, 15), (2, 100, 256, 4, 9), (3, 130, 512, 8, 0),
                                             (64, 144, 512, 8, 15), (2, 7, 128, 2, 15), (3, 81, 512, 8, 31),
                                             (3, 169, 512, 8, 15), (2, 196, 512, 8, 21), (2, 208, 512, 8, 0),
-                                            (3, 177, 256, 4, 9)])
+                                            (3, 177, 256, 4, 9),
+                                            # generic head dims (crmsa_heads = 1: head dim = dim), no EPEG
+                                            (3, 64, 512, 1, 0), (5, 64, 512, 2, 0), (3, 64, 96, 1, 0), (1, 100, 64, 8, 0)])
 def test_region_attention_backward(R, P, D, heads, ek):
     """Attention backward (recomputed probabilities, EPEG adjoint, tap gradients) against float64 autograd of the
     explicit formulation (scores [P,P], depth-wise conv along the query axis WITH a bias, softmax, A V)."""
@@ -851,6 +853,7 @@ TRAIN_CASES = {
     "noepeg_nobias_n500": (500, dict(mlp_dim=512, epeg=False, qkv_bias=False)),
     "d256_n333": (333, dict(mlp_dim=256, n_heads=4, crmsa_heads=4, epeg_k=9)),
     "p169_n10000": (10000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 169 tokens (MT = 11)
+    "brca_r50_heads1_n2000": (2000, dict(mlp_dim=512, epeg_k=17, crmsa_k=3, crmsa_heads=1)),   # README.md:98
 }
 
 
