@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 9
+#define RRT_ABI_VERSION 10
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -302,9 +302,9 @@ int rrt_linear_backward_f32(const float *dY, const float *X, const float *W, flo
                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- row f2: training.  Forward that stashes what the backward needs, and the backward itself ----
- * Supported: the default path (1-D 'attn' EPEG R-MSA layers, CR-MSA with the phi matrix, all_shortcut), head dim 64
- * in R-MSA and in CR-MSA's inner attention, regions of <= 208 tokens (N <= 12544 at region_num = 8), dim <= 1024,
- * ffn = 0, crmsa_mlp = 0, F32 compute.  Anything else: RRT_E_UNSUPPORTED.
+ * Supported: the default path (1-D 'attn' EPEG R-MSA layers, CR-MSA with the phi matrix or the MLP phi,
+ * all_shortcut), head dim 64 in R-MSA (any multiple of 4 in CR-MSA's inner attention), regions of <= 208 tokens (N <= 12544 at region_num = 8), dim <= 1024,
+ * ffn = 0, F32 compute.  Anything else: RRT_E_UNSUPPORTED.
  * drop_p / drop_seed: the train-mode proj_drop of every InnerAttention (rmsa.py:70,132; p = drop_out): a stateless
  * mask, element kept iff hash(seed, layer, index) >= p * 2^32, kept values scaled by 1/(1-p); the backward call
  * must receive the same (drop_p, drop_seed) as its forward.  drop_p = 0: no dropout.
@@ -319,7 +319,8 @@ typedef struct rrt_attn_grads {
 typedef struct rrt_encoder_grads {
   rrt_attn_grads rmsa[RRT_MAX_RMSA_LAYERS];
   rrt_attn_grads crmsa;
-  float *phi;                  /* [dim, crmsa_k] */
+  float *phi;                  /* [dim, crmsa_k]                              (crmsa_mlp = 0) */
+  float *phi0_w, *phi2_w;      /* [dim/4, dim], [crmsa_k, dim/4]              (crmsa_mlp = 1) */
   float *norm;                 /* [2, dim] final LayerNorm */
 } rrt_encoder_grads;
 

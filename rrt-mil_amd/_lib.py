@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _f32p = C.POINTER(C.c_float)
 
@@ -48,7 +48,7 @@ class AttnGrads(C.Structure):
 
 class EncoderGrads(C.Structure):
     _fields_ = [("rmsa", AttnGrads * RRT_MAX_RMSA_LAYERS), ("crmsa", AttnGrads), ("phi", C.c_void_p),
-                ("norm", C.c_void_p)]
+                ("phi0_w", C.c_void_p), ("phi2_w", C.c_void_p), ("norm", C.c_void_p)]
 
 
 class MilDesc(C.Structure):

@@ -852,7 +852,7 @@ namespace {
 
 struct Stash {
   float *u[RRT_MAX_RMSA_LAYERS], *qkv[RRT_MAX_RMSA_LAYERS], *o[RRT_MAX_RMSA_LAYERS], *xout[RRT_MAX_RMSA_LAYERS];
-  float *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *x2;
+  float *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *x2, *v8, *hid;
   size_t bytes;
 };
 
@@ -880,6 +880,10 @@ Stash carve_stash(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const
     s.rep_qkv = take(k * R8 * 3 * D);
     s.rep_o = take(k * R8 * D);
     s.rep2 = take(k * R8 * D);
+    if (d.crmsa_mlp) {
+      s.v8 = take(Np8 * D);
+      s.hid = take(Np8 * (D / 4));
+    }
   }
   s.x2 = take((size_t)N * D);
   s.bytes = off;
@@ -888,7 +892,7 @@ Stash carve_stash(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const
 
 struct BwdWs {
   float *dx2, *dxa, *dxb, *dz, *dO, *dqkv, *lnpart, *attnpart, *dWd, *dC, *dlg, *Cw, *d_rep2, *d_rep_o,
-      *d_rep_qkv, *d_rep, *rows, *dxpart;
+      *d_rep_qkv, *d_rep, *rows, *dxpart, *th, *dhid, *dvphi, *w1t, *tnscratch;
   char* lin;
   size_t bytes;
 };
@@ -930,6 +934,15 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     w.d_rep = take(k * R8 * D);
     w.rows = take((2 + k) * D);
     w.dxpart = take(crmsa_bwd_dx_workspace((int)D, (int)k) / sizeof(float));
+    if (d.crmsa_mlp) {
+      w.th = take(Np8 * (D / 4));
+      w.dhid = take(Np8 * (D / 4));
+      w.dvphi = take(Np8 * D);
+      w.w1t = take(D * (D / 4));
+      const size_t a1 = linear_bwd_workspace((int)Np8, (int)(D / 4), (int)D);     // dW1 partials dominate
+      const size_t a2 = linear_bwd_workspace((int)Np8, (int)k, (int)(D / 4));
+      w.tnscratch = take((a1 > a2 ? a1 : a2) / sizeof(float));
+    }
     if (!w.attnpart) w.attnpart = take(attn_bwd_workspace((int)k, d.crmsa_heads, 0) / sizeof(float));
     const size_t l3 = linear_bwd_workspace((int)(k * R8), 3 * (int)D, (int)D);
     if (l3 > lin) lin = l3;
@@ -943,7 +956,6 @@ int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8)
   int rc = check_desc(d, N);
   if (rc) return rc;
   if (d->ffn) return unsupported("training: ffn=True is not built");
-  if (d->crmsa_mlp) return unsupported("training: crmsa_mlp=True is not built");
   if (d->compute != RRT_COMPUTE_F32) return unsupported("training: fp32 only");
   if (d->dim > 1024) return unsupported("training: dim > 1024");
   memset(g, 0, sizeof(*g));
@@ -1043,11 +1055,23 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
   if (!w->norm_w || !w->norm_b) return RRT_E_INVALID;
   if (desc->cr_msa) {
     const rrt_attn_weights& cw = w->crmsa;
-    if (!cw.norm_w || !cw.norm_b || !cw.qkv_w || !cw.proj_w || !cw.proj_b || !w->phi) return RRT_E_INVALID;
+    if (!cw.norm_w || !cw.norm_b || !cw.qkv_w || !cw.proj_w || !cw.proj_b) return RRT_E_INVALID;
+    if (desc->crmsa_mlp ? (!w->phi0_w || !w->phi2_w) : !w->phi) return RRT_E_INVALID;
     const GridDev gd8 = to_dev(g8);
     const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
-    RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, s.mean_rstd, s.logits, D, k, gd8, st));
-    RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, s.mean_rstd, s.logits, s.wdisp, s.rep, D, k, gd8, st));
+    if (desc->crmsa_mlp) {
+      // the LayerNorm statistics the backward needs come out of the logits kernel (run on the first D*k floats of
+      // W1 as a stand-in phi; its logits are overwritten by the MLP's two lines below)
+      RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi0_w, s.mean_rstd, s.logits, D, k, gd8, st));
+      RRT_TRY(launch_ln_partition(xin, cw.norm_w, cw.norm_b, s.v8, D, gd8, st));
+      LinearEpilogue e0{};
+      RRT_TRY(launch_linear(s.v8, w->phi0_w, s.hid, gd8.Np, D / 4, D, e0, st));
+      RRT_TRY(launch_crmsa_mlp_logits(s.hid, w->phi2_w, s.logits, gd8.Np, D / 4, k, st));
+      RRT_TRY(launch_crmsa_combine(s.v8, nullptr, nullptr, nullptr, s.logits, s.wdisp, s.rep, D, k, gd8, st));
+    } else {
+      RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, s.mean_rstd, s.logits, D, k, gd8, st));
+      RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, s.mean_rstd, s.logits, s.wdisp, s.rep, D, k, gd8, st));
+    }
     LinearEpilogue ep{};
     ep.bias = cw.qkv_b;
     ep.q_cols = D;
@@ -1101,7 +1125,8 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
   if (desc->cr_msa) {
     const rrt_attn_weights& cw = w->crmsa;
     const rrt_attn_grads& cg = gr->crmsa;
-    if (!cg.norm || !cg.qkv_w || !cg.proj_w || !cg.proj_b || !gr->phi || (cw.qkv_b && !cg.qkv_b)) return RRT_E_INVALID;
+    if (!cg.norm || !cg.qkv_w || !cg.proj_w || !cg.proj_b || (cw.qkv_b && !cg.qkv_b)) return RRT_E_INVALID;
+    if (desc->crmsa_mlp ? (!gr->phi0_w || !gr->phi2_w) : !gr->phi) return RRT_E_INVALID;
     const GridDev gd8 = to_dev(g8);
     const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
     const float* x1 = L > 0 ? s.xout[L - 1] : x;
@@ -1116,10 +1141,26 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
                                    b.lin, st));
     RRT_TRY(launch_crmsa_tokdot(x1, s.mean_rstd, cw.norm_w, cw.norm_b, b.d_rep, b.dC, D, k, gd8, st));
     RRT_TRY(launch_crmsa_bwd_region(s.logits, b.dC, b.dWd, b.dlg, b.Cw, k, gd8, st));
-    RRT_TRY(launch_crmsa_bwd_dx(x1, b.dx2, s.mean_rstd, cw.norm_w, cw.norm_b, w->phi, b.Cw, b.dlg, b.d_rep, b.dxa,
-                                b.rows, b.dxpart, D, k, gd8, st));
-    RRT_TRY(hipMemcpyAsync(cg.norm, b.rows, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
-    RRT_TRY(launch_transpose(b.rows + 2 * (size_t)D, gr->phi, k, D, st));      // [k, D] -> phi's [D, k]
+    if (desc->crmsa_mlp) {
+      // phi = Linear(D, D/4) -> Tanh -> Linear(D/4, k) (rmsa.py:248-252): d hid, then the two weight gradients as
+      // TN products over the Np8 slots and the logits' path into v as a GEMM row block (pad slots carry v = 0 and
+      // tanh(0) = 0, so they add nothing to dW1 / dW2)
+      const int hdim = D / 4;
+      RRT_TRY(launch_crmsa_mlp_bwd_hidden(s.hid, b.dlg, w->phi2_w, b.th, b.dhid, (size_t)gd8.Np, hdim, k, st));
+      RRT_TRY(launch_gemm_tn(b.dlg, b.th, gr->phi2_w, b.tnscratch, gd8.Np, k, hdim, st));          // dW2 [k, D/4]
+      RRT_TRY(launch_gemm_tn(b.dhid, s.v8, gr->phi0_w, b.tnscratch, gd8.Np, hdim, D, st));         // dW1 [D/4, D]
+      RRT_TRY(launch_transpose(w->phi0_w, b.w1t, hdim, D, st));                                    // W1^T [D, D/4]
+      LinearEpilogue ev{};
+      RRT_TRY(launch_linear(b.dhid, b.w1t, b.dvphi, gd8.Np, D, hdim, ev, st));                     // d v_phi = d hid . W1
+      RRT_TRY(launch_crmsa_bwd_dx(x1, b.dx2, s.mean_rstd, cw.norm_w, cw.norm_b, b.dvphi, b.Cw, b.dlg, b.d_rep, b.dxa,
+                                  b.rows, b.dxpart, D, k, gd8, true, st));
+      RRT_TRY(hipMemcpyAsync(cg.norm, b.rows, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+      RRT_TRY(launch_crmsa_bwd_dx(x1, b.dx2, s.mean_rstd, cw.norm_w, cw.norm_b, w->phi, b.Cw, b.dlg, b.d_rep, b.dxa,
+                                  b.rows, b.dxpart, D, k, gd8, false, st));
+      RRT_TRY(hipMemcpyAsync(cg.norm, b.rows, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+      RRT_TRY(launch_transpose(b.rows + 2 * (size_t)D, gr->phi, k, D, st));      // [k, D] -> phi's [D, k]
+    }
     cur = b.dxa;
   }
   for (int li = L - 1; li >= 0; --li) {

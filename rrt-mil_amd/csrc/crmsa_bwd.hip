@@ -242,7 +242,25 @@ __global__ __launch_bounds__(256) void crmsa_bwd_region_kernel(const float* __re
 
 // ---- dx1 = dx2 + LN2'(dv), dv_t = sum_n C[slot,n] d rep[n,r] + d Lg[slot,n] phi_n ; partials of d gamma2, d beta2, d phi
 constexpr int DXB_BLOCKS = 512;
-template <int NV>
+// crmsa_mlp (phi = Linear(D, D/4) -> Tanh -> Linear(D/4, k), rmsa.py:248-252): th = tanh(hid),
+// d hid = (d logits . W2) o (1 - th^2).  One thread per hidden element.
+__global__ __launch_bounds__(256) void crmsa_mlp_bwd_hidden_kernel(const float* __restrict__ hid,
+                                                                   const float* __restrict__ dlg,
+                                                                   const float* __restrict__ w2, float* __restrict__ th,
+                                                                   float* __restrict__ dhid, size_t rows, int hdim,
+                                                                   int k) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * (size_t)hdim) return;
+  const size_t r = i / hdim;
+  const int j = (int)(i - r * hdim);
+  const float t = tanhf(hid[i]);
+  float d = 0.f;
+  for (int n = 0; n < k; ++n) d += dlg[r * k + n] * w2[(size_t)n * hdim + j];
+  th[i] = t;
+  dhid[i] = d * (1.0f - t * t);
+}
+
+template <int NV, bool MLP>
 __global__ __launch_bounds__(256) void crmsa_bwd_dx_kernel(const float* __restrict__ x1, const float* __restrict__ dx2,
                                                            const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ gamma,
@@ -251,14 +269,17 @@ __global__ __launch_bounds__(256) void crmsa_bwd_dx_kernel(const float* __restri
                                                            const float* __restrict__ Cw, const float* __restrict__ dlg,
                                                            const float* __restrict__ drep, float* __restrict__ dx1,
                                                            float* __restrict__ part, int dim, int k, GridDev g) {
+  // MLP: `phi` is d v_phi [Np8, dim] (region-major rows, = d hid . W1): the logits' path arrives as a row
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* phi_t = (float*)smem;                                  // [k][dim]
-  float4* red = (float4*)(phi_t + (size_t)k * dim);             // [3 waves][2 + k][NV * 64]
+  float* phi_t = (float*)smem;                                  // [k][dim]   (matrix phi only)
+  float4* red = (float4*)(phi_t + (MLP ? 0 : (size_t)k * dim)); // [3 waves][rows][NV * 64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int R = g.rs * g.rs;
-  for (int idx = threadIdx.x; idx < dim * k; idx += 256) {
-    const int d = idx / k, n = idx - d * k;
-    phi_t[n * dim + d] = phi[idx];
+  if (!MLP) {
+    for (int idx = threadIdx.x; idx < dim * k; idx += 256) {
+      const int d = idx / k, n = idx - d * k;
+      phi_t[n * dim + d] = phi[idx];
+    }
   }
   __syncthreads();
   const float inv_d = 1.0f / (float)dim;
@@ -291,16 +312,17 @@ __global__ __launch_bounds__(256) void crmsa_bwd_dx_kernel(const float* __restri
         xh[v] = make_float4((xr.x - mean) * rstd, (xr.y - mean) * rstd, (xr.z - mean) * rstd, (xr.w - mean) * rstd);
         const float4 vv = make_float4(xh[v].x * gm[v].x + bt[v].x, xh[v].y * gm[v].y + bt[v].y,
                                       xh[v].z * gm[v].z + bt[v].z, xh[v].w * gm[v].w + bt[v].w);
+        if (MLP) dv[v] = *(const float4*)(phi + (size_t)slot * dim + c);
 #pragma unroll
         for (int n = 0; n < KMAX; ++n)
           if (n < k) {
             const float4 dr = *(const float4*)(drep + ((size_t)n * R + reg) * dim + c);
-            const float4 ph = *(const float4*)(phi_t + n * dim + c);
-            dv[v].x += cw[n] * dr.x + dl[n] * ph.x;
-            dv[v].y += cw[n] * dr.y + dl[n] * ph.y;
-            dv[v].z += cw[n] * dr.z + dl[n] * ph.z;
-            dv[v].w += cw[n] * dr.w + dl[n] * ph.w;
-            dph[n][v].x += dl[n] * vv.x; dph[n][v].y += dl[n] * vv.y; dph[n][v].z += dl[n] * vv.z; dph[n][v].w += dl[n] * vv.w;
+            dv[v].x += cw[n] * dr.x; dv[v].y += cw[n] * dr.y; dv[v].z += cw[n] * dr.z; dv[v].w += cw[n] * dr.w;
+            if (!MLP) {
+              const float4 ph = *(const float4*)(phi_t + n * dim + c);
+              dv[v].x += dl[n] * ph.x; dv[v].y += dl[n] * ph.y; dv[v].z += dl[n] * ph.z; dv[v].w += dl[n] * ph.w;
+              dph[n][v].x += dl[n] * vv.x; dph[n][v].y += dl[n] * vv.y; dph[n][v].z += dl[n] * vv.z; dph[n][v].w += dl[n] * vv.w;
+            }
           }
         dg[v].x += dv[v].x * xh[v].x; dg[v].y += dv[v].y * xh[v].y; dg[v].z += dv[v].z * xh[v].z; dg[v].w += dv[v].w * xh[v].w;
         db[v].x += dv[v].x; db[v].y += dv[v].y; db[v].z += dv[v].z; db[v].w += dv[v].w;
@@ -324,8 +346,8 @@ __global__ __launch_bounds__(256) void crmsa_bwd_dx_kernel(const float* __restri
       }
     }
   }
-  // block partials: rows 0,1 = d gamma, d beta; rows 2.. = d phi^T [k][dim]
-  const int rows = 2 + k;
+  // block partials: rows 0,1 = d gamma, d beta; rows 2.. = d phi^T [k][dim] (matrix phi only)
+  const int rows = MLP ? 2 : 2 + k;
   if (wave > 0) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -333,7 +355,7 @@ __global__ __launch_bounds__(256) void crmsa_bwd_dx_kernel(const float* __restri
       red[((wave - 1) * rows + 1) * (NV * 64) + v * 64 + lane] = db[v];
 #pragma unroll
       for (int n = 0; n < KMAX; ++n)
-        if (n < k) red[((wave - 1) * rows + 2 + n) * (NV * 64) + v * 64 + lane] = dph[n][v];
+        if (!MLP && n < k) red[((wave - 1) * rows + 2 + n) * (NV * 64) + v * 64 + lane] = dph[n][v];
     }
   }
   __syncthreads();
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(256) void crmsa_bwd_dx_kernel(const float* __restri
         *(float4*)(out + dim + c) = b;
 #pragma unroll
         for (int n = 0; n < KMAX; ++n)
-          if (n < k) {
+          if (!MLP && n < k) {
             float4 d = dph[n][v];
 #pragma unroll
             for (int w = 0; w < 3; ++w) {
@@ -407,20 +429,28 @@ hipError_t launch_crmsa_bwd_region(const float* lg, const float* dC, const float
 
 size_t crmsa_bwd_dx_workspace(int dim, int k) { return (size_t)DXB_BLOCKS * (2 + k) * dim * sizeof(float); }
 
-// out_rows [2 + k, dim]: d gamma2, d beta2, d phi^T
+hipError_t launch_crmsa_mlp_bwd_hidden(const float* hid, const float* dlg, const float* w2, float* th, float* dhid,
+                                       size_t rows, int hdim, int k, hipStream_t st) {
+  const size_t n = rows * (size_t)hdim;
+  crmsa_mlp_bwd_hidden_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(hid, dlg, w2, th, dhid, rows, hdim, k);
+  return hipGetLastError();
+}
+
+// out_rows [2 + k, dim]: d gamma2, d beta2, d phi^T.  mlp: `phi` = d v_phi rows [Np8, dim], out_rows [2, dim]
 hipError_t launch_crmsa_bwd_dx(const float* x1, const float* dx2, const float* mean_rstd, const float* gamma,
                                const float* beta, const float* phi, const float* Cw, const float* dlg,
                                const float* drep, float* dx1, float* out_rows, float* part, int dim, int k,
-                               const GridDev& g, hipStream_t st) {
+                               const GridDev& g, bool mlp, hipStream_t st) {
   if (dim > 1024) return hipErrorInvalidValue;
   const int need = (g.L + 3) / 4;
   const int blocks = need < DXB_BLOCKS ? need : DXB_BLOCKS;
   const int nvv = dim <= 256 ? 1 : (dim <= 512 ? 2 : 4);
-  const size_t lds = (size_t)k * dim * 4 + (size_t)3 * (2 + k) * nvv * 64 * sizeof(float4);
+  const int rows = mlp ? 2 : 2 + k;
+  const size_t lds = (mlp ? 0 : (size_t)k * dim * 4) + (size_t)3 * rows * nvv * 64 * sizeof(float4);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
 #define RRT_DX(NV)                                                                                          \
   do {                                                                                                      \
-    auto kern = crmsa_bwd_dx_kernel<NV>;                                                                    \
+    auto kern = mlp ? crmsa_bwd_dx_kernel<NV, true> : crmsa_bwd_dx_kernel<NV, false>;                       \
     if (lds > 64 * 1024)                                                                                    \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
     kern<<<dim3(blocks), 256, lds, st>>>(x1, dx2, mean_rstd, gamma, beta, phi, Cw, dlg, drep, dx1, part, dim, k, g); \
@@ -431,5 +461,5 @@ hipError_t launch_crmsa_bwd_dx(const float* x1, const float* dx2, const float* m
 #undef RRT_DX
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return launch_reduce_partials(part, out_rows, blocks, (size_t)(2 + k) * dim, st);
+  return launch_reduce_partials(part, out_rows, blocks, (size_t)rows * dim, st);
 }

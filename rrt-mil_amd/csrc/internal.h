@@ -99,4 +99,6 @@ size_t crmsa_bwd_dx_workspace(int dim, int k);
 hipError_t launch_crmsa_bwd_dx(const float* x1, const float* dx2, const float* mean_rstd, const float* gamma,
                                const float* beta, const float* phi, const float* Cw, const float* dlg,
                                const float* drep, float* dx1, float* out_rows, float* part, int dim, int k,
-                               const GridDev& g, hipStream_t st);
+                               const GridDev& g, bool mlp, hipStream_t st);
+hipError_t launch_crmsa_mlp_bwd_hidden(const float* hid, const float* dlg, const float* w2, float* th, float* dhid,
+                                       size_t rows, int hdim, int k, hipStream_t st);

@@ -304,9 +304,15 @@ class RRTEncoder(nn.Module):
             attn(f"layers.{i}.", layer, gs.rmsa[i])
         if self._desc.cr_msa:
             attn("cr_msa.", self.cr_msa, gs.crmsa)
-            gphi = torch.empty_like(self.cr_msa.attn.phi)
-            by_name["cr_msa.attn.phi"] = gphi
-            gs.phi = gphi.data_ptr()
+            if self._desc.crmsa_mlp:
+                g0 = torch.empty_like(self.cr_msa.attn.phi[0].weight)
+                g2 = torch.empty_like(self.cr_msa.attn.phi[2].weight)
+                by_name["cr_msa.attn.phi.0.weight"], by_name["cr_msa.attn.phi.2.weight"] = g0, g2
+                gs.phi0_w, gs.phi2_w = g0.data_ptr(), g2.data_ptr()
+            else:
+                gphi = torch.empty_like(self.cr_msa.attn.phi)
+                by_name["cr_msa.attn.phi"] = gphi
+                gs.phi = gphi.data_ptr()
         grads = [by_name[name] for name, _ in self.named_parameters()]
         self._keep_grads = by_name          # the struct holds raw pointers: keep the tensors alive through the call
         return grads, gs

@@ -854,6 +854,8 @@ TRAIN_CASES = {
     "d256_n333": (333, dict(mlp_dim=256, n_heads=4, crmsa_heads=4, epeg_k=9)),
     "p169_n10000": (10000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 169 tokens (MT = 11)
     "brca_r50_heads1_n2000": (2000, dict(mlp_dim=512, epeg_k=17, crmsa_k=3, crmsa_heads=1)),   # README.md:98
+    "nsclc_plip_mlp_n1800": (1800, dict(mlp_dim=512, epeg_k=13, crmsa_k=3, crmsa_heads=1, all_shortcut=True,
+                                        crmsa_mlp=True)),                                        # README.md:119
 }
 
 
@@ -866,7 +868,7 @@ def test_encoder_backward_matches_autograd(case):
     N, cfg = TRAIN_CASES[case]
     D = cfg["mlp_dim"]
     st = synth.encoder_state(**{k: v for k, v in cfg.items() if k in ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k",
-                                                                      "cr_msa", "crmsa_k", "qkv_bias")})
+                                                                      "cr_msa", "crmsa_k", "qkv_bias", "crmsa_mlp")})
     x = synth.bag(N, D, tag="train/" + case)
     G = synth.normal("train/G/" + case, (N, D))
     # oracle
