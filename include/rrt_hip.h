@@ -284,8 +284,10 @@ int rrt_executor_destroy(rrt_executor *ex);
  * requested (it is the reduction length of that product). */
 /* Region attention backward (rmsa.py:103-122): qkv [n_regions*P, 3*dim] as the forward stage wrote it (q scaled),
  * o = the forward output, d_o its gradient  ->  d_qkv (gradient w.r.t. the qkv linear's raw output, same layout)
- * and d_pe_w [heads, epeg_k] (NULL allowed; the conv bias gradient is exactly zero).  Head dim 64, P <= 208.
- * workspace: n_regions * heads * max(epeg_k, 1) floats. */
+ * and d_pe_w [heads, epeg_k] (NULL allowed; the conv bias gradient is exactly zero).  Head dim 64: any P (<= 208: one resident kernel; larger: a streaming four-kernel variant);
+ * other head dims: no EPEG and P <= 128.  workspace: rrt_region_attention_backward_workspace_size bytes. */
+int rrt_region_attention_backward_workspace_size(int32_t n_regions, int32_t P, int32_t dim, int32_t heads,
+                                                 int32_t epeg_k, size_t *bytes);
 int rrt_region_attention_backward_f32(const float *qkv, const float *pe_w, const float *o, const float *d_o,
                                       float *d_qkv, float *d_pe_w, int32_t n_regions, int32_t P, int32_t dim,
                                       int32_t heads, int32_t epeg_k, void *workspace, size_t workspace_bytes,
@@ -303,7 +305,7 @@ int rrt_linear_backward_f32(const float *dY, const float *X, const float *W, flo
 
 /* ---- row f2: training.  Forward that stashes what the backward needs, and the backward itself ----
  * Supported: the default path (1-D 'attn' EPEG R-MSA layers, CR-MSA with the phi matrix or the MLP phi,
- * all_shortcut), head dim 64 in R-MSA (any multiple of 4 in CR-MSA's inner attention), regions of <= 208 tokens (N <= 12544 at region_num = 8), dim <= 1024,
+ * all_shortcut), head dim 64 in R-MSA (any multiple of 4 in CR-MSA's inner attention), bags of any size, dim <= 1024,
  * ffn = 0, F32 compute.  Anything else: RRT_E_UNSUPPORTED.
  * drop_p / drop_seed: the train-mode proj_drop of every InnerAttention (rmsa.py:70,132; p = drop_out): a stateless
  * mask, element kept iff hash(seed, layer, index) >= p * 2^32, kept values scaled by 1/(1-p); the backward call

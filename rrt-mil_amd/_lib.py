@@ -115,6 +115,7 @@ SIGNATURES = {
     "rrt_executor_forward": (C.c_int, [C.c_void_p, C.POINTER(EncoderWeights), C.POINTER(Bag), C.c_int32,
                                        C.c_void_p]),
     "rrt_executor_destroy": (C.c_int, [C.c_void_p]),
+    "rrt_region_attention_backward_workspace_size": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_size_t)]),
     "rrt_region_attention_backward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_void_p, C.c_size_t,
                                                                                        C.c_void_p]),
     "rrt_layernorm_backward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.POINTER(Grid), C.c_void_p,

@@ -801,6 +801,13 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
 // ------------------------------------------------------------------ row f2 building blocks (backward stages)
 extern "C" {
 
+int rrt_region_attention_backward_workspace_size(int32_t n_regions, int32_t P, int32_t dim, int32_t heads,
+                                                 int32_t epeg_k, size_t* bytes) {
+  if (!bytes || n_regions <= 0 || P <= 0 || dim <= 0 || heads <= 0) return RRT_E_INVALID;
+  *bytes = attn_bwd_workspace(n_regions, P, dim, heads, epeg_k);
+  return RRT_OK;
+}
+
 int rrt_region_attention_backward_f32(const float* qkv, const float* pe_w, const float* o, const float* d_o,
                                       float* d_qkv, float* d_pe_w, int32_t n_regions, int32_t P, int32_t dim,
                                       int32_t heads, int32_t epeg_k, void* workspace, size_t workspace_bytes,
@@ -810,7 +817,7 @@ int rrt_region_attention_backward_f32(const float* qkv, const float* pe_w, const
   if (ek > 0 && ek % 2 == 0) return unsupported("epeg_k must be odd");
   if (!attn_bwd_supported(P, dim, heads, ek))
     return unsupported("attention backward: needs head dim 64 with P <= 208, or (no EPEG, P <= 128, head dim % 4 == 0)");
-  if (!workspace || workspace_bytes < attn_bwd_workspace(n_regions, heads, ek)) return RRT_E_WORKSPACE;
+  if (!workspace || workspace_bytes < attn_bwd_workspace(n_regions, P, dim, heads, ek)) return RRT_E_WORKSPACE;
   return (int)launch_attention_backward(qkv, pe_w, o, d_o, d_qkv, d_pe_w, (float*)workspace, n_regions, P, dim,
                                         heads, ek, (hipStream_t)stream);
 }
@@ -918,7 +925,7 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     w.dO = take(Np * D);
     w.dqkv = take(Np * 3 * D);
     const int R = g.regions_side * g.regions_side;
-    w.attnpart = take(attn_bwd_workspace(R, d.n_heads, d.epeg ? d.epeg_k : 0) / sizeof(float));
+    w.attnpart = take(attn_bwd_workspace(R, g.s * g.s, (int)D, d.n_heads, d.epeg ? d.epeg_k : 0) / sizeof(float));
     lin = linear_bwd_workspace((int)Np, 3 * (int)D, (int)D);
     const size_t l2 = linear_bwd_workspace((int)Np, (int)D, (int)D);
     if (l2 > lin) lin = l2;
@@ -943,7 +950,7 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
       const size_t a2 = linear_bwd_workspace((int)Np8, (int)k, (int)(D / 4));
       w.tnscratch = take((a1 > a2 ? a1 : a2) / sizeof(float));
     }
-    if (!w.attnpart) w.attnpart = take(attn_bwd_workspace((int)k, d.crmsa_heads, 0) / sizeof(float));
+    if (!w.attnpart) w.attnpart = take(attn_bwd_workspace((int)k, (int)R8, (int)D, d.crmsa_heads, 0) / sizeof(float));
     const size_t l3 = linear_bwd_workspace((int)(k * R8), 3 * (int)D, (int)D);
     if (l3 > lin) lin = l3;
   }

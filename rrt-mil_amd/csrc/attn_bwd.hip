@@ -379,6 +379,278 @@ hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, co
   return hipGetLastError();
 }
 
+// ======================================================================================= streaming variant
+// Regions of any size (P > 208: bags beyond ~12.5 k tokens at region_num = 8): the same mathematics with the
+// "other" operand streamed through LDS in 128-row chunks instead of resident.  Four kernels:
+//   stencil:  q~ = log2(e) (I + T_w) q            -> a [rows, D] buffer (global)
+//   q pass:   block = (region, head, 6 query tiles); sweep 1 over key chunks: online row max / sum -> lse;
+//             sweep 2: A, dA, dS, dQ~ += dS K.  Writes dQ~ rows (parked in dq), lse, D.
+//   kv pass:  block = (region, head, 6 key tiles); one sweep over query chunks (Q~, dO chunks resident) with
+//             A = exp2(S - lse): dV += A^T dO, dK += dS^T Q~.
+//   adjoint:  dq = scale (I + T_w)^T dQ~ and the tap gradients, block = (region, head).
+constexpr int CK = 128, CT = CK / 16;     // chunk rows / row tiles per chunk
+
+__global__ __launch_bounds__(256) void attn_stencil_kernel(const float* __restrict__ qkv, const float* __restrict__ pe_w,
+                                                           float* __restrict__ qt, int P, int D, int heads,
+                                                           int epeg_k, long n_rows) {
+  // thread = (row, 16-byte slot of one head): qt[row, head*64 + 4s ..] ; rows stay inside their region
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int slots = D / 4;
+  if (idx >= n_rows * slots) return;
+  const long row = idx / slots;
+  const int c = (int)(idx - row * slots) * 4, head = c / HD;
+  const int i = (int)(row % P);
+  const int half = epeg_k >> 1;
+  const float* w = pe_w + head * epeg_k;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = -half; t <= half; ++t) {
+    const int j = i + t;
+    if (j < 0 || j >= P) continue;
+    float wt = epeg_k > 0 ? w[t + half] : 0.f;
+    if (t == 0) wt += 1.0f;
+    const float4 v = *(const float4*)(qkv + (size_t)(row + t) * 3 * D + c);
+    acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
+  }
+  *(float4*)(qt + (size_t)row * D + c) = make_float4(acc.x * LOG2E, acc.y * LOG2E, acc.z * LOG2E, acc.w * LOG2E);
+}
+
+// rows [r0, r0 + CK) of a [.., stride]-strided tensor (head columns) -> swizzled LDS chunk; rows >= P: zeros
+__device__ __forceinline__ void load_chunk(float* dst, const float* src, size_t stride, size_t row0, int r0, int P,
+                                           int tid) {
+  for (int idx = tid; idx < CK * 16; idx += 384) {
+    const int m = idx >> 4, s = idx & 15;
+    const float4 v = (r0 + m < P) ? *(const float4*)(src + (row0 + r0 + m) * stride + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(dst + m * HD + ((s ^ (m & 15)) << 2)) = v;
+  }
+}
+
+__global__ __launch_bounds__(384) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ qt,
+                                                         const float* __restrict__ O, const float* __restrict__ dO,
+                                                         float* __restrict__ dqkv, float* __restrict__ lse_g,
+                                                         float* __restrict__ dd_g, int P, int D, int heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Ks = (float*)smem;
+  float* Vs = Ks + CK * HD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int head = blockIdx.x, reg = blockIdx.y;
+  const size_t row0 = (size_t)reg * P;
+  const int ld = 3 * D;
+  const int i0 = (blockIdx.z * 6 + wave) * 16;
+  const bool active = i0 < P;
+  const int m = i0 + lr;
+  float4 fq[4], fg[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bool ok = active && m < P;
+    fq[c] = ok ? *(const float4*)(qt + (row0 + m) * D + head * HD + 4 * (4 * c + lg)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    fg[c] = ok ? *(const float4*)(dO + (row0 + m) * D + head * HD + 4 * (4 * c + lg)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float dsum = 0.f;
+  if (active && m < P) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 o4 = *(const float4*)(O + (row0 + m) * D + head * HD + 4 * (4 * c + lg));
+      dsum += (fg[c].x * o4.x + fg[c].y * o4.y) + (fg[c].z * o4.z + fg[c].w * o4.w);
+    }
+  }
+  dsum += __shfl_xor(dsum, 16);
+  dsum += __shfl_xor(dsum, 32);
+  // sweep 1: online row max / sum over the key chunks
+  float mrun = NEG_BIG, lrun = 0.f;
+  for (int r0 = 0; r0 < P; r0 += CK) {
+    __syncthreads();
+    load_chunk(Ks, qkv + D + head * HD, (size_t)ld, row0, r0, P, tid);
+    __syncthreads();
+    if (active) {
+      f32x4 s[CT];
+      tile_scores<CT>(Ks, fq, lr, lg, s);
+      float cmax = NEG_BIG;
+#pragma unroll
+      for (int jt = 0; jt < CT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r0 + jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;
+          cmax = fmaxf(cmax, s[jt][r]);
+        }
+      cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+      cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+      const float mnew = fmaxf(mrun, cmax);
+      float psum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < CT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) psum += __builtin_amdgcn_exp2f(s[jt][r] - mnew);
+      psum += __shfl_xor(psum, 16);
+      psum += __shfl_xor(psum, 32);
+      lrun = lrun * __builtin_amdgcn_exp2f(mrun - mnew) + psum;
+      mrun = mnew;
+    }
+  }
+  const float lse = mrun + __builtin_amdgcn_logf(lrun);
+  // sweep 2: A, dA, dS, dQ~
+  f32x4 dqt[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dqt[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r0 = 0; r0 < P; r0 += CK) {
+    __syncthreads();
+    load_chunk(Ks, qkv + D + head * HD, (size_t)ld, row0, r0, P, tid);
+    load_chunk(Vs, qkv + 2 * D + head * HD, (size_t)ld, row0, r0, P, tid);
+    __syncthreads();
+    if (active) {
+      f32x4 s[CT];
+      tile_scores<CT>(Ks, fq, lr, lg, s);
+      {
+        f32x4 da[CT];
+        tile_scores<CT>(Vs, fg, lr, lg, da);
+#pragma unroll
+        for (int jt = 0; jt < CT; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = r0 + jt * 16 + 4 * lg + r < P;
+            const float p = ok ? __builtin_amdgcn_exp2f(s[jt][r] - lse) : 0.f;
+            s[jt][r] = p * (da[jt][r] - dsum);
+          }
+      }
+      tile_apply<CT>(Ks, s, lr, lg, dqt);
+    }
+  }
+  if (active) {
+    if (lg == 0 && m < P) {
+      lse_g[(row0 + m) * heads + head] = lse;
+      dd_g[(row0 + m) * heads + head] = dsum;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * lg + r;
+      if (i < P)
+        *(float4*)(dqkv + (row0 + i) * ld + head * HD + (lr << 2)) = make_float4(dqt[0][r], dqt[1][r], dqt[2][r], dqt[3][r]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(384) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ qt,
+                                                          const float* __restrict__ dO, const float* __restrict__ lse_g,
+                                                          const float* __restrict__ dd_g, float* __restrict__ dqkv,
+                                                          int P, int D, int heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Qs = (float*)smem;
+  float* Gs = Qs + CK * HD;
+  float* lse = Gs + CK * HD;            // [CK]
+  float* dd = lse + CK;                 // [CK]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int head = blockIdx.x, reg = blockIdx.y;
+  const size_t row0 = (size_t)reg * P;
+  const int ld = 3 * D;
+  const int j0 = (blockIdx.z * 6 + wave) * 16;
+  const bool active = j0 < P;
+  const int m = j0 + lr;
+  float4 fk[4], fv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bool ok = active && m < P;
+    const float* src = qkv + (row0 + m) * ld + head * HD + 4 * (4 * c + lg);
+    fk[c] = ok ? *(const float4*)(src + D) : make_float4(0.f, 0.f, 0.f, 0.f);
+    fv[c] = ok ? *(const float4*)(src + 2 * D) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  f32x4 dv[4], dk[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dv[c] = dk[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r0 = 0; r0 < P; r0 += CK) {
+    __syncthreads();
+    load_chunk(Qs, qt + head * HD, (size_t)D, row0, r0, P, tid);
+    load_chunk(Gs, dO + head * HD, (size_t)D, row0, r0, P, tid);
+    if (tid < CK) {
+      const bool ok = r0 + tid < P;
+      lse[tid] = ok ? lse_g[(row0 + r0 + tid) * heads + head] : 0.f;
+      dd[tid] = ok ? dd_g[(row0 + r0 + tid) * heads + head] : 0.f;
+    }
+    __syncthreads();
+    if (active) {
+      f32x4 a[CT], ds[CT];
+      tile_scores<CT>(Qs, fk, lr, lg, a);
+      tile_scores<CT>(Gs, fv, lr, lg, ds);
+#pragma unroll
+      for (int it = 0; it < CT; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = it * 16 + 4 * lg + r;
+          const bool ok = r0 + q < P;
+          const float p = ok ? __builtin_amdgcn_exp2f(a[it][r] - lse[q]) : 0.f;
+          a[it][r] = p;
+          ds[it][r] = ok ? p * (ds[it][r] - dd[q]) : 0.f;
+        }
+      tile_apply<CT>(Gs, a, lr, lg, dv);
+      tile_apply<CT>(Qs, ds, lr, lg, dk);
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = j0 + 4 * lg + r;
+      if (key < P) {
+        float* dst = dqkv + (row0 + key) * ld + head * HD + (lr << 2);
+        *(float4*)(dst + D) = make_float4(dk[0][r] * LN2, dk[1][r] * LN2, dk[2][r] * LN2, dk[3][r] * LN2);
+        *(float4*)(dst + 2 * D) = make_float4(dv[0][r], dv[1][r], dv[2][r], dv[3][r]);
+      }
+    }
+  }
+}
+
+// dq = scale (I + T_w)^T dQ~ (dQ~ parked in the dq columns; staged through `tmp` so the in-place update never reads
+// a row it has already overwritten) and the tap-gradient partials.  Block = (region, head).
+__global__ __launch_bounds__(256) void attn_adjoint_kernel(const float* __restrict__ qkv, const float* __restrict__ pe_w,
+                                                           float* __restrict__ dqkv, float* __restrict__ tmp,
+                                                           float* __restrict__ dpe_part, int P, int D, int heads,
+                                                           int epeg_k, float q_scale) {
+  __shared__ float wred[4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.x, reg = blockIdx.y;
+  const size_t row0 = (size_t)reg * P;
+  const int ld = 3 * D, half = epeg_k >> 1;
+  const float* w = pe_w + head * epeg_k;
+  const int s = tid & 15;
+  // copy dQ~ rows of this (region, head) to tmp [rows, D] (head columns)
+  for (int i = tid >> 4; i < P; i += 16)
+    *(float4*)(tmp + (row0 + i) * D + head * HD + 4 * s) = *(const float4*)(dqkv + (row0 + i) * ld + head * HD + 4 * s);
+  __syncthreads();
+  for (int i = tid >> 4; i < P; i += 16) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = -half; t <= half; ++t) {          // dq_i = sum_j wt[i - j + half] dQ~_j ,  j = i + t
+      const int j = i + t;
+      if (j < 0 || j >= P) continue;
+      float wt = epeg_k > 0 ? w[half - t] : 0.f;
+      if (t == 0) wt += 1.0f;
+      const float4 v = *(const float4*)(tmp + (row0 + j) * D + head * HD + 4 * s);
+      acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
+    }
+    *(float4*)(dqkv + (row0 + i) * ld + head * HD + 4 * s) =
+        make_float4(acc.x * q_scale, acc.y * q_scale, acc.z * q_scale, acc.w * q_scale);
+  }
+  if (epeg_k > 0) {
+    for (int t = 0; t < epeg_k; ++t) {
+      float acc = 0.f;
+      for (int i = tid >> 4; i < P; i += 16) {
+        const int j = i + t - half;
+        if (j >= 0 && j < P) {
+          const float4 g4 = *(const float4*)(tmp + (row0 + i) * D + head * HD + 4 * s);
+          const float4 q4 = *(const float4*)(qkv + (row0 + j) * ld + head * HD + 4 * s);
+          acc += (g4.x * q4.x + g4.y * q4.y) + (g4.z * q4.z + g4.w * q4.w);
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) wred[wave * 64 + t] = acc;
+    }
+    __syncthreads();
+    if (tid < epeg_k)
+      dpe_part[((size_t)reg * heads + head) * epeg_k + tid] =
+          (wred[tid] + wred[64 + tid]) + (wred[128 + tid] + wred[192 + tid]);
+  }
+}
+
 // ---- any head dim (crmsa_heads = 1 -> head dim = dim), no EPEG, short sequences: CR-MSA's inner attention over
 // the k x 64 representatives.  VALU only: one block per (sequence, head), a wave per query / key row, the head dim
 // across the lanes; A and dS [P, P] in LDS.  (Published TCGA-BRCA-R50 / NSCLC-PLIP configs: 3 x 64 rows.)
@@ -481,12 +753,19 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const float* __re
 bool attn_bwd_supported(int P, int D, int heads, int epeg_k) {
   if (heads <= 0 || P <= 0 || D % heads) return false;
   const int hd = D / heads;
-  if (hd == HD) return P <= 208 && epeg_k >= 0 && epeg_k <= 63;
+  if (hd == HD) return epeg_k >= 0 && epeg_k <= 63;            // P <= 208 resident kernel, larger: streaming
   return epeg_k == 0 && P <= 128 && hd % 4 == 0;
 }
 
-size_t attn_bwd_workspace(int n_regions, int heads, int epeg_k) {
-  return (size_t)n_regions * heads * (epeg_k > 0 ? epeg_k : 1) * sizeof(float);
+// tap partials [n_regions, heads, k]; streaming variant (P > 208, head dim 64): + q~ [rows, D], tmp [rows, D],
+// lse and D [rows, heads]
+size_t attn_bwd_workspace(int n_regions, int P, int D, int heads, int epeg_k) {
+  size_t b = ((size_t)n_regions * heads * (epeg_k > 0 ? epeg_k : 1) * sizeof(float) + 255) / 256 * 256;
+  if (D == heads * HD && P > 208) {
+    const size_t rows = (size_t)n_regions * P;
+    b += (2 * rows * D + 2 * rows * heads) * sizeof(float) + 1024;
+  }
+  return b;
 }
 
 // dqkv [n_regions*P, 3D] (gradient w.r.t. the qkv linear's raw output); dpe [heads, epeg_k] or null
@@ -503,7 +782,26 @@ hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const 
                                                                       1.0f / sqrtf((float)(D / heads)));
     return hipGetLastError();
   }
-  if (P > 176) e = launch_bwd_mt<13>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
+  if (P > 208) {
+    const size_t rows = (size_t)n_regions * P;
+    char* base = (char*)dpe_part + ((size_t)n_regions * heads * (epeg_k > 0 ? epeg_k : 1) * sizeof(float) + 255) / 256 * 256;
+    float* qt = (float*)base;
+    float* tmp = qt + rows * D;
+    float* lse_g = tmp + rows * D;
+    float* dd_g = lse_g + rows * heads;
+    const float q_scale = 1.0f / sqrtf((float)HD);
+    const long n4 = (long)rows * (D / 4);
+    attn_stencil_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(qkv, pe_w, qt, P, D, heads, epeg_k, (long)rows);
+    const int groups = (P + 95) / 96;
+    const size_t lq = (size_t)2 * CK * HD * sizeof(float), lkv = lq + 2 * CK * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lkv);
+    attn_bwd_q_kernel<<<dim3(heads, n_regions, groups), 384, lq, st>>>(qkv, qt, O, dO, dqkv, lse_g, dd_g, P, D, heads);
+    attn_bwd_kv_kernel<<<dim3(heads, n_regions, groups), 384, lkv, st>>>(qkv, qt, dO, lse_g, dd_g, dqkv, P, D, heads);
+    attn_adjoint_kernel<<<dim3(heads, n_regions), 256, 0, st>>>(qkv, pe_w, dqkv, tmp, dpe_part, P, D, heads, epeg_k,
+                                                                 q_scale);
+    e = hipGetLastError();
+  } else if (P > 176) e = launch_bwd_mt<13>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   else if (P > 144) e = launch_bwd_mt<11>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   else if (P > 128) e = launch_bwd_mt<9>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   else if (P > 112) e = launch_bwd_mt<8>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);

@@ -79,7 +79,7 @@ hipError_t launch_ln_backward(const float* dy, const float* x, const float* gamm
 // region attention backward (attn_bwd.hip): head dim 64, P <= 144.  dqkv: gradient w.r.t. the qkv linear's raw
 // output [n_regions*P, 3D]; dpe [heads, epeg_k] or null; dpe_part: attn_bwd_workspace bytes
 bool attn_bwd_supported(int P, int D, int heads, int epeg_k);
-size_t attn_bwd_workspace(int n_regions, int heads, int epeg_k);
+size_t attn_bwd_workspace(int n_regions, int P, int D, int heads, int epeg_k);
 hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const float* O, const float* dO,
                                      float* dqkv, float* dpe, float* dpe_part, int n_regions, int P, int D,
                                      int heads, int epeg_k, hipStream_t st);

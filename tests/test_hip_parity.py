@@ -797,6 +797,9 @@ def test_layernorm_backward(L, D, rn):
                                             (64, 144, 512, 8, 15), (2, 7, 128, 2, 15), (3, 81, 512, 8, 31),
                                             (3, 169, 512, 8, 15), (2, 196, 512, 8, 21), (2, 208, 512, 8, 0),
                                             (3, 177, 256, 4, 9),
+                                            # streaming variant: regions beyond the resident kernel's 208 tokens
+                                            (2, 256, 512, 8, 15), (1, 484, 512, 8, 21), (2, 324, 256, 4, 0),
+                                            (3, 209, 512, 8, 9),
                                             # generic head dims (crmsa_heads = 1: head dim = dim), no EPEG
                                             (3, 64, 512, 1, 0), (5, 64, 512, 2, 0), (3, 64, 96, 1, 0), (1, 100, 64, 8, 0)])
 def test_region_attention_backward(R, P, D, heads, ek):
@@ -828,7 +831,9 @@ def test_region_attention_backward(R, P, D, heads, ek):
     _cmp(o.cpu().numpy(), Oref.detach().numpy(), 5e-5, "forward O")
     dqkv = torch.full((R * P, 3 * D), float("nan"), device=DEV)
     dpe = torch.full((heads, max(ek, 1)), float("nan"), device=DEV)
-    ws = torch.full((R * heads * max(ek, 1) * 4,), 0xFF, dtype=torch.uint8, device=DEV)
+    need = C.c_size_t()
+    _lib.check(lib.rrt_region_attention_backward_workspace_size(R, P, D, heads, ek, C.byref(need)), "attn bwd ws")
+    ws = torch.full((need.value,), 0xFF, dtype=torch.uint8, device=DEV)
     _lib.check(lib.rrt_region_attention_backward_f32(p(d_stash), p(d_pe) if ek else None, p(o), p(d_dO), p(dqkv),
                                                      p(dpe) if ek else None, R, P, D, heads, ek, p(ws), ws.numel(),
                                                      stream()), "attention_backward")
@@ -853,6 +858,7 @@ TRAIN_CASES = {
     "noepeg_nobias_n500": (500, dict(mlp_dim=512, epeg=False, qkv_bias=False)),
     "d256_n333": (333, dict(mlp_dim=256, n_heads=4, crmsa_heads=4, epeg_k=9)),
     "p169_n10000": (10000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 169 tokens (MT = 11)
+    "p256_n15000": (15000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 256 tokens: streaming
     "brca_r50_heads1_n2000": (2000, dict(mlp_dim=512, epeg_k=17, crmsa_k=3, crmsa_heads=1)),   # README.md:98
     "nsclc_plip_mlp_n1800": (1800, dict(mlp_dim=512, epeg_k=13, crmsa_k=3, crmsa_heads=1, all_shortcut=True,
                                         crmsa_mlp=True)),                                        # README.md:119
