@@ -14,6 +14,8 @@
 // statistics, D and dQ~ (parked in the dq columns of the output); pass B (a wave owns 16-key tiles; the same two
 // MFMA helpers with the roles of Q~ and K exchanged) produces dK and dV.  Scores are in base-2 units (log2(e)
 // folded into Q~).  Requires head dim 64 and P <= 208.
+#include <stdlib.h>
+
 #include "internal.h"
 
 namespace {
@@ -761,7 +763,7 @@ bool attn_bwd_supported(int P, int D, int heads, int epeg_k) {
 // lse and D [rows, heads]
 size_t attn_bwd_workspace(int n_regions, int P, int D, int heads, int epeg_k) {
   size_t b = ((size_t)n_regions * heads * (epeg_k > 0 ? epeg_k : 1) * sizeof(float) + 255) / 256 * 256;
-  if (D == heads * HD && P > 208) {
+  if (D == heads * HD && P > 48) {    // (streaming buffers also when the tuning hook forces that variant)
     const size_t rows = (size_t)n_regions * P;
     b += (2 * rows * D + 2 * rows * heads) * sizeof(float) + 1024;
   }
@@ -782,7 +784,8 @@ hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const 
                                                                       1.0f / sqrtf((float)(D / heads)));
     return hipGetLastError();
   }
-  if (P > 208) {
+  static const bool force_stream = getenv("RRT_ATTN_BWD_STREAM") != nullptr;   // tuning hook
+  if (P > 208 || (force_stream && P > 48)) {
     const size_t rows = (size_t)n_regions * P;
     char* base = (char*)dpe_part + ((size_t)n_regions * heads * (epeg_k > 0 ? epeg_k : 1) * sizeof(float) + 255) / 256 * 256;
     float* qt = (float*)base;
