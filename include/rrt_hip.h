@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 10
+#define RRT_ABI_VERSION 11
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -306,7 +306,7 @@ int rrt_linear_backward_f32(const float *dY, const float *X, const float *W, flo
 /* ---- row f2: training.  Forward that stashes what the backward needs, and the backward itself ----
  * Supported: the default path (1-D 'attn' EPEG R-MSA layers, CR-MSA with the phi matrix or the MLP phi,
  * all_shortcut), head dim 64 in R-MSA (any multiple of 4 in CR-MSA's inner attention), bags of any size, dim <= 1024,
- * ffn = 0, F32 compute.  Anything else: RRT_E_UNSUPPORTED.
+ * F32 compute.  Anything else: RRT_E_UNSUPPORTED.
  * drop_p / drop_seed: the train-mode proj_drop of every InnerAttention (rmsa.py:70,132; p = drop_out): a stateless
  * mask, element kept iff hash(seed, layer, index) >= p * 2^32, kept values scaled by 1/(1-p); the backward call
  * must receive the same (drop_p, drop_seed) as its forward.  drop_p = 0: no dropout.
@@ -317,6 +317,9 @@ typedef struct rrt_attn_grads {
   float *qkv_w, *qkv_b;        /* qkv_b NULL when qkv_bias = False */
   float *proj_w, *proj_b;
   float *pe_w;                 /* [heads, epeg_k] or NULL */
+  float *norm2;                /* ffn = 1: [2, dim] */
+  float *fc1_w, *fc1_b;        /* ffn = 1: [ffn_hidden, dim], [ffn_hidden] */
+  float *fc2_w, *fc2_b;        /* ffn = 1: [dim, ffn_hidden], [dim] */
 } rrt_attn_grads;
 typedef struct rrt_encoder_grads {
   rrt_attn_grads rmsa[RRT_MAX_RMSA_LAYERS];

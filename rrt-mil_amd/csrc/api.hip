@@ -860,6 +860,10 @@ namespace {
 struct Stash {
   float *u[RRT_MAX_RMSA_LAYERS], *qkv[RRT_MAX_RMSA_LAYERS], *o[RRT_MAX_RMSA_LAYERS], *xout[RRT_MAX_RMSA_LAYERS];
   float *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *x2, *v8, *hid;
+  // ffn = 1: per TransLayer (index n_rmsa_layers = CR-MSA's) LN2 output, fc1 pre-activation, layer output;
+  // xcr = CR-MSA's output before its FFN; hscr = one scratch for act(hpre)
+  float *ffn_u[RRT_MAX_RMSA_LAYERS + 1], *ffn_hpre[RRT_MAX_RMSA_LAYERS + 1], *xf[RRT_MAX_RMSA_LAYERS + 1];
+  float *xcr, *hscr;
   size_t bytes;
 };
 
@@ -893,13 +897,24 @@ Stash carve_stash(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const
     }
   }
   s.x2 = take((size_t)N * D);
+  if (d.ffn) {
+    const int nl = d.n_rmsa_layers + (d.cr_msa ? 1 : 0);
+    for (int l = 0; l < nl; ++l) {
+      const int idx = l < d.n_rmsa_layers ? l : RRT_MAX_RMSA_LAYERS;
+      s.ffn_u[idx] = take((size_t)N * D);
+      s.ffn_hpre[idx] = take((size_t)N * d.ffn_hidden);
+      s.xf[idx] = take((size_t)N * D);
+    }
+    if (d.cr_msa) s.xcr = take((size_t)N * D);
+    s.hscr = take((size_t)N * d.ffn_hidden);
+  }
   s.bytes = off;
   return s;
 }
 
 struct BwdWs {
   float *dx2, *dxa, *dxb, *dz, *dO, *dqkv, *lnpart, *attnpart, *dWd, *dC, *dlg, *Cw, *d_rep2, *d_rep_o,
-      *d_rep_qkv, *d_rep, *rows, *dxpart, *th, *dhid, *dvphi, *w1t, *tnscratch;
+      *d_rep_qkv, *d_rep, *rows, *dxpart, *th, *dhid, *dvphi, *w1t, *tnscratch, *fh, *fdh, *fdu;
   char* lin;
   size_t bytes;
 };
@@ -954,6 +969,14 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     const size_t l3 = linear_bwd_workspace((int)(k * R8), 3 * (int)D, (int)D);
     if (l3 > lin) lin = l3;
   }
+  if (d.ffn) {
+    w.fh = take((size_t)N * d.ffn_hidden);
+    w.fdh = take((size_t)N * d.ffn_hidden);
+    w.fdu = take((size_t)N * D);
+    const size_t f1 = linear_bwd_workspace((int)N, (int)D, d.ffn_hidden), f2 = linear_bwd_workspace((int)N, d.ffn_hidden, (int)D);
+    if (f1 > lin) lin = f1;
+    if (f2 > lin) lin = f2;
+  }
   w.lin = takeb(lin ? lin : 256);
   w.bytes = off;
   return w;
@@ -962,7 +985,6 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
 int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8) {
   int rc = check_desc(d, N);
   if (rc) return rc;
-  if (d->ffn) return unsupported("training: ffn=True is not built");
   if (d->compute != RRT_COMPUTE_F32) return unsupported("training: fp32 only");
   if (d->dim > 1024) return unsupported("training: dim > 1024");
   memset(g, 0, sizeof(*g));
@@ -1034,6 +1056,34 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     e = (call);                         \
     if (e != hipSuccess) return (int)e; \
   } while (0)
+  // TransLayer's FFN (ffn = 1): xf = xi + fc2(act(fc1(LN2(xi)))), stashing LN2's output and the pre-activation
+  GridDev gid{};
+  {
+    const int Hs = (int)ceil_sqrt(N);
+    gid.L = (int)N;
+    gid.H = gid.s = Hs;
+    gid.rs = 1;
+    gid.P = gid.Np = Hs * Hs;
+    gid.inv_H = gid.inv_s = 1.0f / (float)Hs;
+    gid.inv_rs = 1.0f;
+    gid.inv_P = 1.0f / (float)gid.P;
+  }
+  auto train_ffn = [&](const rrt_attn_weights& lw, const float* xi, int idx) -> int {
+    if (!lw.norm2_w || !lw.norm2_b || !lw.fc1_w || !lw.fc1_b || !lw.fc2_w || !lw.fc2_b) return RRT_E_INVALID;
+    hipError_t fe = launch_layernorm(xi, nullptr, lw.norm2_w, lw.norm2_b, s.ffn_u[idx], (int)N, D, st);
+    if (fe != hipSuccess) return (int)fe;
+    LinearEpilogue e1{};
+    e1.bias = lw.fc1_b;
+    fe = launch_linear(s.ffn_u[idx], lw.fc1_w, s.ffn_hpre[idx], (int)N, desc->ffn_hidden, D, e1, st);
+    if (fe != hipSuccess) return (int)fe;
+    fe = launch_act_forward(s.ffn_hpre[idx], s.hscr, (size_t)N * desc->ffn_hidden, desc->ffn_act, st);
+    if (fe != hipSuccess) return (int)fe;
+    LinearEpilogue e2{};
+    e2.bias = lw.fc2_b;
+    e2.resid = xi;
+    e2.g = gid;
+    return (int)launch_linear(s.hscr, lw.fc2_w, s.xf[idx], (int)N, D, desc->ffn_hidden, e2, st);
+  };
   const float* xin = x;
   for (int li = 0; li < desc->n_rmsa_layers; ++li) {
     const rrt_attn_weights& lw = w->rmsa[li];
@@ -1057,6 +1107,11 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     ep2.drop_seed = dc.seed(drop_seed, li);
     RRT_TRY(launch_linear(s.o[li], lw.proj_w, s.xout[li], gd.Np, D, D, ep2, st));
     xin = s.xout[li];
+    if (desc->ffn) {
+      rc = train_ffn(lw, xin, li);
+      if (rc) return rc;
+      xin = s.xf[li];
+    }
   }
   const float* x0 = desc->all_shortcut ? x : nullptr;
   if (!w->norm_w || !w->norm_b) return RRT_E_INVALID;
@@ -1091,7 +1146,15 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     ep2.drop_scale = dc.scale;
     ep2.drop_seed = dc.seed(drop_seed, DROP_LAYER_CRMSA);
     RRT_TRY(launch_linear(s.rep_o, cw.proj_w, s.rep2, k * R8, D, D, ep2, st));
-    RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, s.wdisp, s.rep2, nullptr, nullptr, s.x2, D, k, gd8, st));   // x2, no LN
+    if (desc->ffn) {
+      // CR-MSA's TransLayer: x1 + dispatch -> xcr, FFN -> xf, then the shortcut, then the final LayerNorm
+      RRT_TRY(launch_crmsa_dispatch_ln(xin, nullptr, s.wdisp, s.rep2, nullptr, nullptr, s.xcr, D, k, gd8, st));
+      rc = train_ffn(cw, s.xcr, RRT_MAX_RMSA_LAYERS);
+      if (rc) return rc;
+      RRT_TRY(launch_layernorm(s.xf[RRT_MAX_RMSA_LAYERS], x0, nullptr, nullptr, s.x2, (int)N, D, st));
+    } else {
+      RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, s.wdisp, s.rep2, nullptr, nullptr, s.x2, D, k, gd8, st));  // x2, no LN
+    }
   } else {
     RRT_TRY(launch_layernorm(xin, x0, nullptr, nullptr, s.x2, (int)N, D, st));                            // x2 = x1 (+ x)
   }
@@ -1129,6 +1192,29 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
   // final LayerNorm
   RRT_TRY(launch_ln_backward(dy, s.x2, w->norm_w, nullptr, b.dx2, gr->norm, b.lnpart, N, D, nullptr, st));
   const float* cur = b.dx2;   // gradient w.r.t. the activations entering the stage being undone
+  // FFN backward (ffn = 1): given d xf in `cur`, the gradient w.r.t. the FFN's input xi goes to the other
+  // ping-pong buffer; fc2 / fc1 through the linear backward, the activation through its own pass, LN2 last
+  auto ffn_backward = [&](const rrt_attn_weights& lw, const rrt_attn_grads& lg, const float* xi, int idx) -> int {
+    if (!lg.norm2 || !lg.fc1_w || !lg.fc1_b || !lg.fc2_w || !lg.fc2_b) return RRT_E_INVALID;
+    const int Hd = desc->ffn_hidden;
+    hipError_t fe = launch_act_forward(s.ffn_hpre[idx], b.fh, (size_t)N * Hd, desc->ffn_act, st);
+    if (fe != hipSuccess) return (int)fe;
+    fe = launch_linear_backward(cur, b.fh, lw.fc2_w, b.fdh, lg.fc2_w, lg.fc2_b, N, D, Hd, 0, b.lin, st);
+    if (fe != hipSuccess) return (int)fe;
+    fe = launch_act_backward(b.fdh, s.ffn_hpre[idx], (size_t)N * Hd, desc->ffn_act, st);
+    if (fe != hipSuccess) return (int)fe;
+    fe = launch_linear_backward(b.fdh, s.ffn_u[idx], lw.fc1_w, b.fdu, lg.fc1_w, lg.fc1_b, N, Hd, D, 0, b.lin, st);
+    if (fe != hipSuccess) return (int)fe;
+    float* nxt = (cur == b.dxa) ? b.dxb : b.dxa;
+    fe = launch_ln_backward(b.fdu, xi, lw.norm2_w, cur, nxt, lg.norm2, b.lnpart, N, D, nullptr, st);
+    if (fe != hipSuccess) return (int)fe;
+    cur = nxt;
+    return RRT_OK;
+  };
+  if (desc->cr_msa && desc->ffn) {
+    rc = ffn_backward(w->crmsa, gr->crmsa, s.xcr, RRT_MAX_RMSA_LAYERS);
+    if (rc) return rc;
+  }
   if (desc->cr_msa) {
     const rrt_attn_weights& cw = w->crmsa;
     const rrt_attn_grads& cg = gr->crmsa;
@@ -1136,9 +1222,11 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     if (desc->crmsa_mlp ? (!gr->phi0_w || !gr->phi2_w) : !gr->phi) return RRT_E_INVALID;
     const GridDev gd8 = to_dev(g8);
     const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
-    const float* x1 = L > 0 ? s.xout[L - 1] : x;
-    RRT_TRY(launch_crmsa_tokdot(b.dx2, nullptr, nullptr, nullptr, s.rep2, b.dWd, D, k, gd8, st));
-    RRT_TRY(launch_crmsa_wsum(b.dx2, s.wdisp, b.d_rep2, D, k, gd8, st));
+    const float* x1 = L > 0 ? (desc->ffn ? s.xf[L - 1] : s.xout[L - 1]) : x;
+    const float* up = cur;                                   // d x2 (after the FFN backward when ffn = 1)
+    float* dx1 = (cur == b.dxa) ? b.dxb : b.dxa;
+    RRT_TRY(launch_crmsa_tokdot(up, nullptr, nullptr, nullptr, s.rep2, b.dWd, D, k, gd8, st));
+    RRT_TRY(launch_crmsa_wsum(up, s.wdisp, b.d_rep2, D, k, gd8, st));
     RRT_TRY(launch_apply_drop_mask(b.d_rep2, k * R8, D, dc.thresh, dc.seed(drop_seed, DROP_LAYER_CRMSA), dc.scale, st));
     RRT_TRY(launch_linear_backward(b.d_rep2, s.rep_o, cw.proj_w, b.d_rep_o, cg.proj_w, cg.proj_b, k * R8, D, D, 0,
                                    b.lin, st));
@@ -1159,16 +1247,16 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
       RRT_TRY(launch_transpose(w->phi0_w, b.w1t, hdim, D, st));                                    // W1^T [D, D/4]
       LinearEpilogue ev{};
       RRT_TRY(launch_linear(b.dhid, b.w1t, b.dvphi, gd8.Np, D, hdim, ev, st));                     // d v_phi = d hid . W1
-      RRT_TRY(launch_crmsa_bwd_dx(x1, b.dx2, s.mean_rstd, cw.norm_w, cw.norm_b, b.dvphi, b.Cw, b.dlg, b.d_rep, b.dxa,
+      RRT_TRY(launch_crmsa_bwd_dx(x1, up, s.mean_rstd, cw.norm_w, cw.norm_b, b.dvphi, b.Cw, b.dlg, b.d_rep, dx1,
                                   b.rows, b.dxpart, D, k, gd8, true, st));
       RRT_TRY(hipMemcpyAsync(cg.norm, b.rows, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
-      RRT_TRY(launch_crmsa_bwd_dx(x1, b.dx2, s.mean_rstd, cw.norm_w, cw.norm_b, w->phi, b.Cw, b.dlg, b.d_rep, b.dxa,
+      RRT_TRY(launch_crmsa_bwd_dx(x1, up, s.mean_rstd, cw.norm_w, cw.norm_b, w->phi, b.Cw, b.dlg, b.d_rep, dx1,
                                   b.rows, b.dxpart, D, k, gd8, false, st));
       RRT_TRY(hipMemcpyAsync(cg.norm, b.rows, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
       RRT_TRY(launch_transpose(b.rows + 2 * (size_t)D, gr->phi, k, D, st));      // [k, D] -> phi's [D, k]
     }
-    cur = b.dxa;
+    cur = dx1;
   }
   for (int li = L - 1; li >= 0; --li) {
     const rrt_attn_weights& lw = w->rmsa[li];
@@ -1176,7 +1264,11 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     if (!lg.norm || !lg.qkv_w || !lg.proj_w || !lg.proj_b || (lw.qkv_b && !lg.qkv_b) || (desc->epeg && !lg.pe_w))
       return RRT_E_INVALID;
     const GridDev gd = to_dev(g);
-    const float* xin = li > 0 ? s.xout[li - 1] : x;
+    const float* xin = li > 0 ? (desc->ffn ? s.xf[li - 1] : s.xout[li - 1]) : x;
+    if (desc->ffn) {
+      rc = ffn_backward(lw, lg, s.xout[li], li);
+      if (rc) return rc;
+    }
     RRT_TRY(launch_partition_rows(cur, b.dz, D, gd, dc.thresh, dc.seed(drop_seed, li), dc.scale, st));
     RRT_TRY(launch_linear_backward(b.dz, s.o[li], lw.proj_w, b.dO, lg.proj_w, lg.proj_b, gd.Np, D, D, 0, b.lin, st));
     RRT_TRY(launch_attention_backward(s.qkv[li], desc->epeg ? lw.pe_w : nullptr, s.o[li], b.dO, b.dqkv,

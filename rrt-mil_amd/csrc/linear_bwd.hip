@@ -5,6 +5,8 @@
 // a "TN" product on the fp32 matrix cores with split-K over row chunks (a 512 x 512 x 9216 product has only
 // 16 output tiles; the chunks make it >= 2 blocks per CU), partial products summed by a small reduce kernel
 // in a fixed order (bit-reproducible, no atomics).
+#include <stdlib.h>
+
 #include "internal.h"
 
 namespace {
@@ -160,7 +162,8 @@ inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 int linear_bwd_chunks(int M, int N, int K, int* rows_per_chunk) {
   const long tiles = (long)((N + TN_BN - 1) / TN_BN) * ((K + TN_BK - 1) / TN_BK);
-  int S = (int)((768 + tiles - 1) / tiles);                 // ~3 blocks per CU
+  static const int target = getenv("RRT_TN_BLOCKS") ? atoi(getenv("RRT_TN_BLOCKS")) : 768;   // ~3 blocks per CU
+  int S = (int)((target + tiles - 1) / tiles);
   const int max_s = (M + 4 * TN_BM - 1) / (4 * TN_BM);      // at least 128 rows per chunk
   if (S > max_s) S = max_s;
   if (S < 1) S = 1;

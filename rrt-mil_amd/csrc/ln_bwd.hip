@@ -134,6 +134,40 @@ __global__ __launch_bounds__(256) void partition_rows_kernel(const float* __rest
   }
 }
 
+// FFN activation (TransLayer's Mlp, rrt.py:25-41) as its own pass in training: the pre-activation is stashed
+// (GELU's derivative needs it), h = act(hpre) is rebuilt where it is consumed.
+__global__ __launch_bounds__(256) void act_forward_kernel(const float* __restrict__ hpre, float* __restrict__ h,
+                                                          size_t n, int act) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 v = *(const float4*)(hpre + i);
+  if (act == RRT_ACT_GELU) {
+    v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752f));
+    v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752f));
+    v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752f));
+    v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752f));
+  } else {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  }
+  *(float4*)(h + i) = v;
+}
+
+__device__ __forceinline__ float act_grad(float x, int act) {
+  if (act == RRT_ACT_GELU)      // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  return x > 0.f ? 1.0f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void act_backward_kernel(float* __restrict__ dh, const float* __restrict__ hpre,
+                                                           size_t n, int act) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 g = *(const float4*)(dh + i);
+  const float4 x = *(const float4*)(hpre + i);
+  g.x *= act_grad(x.x, act); g.y *= act_grad(x.y, act); g.z *= act_grad(x.z, act); g.w *= act_grad(x.w, act);
+  *(float4*)(dh + i) = g;
+}
+
 __global__ __launch_bounds__(256) void apply_drop_mask_kernel(float* __restrict__ buf, size_t n, unsigned thresh,
                                                               unsigned seed, float scale) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -147,6 +181,16 @@ hipError_t launch_partition_rows(const float* src, float* dst, int dim, const Gr
   const int need = (g.Np + 3) / 4;
   partition_rows_kernel<<<dim3(need < 4096 ? need : 4096), 256, 0, st>>>(src, dst, dim, g, drop_thresh, drop_seed,
                                                                       drop_scale);
+  return hipGetLastError();
+}
+
+hipError_t launch_act_forward(const float* hpre, float* h, size_t n, int act, hipStream_t st) {
+  act_forward_kernel<<<dim3((unsigned)((n / 4 + 255) / 256)), 256, 0, st>>>(hpre, h, n, act);
+  return hipGetLastError();
+}
+
+hipError_t launch_act_backward(float* dh, const float* hpre, size_t n, int act, hipStream_t st) {
+  act_backward_kernel<<<dim3((unsigned)((n / 4 + 255) / 256)), 256, 0, st>>>(dh, hpre, n, act);
   return hipGetLastError();
 }
 

@@ -298,6 +298,14 @@ class RRTEncoder(nn.Module):
                 ag.pe_w = gw.data_ptr()
                 if ia.pe.bias is not None:
                     by_name[prefix + "attn.attn.pe.bias"] = torch.zeros_like(ia.pe.bias)
+            if layer.ffn:
+                ag.norm2 = ln(prefix + "norm2")
+                for nm in ("fc1", "fc2"):
+                    mod = getattr(layer.mlp, nm)
+                    gw, gb = torch.empty_like(mod.weight), torch.empty_like(mod.bias)
+                    by_name[f"{prefix}mlp.{nm}.weight"], by_name[f"{prefix}mlp.{nm}.bias"] = gw, gb
+                    setattr(ag, nm + "_w", gw.data_ptr())
+                    setattr(ag, nm + "_b", gb.data_ptr())
 
         gs.norm = ln("norm")
         for i, layer in enumerate(self.layers.children()):
@@ -457,6 +465,9 @@ class RRTEncoder(nn.Module):
             raise _lib.RRTHipError("rrt_mil_amd.RRTEncoder runs on MI355X only; there is no CPU fallback")
         if self._compute_mode() != _lib.COMPUTE_F32:
             raise NotImplementedError("training under autocast / reduced-precision operands is not built")
+        if self._desc.ffn and self.drop_out > 0:
+            raise NotImplementedError("training with ffn=True and drop_out > 0: the Mlp's two dropouts "
+                                      "(modules/rrt.py:38-40) are not built; use drop_out=0")
         x2d = x2d.float().contiguous()
         if x2d.shape[1] != self.final_dim:
             raise ValueError(f"expected feature dim {self.final_dim}, got {x2d.shape[1]}")

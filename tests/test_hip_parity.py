@@ -860,6 +860,9 @@ TRAIN_CASES = {
     "p169_n10000": (10000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 169 tokens (MT = 11)
     "p256_n15000": (15000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 256 tokens: streaming
     "brca_r50_heads1_n2000": (2000, dict(mlp_dim=512, epeg_k=17, crmsa_k=3, crmsa_heads=1)),   # README.md:98
+    "ffn_gelu_n1200": (1200, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, ffn=True, mlp_ratio=2.0)),
+    "ffn_relu_sc_n700": (700, dict(mlp_dim=256, n_heads=4, crmsa_heads=4, ffn=True, ffn_act="relu", all_shortcut=True,
+                                   n_layers=3, mlp_ratio=1.0)),
     "nsclc_plip_mlp_n1800": (1800, dict(mlp_dim=512, epeg_k=13, crmsa_k=3, crmsa_heads=1, all_shortcut=True,
                                         crmsa_mlp=True)),                                        # README.md:119
 }
@@ -874,7 +877,7 @@ def test_encoder_backward_matches_autograd(case):
     N, cfg = TRAIN_CASES[case]
     D = cfg["mlp_dim"]
     st = synth.encoder_state(**{k: v for k, v in cfg.items() if k in ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k",
-                                                                      "cr_msa", "crmsa_k", "qkv_bias", "crmsa_mlp")})
+                                                                      "cr_msa", "crmsa_k", "qkv_bias", "crmsa_mlp", "ffn", "mlp_ratio")})
     x = synth.bag(N, D, tag="train/" + case)
     G = synth.normal("train/G/" + case, (N, D))
     # oracle
