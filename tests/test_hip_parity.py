@@ -960,3 +960,40 @@ def test_encoder_backward_with_dropout(case, p):
     enc.eval()
     assert torch.equal(enc(xd.unsqueeze(0)), enc(xd.unsqueeze(0)))
 
+
+def test_rrtmil_learns_synthetic_task():
+    """The reference's training loop in miniature (main.py:439-470): RRTMIL.train(), default dropouts, Adam, one bag
+    per step, cross-entropy on the bag label.  Two classes of synthetic bags that differ in a handful of 'tumour'
+    patches; the loss must fall and held-out bags must be classified (eval() under no_grad = the inference path)."""
+    from rrt_mil_amd import RRTMIL
+    torch.manual_seed(2021)
+    dev_ = torch.device("cuda:0")
+    rng = np.random.RandomState(0)
+    direction = rng.randn(256).astype(np.float32)
+
+    def make_bag(label, n):
+        x = np.maximum(rng.randn(n, 256), 0).astype(np.float32)
+        if label:
+            idx = rng.choice(n, size=max(4, n // 50), replace=False)
+            x[idx] += 1.5 * np.maximum(direction, 0)
+        return torch.from_numpy(x).unsqueeze(0)
+
+    train = [(make_bag(i % 2, int(rng.randint(600, 1500))), i % 2) for i in range(24)]
+    test = [(make_bag(i % 2, int(rng.randint(600, 1500))), i % 2) for i in range(10)]
+    mil = RRTMIL(input_dim=256, n_classes=2, epeg_k=15, crmsa_k=3).to(dev_)
+    opt = torch.optim.Adam(mil.parameters(), lr=2e-4)
+    first, last = [], []
+    for epoch in range(9):
+        mil.train()
+        for x, y in train:
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.cross_entropy(mil(x.to(dev_)), torch.tensor([y], device=dev_))
+            loss.backward()
+            opt.step()
+            (first if epoch == 0 else last if epoch == 8 else []).append(float(loss.detach()))
+    assert np.mean(last) < 0.5 * np.mean(first), (np.mean(first), np.mean(last))
+    mil.eval()
+    with torch.no_grad():
+        correct = sum(int(mil(x.to(dev_)).argmax(-1).item() == y) for x, y in test)
+    assert correct >= 8, f"{correct}/10 held-out bags"
+
