@@ -227,11 +227,12 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None):
         o = (attn @ v).transpose(1, 2).reshape(B_, P, D)
         return proj_drop(F.linear(o, st[pfx + "proj.weight"], st[pfx + "proj.bias"]), key)
 
-    def ffn(t, pfx):                                                         # modules/rrt.py:25-41,127-129
+    def ffn(t, pfx, key=None):                                               # modules/rrt.py:25-41,127-129
         u = F.layer_norm(t, (D,), st[pfx + "norm2.weight"], st[pfx + "norm2.bias"], 1e-5)
         h = F.linear(u, st[pfx + "mlp.fc1.weight"], st[pfx + "mlp.fc1.bias"])
         h = F.gelu(h) if c["ffn_act"] == "gelu" else F.relu(h)
-        return t + F.linear(h, st[pfx + "mlp.fc2.weight"], st[pfx + "mlp.fc2.bias"])
+        h = proj_drop(h, ("ffn1", key))                                      # Mlp.drop after the activation ...
+        return t + proj_drop(F.linear(h, st[pfx + "mlp.fc2.weight"], st[pfx + "mlp.fc2.bias"]), ("ffn2", key))  # ... and after fc2
 
     with (contextlib.nullcontext() if grad else torch.no_grad()):
         for li in range(c["n_layers"] - 1):
@@ -245,7 +246,7 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None):
                 z = z[:, :-add]
             x = x + z
             if c["ffn"]:
-                x = ffn(x, p)
+                x = ffn(x, p, li)
         if c["cr_msa"]:
             p = "cr_msa."
             v = F.layer_norm(x, (D,), st[p + "norm.weight"], st[p + "norm.bias"], 1e-5)
@@ -272,7 +273,7 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None):
                 z = z[:, :-add]
             x = x + z
             if c["ffn"]:
-                x = ffn(x, p)
+                x = ffn(x, p, "cr_msa")
         if c["all_shortcut"]:
             x = x + x0
         x = F.layer_norm(x, (D,), st["norm.weight"], st["norm.bias"], 1e-5)

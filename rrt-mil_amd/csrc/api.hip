@@ -1076,12 +1076,17 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     e1.bias = lw.fc1_b;
     fe = launch_linear(s.ffn_u[idx], lw.fc1_w, s.ffn_hpre[idx], (int)N, desc->ffn_hidden, D, e1, st);
     if (fe != hipSuccess) return (int)fe;
-    fe = launch_act_forward(s.ffn_hpre[idx], s.hscr, (size_t)N * desc->ffn_hidden, desc->ffn_act, st);
+    // the Mlp's two dropouts (rrt.py:38-40): after the activation and after fc2 (before the residual)
+    fe = launch_act_forward(s.ffn_hpre[idx], s.hscr, (size_t)N * desc->ffn_hidden, desc->ffn_act, dc.thresh,
+                            dc.seed(drop_seed, 200 + 2 * idx), dc.scale, st);
     if (fe != hipSuccess) return (int)fe;
     LinearEpilogue e2{};
     e2.bias = lw.fc2_b;
     e2.resid = xi;
     e2.g = gid;
+    e2.drop_thresh = dc.thresh;
+    e2.drop_scale = dc.scale;
+    e2.drop_seed = dc.seed(drop_seed, 201 + 2 * idx);
     return (int)launch_linear(s.hscr, lw.fc2_w, s.xf[idx], (int)N, D, desc->ffn_hidden, e2, st);
   };
   const float* xin = x;
@@ -1197,11 +1202,19 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
   auto ffn_backward = [&](const rrt_attn_weights& lw, const rrt_attn_grads& lg, const float* xi, int idx) -> int {
     if (!lg.norm2 || !lg.fc1_w || !lg.fc1_b || !lg.fc2_w || !lg.fc2_b) return RRT_E_INVALID;
     const int Hd = desc->ffn_hidden;
-    hipError_t fe = launch_act_forward(s.ffn_hpre[idx], b.fh, (size_t)N * Hd, desc->ffn_act, st);
+    hipError_t fe = launch_act_forward(s.ffn_hpre[idx], b.fh, (size_t)N * Hd, desc->ffn_act, dc.thresh,
+                                       dc.seed(drop_seed, 200 + 2 * idx), dc.scale, st);
     if (fe != hipSuccess) return (int)fe;
-    fe = launch_linear_backward(cur, b.fh, lw.fc2_w, b.fdh, lg.fc2_w, lg.fc2_b, N, D, Hd, 0, b.lin, st);
+    const float* dyf = cur;                        // d(fc2 output): the residual's gradient through the second mask
+    if (dc.thresh) {
+      fe = launch_copy_drop_mask(cur, b.fdu, (size_t)N * D, dc.thresh, dc.seed(drop_seed, 201 + 2 * idx), dc.scale, st);
+      if (fe != hipSuccess) return (int)fe;
+      dyf = b.fdu;
+    }
+    fe = launch_linear_backward(dyf, b.fh, lw.fc2_w, b.fdh, lg.fc2_w, lg.fc2_b, N, D, Hd, 0, b.lin, st);
     if (fe != hipSuccess) return (int)fe;
-    fe = launch_act_backward(b.fdh, s.ffn_hpre[idx], (size_t)N * Hd, desc->ffn_act, st);
+    fe = launch_act_backward(b.fdh, s.ffn_hpre[idx], (size_t)N * Hd, desc->ffn_act, dc.thresh,
+                             dc.seed(drop_seed, 200 + 2 * idx), dc.scale, st);
     if (fe != hipSuccess) return (int)fe;
     fe = launch_linear_backward(b.fdh, s.ffn_u[idx], lw.fc1_w, b.fdu, lg.fc1_w, lg.fc1_b, N, Hd, D, 0, b.lin, st);
     if (fe != hipSuccess) return (int)fe;

@@ -103,5 +103,10 @@ hipError_t launch_crmsa_bwd_dx(const float* x1, const float* dx2, const float* m
 hipError_t launch_crmsa_mlp_bwd_hidden(const float* hid, const float* dlg, const float* w2, float* th, float* dhid,
                                        size_t rows, int hdim, int k, hipStream_t st);
 // FFN activation as a pass (n % 4 == 0): h = act(hpre) ; dh *= act'(hpre)   (act = RRT_ACT_GELU / RRT_ACT_RELU)
-hipError_t launch_act_forward(const float* hpre, float* h, size_t n, int act, hipStream_t st);
-hipError_t launch_act_backward(float* dh, const float* hpre, size_t n, int act, hipStream_t st);
+// (thresh != 0: with the Mlp's dropout mask on the activation's output / its adjoint)
+hipError_t launch_act_forward(const float* hpre, float* h, size_t n, int act, unsigned thresh, unsigned seed,
+                              float scale, hipStream_t st);
+hipError_t launch_act_backward(float* dh, const float* hpre, size_t n, int act, unsigned thresh, unsigned seed,
+                               float scale, hipStream_t st);
+hipError_t launch_copy_drop_mask(const float* src, float* dst, size_t n, unsigned drop_thresh, unsigned drop_seed,
+                                 float drop_scale, hipStream_t st);

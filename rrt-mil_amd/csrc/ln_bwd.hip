@@ -136,8 +136,10 @@ __global__ __launch_bounds__(256) void partition_rows_kernel(const float* __rest
 
 // FFN activation (TransLayer's Mlp, rrt.py:25-41) as its own pass in training: the pre-activation is stashed
 // (GELU's derivative needs it), h = act(hpre) is rebuilt where it is consumed.
+// (thresh != 0: the Mlp's first Dropout, rrt.py:38, on the activation's output; same stateless mask as proj_drop)
 __global__ __launch_bounds__(256) void act_forward_kernel(const float* __restrict__ hpre, float* __restrict__ h,
-                                                          size_t n, int act) {
+                                                          size_t n, int act, unsigned thresh, unsigned seed,
+                                                          float scale) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   float4 v = *(const float4*)(hpre + i);
@@ -149,6 +151,12 @@ __global__ __launch_bounds__(256) void act_forward_kernel(const float* __restric
   } else {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
   }
+  if (thresh) {
+    v.x = rrt_drop_keep(seed, i, thresh) ? v.x * scale : 0.f;
+    v.y = rrt_drop_keep(seed, i + 1, thresh) ? v.y * scale : 0.f;
+    v.z = rrt_drop_keep(seed, i + 2, thresh) ? v.z * scale : 0.f;
+    v.w = rrt_drop_keep(seed, i + 3, thresh) ? v.w * scale : 0.f;
+  }
   *(float4*)(h + i) = v;
 }
 
@@ -159,19 +167,26 @@ __device__ __forceinline__ float act_grad(float x, int act) {
 }
 
 __global__ __launch_bounds__(256) void act_backward_kernel(float* __restrict__ dh, const float* __restrict__ hpre,
-                                                           size_t n, int act) {
+                                                           size_t n, int act, unsigned thresh, unsigned seed,
+                                                           float scale) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   float4 g = *(const float4*)(dh + i);
   const float4 x = *(const float4*)(hpre + i);
+  if (thresh) {
+    g.x = rrt_drop_keep(seed, i, thresh) ? g.x * scale : 0.f;
+    g.y = rrt_drop_keep(seed, i + 1, thresh) ? g.y * scale : 0.f;
+    g.z = rrt_drop_keep(seed, i + 2, thresh) ? g.z * scale : 0.f;
+    g.w = rrt_drop_keep(seed, i + 3, thresh) ? g.w * scale : 0.f;
+  }
   g.x *= act_grad(x.x, act); g.y *= act_grad(x.y, act); g.z *= act_grad(x.z, act); g.w *= act_grad(x.w, act);
   *(float4*)(dh + i) = g;
 }
 
-__global__ __launch_bounds__(256) void apply_drop_mask_kernel(float* __restrict__ buf, size_t n, unsigned thresh,
-                                                              unsigned seed, float scale) {
+__global__ __launch_bounds__(256) void apply_drop_mask_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              size_t n, unsigned thresh, unsigned seed, float scale) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) buf[i] = rrt_drop_keep(seed, i, thresh) ? buf[i] * scale : 0.f;
+  if (i < n) dst[i] = rrt_drop_keep(seed, i, thresh) ? src[i] * scale : 0.f;
 }
 
 }  // namespace
@@ -184,13 +199,15 @@ hipError_t launch_partition_rows(const float* src, float* dst, int dim, const Gr
   return hipGetLastError();
 }
 
-hipError_t launch_act_forward(const float* hpre, float* h, size_t n, int act, hipStream_t st) {
-  act_forward_kernel<<<dim3((unsigned)((n / 4 + 255) / 256)), 256, 0, st>>>(hpre, h, n, act);
+hipError_t launch_act_forward(const float* hpre, float* h, size_t n, int act, unsigned thresh, unsigned seed,
+                              float scale, hipStream_t st) {
+  act_forward_kernel<<<dim3((unsigned)((n / 4 + 255) / 256)), 256, 0, st>>>(hpre, h, n, act, thresh, seed, scale);
   return hipGetLastError();
 }
 
-hipError_t launch_act_backward(float* dh, const float* hpre, size_t n, int act, hipStream_t st) {
-  act_backward_kernel<<<dim3((unsigned)((n / 4 + 255) / 256)), 256, 0, st>>>(dh, hpre, n, act);
+hipError_t launch_act_backward(float* dh, const float* hpre, size_t n, int act, unsigned thresh, unsigned seed,
+                               float scale, hipStream_t st) {
+  act_backward_kernel<<<dim3((unsigned)((n / 4 + 255) / 256)), 256, 0, st>>>(dh, hpre, n, act, thresh, seed, scale);
   return hipGetLastError();
 }
 
@@ -198,7 +215,15 @@ hipError_t launch_apply_drop_mask(float* buf, int rows, int cols, unsigned drop_
                                   float drop_scale, hipStream_t st) {
   if (!drop_thresh) return hipSuccess;
   const size_t n = (size_t)rows * cols;
-  apply_drop_mask_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(buf, n, drop_thresh, drop_seed, drop_scale);
+  apply_drop_mask_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(buf, buf, n, drop_thresh, drop_seed,
+                                                                            drop_scale);
+  return hipGetLastError();
+}
+
+hipError_t launch_copy_drop_mask(const float* src, float* dst, size_t n, unsigned drop_thresh, unsigned drop_seed,
+                                 float drop_scale, hipStream_t st) {
+  apply_drop_mask_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(src, dst, n, drop_thresh, drop_seed,
+                                                                            drop_scale);
   return hipGetLastError();
 }
 

@@ -465,9 +465,6 @@ class RRTEncoder(nn.Module):
             raise _lib.RRTHipError("rrt_mil_amd.RRTEncoder runs on MI355X only; there is no CPU fallback")
         if self._compute_mode() != _lib.COMPUTE_F32:
             raise NotImplementedError("training under autocast / reduced-precision operands is not built")
-        if self._desc.ffn and self.drop_out > 0:
-            raise NotImplementedError("training with ffn=True and drop_out > 0: the Mlp's two dropouts "
-                                      "(modules/rrt.py:38-40) are not built; use drop_out=0")
         x2d = x2d.float().contiguous()
         if x2d.shape[1] != self.final_dim:
             raise ValueError(f"expected feature dim {self.final_dim}, got {x2d.shape[1]}")

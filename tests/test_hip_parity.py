@@ -914,7 +914,8 @@ def test_encoder_backward_matches_autograd(case):
     assert enc.eval()(xd.unsqueeze(0)).grad_fn is None
 
 
-@pytest.mark.parametrize("case,p", [("default_n1500", 0.1), ("c16_n2600", 0.25), ("nsclc_layers3_n900", 0.1)])
+@pytest.mark.parametrize("case,p", [("default_n1500", 0.1), ("c16_n2600", 0.25), ("nsclc_layers3_n900", 0.1),
+                                    ("ffn_gelu_n1200", 0.1), ("ffn_relu_sc_n700", 0.2)])
 def test_encoder_backward_with_dropout(case, p):
     """Train-mode proj_drop (the reference's default drop_out=0.1): the kernels' stateless mask is rebuilt in
     numpy and handed to the float64 oracle, so forward and every gradient can be compared exactly; the masks
@@ -924,7 +925,7 @@ def test_encoder_backward_with_dropout(case, p):
     N, cfg = TRAIN_CASES[case]
     D = cfg["mlp_dim"]
     st = synth.encoder_state(**{k: v for k, v in cfg.items() if k in ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k",
-                                                                      "cr_msa", "crmsa_k", "qkv_bias")})
+                                                                      "cr_msa", "crmsa_k", "qkv_bias", "ffn", "mlp_ratio")})
     x = synth.bag(N, D, tag="train/" + case)
     G = synth.normal("train/G/" + case, (N, D))
     seed = 0x1234_5678_9ABC_DEF
@@ -932,10 +933,15 @@ def test_encoder_backward_with_dropout(case, p):
     n_layers = cfg.get("n_layers", 2) - 1
     masks = {li: dropout_keep(seed, li, H * H, D, p) for li in range(n_layers)}
     masks["cr_msa"] = dropout_keep(seed, 100, cfg.get("crmsa_k", 3) * 64, D, p)
+    if cfg.get("ffn"):                            # the Mlp's two dropouts per TransLayer (api.hip: layers 200 + 2 i, + 1)
+        hid = int(D * cfg.get("mlp_ratio", 4.0))
+        for key, idx in [(li, li) for li in range(n_layers)] + [("cr_msa", 8)]:
+            masks[("ffn1", key)] = dropout_keep(seed, 200 + 2 * idx, N, hid, p)
+            masks[("ffn2", key)] = dropout_keep(seed, 201 + 2 * idx, N, D, p)
     for m in masks.values():
         assert abs(1.0 - m.mean() - p) < 0.01
     if n_layers > 1:
-        assert 0.7 < (masks[0] == masks[1]).mean() < 0.9          # independent masks agree on p^2 + (1-p)^2
+        assert abs((masks[0] == masks[1]).mean() - (p * p + (1 - p) ** 2)) < 0.02   # independent masks
     y64, x_leaf, params = O.forward_eager(x, st, cfg, grad=True, drop=(p, masks))
     (y64 * torch.from_numpy(G).double()).sum().backward()
     enc = RRTEncoder(drop_out=p, **cfg)
