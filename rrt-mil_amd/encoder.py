@@ -463,8 +463,8 @@ class RRTEncoder(nn.Module):
         """One bag with an autograd graph (rrt_encoder_forward_train_f32 / rrt_encoder_backward_f32)."""
         if not x2d.is_cuda:
             raise _lib.RRTHipError("rrt_mil_amd.RRTEncoder runs on MI355X only; there is no CPU fallback")
-        if self._compute_mode() != _lib.COMPUTE_F32:
-            raise NotImplementedError("training under autocast / reduced-precision operands is not built")
+        # training arithmetic is fp32 whatever the autocast state (the reference's --amp training gets a superset
+        # of the precision it asked for; GradScaler's scaled loss flows through unchanged)
         x2d = x2d.float().contiguous()
         if x2d.shape[1] != self.final_dim:
             raise ValueError(f"expected feature dim {self.final_dim}, got {x2d.shape[1]}")
