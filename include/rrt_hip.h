@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 11
+#define RRT_ABI_VERSION 12
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -39,6 +39,7 @@ enum {
  * autocast-class numerics of the reference's --amp path (main.py:101-102,439); LayerNorm,
  * softmax, attention, residuals and all intermediates in HBM stay fp32 in every mode. */
 enum { RRT_COMPUTE_F32 = 0, RRT_COMPUTE_BF16 = 1, RRT_COMPUTE_F16 = 2 };
+enum { RRT_POS_NONE = 0, RRT_POS_PEG = 1, RRT_POS_PPEG = 2 };
 
 /* Elementwise activations of the caller-side layers (patch_to_emb, DAttention). */
 enum { RRT_ACT_NONE = 0, RRT_ACT_RELU = 1, RRT_ACT_GELU = 2, RRT_ACT_TANH = 3, RRT_ACT_SIGMOID = 4 };
@@ -75,6 +76,10 @@ typedef struct rrt_encoder_desc {
   int32_t ffn;             /* 1: every TransLayer (CR-MSA's too) ends with x + Mlp(LN2(x)), rrt.py:105-106,127-129 */
   int32_t ffn_act;         /* RRT_ACT_GELU (ffn_act='gelu') or RRT_ACT_RELU (anything else), rrt.py:105 */
   int32_t ffn_hidden;      /* int(dim * mlp_ratio), a multiple of 32 */
+  int32_t pos;             /* RRT_POS_NONE / RRT_POS_PEG / RRT_POS_PPEG (pos=, modules/emb_position.py:24-82) */
+  int32_t pos_pos;         /* -1: before the first layer; 0: before layer index 1 (needs n_layers >= 3), rrt.py:181-187 */
+  int32_t peg_k;           /* odd, <= 11 */
+  int32_t peg_1d;          /* 1: (k, 1) kernels (peg_1d / conv_1d) */
 } rrt_encoder_desc;
 
 /* One TransLayer's parameters: InnerAttention, modules/rmsa.py:57-89 (+ the optional FFN).  Row-major, fp32.
@@ -99,6 +104,9 @@ typedef struct rrt_encoder_weights {
   const float *phi0_w, *phi2_w;                   /* cr_msa.attn.phi.0.weight [dim/4, dim],
                                                      cr_msa.attn.phi.2.weight [crmsa_k, dim/4] (crmsa_mlp = 1) */
   const float *norm_w, *norm_b;                   /* final norm.* (modules/rrt.py:139,195) */
+  /* pos_embedding.proj / proj1 / proj2 (depth-wise [dim, 1, k, k] or [dim, 1, k, 1]; PEG: only [0]); biases may be
+   * NULL (peg_bias = False) */
+  const float *pos_w[3], *pos_b[3];
 } rrt_encoder_weights;
 
 int         rrt_abi_version(void);

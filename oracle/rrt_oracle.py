@@ -58,7 +58,8 @@ def partition_index(H, s):
 _DEFAULTS = dict(mlp_dim=512, region_num=8, n_layers=2, n_heads=8, epeg=True, epeg_k=15,
                  region_size=0, min_region_num=0, min_region_ratio=0.0, qkv_bias=True,
                  cr_msa=True, crmsa_k=3, all_shortcut=False, crmsa_mlp=False, crmsa_heads=8,
-                 epeg_bias=True, ffn=False, ffn_act="gelu", mlp_ratio=4.0)
+                 epeg_bias=True, ffn=False, ffn_act="gelu", mlp_ratio=4.0, pos="none", pos_pos=0, peg_k=7,
+                 peg_1d=False, peg_bias=True)
 
 
 def _cfg(cfg):
@@ -118,6 +119,30 @@ def _ffn64(x, st, pfx, act):
     return x + h @ g("mlp.fc2.weight").T + g("mlp.fc2.bias")
 
 
+def _pos64(x, st, kind, conv_1d):
+    """PEG / PPEG (modules/emb_position.py:24-82): wrap-pad the tokens to an H x H grid (PPEG: zero-pad to 7 x 7),
+    depth-wise convs with zero borders + identity, keep the first N tokens."""
+    N, D = x.shape
+    H = int(np.ceil(np.sqrt(N)))
+    add = H * H - N
+    xh = np.concatenate([x, x[:add]], 0)
+    if kind == "ppeg" and H < 7:
+        xh = np.concatenate([xh, np.zeros((49 - H * H, D))], 0)
+        H = 7
+    grid = xh.reshape(H, H, D)
+    out = grid.copy()
+    for name in ("proj", "proj1", "proj2") if kind == "ppeg" else ("proj",):
+        w = st[f"pos_embedding.{name}.weight"].astype(np.float64)           # [D, 1, kh, kw]
+        kh, kw = w.shape[2], w.shape[3]
+        gp = np.pad(grid, ((kh // 2, kh // 2), (kw // 2, kw // 2), (0, 0)))
+        for di in range(kh):
+            for dj in range(kw):
+                out += gp[di:di + H, dj:dj + H, :] * w[:, 0, di, dj]
+        if f"pos_embedding.{name}.bias" in st:
+            out += st[f"pos_embedding.{name}.bias"].astype(np.float64)
+    return out.reshape(H * H, D)[:N]
+
+
 def forward_f64(x, state, cfg=None, taps=None):
     """x: (N, D) array -> (N, D) float64.  ``state``: {reference state_dict key: array}."""
     c = _cfg(cfg)
@@ -125,7 +150,12 @@ def forward_f64(x, state, cfg=None, taps=None):
     x = np.asarray(x, dtype=np.float64)
     N, D = x.shape
     x0 = x
+    use_pos = c["pos"] in ("peg", "ppeg")
+    if use_pos and c["pos_pos"] == -1:                                      # modules/rrt.py:181-182
+        x = _pos64(x, st, c["pos"], c["peg_1d"])
     for li in range(c["n_layers"] - 1):                                     # R-MSA TransLayers
+        if use_pos and li == 1 and c["pos_pos"] == 0:                       # modules/rrt.py:185-187
+            x = _pos64(x, st, c["pos"], c["peg_1d"])
         p = f"layers.{li}."
         u = _ln64(x, st[p + "norm.weight"].astype(np.float64), st[p + "norm.bias"].astype(np.float64))
         H, s, add = grid(N, c["region_num"], c["region_size"], c["min_region_num"], c["min_region_ratio"])
@@ -234,8 +264,30 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None):
         h = proj_drop(h, ("ffn1", key))                                      # Mlp.drop after the activation ...
         return t + proj_drop(F.linear(h, st[pfx + "mlp.fc2.weight"], st[pfx + "mlp.fc2.bias"]), ("ffn2", key))  # ... and after fc2
 
+    def pos_embed(t):                                                        # modules/emb_position.py:24-82
+        Hh = int(np.ceil(np.sqrt(N)))
+        add = Hh * Hh - N
+        t = torch.cat([t, t[:, :add, :]], dim=1)
+        if c["pos"] == "ppeg" and Hh < 7:
+            t = torch.cat([t, torch.zeros((B, 49 - Hh * Hh, D), dtype=t.dtype)], dim=1)
+            add += 49 - Hh * Hh
+            Hh = 7
+        feat = t.transpose(1, 2).reshape(B, D, Hh, Hh)
+        out = feat
+        for name in ("proj", "proj1", "proj2") if c["pos"] == "ppeg" else ("proj",):
+            wt = st[f"pos_embedding.{name}.weight"]
+            out = out + F.conv2d(feat, wt, st.get(f"pos_embedding.{name}.bias"),
+                                 padding=(wt.shape[2] // 2, wt.shape[3] // 2), groups=D)
+        out = out.flatten(2).transpose(1, 2)
+        return out[:, :-add] if add > 0 else out
+
+    use_pos = c["pos"] in ("peg", "ppeg")
     with (contextlib.nullcontext() if grad else torch.no_grad()):
+        if use_pos and c["pos_pos"] == -1:
+            x = pos_embed(x)
         for li in range(c["n_layers"] - 1):
+            if use_pos and li == 1 and c["pos_pos"] == 0:
+                x = pos_embed(x)
             p = f"layers.{li}."
             u = F.layer_norm(x, (D,), st[p + "norm.weight"], st[p + "norm.bias"], 1e-5)
             H, s, add = grid(N, c["region_num"], c["region_size"], c["min_region_num"], c["min_region_ratio"])

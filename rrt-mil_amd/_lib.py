@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _f32p = C.POINTER(C.c_float)
 
@@ -27,7 +27,8 @@ class EncoderDesc(C.Structure):
                 ("min_region_ratio", C.c_float), ("epeg", C.c_int32), ("epeg_k", C.c_int32),
                 ("cr_msa", C.c_int32), ("crmsa_k", C.c_int32), ("crmsa_heads", C.c_int32),
                 ("crmsa_mlp", C.c_int32), ("all_shortcut", C.c_int32), ("compute", C.c_int32),
-                ("ffn", C.c_int32), ("ffn_act", C.c_int32), ("ffn_hidden", C.c_int32)]
+                ("ffn", C.c_int32), ("ffn_act", C.c_int32), ("ffn_hidden", C.c_int32),
+                ("pos", C.c_int32), ("pos_pos", C.c_int32), ("peg_k", C.c_int32), ("peg_1d", C.c_int32)]
 
 
 class AttnWeights(C.Structure):
@@ -39,7 +40,8 @@ class AttnWeights(C.Structure):
 class EncoderWeights(C.Structure):
     _fields_ = [("rmsa", AttnWeights * RRT_MAX_RMSA_LAYERS), ("crmsa", AttnWeights),
                 ("phi", C.c_void_p), ("phi0_w", C.c_void_p), ("phi2_w", C.c_void_p),
-                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p)]
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
+                ("pos_w", C.c_void_p * 3), ("pos_b", C.c_void_p * 3)]
 
 
 class AttnGrads(C.Structure):
@@ -137,6 +139,7 @@ SIGNATURES = {
 }
 
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
+POS_NONE, POS_PEG, POS_PPEG = 0, 1, 2
 
 # stage-boundary event slots of rrt_encoder_forward_events_f32 (enum in include/rrt_hip.h)
 EV_START, EV_LN_PARTITION, EV_QKV, EV_ATTN, EV_PROJ, EV_CR_COMBINE, EV_CR_INNER, EV_END, EV_COUNT = range(9)

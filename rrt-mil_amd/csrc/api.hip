@@ -26,7 +26,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
   float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *v8, *hid;
-  float *ffn_ln, *ffn_hid;
+  float *ffn_ln, *ffn_hid, *xp;
   size_t bytes;
 };
 
@@ -68,6 +68,7 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
       w.hid = take(Np8 * (D / 4));
     }
   }
+  if (d.pos) w.xp = take((size_t)N * D);
   w.bytes = off ? off : 256;
   return w;
 }
@@ -91,6 +92,11 @@ int check_desc(const rrt_encoder_desc* d, int64_t N) {
     if (d->ffn_hidden <= 0 || d->ffn_hidden % 32 != 0)
       return unsupported("ffn: hidden width int(dim * mlp_ratio) must be a positive multiple of 32");
     if (d->ffn_act != RRT_ACT_GELU && d->ffn_act != RRT_ACT_RELU) return unsupported("ffn_act must be gelu or relu");
+  }
+  if (d->pos) {
+    if (d->pos != RRT_POS_PEG && d->pos != RRT_POS_PPEG) return unsupported("pos must be none / peg / ppeg");
+    if (d->peg_k <= 0 || d->peg_k % 2 == 0 || d->peg_k > 11) return unsupported("peg_k must be odd and <= 11");
+    if (d->pos_pos != -1 && d->pos_pos != 0) return unsupported("pos_pos must be -1 or 0");
   }
   if (N > (int64_t)4000000) return unsupported("bag larger than 4e6 tokens");
   if (d->compute < 0 || d->compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
@@ -263,8 +269,25 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
   };
 
   const float* xin = x;   // current activations [N, D]
+  // PEG / PPEG (ablation): before the first layer (pos_pos = -1) or before layer index 1 (pos_pos = 0), rrt.py:181-187
+  auto pos_embed = [&]() -> int {
+    if (!w->pos_w[0] || (desc->pos == RRT_POS_PPEG && (!w->pos_w[1] || !w->pos_w[2]))) return RRT_E_INVALID;
+    hipError_t pe = launch_peg(xin, w->pos_w, w->pos_b, ws.xp, (int)N, D, desc->peg_k, desc->peg_1d,
+                               desc->pos == RRT_POS_PPEG, st);
+    if (pe != hipSuccess) return (int)pe;
+    xin = ws.xp;
+    return RRT_OK;
+  };
+  if (desc->pos && desc->pos_pos == -1) {
+    rc = pos_embed();
+    if (rc) return rc;
+  }
   // ---- R-MSA TransLayers: x = x + unpart(InnerAttention(part(pad(LN(x)))))  (rrt.py:117-125)
   for (int li = 0; li < desc->n_rmsa_layers; ++li) {
+    if (li == 1 && desc->pos && desc->pos_pos == 0) {
+      rc = pos_embed();
+      if (rc) return rc;
+    }
     const rrt_attn_weights& lw = w->rmsa[li];
     if (!lw.norm_w || !lw.norm_b || !lw.qkv_w || !lw.proj_w || !lw.proj_b) return RRT_E_INVALID;
     if (desc->epeg && !lw.pe_w) return RRT_E_INVALID;
@@ -985,6 +1008,7 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
 int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8) {
   int rc = check_desc(d, N);
   if (rc) return rc;
+  if (d->pos) return unsupported("training: pos='peg'/'ppeg' is not built");
   if (d->compute != RRT_COMPUTE_F32) return unsupported("training: fp32 only");
   if (d->dim > 1024) return unsupported("training: dim > 1024");
   memset(g, 0, sizeof(*g));

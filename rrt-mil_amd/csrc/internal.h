@@ -110,3 +110,6 @@ hipError_t launch_act_backward(float* dh, const float* hpre, size_t n, int act, 
                                float scale, hipStream_t st);
 hipError_t launch_copy_drop_mask(const float* src, float* dst, size_t n, unsigned drop_thresh, unsigned drop_seed,
                                  float drop_scale, hipStream_t st);
+// PEG / PPEG positional encoders (peg.hip): y [N, C] = stencil over the wrapped H x H token grid
+hipError_t launch_peg(const float* x, const float* const* w, const float* const* b, float* y, int N, int C, int k,
+                      int conv_1d, int ppeg, hipStream_t st);

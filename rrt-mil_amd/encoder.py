@@ -95,6 +95,28 @@ class CrossRegionAttntion(nn.Module):
             nn.init.kaiming_uniform_(self.phi, a=math.sqrt(5))
 
 
+class PEG(nn.Module):
+    """Holder mirroring modules/emb_position.py:60-82 (one depth-wise conv + identity)."""
+
+    def __init__(self, dim=512, k=7, bias=True, conv_1d=False):
+        super().__init__()
+        ks, pad = ((k, 1), (k // 2, 0)) if conv_1d else (k, k // 2)
+        self.proj = nn.Conv2d(dim, dim, ks, 1, pad, groups=dim, bias=bias)
+
+
+class PPEG(nn.Module):
+    """Holder mirroring modules/emb_position.py:24-58 (k, 5 and 3 depth-wise convs + identity)."""
+
+    def __init__(self, dim=512, k=7, conv_1d=False, bias=True):
+        super().__init__()
+
+        def conv(kk):
+            ks, pad = ((kk, 1), (kk // 2, 0)) if conv_1d else (kk, kk // 2)
+            return nn.Conv2d(dim, dim, ks, 1, pad, groups=dim, bias=bias)
+
+        self.proj, self.proj1, self.proj2 = conv(k), conv(5), conv(3)
+
+
 class Mlp(nn.Module):
     """Holder mirroring modules/rrt.py:25-41 (TransLayer's FFN when ffn=True)."""
 
@@ -196,8 +218,9 @@ class RRTEncoder(nn.Module):
                  crmsa_k=3, all_shortcut=False, crmsa_mlp=False, crmsa_heads=8, need_init=False,
                  **kwargs):
         super().__init__()
-        if pos not in ('none', None):
-            raise NotImplementedError("pos='ppeg'/'peg'/'sincos' are reference ablations, not on the HIP path")
+        if pos == 'sincos':
+            raise NotImplementedError("pos='sincos' is out of scope (the reference's SINCOS needs numpy < 1.24 and a "
+                                      "4-D input it never receives)")
         self.final_dim = mlp_dim
         self.norm = nn.LayerNorm(self.final_dim)
         self.all_shortcut = all_shortcut
@@ -214,7 +237,12 @@ class RRTEncoder(nn.Module):
                                   ffn=ffn, ffn_act=ffn_act, mlp_ratio=mlp_ratio, trans_dim=trans_dim,
                                   attn='crmsa', qkv_bias=qkv_bias, crmsa_k=crmsa_k, crmsa_mlp=crmsa_mlp,
                                   **kwargs) if cr_msa else nn.Identity())
-        self.pos_embedding = nn.Identity()
+        if pos == 'ppeg':
+            self.pos_embedding = PPEG(dim=mlp_dim, k=peg_k, bias=peg_bias, conv_1d=peg_1d)
+        elif pos == 'peg':
+            self.pos_embedding = PEG(mlp_dim, k=peg_k, bias=peg_bias, conv_1d=peg_1d)
+        else:
+            self.pos_embedding = nn.Identity()
         self.pos_pos = pos_pos
         self.drop_out = drop_out
         self._desc = _lib.EncoderDesc(
@@ -223,7 +251,11 @@ class RRTEncoder(nn.Module):
             epeg=int(bool(epeg)), epeg_k=epeg_k, cr_msa=int(bool(cr_msa)), crmsa_k=crmsa_k,
             crmsa_heads=crmsa_heads, crmsa_mlp=int(bool(crmsa_mlp)), all_shortcut=int(bool(all_shortcut)),
             compute=_lib.COMPUTE_F32, ffn=int(bool(ffn)),
-            ffn_act=_lib.ACT_GELU if ffn_act == 'gelu' else _lib.ACT_RELU, ffn_hidden=int(mlp_dim * mlp_ratio))
+            ffn_act=_lib.ACT_GELU if ffn_act == 'gelu' else _lib.ACT_RELU, ffn_hidden=int(mlp_dim * mlp_ratio),
+            pos={'peg': _lib.POS_PEG, 'ppeg': _lib.POS_PPEG}.get(pos, _lib.POS_NONE), pos_pos=pos_pos, peg_k=peg_k,
+            peg_1d=int(bool(peg_1d)))
+        if self._desc.pos and pos_pos not in (-1, 0):
+            self._desc.pos = _lib.POS_NONE       # the reference only applies pos_embedding at pos_pos -1 / 0 (rrt.py:181-187)
         # None: exact fp32 unless the call runs under torch autocast (then bf16/fp16 MFMA operands in
         # the Linear layers, like the reference's --amp path); or force torch.float32/bfloat16/float16
         self.compute_dtype = None
@@ -266,6 +298,11 @@ class RRTEncoder(nn.Module):
             else:
                 w.phi = self._ptr(self.cr_msa.attn.phi)
         w.norm_w, w.norm_b = self._ptr(self.norm.weight), self._ptr(self.norm.bias)
+        if self._desc.pos:
+            for i, name in enumerate(("proj", "proj1", "proj2")):
+                conv = getattr(self.pos_embedding, name, None)
+                if conv is not None:
+                    w.pos_w[i], w.pos_b[i] = self._ptr(conv.weight), self._ptr(conv.bias)
         return w
 
     def _grad_buffers(self, device):

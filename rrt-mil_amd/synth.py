@@ -41,7 +41,8 @@ def normal(name: str, shape, dtype=np.float32) -> np.ndarray:
 
 def encoder_state_shapes(mlp_dim=512, n_layers=2, n_heads=8, epeg=True, epeg_k=15,
                          cr_msa=True, crmsa_k=3, crmsa_mlp=False, qkv_bias=True,
-                         epeg_bias=True, ffn=False, mlp_ratio=4., **_unused):
+                         epeg_bias=True, ffn=False, mlp_ratio=4., pos='none', peg_k=7, peg_1d=False,
+                         peg_bias=True, **_unused):
     """Ordered {state_dict key: shape} of the default-path RRTEncoder."""
     D = mlp_dim
     sh = {"norm.weight": (D,), "norm.bias": (D,)}
@@ -82,6 +83,13 @@ def encoder_state_shapes(mlp_dim=512, n_layers=2, n_heads=8, epeg=True, epeg_k=1
         else:
             sh["cr_msa.attn.phi"] = (D, crmsa_k)
         mlp("cr_msa.")
+    if pos in ("peg", "ppeg"):            # modules/emb_position.py:24-82 under pos_embedding.*
+        for name, kk in (("proj", peg_k), ("proj1", 5), ("proj2", 3)):
+            if name != "proj" and pos == "peg":
+                continue
+            sh[f"pos_embedding.{name}.weight"] = (D, 1, kk, 1 if peg_1d else kk)
+            if peg_bias:
+                sh[f"pos_embedding.{name}.bias"] = (D,)
     return sh
 
 
@@ -95,6 +103,9 @@ def encoder_state(**cfg):
             out[k] = 1.0 + uniform(k, shape, -0.25, 0.25)
         elif k.endswith(("norm.bias", "norm2.bias")):
             out[k] = uniform(k, shape, -0.1, 0.1)
+        elif k.startswith("pos_embedding.") and k.endswith(".weight"):
+            b = 1.0 / np.sqrt(shape[2] * shape[3])
+            out[k] = uniform(k, shape, -b, b)
         elif k.endswith("pe.weight"):
             b = 1.0 / np.sqrt(shape[2])
             out[k] = uniform(k, shape, -b, b)

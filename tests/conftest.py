@@ -28,7 +28,7 @@ def golden_names(prefix=""):
 
 
 STATE_KEYS = ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k", "cr_msa", "crmsa_k",
-              "crmsa_mlp", "qkv_bias", "epeg_bias", "ffn", "mlp_ratio")
+              "crmsa_mlp", "qkv_bias", "epeg_bias", "ffn", "mlp_ratio", "pos", "peg_k", "peg_1d", "peg_bias")
 
 
 def synth_case(g):

@@ -106,10 +106,20 @@ def test_cpu_tensor_and_ablations_raise():
     enc = RRTEncoder(mlp_dim=64).eval()
     with pytest.raises(_lib.RRTHipError):
         enc(torch.zeros(1, 10, 64))
-    for kw in (dict(pos='ppeg'), dict(attn='ntrans'), dict(epeg_2d=True),
+    for kw in (dict(pos='sincos'), dict(attn='ntrans'), dict(epeg_2d=True),
                dict(epeg_type='value_bf'), dict(region_attn='ntrans')):
         with pytest.raises(NotImplementedError):
             RRTEncoder(mlp_dim=64, **kw)
+
+
+def test_pos_state_dict_surface():
+    """pos='ppeg' / 'peg' (modules/emb_position.py:24-82): pos_embedding.proj{,1,2} depth-wise convs."""
+    for cfg in (dict(mlp_dim=64, pos='ppeg', pos_pos=-1), dict(mlp_dim=64, pos='peg', peg_k=5, peg_1d=True, peg_bias=False)):
+        enc = RRTEncoder(**cfg)
+        st = synth.encoder_state(**cfg)
+        enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+        assert enc._desc.pos == (_lib.POS_PPEG if cfg['pos'] == 'ppeg' else _lib.POS_PEG)
+    assert RRTEncoder(mlp_dim=64, pos='peg', peg_k=5, peg_1d=True).pos_embedding.proj.weight.shape == (64, 1, 5, 1)
 
 
 def test_ffn_state_dict_surface():

@@ -24,7 +24,7 @@ os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(8)
 
 STATE_KEYS = ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k", "cr_msa", "crmsa_k",
-              "crmsa_mlp", "qkv_bias", "epeg_bias", "ffn", "mlp_ratio")
+              "crmsa_mlp", "qkv_bias", "epeg_bias", "ffn", "mlp_ratio", "pos", "peg_k", "peg_1d", "peg_bias")
 
 
 def run_ref(N, cfg, hooks=False, tag="bag"):
@@ -223,6 +223,26 @@ def main():
         else:
             ri = np.arange(0, N, 8)
             save(f"G12_ffn_{tag}", cfg=cfg_array(cfg), n=np.array(N), rows=ri, y_rows=y[ri], y_sums=checksums(y))
+
+    # G14: the ablation positional encoders PEG / PPEG (modules/emb_position.py:24-82, rrt.py:181-187)
+    pos_variants = {
+        "ppeg_d64_n300": (300, dict(mlp_dim=64, pos="ppeg", pos_pos=-1)),
+        "ppeg_d512_n1000": (1000, dict(mlp_dim=512, pos="ppeg", pos_pos=-1)),
+        "peg_mid_d64_n700": (700, dict(mlp_dim=64, pos="peg", pos_pos=0, n_layers=3)),
+        "peg1d_k5_nobias_d64_n500": (500, dict(mlp_dim=64, pos="peg", pos_pos=-1, peg_1d=True, peg_k=5, peg_bias=False)),
+        "ppeg_tiny_d64_n30": (30, dict(mlp_dim=64, pos="ppeg", pos_pos=-1)),          # H = 6 < 7: zero-padded to 7 x 7
+        "ppeg_k3_d64_n260": (260, dict(mlp_dim=64, pos="ppeg", pos_pos=-1, peg_k=3)),
+        "ppeg_unused_d64_n200": (200, dict(mlp_dim=64, pos="ppeg", pos_pos=0)),       # n_layers = 2: never applied
+    }
+    for tag, (N, extra) in pos_variants.items():
+        cfg = dict(epeg_k=15, crmsa_k=3, region_num=8)
+        cfg.update(extra)
+        x, y, _, _ = run_ref(N, cfg)
+        if N <= 700:
+            save(f"G14_pos_{tag}", cfg=cfg_array(cfg), n=np.array(N), y=y)
+        else:
+            ri = np.arange(0, N, 8)
+            save(f"G14_pos_{tag}", cfg=cfg_array(cfg), n=np.array(N), rows=ri, y_rows=y[ri], y_sums=checksums(y))
 
     # G11: RRTMIL caller variants (modules/datten.py gated / bias / activations, rrt.py act=, n_classes,
     # input_dim), with both forms of the returned attention row (normalised / no_norm raw scores)
