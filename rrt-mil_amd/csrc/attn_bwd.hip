@@ -82,8 +82,10 @@ __device__ __forceinline__ void tile_apply(const float* X, const f32x4 (&p)[MT],
     }
 }
 
-template <int MT>
-__global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restrict__ qkv,
+// NW waves per block: 6 (the forward fused kernel's schedule) up to 9 row tiles; 4 for 11 / 13 row tiles -- one wave
+// per SIMD owns the whole 512-entry register file, and the two [MT]-long score arrays no longer spill.
+template <int MT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __restrict__ qkv,
                                                           const float* __restrict__ pe_w,
                                                           const float* __restrict__ O,
                                                           const float* __restrict__ dO,
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
   const int ld = 3 * D;
 
   // ---- phase 0: q, k, v tiles -> LDS (XOR-swizzled 16-byte slots, rows >= P are zeros)
-  for (int idx = tid; idx < BM * 16; idx += 384) {
+  for (int idx = tid; idx < BM * 16; idx += NW * 64) {
     const int m = idx >> 4, s = idx & 15;
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
     if (m < P) {
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
   __syncthreads();
 
   // ---- phase 1: Q~ = log2(e) * (I + T_w) q, in place (the forward's sliding-window stencil)
-  constexpr int RUN = (BM * 16 + 383) / 384;
+  constexpr int RUN = (BM * 16 + NW * 64 - 1) / (NW * 64);
   const int half = epeg_k >> 1;
   const float* w = pe_w + head * epeg_k;
   {
@@ -168,10 +170,12 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
 
   // tile -> wave schedule of the forward fused kernel (balanced per SIMD; at most three tiles per wave)
   auto tile_of = [&](int pass) {
+    if (NW == 4) return wave + 4 * pass;            // 4 waves, one per SIMD: tiles round-robin
     if (pass == 0) return wave;
     if (pass == 1) return wave >= 2 ? wave + 4 : (wave == 0 ? 12 : MT);
     return (wave == 2 || wave == 3) ? wave + 8 : MT;
   };
+  constexpr int NPASS = NW == 4 ? (MT + 3) / 4 : 3;
   // fragment rows of a [rows, D]-strided global tensor: lane (lr, lg) <- row[4*(4c + lg) .. +3]
   auto global_frags = [&](const float* base, size_t stride, int m, float4 (&f)[4]) {
 #pragma unroll
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
 
   // ---- pass A: query tiles.  Row statistics, D, dQ~
 #pragma unroll 1
-  for (int ps = 0; ps < 3; ++ps) {
+  for (int ps = 0; ps < NPASS; ++ps) {
     const int t = tile_of(ps);
     const int i0 = t * 16;
     if (t >= MT || i0 >= P) break;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
     }
   }
   __syncthreads();                                  // V is dead: the third tile becomes dO
-  for (int idx = tid; idx < BM * 16; idx += 384) {
+  for (int idx = tid; idx < BM * 16; idx += NW * 64) {
     const int m = idx >> 4, s = idx & 15;
     const float4 g4 = m < P ? *(const float4*)(dO + (row0 + m) * D + head * HD + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
     *(float4*)(Xs + m * HD + ((s ^ (m & 15)) << 2)) = g4;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
 
   // ---- pass B: key tiles.  dV = A^T dO, dK = dS^T Q~ (Q~ carries log2 e: x ln 2)
 #pragma unroll 1
-  for (int ps = 0; ps < 3; ++ps) {
+  for (int ps = 0; ps < NPASS; ++ps) {
     const int t = tile_of(ps);
     const int j0 = t * 16;
     if (t >= MT || j0 >= P) break;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
 
   // ---- parked dQ~ rows -> LDS over the dead dO tile (rows >= P: zeros)
   float* Gs = Xs;
-  for (int idx = tid; idx < BM * 16; idx += 384) {
+  for (int idx = tid; idx < BM * 16; idx += NW * 64) {
     const int m = idx >> 4, s = idx & 15;
     const float4 g4 = m < P ? *(const float4*)(dq_park + (row0 + m) * ld + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
     *(float4*)(Gs + m * HD + ((s ^ (m & 15)) << 2)) = g4;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
     const int s = tid & 15;
     for (int t = 0; t < epeg_k; ++t) {
       float acc = 0.f;
-      for (int i = tid >> 4; i < P; i += 24) {
+      for (int i = tid >> 4; i < P; i += NW * 4) {
         const int j = i + t - half;
         if (j >= 0 && j < P) {
           const float4 g4 = *(const float4*)(Gs + i * HD + ((s ^ (i & 15)) << 2));
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(384, 1) void attn_bwd_kernel(const float* __restric
     if (tid < epeg_k) {
       float a = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < 6; ++wv) a += wred[wv * 64 + tid];
+      for (int wv = 0; wv < NW; ++wv) a += wred[wv * 64 + tid];
       dpe_part[((size_t)reg * heads + head) * epeg_k + tid] = a;
     }
   }
@@ -373,11 +377,19 @@ hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, co
                          float* dpe_part, int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
   constexpr size_t LDS = ((size_t)3 * 16 * MT * HD + 2 * 16 * MT + 6 * 64) * sizeof(float);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = attn_bwd_kernel<MT>;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
   const float q_scale = 1.0f / sqrtf((float)HD);
-  kern<<<dim3(n_regions * heads), dim3(384), LDS, st>>>(qkv, pe_w, O, dO, dqkv, dpe_part, P, D, heads,
-                                                       pe_w ? epeg_k : 0, q_scale);
+  static const bool six = getenv("RRT_ATTN_BWD_NW6") != nullptr;     // tuning hook (A/B of the two schedules)
+  if (MT >= 11 && !six) {           // measured: 9 tiles 221 (6 waves) vs 241 us; 11: 350 vs 291; 13: 516 vs 400
+    auto kern = attn_bwd_kernel<MT, 4>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    kern<<<dim3(n_regions * heads), dim3(256), LDS, st>>>(qkv, pe_w, O, dO, dqkv, dpe_part, P, D, heads,
+                                                          pe_w ? epeg_k : 0, q_scale);
+  } else {
+    auto kern = attn_bwd_kernel<MT, 6>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    kern<<<dim3(n_regions * heads), dim3(384), LDS, st>>>(qkv, pe_w, O, dO, dqkv, dpe_part, P, D, heads,
+                                                          pe_w ? epeg_k : 0, q_scale);
+  }
   return hipGetLastError();
 }
 
