@@ -206,8 +206,7 @@ class _EncoderFunction(torch.autograd.Function):
                                               dx.data_ptr() if dx is not None else None, n, ws.data_ptr(), ws.numel(),
                                               ctx.drop[0], ctx.drop[1], torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "rrt_encoder_backward_f32")
-        ctx.stash = None
-        return (None, dx) + tuple(grads)
+        return (None, dx) + tuple(grads)      # (the stash lives as long as the graph node: retain_graph works)
 
 
 class RRTEncoder(nn.Module):

@@ -912,6 +912,16 @@ def test_encoder_backward_matches_autograd(case):
         rel(prm.grad.cpu().numpy(), ref.numpy().reshape(prm.shape), name)
     # eval() never records a graph
     assert enc.eval()(xd.unsqueeze(0)).grad_fn is None
+    if case == "default_n1500":
+        # a second backward through a retained graph gives the same gradients again (accumulated: x2)
+        enc.train()
+        enc.zero_grad(set_to_none=True)
+        y2 = enc(xd.unsqueeze(0)).squeeze(0)
+        loss = (y2 * dev(G)).sum()
+        loss.backward(retain_graph=True)
+        g1 = enc.norm.weight.grad.clone()
+        loss.backward()
+        assert torch.allclose(enc.norm.weight.grad, 2 * g1, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("case,p", [("default_n1500", 0.1), ("c16_n2600", 0.25), ("nsclc_layers3_n900", 0.1),
