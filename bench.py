@@ -168,7 +168,8 @@ def main():
     # bags in flight on different streams share a phase gate: their MFMA-bound R-MSA cores take turns
     # instead of time-slicing the matrix pipes, and the other bag's memory-bound kernels fill the gaps
     gate = C.c_void_p()
-    if S > 1 and os.environ.get("RRT_BENCH_GATE", "1") != "0":
+    if (S == 2 or os.environ.get("RRT_BENCH_GATE") == "1") and os.environ.get("RRT_BENCH_GATE", "1") != "0":
+        # (the gate pays at two bags in flight; with three or more, free-running streams are faster -- DESIGN.md §5)
         _lib.check(lib.rrt_phase_gate_create(C.byref(gate)), "phase gate")
 
     def step(i, timed):
