@@ -215,8 +215,12 @@ __global__ __launch_bounds__(256) void crmsa_bwd_region_kernel(const float* __re
         const float dc = dC[base + (size_t)p * k + n];
         Cw[base + (size_t)p * k + n] = c;
         dlg[base + (size_t)p * k + n] = c * (dc - s_sc[n]) + dk[n] * (ddk[n] - sd) + dM / den;
-        dmn[n] += dM * (v[n] - s_mx[n] - 1e-8f) / (den * den);
-        dmx[n] -= dM * (v[n] - s_mn[n]) / (den * den);
+        // d/d mn = -1/den + (Lg - mn)/den^2 in THIS form (as autograd decomposes the quotient): at the arg-min slot
+        // the -dM/den term cancels the direct dM/den exactly -- with one-token regions den = 1e-8 and the
+        // simplified (Lg - mx - eps)/den^2 left O(10 dM) of rounding garbage behind
+        const float t2 = dM * (v[n] - s_mn[n]) / (den * den);
+        dmn[n] += t2 - dM / den;
+        dmx[n] -= t2;
       }
   }
 #pragma unroll

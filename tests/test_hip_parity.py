@@ -857,6 +857,14 @@ TRAIN_CASES = {
     "nsclc_layers3_n900": (900, dict(mlp_dim=512, epeg_k=21, crmsa_k=5, n_layers=3)),
     "noepeg_nobias_n500": (500, dict(mlp_dim=512, epeg=False, qkv_bias=False)),
     "d256_n333": (333, dict(mlp_dim=256, n_heads=4, crmsa_heads=4, epeg_k=9)),
+    # edge geometry: one-token regions, a single token, pads outnumbering tokens, region_num 4, the "give up region
+    # attention" branch (one region = the whole bag), region_size override
+    "edge_n50_p1": (50, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),
+    "edge_n1": (1, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),
+    "edge_n65": (65, dict(mlp_dim=512, epeg_k=15, crmsa_k=5)),
+    "edge_rn4_n777": (777, dict(mlp_dim=512, epeg_k=9, crmsa_k=3, region_num=4)),
+    "edge_minnum_n90": (90, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, min_region_num=100)),
+    "edge_rs5_n500": (500, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_size=5)),
     "p169_n10000": (10000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 169 tokens (MT = 11)
     "p256_n15000": (15000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 256 tokens: streaming
     "brca_r50_heads1_n2000": (2000, dict(mlp_dim=512, epeg_k=17, crmsa_k=3, crmsa_heads=1)),   # README.md:98
@@ -894,9 +902,15 @@ def test_encoder_backward_matches_autograd(case):
     (y * dev(G)).sum().backward()
     torch.cuda.synchronize()
 
+    # gradients that are mathematically zero (e.g. every score-path gradient when a region holds one token: the
+    # softmax over a single key is constant) come out as fp32 rounding noise: the error floor is relative to the
+    # largest gradient of the whole model, not to the (vanishing) tensor itself
+    floor = 1e-3 * max([float(x_leaf.grad.abs().max())] + [float(v.grad.abs().max()) for v in params.values()
+                                                           if v.grad is not None])
+
     def rel(got, ref, what):
         ref = ref.astype(np.float64)
-        scale = max(np.abs(ref).max(), 1e-6)
+        scale = max(np.abs(ref).max(), floor, 1e-6)
         err = np.abs(got.astype(np.float64) - ref).max() / scale
         assert np.isfinite(got).all(), what
         assert err <= 2e-3, f"{case} {what}: max error {err:.2e} of the largest gradient entry"
