@@ -865,6 +865,11 @@ TRAIN_CASES = {
     "edge_rn4_n777": (777, dict(mlp_dim=512, epeg_k=9, crmsa_k=3, region_num=4)),
     "edge_minnum_n90": (90, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, min_region_num=100)),
     "edge_rs5_n500": (500, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_size=5)),
+    "edge_k31_n130": (130, dict(mlp_dim=512, epeg_k=31, crmsa_k=1)),                 # taps far wider than the 4-token regions
+    "edge_crk8_n400": (400, dict(mlp_dim=512, epeg_k=15, crmsa_k=8)),
+    "edge_crmsa_only_sc_n300": (300, dict(mlp_dim=512, n_layers=1, crmsa_k=3, all_shortcut=True)),
+    "edge_rn16_n2000": (2000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=16)),
+    "edge_d1024_n300": (300, dict(mlp_dim=1024, n_heads=16, crmsa_heads=16, epeg_k=15, crmsa_k=3)),
     "p169_n10000": (10000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 169 tokens (MT = 11)
     "p256_n15000": (15000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 256 tokens: streaming
     "brca_r50_heads1_n2000": (2000, dict(mlp_dim=512, epeg_k=17, crmsa_k=3, crmsa_heads=1)),   # README.md:98
@@ -1026,4 +1031,18 @@ def test_rrtmil_learns_synthetic_task():
     with torch.no_grad():
         correct = sum(int(mil(x.to(dev_)).argmax(-1).item() == y) for x, y in test)
     assert correct >= 8, f"{correct}/10 held-out bags"
+
+
+def test_training_limits_raise():
+    """Outside the built training envelope the call raises (no silent fallback): R-MSA head dim != 64, dim > 1024,
+    PEG / PPEG."""
+    from rrt_mil_amd import RRTEncoder
+    x = torch.randn(1, 200, 64, device="cuda:0", requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        RRTEncoder(mlp_dim=64, drop_out=0.).to("cuda:0").train()(x)                 # head dim 8
+    x = torch.randn(1, 200, 512, device="cuda:0", requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        RRTEncoder(mlp_dim=512, pos="ppeg", pos_pos=-1, drop_out=0.).to("cuda:0").train()(x)
+    with pytest.raises(NotImplementedError):
+        RRTEncoder(mlp_dim=2048, n_heads=32, crmsa_heads=32).to("cuda:0").train()(torch.randn(1, 64, 2048, device="cuda:0"))
 
