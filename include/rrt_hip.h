@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 12
+#define RRT_ABI_VERSION 13
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -335,6 +335,7 @@ typedef struct rrt_encoder_grads {
   float *phi;                  /* [dim, crmsa_k]                              (crmsa_mlp = 0) */
   float *phi0_w, *phi2_w;      /* [dim/4, dim], [crmsa_k, dim/4]              (crmsa_mlp = 1) */
   float *norm;                 /* [2, dim] final LayerNorm */
+  float *pos_w[3], *pos_b[3];  /* pos_embedding.proj / proj1 / proj2 (pos != none) */
 } rrt_encoder_grads;
 
 int rrt_encoder_train_sizes(const rrt_encoder_desc *desc, int64_t n_tokens, size_t *stash_bytes,

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _f32p = C.POINTER(C.c_float)
 
@@ -51,7 +51,8 @@ class AttnGrads(C.Structure):
 
 class EncoderGrads(C.Structure):
     _fields_ = [("rmsa", AttnGrads * RRT_MAX_RMSA_LAYERS), ("crmsa", AttnGrads), ("phi", C.c_void_p),
-                ("phi0_w", C.c_void_p), ("phi2_w", C.c_void_p), ("norm", C.c_void_p)]
+                ("phi0_w", C.c_void_p), ("phi2_w", C.c_void_p), ("norm", C.c_void_p),
+                ("pos_w", C.c_void_p * 3), ("pos_b", C.c_void_p * 3)]
 
 
 class MilDesc(C.Structure):

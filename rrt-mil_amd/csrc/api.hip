@@ -886,7 +886,7 @@ struct Stash {
   // ffn = 1: per TransLayer (index n_rmsa_layers = CR-MSA's) LN2 output, fc1 pre-activation, layer output;
   // xcr = CR-MSA's output before its FFN; hscr = one scratch for act(hpre)
   float *ffn_u[RRT_MAX_RMSA_LAYERS + 1], *ffn_hpre[RRT_MAX_RMSA_LAYERS + 1], *xf[RRT_MAX_RMSA_LAYERS + 1];
-  float *xcr, *hscr;
+  float *xcr, *hscr, *xp;     // xp: output of the PEG / PPEG stage (pos != none)
   size_t bytes;
 };
 
@@ -931,6 +931,7 @@ Stash carve_stash(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const
     if (d.cr_msa) s.xcr = take((size_t)N * D);
     s.hscr = take((size_t)N * d.ffn_hidden);
   }
+  if (d.pos) s.xp = take((size_t)N * D);
   s.bytes = off;
   return s;
 }
@@ -938,7 +939,7 @@ Stash carve_stash(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const
 struct BwdWs {
   float *dx2, *dxa, *dxb, *dz, *dO, *dqkv, *lnpart, *attnpart, *dWd, *dC, *dlg, *Cw, *d_rep2, *d_rep_o,
       *d_rep_qkv, *d_rep, *rows, *dxpart, *th, *dhid, *dvphi, *w1t, *tnscratch, *fh, *fdh, *fdu;
-  char* lin;
+  char *lin, *pegws;
   size_t bytes;
 };
 
@@ -1001,6 +1002,7 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     if (f2 > lin) lin = f2;
   }
   w.lin = takeb(lin ? lin : 256);
+  if (d.pos) w.pegws = takeb(peg_bwd_workspace((int)N, (int)D, d.peg_k, d.pos == RRT_POS_PPEG));
   w.bytes = off;
   return w;
 }
@@ -1008,7 +1010,6 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
 int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8) {
   int rc = check_desc(d, N);
   if (rc) return rc;
-  if (d->pos) return unsupported("training: pos='peg'/'ppeg' is not built");
   if (d->compute != RRT_COMPUTE_F32) return unsupported("training: fp32 only");
   if (d->dim > 1024) return unsupported("training: dim > 1024");
   memset(g, 0, sizeof(*g));
@@ -1114,7 +1115,17 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     return (int)launch_linear(s.hscr, lw.fc2_w, s.xf[idx], (int)N, D, desc->ffn_hidden, e2, st);
   };
   const float* xin = x;
+  const bool pos_first = desc->pos && desc->pos_pos == -1, pos_mid = desc->pos && desc->pos_pos == 0;
+  if (desc->pos && (!w->pos_w[0] || (desc->pos == RRT_POS_PPEG && (!w->pos_w[1] || !w->pos_w[2])))) return RRT_E_INVALID;
+  if (pos_first) {
+    RRT_TRY(launch_peg(xin, w->pos_w, w->pos_b, s.xp, (int)N, D, desc->peg_k, desc->peg_1d, desc->pos == RRT_POS_PPEG, st));
+    xin = s.xp;
+  }
   for (int li = 0; li < desc->n_rmsa_layers; ++li) {
+    if (pos_mid && li == 1) {
+      RRT_TRY(launch_peg(xin, w->pos_w, w->pos_b, s.xp, (int)N, D, desc->peg_k, desc->peg_1d, desc->pos == RRT_POS_PPEG, st));
+      xin = s.xp;
+    }
     const rrt_attn_weights& lw = w->rmsa[li];
     if (!lw.norm_w || !lw.norm_b || !lw.qkv_w || !lw.proj_w || !lw.proj_b) return RRT_E_INVALID;
     if (desc->epeg && !lw.pe_w) return RRT_E_INVALID;
@@ -1248,6 +1259,20 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     cur = nxt;
     return RRT_OK;
   };
+  // PEG / PPEG backward: d(stage output) in `cur` -> d(stage input) in the other buffer, plus the convs' gradients
+  auto peg_backward = [&](const float* xstage_in) -> int {
+    const bool ppeg = desc->pos == RRT_POS_PPEG;
+    for (int i = 0; i < (ppeg ? 3 : 1); ++i)
+      if (!gr->pos_w[i] || (w->pos_b[i] && !gr->pos_b[i])) return RRT_E_INVALID;
+    float* nxt = (cur == b.dxa) ? b.dxb : b.dxa;
+    float* dbp[3] = {w->pos_b[0] ? gr->pos_b[0] : nullptr, w->pos_b[1] ? gr->pos_b[1] : nullptr,
+                     w->pos_b[2] ? gr->pos_b[2] : nullptr};
+    hipError_t pe = launch_peg_backward(xstage_in, cur, w->pos_w, nxt, gr->pos_w, dbp, N, D, desc->peg_k,
+                                        desc->peg_1d, ppeg, b.pegws, st);
+    if (pe != hipSuccess) return (int)pe;
+    cur = nxt;
+    return RRT_OK;
+  };
   if (desc->cr_msa && desc->ffn) {
     rc = ffn_backward(w->crmsa, gr->crmsa, s.xcr, RRT_MAX_RMSA_LAYERS);
     if (rc) return rc;
@@ -1259,7 +1284,7 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     if (desc->crmsa_mlp ? (!gr->phi0_w || !gr->phi2_w) : !gr->phi) return RRT_E_INVALID;
     const GridDev gd8 = to_dev(g8);
     const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
-    const float* x1 = L > 0 ? (desc->ffn ? s.xf[L - 1] : s.xout[L - 1]) : x;
+    const float* x1 = L > 0 ? (desc->ffn ? s.xf[L - 1] : s.xout[L - 1]) : (desc->pos && desc->pos_pos == -1 ? s.xp : x);
     const float* up = cur;                                   // d x2 (after the FFN backward when ffn = 1)
     float* dx1 = (cur == b.dxa) ? b.dxb : b.dxa;
     RRT_TRY(launch_crmsa_tokdot(up, nullptr, nullptr, nullptr, s.rep2, b.dWd, D, k, gd8, st));
@@ -1301,7 +1326,9 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     if (!lg.norm || !lg.qkv_w || !lg.proj_w || !lg.proj_b || (lw.qkv_b && !lg.qkv_b) || (desc->epeg && !lg.pe_w))
       return RRT_E_INVALID;
     const GridDev gd = to_dev(g);
-    const float* xin = li > 0 ? (desc->ffn ? s.xf[li - 1] : s.xout[li - 1]) : x;
+    const bool pos_in = desc->pos && ((desc->pos_pos == -1 && li == 0) || (desc->pos_pos == 0 && li == 1));
+    const float* xprev = li > 0 ? (desc->ffn ? s.xf[li - 1] : s.xout[li - 1]) : x;   // before a PEG stage, if any
+    const float* xin = pos_in ? s.xp : xprev;
     if (desc->ffn) {
       rc = ffn_backward(lw, lg, s.xout[li], li);
       if (rc) return rc;
@@ -1316,6 +1343,14 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     float* nxt = (cur == b.dxa) ? b.dxb : b.dxa;
     RRT_TRY(launch_ln_backward(b.dz, xin, lw.norm_w, cur, nxt, lg.norm, b.lnpart, N, D, &gd, st));
     cur = nxt;
+    if (pos_in) {
+      rc = peg_backward(xprev);
+      if (rc) return rc;
+    }
+  }
+  if (desc->pos && desc->pos_pos == -1 && L == 0) {       // no R-MSA layer: the PEG stage feeds CR-MSA directly
+    rc = peg_backward(x);
+    if (rc) return rc;
   }
   if (dx) RRT_TRY(launch_layernorm(cur, desc->all_shortcut ? b.dx2 : nullptr, nullptr, nullptr, dx, N, D, st));
 #undef RRT_TRY

@@ -113,3 +113,6 @@ hipError_t launch_copy_drop_mask(const float* src, float* dst, size_t n, unsigne
 // PEG / PPEG positional encoders (peg.hip): y [N, C] = stencil over the wrapped H x H token grid
 hipError_t launch_peg(const float* x, const float* const* w, const float* const* b, float* y, int N, int C, int k,
                       int conv_1d, int ppeg, hipStream_t st);
+size_t peg_bwd_workspace(int N, int C, int k, int ppeg);
+hipError_t launch_peg_backward(const float* x, const float* dy, const float* const* w, float* dx, float* const* dw,
+                               float* const* db, int N, int C, int k, int conv_1d, int ppeg, void* ws, hipStream_t st);

@@ -357,6 +357,22 @@ class RRTEncoder(nn.Module):
                 gphi = torch.empty_like(self.cr_msa.attn.phi)
                 by_name["cr_msa.attn.phi"] = gphi
                 gs.phi = gphi.data_ptr()
+        if self._desc.pos:
+            for i, name in enumerate(("proj", "proj1", "proj2")):
+                conv = getattr(self.pos_embedding, name, None)
+                if conv is None:
+                    continue
+                gw = torch.empty_like(conv.weight)
+                by_name[f"pos_embedding.{name}.weight"] = gw
+                gs.pos_w[i] = gw.data_ptr()
+                if conv.bias is not None:
+                    gb = torch.empty_like(conv.bias)
+                    by_name[f"pos_embedding.{name}.bias"] = gb
+                    gs.pos_b[i] = gb.data_ptr()
+        elif not isinstance(self.pos_embedding, nn.Identity):
+            # constructed but never applied (pos_pos outside {-1, 0}): zero gradients, as autograd would leave None
+            for name, prm in self.pos_embedding.named_parameters():
+                by_name["pos_embedding." + name] = torch.zeros_like(prm)
         grads = [by_name[name] for name, _ in self.named_parameters()]
         self._keep_grads = by_name          # the struct holds raw pointers: keep the tensors alive through the call
         return grads, gs

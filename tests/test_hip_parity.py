@@ -870,6 +870,12 @@ TRAIN_CASES = {
     "edge_crmsa_only_sc_n300": (300, dict(mlp_dim=512, n_layers=1, crmsa_k=3, all_shortcut=True)),
     "edge_rn16_n2000": (2000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=16)),
     "edge_d1024_n300": (300, dict(mlp_dim=1024, n_heads=16, crmsa_heads=16, epeg_k=15, crmsa_k=3)),
+    "pos_ppeg_first_n900": (900, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, pos="ppeg", pos_pos=-1)),
+    "pos_peg_mid_n700": (700, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, pos="peg", pos_pos=0, n_layers=3)),
+    "pos_peg1d_k5_nobias_n400": (400, dict(mlp_dim=512, crmsa_k=3, pos="peg", pos_pos=-1, peg_1d=True, peg_k=5,
+                                           peg_bias=False)),
+    "pos_ppeg_tiny_n30": (30, dict(mlp_dim=512, crmsa_k=3, pos="ppeg", pos_pos=-1)),
+    "pos_ppeg_crmsa_only_n500": (500, dict(mlp_dim=512, n_layers=1, pos="ppeg", pos_pos=-1, peg_k=3)),
     "p169_n10000": (10000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 169 tokens (MT = 11)
     "p256_n15000": (15000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3)),          # regions of 256 tokens: streaming
     "brca_r50_heads1_n2000": (2000, dict(mlp_dim=512, epeg_k=17, crmsa_k=3, crmsa_heads=1)),   # README.md:98
@@ -890,7 +896,8 @@ def test_encoder_backward_matches_autograd(case):
     N, cfg = TRAIN_CASES[case]
     D = cfg["mlp_dim"]
     st = synth.encoder_state(**{k: v for k, v in cfg.items() if k in ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k",
-                                                                      "cr_msa", "crmsa_k", "qkv_bias", "crmsa_mlp", "ffn", "mlp_ratio")})
+                                                                      "cr_msa", "crmsa_k", "qkv_bias", "crmsa_mlp", "ffn", "mlp_ratio", "pos", "peg_k",
+                                                                      "peg_1d", "peg_bias")})
     x = synth.bag(N, D, tag="train/" + case)
     G = synth.normal("train/G/" + case, (N, D))
     # oracle
@@ -1035,14 +1042,12 @@ def test_rrtmil_learns_synthetic_task():
 
 def test_training_limits_raise():
     """Outside the built training envelope the call raises (no silent fallback): R-MSA head dim != 64, dim > 1024,
-    PEG / PPEG."""
+    (PEG / PPEG train, see the pos_* cases above)."""
     from rrt_mil_amd import RRTEncoder
     x = torch.randn(1, 200, 64, device="cuda:0", requires_grad=True)
     with pytest.raises(NotImplementedError):
         RRTEncoder(mlp_dim=64, drop_out=0.).to("cuda:0").train()(x)                 # head dim 8
     x = torch.randn(1, 200, 512, device="cuda:0", requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        RRTEncoder(mlp_dim=512, pos="ppeg", pos_pos=-1, drop_out=0.).to("cuda:0").train()(x)
     with pytest.raises(NotImplementedError):
         RRTEncoder(mlp_dim=2048, n_heads=32, crmsa_heads=32).to("cuda:0").train()(torch.randn(1, 64, 2048, device="cuda:0"))
 
