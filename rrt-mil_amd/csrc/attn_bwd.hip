@@ -381,12 +381,14 @@ hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, co
   static const bool six = getenv("RRT_ATTN_BWD_NW6") != nullptr;     // tuning hook (A/B of the two schedules)
   if (MT >= 11 && !six) {           // measured: 9 tiles 221 (6 waves) vs 241 us; 11: 350 vs 291; 13: 516 vs 400
     auto kern = attn_bwd_kernel<MT, 4>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    static OncePerDevice once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     kern<<<dim3(n_regions * heads), dim3(256), LDS, st>>>(qkv, pe_w, O, dO, dqkv, dpe_part, P, D, heads,
                                                           pe_w ? epeg_k : 0, q_scale);
   } else {
     auto kern = attn_bwd_kernel<MT, 6>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    static OncePerDevice once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     kern<<<dim3(n_regions * heads), dim3(384), LDS, st>>>(qkv, pe_w, O, dO, dqkv, dpe_part, P, D, heads,
                                                           pe_w ? epeg_k : 0, q_scale);
   }
@@ -809,8 +811,11 @@ hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const 
     attn_stencil_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(qkv, pe_w, qt, P, D, heads, epeg_k, (long)rows);
     const int groups = (P + 95) / 96;
     const size_t lq = (size_t)2 * CK * HD * sizeof(float), lkv = lq + 2 * CK * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lkv);
+    static OncePerDevice once;
+    if (once.first()) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lkv);
+    }
     attn_bwd_q_kernel<<<dim3(heads, n_regions, groups), 384, lq, st>>>(qkv, qt, O, dO, dqkv, lse_g, dd_g, P, D, heads);
     attn_bwd_kv_kernel<<<dim3(heads, n_regions, groups), 384, lkv, st>>>(qkv, qt, dO, lse_g, dd_g, dqkv, P, D, heads);
     attn_adjoint_kernel<<<dim3(heads, n_regions), 256, 0, st>>>(qkv, pe_w, dqkv, tmp, dpe_part, P, D, heads, epeg_k,

@@ -6,6 +6,20 @@
 
 GridDev to_dev(const rrt_grid& g);
 
+// "Raise the dynamic-LDS cap of this kernel" has to happen once per DEVICE (the attribute lives in the device's
+// context): a process that drives two GPUs would otherwise fail its first > 64 KiB launch on the second one.
+struct OncePerDevice {
+  bool seen[64] = {};
+  bool first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    if (seen[d]) return false;
+    seen[d] = true;      // benign race: the attribute call is idempotent
+    return true;
+  }
+};
+
 hipError_t launch_ln_partition(const float* x, const float* gamma, const float* beta, float* u,
                                int dim, const GridDev& g, hipStream_t st);
 

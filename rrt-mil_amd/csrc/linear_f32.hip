@@ -602,11 +602,9 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
     if (use_ws) {
       auto kws = linear_ws_kernel<MT, NT, MODE, PREC>;
       if (LDS_BYTES > 64 * 1024) {
-        static bool donew = false;
-        if (!donew) {
+        static OncePerDevice once;
+        if (once.first())
           (void)hipFuncSetAttribute((const void*)kws, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-          donew = true;
-        }
       }
       kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
       return hipGetLastError();
@@ -614,11 +612,9 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
   }
   auto kern = linear_kernel<MT, NT, MODE, PREC>;
   if (LDS_BYTES > 64 * 1024) {
-    static bool done = false;   // benign race: idempotent attribute
-    if (!done) {
+    static OncePerDevice once;
+    if (once.first())
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      done = true;
-    }
   }
   kern<<<dim3(grid), dim3(256), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
   return hipGetLastError();

@@ -382,11 +382,9 @@ hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const
   constexpr size_t LDS = (STG > QKV ? STG : QKV);   // staging ring, then the Q/K/V tiles (Q~ in place)
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = rmsa_fused_kernel<MT, PREC>;
-  static bool done = false;
-  if (!done) {
+  static OncePerDevice once;
+  if (once.first())
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-    done = true;
-  }
   const float q_scale = 1.0f / sqrtf((float)HD);
   kern<<<dim3(heads * n_regions), dim3(384), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D, heads,
                                                       pe_w ? epeg_k : 0, q_scale);
