@@ -1010,7 +1010,6 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
 int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8) {
   int rc = check_desc(d, N);
   if (rc) return rc;
-  if (d->compute != RRT_COMPUTE_F32) return unsupported("training: fp32 only");
   if (d->dim > 1024) return unsupported("training: dim > 1024");
   memset(g, 0, sizeof(*g));
   if (d->n_rmsa_layers > 0) {
@@ -1098,6 +1097,7 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     hipError_t fe = launch_layernorm(xi, nullptr, lw.norm2_w, lw.norm2_b, s.ffn_u[idx], (int)N, D, st);
     if (fe != hipSuccess) return (int)fe;
     LinearEpilogue e1{};
+    e1.prec = desc->compute;
     e1.bias = lw.fc1_b;
     fe = launch_linear(s.ffn_u[idx], lw.fc1_w, s.ffn_hpre[idx], (int)N, desc->ffn_hidden, D, e1, st);
     if (fe != hipSuccess) return (int)fe;
@@ -1132,6 +1132,7 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     const GridDev gd = to_dev(g);
     RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, s.u[li], D, gd, st));
     LinearEpilogue ep{};
+    ep.prec = desc->compute;
     ep.bias = lw.qkv_b;
     ep.q_cols = D;
     ep.q_scale = 1.0f / sqrtf((float)(D / desc->n_heads));
@@ -1145,6 +1146,7 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     ep2.drop_thresh = dc.thresh;
     ep2.drop_scale = dc.scale;
     ep2.drop_seed = dc.seed(drop_seed, li);
+    ep2.prec = dc.thresh ? RRT_COMPUTE_F32 : desc->compute;      // the dropout epilogue exists in fp32 only
     RRT_TRY(launch_linear(s.o[li], lw.proj_w, s.xout[li], gd.Np, D, D, ep2, st));
     xin = s.xout[li];
     if (desc->ffn) {
@@ -1167,6 +1169,7 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
       RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi0_w, s.mean_rstd, s.logits, D, k, gd8, st));
       RRT_TRY(launch_ln_partition(xin, cw.norm_w, cw.norm_b, s.v8, D, gd8, st));
       LinearEpilogue e0{};
+      e0.prec = desc->compute;
       RRT_TRY(launch_linear(s.v8, w->phi0_w, s.hid, gd8.Np, D / 4, D, e0, st));
       RRT_TRY(launch_crmsa_mlp_logits(s.hid, w->phi2_w, s.logits, gd8.Np, D / 4, k, st));
       RRT_TRY(launch_crmsa_combine(s.v8, nullptr, nullptr, nullptr, s.logits, s.wdisp, s.rep, D, k, gd8, st));
@@ -1175,6 +1178,7 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
       RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, s.mean_rstd, s.logits, s.wdisp, s.rep, D, k, gd8, st));
     }
     LinearEpilogue ep{};
+    ep.prec = desc->compute;
     ep.bias = cw.qkv_b;
     ep.q_cols = D;
     ep.q_scale = 1.0f / sqrtf((float)(D / desc->crmsa_heads));
@@ -1185,6 +1189,7 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     ep2.drop_thresh = dc.thresh;
     ep2.drop_scale = dc.scale;
     ep2.drop_seed = dc.seed(drop_seed, DROP_LAYER_CRMSA);
+    ep2.prec = dc.thresh ? RRT_COMPUTE_F32 : desc->compute;
     RRT_TRY(launch_linear(s.rep_o, cw.proj_w, s.rep2, k * R8, D, D, ep2, st));
     if (desc->ffn) {
       // CR-MSA's TransLayer: x1 + dispatch -> xcr, FFN -> xf, then the shortcut, then the final LayerNorm
@@ -1246,12 +1251,12 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
       if (fe != hipSuccess) return (int)fe;
       dyf = b.fdu;
     }
-    fe = launch_linear_backward(dyf, b.fh, lw.fc2_w, b.fdh, lg.fc2_w, lg.fc2_b, N, D, Hd, 0, b.lin, st);
+    fe = launch_linear_backward(dyf, b.fh, lw.fc2_w, b.fdh, lg.fc2_w, lg.fc2_b, N, D, Hd, desc->compute, b.lin, st);
     if (fe != hipSuccess) return (int)fe;
     fe = launch_act_backward(b.fdh, s.ffn_hpre[idx], (size_t)N * Hd, desc->ffn_act, dc.thresh,
                              dc.seed(drop_seed, 200 + 2 * idx), dc.scale, st);
     if (fe != hipSuccess) return (int)fe;
-    fe = launch_linear_backward(b.fdh, s.ffn_u[idx], lw.fc1_w, b.fdu, lg.fc1_w, lg.fc1_b, N, Hd, D, 0, b.lin, st);
+    fe = launch_linear_backward(b.fdh, s.ffn_u[idx], lw.fc1_w, b.fdu, lg.fc1_w, lg.fc1_b, N, Hd, D, desc->compute, b.lin, st);
     if (fe != hipSuccess) return (int)fe;
     float* nxt = (cur == b.dxa) ? b.dxb : b.dxa;
     fe = launch_ln_backward(b.fdu, xi, lw.norm2_w, cur, nxt, lg.norm2, b.lnpart, N, D, nullptr, st);
@@ -1290,11 +1295,11 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     RRT_TRY(launch_crmsa_tokdot(up, nullptr, nullptr, nullptr, s.rep2, b.dWd, D, k, gd8, st));
     RRT_TRY(launch_crmsa_wsum(up, s.wdisp, b.d_rep2, D, k, gd8, st));
     RRT_TRY(launch_apply_drop_mask(b.d_rep2, k * R8, D, dc.thresh, dc.seed(drop_seed, DROP_LAYER_CRMSA), dc.scale, st));
-    RRT_TRY(launch_linear_backward(b.d_rep2, s.rep_o, cw.proj_w, b.d_rep_o, cg.proj_w, cg.proj_b, k * R8, D, D, 0,
+    RRT_TRY(launch_linear_backward(b.d_rep2, s.rep_o, cw.proj_w, b.d_rep_o, cg.proj_w, cg.proj_b, k * R8, D, D, desc->compute,
                                    b.lin, st));
     RRT_TRY(launch_attention_backward(s.rep_qkv, nullptr, s.rep_o, b.d_rep_o, b.d_rep_qkv, nullptr, b.attnpart, k,
                                       R8, D, desc->crmsa_heads, 0, st));
-    RRT_TRY(launch_linear_backward(b.d_rep_qkv, s.rep, cw.qkv_w, b.d_rep, cg.qkv_w, cg.qkv_b, k * R8, 3 * D, D, 0,
+    RRT_TRY(launch_linear_backward(b.d_rep_qkv, s.rep, cw.qkv_w, b.d_rep, cg.qkv_w, cg.qkv_b, k * R8, 3 * D, D, desc->compute,
                                    b.lin, st));
     RRT_TRY(launch_crmsa_tokdot(x1, s.mean_rstd, cw.norm_w, cw.norm_b, b.d_rep, b.dC, D, k, gd8, st));
     RRT_TRY(launch_crmsa_bwd_region(s.logits, b.dC, b.dWd, b.dlg, b.Cw, k, gd8, st));
@@ -1308,6 +1313,7 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
       RRT_TRY(launch_gemm_tn(b.dhid, s.v8, gr->phi0_w, b.tnscratch, gd8.Np, hdim, D, st));         // dW1 [D/4, D]
       RRT_TRY(launch_transpose(w->phi0_w, b.w1t, hdim, D, st));                                    // W1^T [D, D/4]
       LinearEpilogue ev{};
+      ev.prec = desc->compute;
       RRT_TRY(launch_linear(b.dhid, b.w1t, b.dvphi, gd8.Np, D, hdim, ev, st));                     // d v_phi = d hid . W1
       RRT_TRY(launch_crmsa_bwd_dx(x1, up, s.mean_rstd, cw.norm_w, cw.norm_b, b.dvphi, b.Cw, b.dlg, b.d_rep, dx1,
                                   b.rows, b.dxpart, D, k, gd8, true, st));
@@ -1334,11 +1340,11 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
       if (rc) return rc;
     }
     RRT_TRY(launch_partition_rows(cur, b.dz, D, gd, dc.thresh, dc.seed(drop_seed, li), dc.scale, st));
-    RRT_TRY(launch_linear_backward(b.dz, s.o[li], lw.proj_w, b.dO, lg.proj_w, lg.proj_b, gd.Np, D, D, 0, b.lin, st));
+    RRT_TRY(launch_linear_backward(b.dz, s.o[li], lw.proj_w, b.dO, lg.proj_w, lg.proj_b, gd.Np, D, D, desc->compute, b.lin, st));
     RRT_TRY(launch_attention_backward(s.qkv[li], desc->epeg ? lw.pe_w : nullptr, s.o[li], b.dO, b.dqkv,
                                       desc->epeg ? lg.pe_w : nullptr, b.attnpart, gd.rs * gd.rs, gd.P, D,
                                       desc->n_heads, desc->epeg ? desc->epeg_k : 0, st));
-    RRT_TRY(launch_linear_backward(b.dqkv, s.u[li], lw.qkv_w, b.dz, lg.qkv_w, lg.qkv_b, gd.Np, 3 * D, D, 0, b.lin,
+    RRT_TRY(launch_linear_backward(b.dqkv, s.u[li], lw.qkv_w, b.dz, lg.qkv_w, lg.qkv_b, gd.Np, 3 * D, D, desc->compute, b.lin,
                                    st));                                       // dU -> dz (dead)
     float* nxt = (cur == b.dxa) ? b.dxb : b.dxa;
     RRT_TRY(launch_ln_backward(b.dz, xin, lw.norm_w, cur, nxt, lg.norm, b.lnpart, N, D, &gd, st));

@@ -169,7 +169,9 @@ class _EncoderFunction(torch.autograd.Function):
     def forward(ctx, enc, x2d, *params):
         lib = _lib.load()
         n = x2d.shape[0]
-        enc._desc.compute = _lib.COMPUTE_F32
+        # under autocast (the reference's --amp training) the GEMMs round their operands to bf16 / fp16 like the
+        # inference path does; accumulation, every other kernel and the weight gradients stay fp32
+        enc._desc.compute = enc._compute_mode()
         stash_b, ws_b = C.c_size_t(), C.c_size_t()
         _lib.check(lib.rrt_encoder_train_sizes(C.byref(enc._desc), n, C.byref(stash_b), C.byref(ws_b)),
                    "rrt_encoder_train_sizes")
@@ -185,7 +187,7 @@ class _EncoderFunction(torch.autograd.Function):
                                                    stash.data_ptr(), stash.numel(), drop_p, seed,
                                                    torch.cuda.current_stream(x2d.device).cuda_stream)
         _lib.check(rc, "rrt_encoder_forward_train_f32")
-        ctx.enc, ctx.stash, ctx.ws_bytes, ctx.drop = enc, stash, ws_b.value, (drop_p, seed)
+        ctx.enc, ctx.stash, ctx.ws_bytes, ctx.drop, ctx.compute = enc, stash, ws_b.value, (drop_p, seed), enc._desc.compute
         ctx.save_for_backward(x2d)
         return y
 
@@ -200,6 +202,7 @@ class _EncoderFunction(torch.autograd.Function):
         dx = torch.empty_like(x2d) if ctx.needs_input_grad[1] else None
         ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=dev)
         w = enc._weights()
+        enc._desc.compute = ctx.compute
         with torch.cuda.device(dev):
             rc = lib.rrt_encoder_backward_f32(C.byref(enc._desc), C.byref(w), x2d.data_ptr(), dy.data_ptr(),
                                               ctx.stash.data_ptr(), ctx.stash.numel(), C.byref(gstruct),
@@ -515,8 +518,6 @@ class RRTEncoder(nn.Module):
         """One bag with an autograd graph (rrt_encoder_forward_train_f32 / rrt_encoder_backward_f32)."""
         if not x2d.is_cuda:
             raise _lib.RRTHipError("rrt_mil_amd.RRTEncoder runs on MI355X only; there is no CPU fallback")
-        # training arithmetic is fp32 whatever the autocast state (the reference's --amp training gets a superset
-        # of the precision it asked for; GradScaler's scaled loss flows through unchanged)
         x2d = x2d.float().contiguous()
         if x2d.shape[1] != self.final_dim:
             raise ValueError(f"expected feature dim {self.final_dim}, got {x2d.shape[1]}")

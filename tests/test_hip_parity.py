@@ -1051,3 +1051,36 @@ def test_training_limits_raise():
     with pytest.raises(NotImplementedError):
         RRTEncoder(mlp_dim=2048, n_heads=32, crmsa_heads=32).to("cuda:0").train()(torch.randn(1, 64, 2048, device="cuda:0"))
 
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_training_under_autocast(dt):
+    """The reference's --amp training (main.py:101-102,439): under torch.autocast the GEMMs of the training forward and
+    the activation-gradient GEMMs round their operands; gradients stay close to the fp32 oracle's (and differ from
+    the fp32 run, i.e. the mode really is on)."""
+    from hip_util import DEV, dev
+    from rrt_mil_amd import RRTEncoder
+    N, cfg = TRAIN_CASES["default_n1500"]
+    st = synth.encoder_state(mlp_dim=512, epeg_k=15, crmsa_k=3)
+    x = synth.bag(N, 512, tag="train/default_n1500")
+    G = synth.normal("train/G/default_n1500", (N, 512))
+    y64, x_leaf, params = O.forward_eager(x, st, cfg, grad=True)
+    (y64 * torch.from_numpy(G).double()).sum().backward()
+    enc = RRTEncoder(drop_out=0., **cfg)
+    enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    enc = enc.to(DEV).train()
+    xd = dev(x).requires_grad_(True)
+    with torch.autocast("cuda", dtype=dt):
+        y = enc(xd.unsqueeze(0)).squeeze(0)
+    (y.float() * dev(G)).sum().backward()
+    torch.cuda.synchronize()
+    tol = 3e-2 if dt == torch.bfloat16 else 5e-3
+    worst = 0.0
+    for name, got, ref in [("dx", xd.grad, x_leaf.grad)] + [(n_, p_.grad, params[n_].grad.reshape(p_.shape))
+                                                            for n_, p_ in enc.named_parameters()
+                                                            if not n_.endswith("pe.bias")]:
+        ref = ref.numpy().astype(np.float64)
+        err = np.abs(got.float().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-6)
+        worst = max(worst, err)
+        assert err <= tol, f"{name}: {err:.2e}"
+    assert worst > 1e-5          # reduced-precision operands leave a visible (small) difference
+

@@ -25,6 +25,12 @@ def enc_step():
 def enc_fwd():
     with torch.no_grad(): enc(x)
 print(f"encoder N={N}: train step (fwd+bwd) {timeit(enc_step):.3f} ms   inference forward {timeit(enc_fwd):.3f} ms")
+def enc_step_amp():
+    enc.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = enc(x)
+    (y.float() * G).sum().backward()
+print(f"  under bf16 autocast: train step {timeit(enc_step_amp):.3f} ms")
 mem0 = torch.cuda.max_memory_allocated() / 1e6
 print(f"  peak device memory so far {mem0:.0f} MB")
 
