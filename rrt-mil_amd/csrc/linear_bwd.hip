@@ -112,28 +112,50 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
       }
 }
 
-// ---- out[i] = sum_s part[s][i]  (fixed order; 8 independent 16-byte loads in flight per thread -- the plain
-//      dependent loop was a chain of S memory round trips: 131 us for 16 x 3 MB)
+// ---- out[i] = sum_s part[s][i], fixed order (bit-reproducible).  A block owns 256 consecutive elements; its four
+//      waves split the S partials (wave w takes s = w, w + 4, ...) with up to 12 independent 16-byte loads in flight
+//      each, then combine through LDS in wave order.  (The plain per-thread loop was a chain of S memory round
+//      trips: 131 us for 16 x 3 MB; 8 loads in flight: 37 us; this: one or two trips.)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               int S, size_t n) {
-  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
-  if (i + 3 < n && (n & 3) == 0) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < S; s0 += 8) {
-      float4 b[8];
+  __shared__ float4 comb[3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t i = ((size_t)blockIdx.x * 64 + lane) * 4;
+  const bool vec = (n & 3) == 0 && i + 3 < n;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+    if (vec) {
+      for (int s0 = wave; s0 < S; s0 += 48) {
+        float4 b[12];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        b[u] = s0 + u < S ? *(const float4*)(part + (size_t)(s0 + u) * n + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 12; ++u) {
+          const int s = s0 + 4 * u;
+          b[u] = s < S ? *(const float4*)(part + (size_t)s * n + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+        for (int u = 0; u < 12; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+      }
+    } else {
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int s = wave; s < S; s += 4)
+        for (int e = 0; e < 4; ++e)
+          if (i + e < n) t[e] += part[(size_t)s * n + i + e];
+      a = make_float4(t[0], t[1], t[2], t[3]);
     }
-    *(float4*)(out + i) = a;
-  } else {
-    for (size_t e = i; e < n && e < i + 4; ++e) {
-      float a = 0.f;
-      for (int s = 0; s < S; ++s) a += part[(size_t)s * n + e];
-      out[e] = a;
+  }
+  if (wave > 0) comb[wave - 1][lane] = a;
+  __syncthreads();
+  if (wave == 0 && i < n) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const float4 o = comb[w][lane];
+      a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    }
+    if (vec) *(float4*)(out + i) = a;
+    else {
+      const float t[4] = {a.x, a.y, a.z, a.w};
+      for (int e = 0; e < 4; ++e)
+        if (i + e < n) out[i + e] = t[e];
     }
   }
 }
@@ -187,7 +209,7 @@ hipError_t launch_transpose(const float* in, float* out, int R, int C, hipStream
 }
 
 hipError_t launch_reduce_partials(const float* part, float* out, int S, size_t n, hipStream_t st) {
-  reduce_partials_kernel<<<dim3((unsigned)((n + 1023) / 1024)), 256, 0, st>>>(part, out, S, n);
+  reduce_partials_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(part, out, S, n);
   return hipGetLastError();
 }
 
