@@ -419,13 +419,20 @@ __global__ __launch_bounds__(256) void attn_stencil_kernel(const float* __restri
   const int half = epeg_k >> 1;
   const float* w = pe_w + head * epeg_k;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int t = -half; t <= half; ++t) {
-    const int j = i + t;
-    if (j < 0 || j >= P) continue;
-    float wt = epeg_k > 0 ? w[t + half] : 0.f;
-    if (t == 0) wt += 1.0f;
-    const float4 v = *(const float4*)(qkv + (size_t)(row + t) * 3 * D + c);
-    acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
+  for (int t0 = -half; t0 <= half; t0 += 8) {       // 8 independent loads in flight
+    float4 v[8];
+    float wt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + u, j = i + t;
+      const bool ok = t <= half && j >= 0 && j < P;
+      wt[u] = ok ? ((epeg_k > 0 ? w[t + half] : 0.f) + (t == 0 ? 1.0f : 0.f)) : 0.f;
+      v[u] = ok ? *(const float4*)(qkv + (size_t)(row + t) * 3 * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc.x += wt[u] * v[u].x; acc.y += wt[u] * v[u].y; acc.z += wt[u] * v[u].z; acc.w += wt[u] * v[u].w;
+    }
   }
   *(float4*)(qt + (size_t)row * D + c) = make_float4(acc.x * LOG2E, acc.y * LOG2E, acc.z * LOG2E, acc.w * LOG2E);
 }
@@ -635,30 +642,49 @@ __global__ __launch_bounds__(256) void attn_adjoint_kernel(const float* __restri
   __syncthreads();
   for (int i = tid >> 4; i < P; i += 16) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = -half; t <= half; ++t) {          // dq_i = sum_j wt[i - j + half] dQ~_j ,  j = i + t
-      const int j = i + t;
-      if (j < 0 || j >= P) continue;
-      float wt = epeg_k > 0 ? w[half - t] : 0.f;
-      if (t == 0) wt += 1.0f;
-      const float4 v = *(const float4*)(tmp + (row0 + j) * D + head * HD + 4 * s);
-      acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
+    for (int t0 = -half; t0 <= half; t0 += 8) {    // dq_i = sum_j wt[i - j + half] dQ~_j ,  j = i + t ; 8 loads in flight
+      float4 v[8];
+      float wt[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u, j = i + t;
+        const bool ok = t <= half && j >= 0 && j < P;
+        wt[u] = ok ? ((epeg_k > 0 ? w[half - t] : 0.f) + (t == 0 ? 1.0f : 0.f)) : 0.f;
+        v[u] = ok ? *(const float4*)(tmp + (row0 + j) * D + head * HD + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc.x += wt[u] * v[u].x; acc.y += wt[u] * v[u].y; acc.z += wt[u] * v[u].z; acc.w += wt[u] * v[u].w;
+      }
     }
     *(float4*)(dqkv + (row0 + i) * ld + head * HD + 4 * s) =
         make_float4(acc.x * q_scale, acc.y * q_scale, acc.z * q_scale, acc.w * q_scale);
   }
   if (epeg_k > 0) {
-    for (int t = 0; t < epeg_k; ++t) {
-      float acc = 0.f;
-      for (int i = tid >> 4; i < P; i += 16) {
-        const int j = i + t - half;
-        if (j >= 0 && j < P) {
-          const float4 g4 = *(const float4*)(tmp + (row0 + i) * D + head * HD + 4 * s);
-          const float4 q4 = *(const float4*)(qkv + (row0 + j) * ld + head * HD + 4 * s);
-          acc += (g4.x * q4.x + g4.y * q4.y) + (g4.z * q4.z + g4.w * q4.w);
+    // every thread walks its rows once and keeps all tap partials in registers (one pass over dQ~ and k
+    // independent loads of q per row; the tap-by-tap loop was a chain of k passes: 140 us at P = 144)
+    float tacc[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) tacc[t] = 0.f;
+    for (int i = tid >> 4; i < P; i += 16) {
+      const float4 g4 = *(const float4*)(tmp + (row0 + i) * D + head * HD + 4 * s);
+#pragma unroll
+      for (int t = 0; t < 64; ++t) {
+        if (t < epeg_k) {
+          const int j = i + t - half;
+          if (j >= 0 && j < P) {
+            const float4 q4 = *(const float4*)(qkv + (row0 + j) * ld + head * HD + 4 * s);
+            tacc[t] += (g4.x * q4.x + g4.y * q4.y) + (g4.z * q4.z + g4.w * q4.w);
+          }
         }
       }
-      acc = wave_sum(acc);
-      if (lane == 0) wred[wave * 64 + t] = acc;
+    }
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+      if (t < epeg_k) {
+        const float a = wave_sum(tacc[t]);
+        if (lane == 0) wred[wave * 64 + t] = a;
+      }
     }
     __syncthreads();
     if (tid < epeg_k)
