@@ -14,6 +14,19 @@ specification in SURVEY.md §3.3 (not copied from the reference sources):
                        einsum combine/dispatch, .contiguous() region copies).
                        This is what bench.py times as the CPU baseline ("port").
 
+Reduced precision (the reference's --amp path, main.py:101-102,439; BASELINE configs[2..4]):
+
+* ``forward_eager(..., autocast=torch.bfloat16)`` runs the same aten op sequence under
+  ``torch.autocast('cpu', dtype)`` -- torch's own autocast policy (Linear / matmul / conv2d / einsum in
+  the low-precision dtype, softmax on what they hand over, LayerNorm and the residual stream in
+  fp32).  Pinned by the G16 fixtures (the real reference under the same context).
+* ``forward_f64(..., lowp=...)`` states WHERE the HIP path's reduced modes round, in float64 with
+  explicit round-to-nearest-even to bf16 / fp16 of exactly the tensors the kernels store or feed to
+  the matrix cores in 16 bits (the operands of every GEMM; with ``attn=True`` also Q~, K, P and V of
+  the region attention).  Everything else -- accumulation, LayerNorm, softmax, residuals, CR-MSA's
+  logits / combine / dispatch -- is exact.  The GPU tests hold the kernels to this restatement
+  tightly; its distance to the autocast fixtures is what the autocast-class claim rests on.
+
 Parity pin: both are checked against tests/golden/*.npz, which were produced
 by importing the real reference (/root/reference/modules/rrt.py::RRTEncoder,
 torch 2.10.0 CPU) with tools/make_golden.py in the build container.
@@ -81,16 +94,66 @@ def _softmax64(a, axis):
     return e / e.sum(axis=axis, keepdims=True)
 
 
-def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None):
+def round_lowp(a, dtype):
+    """float64 array -> values representable in ``dtype`` ('bf16' | 'f16'), round-to-nearest-even
+    (through float32 first, like a kernel that holds the value in a 32-bit register), as float64."""
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    if dtype in ("f16", "fp16", "float16"):
+        with np.errstate(over="ignore"):
+            return a32.astype(np.float16).astype(np.float64)
+    if dtype not in ("bf16", "bfloat16"):
+        raise ValueError(dtype)
+    u = a32.view(np.uint32).astype(np.uint64)
+    r = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) >> np.uint64(16)) << np.uint64(16)
+    out = (r & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.float32).astype(np.float64)
+    nan = np.isnan(a32)
+    if nan.any():
+        out[nan] = np.nan
+    return out
+
+
+class LowP:
+    """Rounding points of the HIP path's reduced-precision modes (see the module docstring)."""
+
+    def __init__(self, dtype="bf16", attn=True):
+        self.dtype, self.attn = dtype, attn
+
+    def r(self, a):
+        return round_lowp(a, self.dtype)
+
+
+def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None, lowp=None, attn_lowp=None):
     """x: [B_, P, D] -> [B_, P, D]   (modules/rmsa.py:91-134, 'attn' EPEG only)."""
     B_, P, D = x.shape
     hd = D // heads
     W = st[pfx + "qkv.weight"].astype(np.float64)
+    if lowp is not None:                                                    # GEMM operands in 16 bits
+        x, W = lowp.r(x), lowp.r(W)
     qkv = x @ W.T
     if pfx + "qkv.bias" in st:
         qkv = qkv + st[pfx + "qkv.bias"].astype(np.float64)
     qkv = qkv.reshape(B_, P, 3, heads, hd).transpose(2, 0, 3, 1, 4)       # [3,B_,h,P,hd]
     q, k, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]
+    if attn_lowp is not None:
+        # the kernels' form (DESIGN.md identities 1, 2): Q~ = Q + T Q built in fp32, then Q~, K, V and the
+        # unnormalised probabilities exp(S - max) go to the matrix cores in 16 bits; the row sum is taken over the
+        # unrounded probabilities (fp32 registers) and divides the fp32 accumulator at the end
+        qt = q
+        if pfx + "pe.weight" in st:
+            w = st[pfx + "pe.weight"].astype(np.float64).reshape(heads, epeg_k)
+            half = epeg_k // 2
+            qp = np.pad(q, ((0, 0), (0, 0), (half, half), (0, 0)))
+            qt = q.copy()
+            for t in range(epeg_k):
+                qt += w[None, :, t, None, None] * qp[:, :, t:t + P, :]
+        S = attn_lowp.r(qt) @ attn_lowp.r(k).transpose(0, 1, 3, 2)
+        e = np.exp(S - S.max(-1, keepdims=True))
+        O = (attn_lowp.r(e) @ attn_lowp.r(v)) / e.sum(-1, keepdims=True)
+        O = O.transpose(0, 2, 1, 3).reshape(B_, P, D)
+        Wp = st[pfx + "proj.weight"].astype(np.float64)
+        if lowp is not None:
+            O, Wp = lowp.r(O), lowp.r(Wp)
+        return O @ Wp.T + st[pfx + "proj.bias"].astype(np.float64)
     S = q @ k.transpose(0, 1, 3, 2)                                         # [B_,h,P,P]
     if pfx + "pe.weight" in st:
         w = st[pfx + "pe.weight"].astype(np.float64).reshape(heads, epeg_k)
@@ -104,19 +167,24 @@ def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None):
         S = S + E
     A = _softmax64(S, -1)
     O = (A @ v).transpose(0, 2, 1, 3).reshape(B_, P, D)
-    out = O @ st[pfx + "proj.weight"].astype(np.float64).T + st[pfx + "proj.bias"].astype(np.float64)
+    Wp = st[pfx + "proj.weight"].astype(np.float64)
+    if taps is not None:
+        taps[pfx + "proj_in"] = O
+    if lowp is not None:
+        O, Wp = lowp.r(O), lowp.r(Wp)
+    out = O @ Wp.T + st[pfx + "proj.bias"].astype(np.float64)
     if taps is not None:
         taps[pfx + "scores_in"] = S
-        taps[pfx + "proj_in"] = O
     return out
 
 
-def _ffn64(x, st, pfx, act):
+def _ffn64(x, st, pfx, act, lowp=None):
     """TransLayer's optional FFN (ffn=True): x + fc2(act(fc1(LN2(x)))), modules/rrt.py:25-41,127-129."""
     g = lambda k: st[pfx + k].astype(np.float64)
+    r = (lambda a: a) if lowp is None else lowp.r
     u = _ln64(x, g("norm2.weight"), g("norm2.bias"))
-    h = _act64(u @ g("mlp.fc1.weight").T + g("mlp.fc1.bias"), "gelu" if act == "gelu" else "relu")
-    return x + h @ g("mlp.fc2.weight").T + g("mlp.fc2.bias")
+    h = _act64(r(u) @ r(g("mlp.fc1.weight")).T + g("mlp.fc1.bias"), "gelu" if act == "gelu" else "relu")
+    return x + r(h) @ r(g("mlp.fc2.weight")).T + g("mlp.fc2.bias")
 
 
 def _pos64(x, st, kind, conv_1d):
@@ -143,9 +211,11 @@ def _pos64(x, st, kind, conv_1d):
     return out.reshape(H * H, D)[:N]
 
 
-def forward_f64(x, state, cfg=None, taps=None):
-    """x: (N, D) array -> (N, D) float64.  ``state``: {reference state_dict key: array}."""
+def forward_f64(x, state, cfg=None, taps=None, lowp=None):
+    """x: (N, D) array -> (N, D) float64.  ``state``: {reference state_dict key: array}.
+    lowp: None (exact) or a LowP -- the rounding points of the HIP path's bf16 / fp16 modes."""
     c = _cfg(cfg)
+    attn_lowp = lowp if (lowp is not None and lowp.attn) else None
     st = state
     x = np.asarray(x, dtype=np.float64)
     N, D = x.shape
@@ -162,12 +232,12 @@ def forward_f64(x, state, cfg=None, taps=None):
         up = np.concatenate([u, np.zeros((add, D))], 0)                     # pad rows are exact zeros (T5)
         perm = partition_index(H, s)
         U = up[perm].reshape(-1, s * s, D)
-        Z = _inner_attention64(U, st, p + "attn.attn.", c["n_heads"], c["epeg_k"], taps)
+        Z = _inner_attention64(U, st, p + "attn.attn.", c["n_heads"], c["epeg_k"], taps, lowp, attn_lowp)
         z = np.empty((H * H, D))
         z[perm] = Z.reshape(-1, D)
         x = x + z[:N]
         if c["ffn"]:
-            x = _ffn64(x, st, p, c["ffn_act"])
+            x = _ffn64(x, st, p, c["ffn_act"], lowp)
         if taps is not None:
             taps[p + "out"] = x
     if c["cr_msa"]:
@@ -180,7 +250,8 @@ def forward_f64(x, state, cfg=None, taps=None):
         perm = partition_index(H, s)
         V = vp[perm].reshape(-1, s * s, D)                                   # [R,P,D]
         if c["crmsa_mlp"]:
-            h1 = np.tanh(V @ st[p + "attn.phi.0.weight"].astype(np.float64).T)
+            W1 = st[p + "attn.phi.0.weight"].astype(np.float64)
+            h1 = np.tanh(V @ W1.T) if lowp is None else np.tanh(lowp.r(V) @ lowp.r(W1).T)
             Lg = (h1 @ st[p + "attn.phi.2.weight"].astype(np.float64).T).transpose(0, 2, 1)
         else:
             Lg = (V @ st[p + "attn.phi"].astype(np.float64)).transpose(0, 2, 1)   # [R,k,P]
@@ -189,13 +260,14 @@ def forward_f64(x, state, cfg=None, taps=None):
         mn, mx = Lg.min(-1, keepdims=True), Lg.max(-1, keepdims=True)
         Mm = (Lg - mn) / (mx - mn + 1e-8)
         rep = (Cw @ V).transpose(1, 0, 2)                                    # [k,R,D]
-        rep2 = _inner_attention64(rep, st, p + "attn.attn.", c["crmsa_heads"], 0, taps)
+        # (the representatives' 64-token attention stays in fp32 in every mode: only its GEMM operands round)
+        rep2 = _inner_attention64(rep, st, p + "attn.attn.", c["crmsa_heads"], 0, taps, lowp, None)
         out = np.einsum("rnp,nrd->rpd", Mm * Dw, rep2)                       # [R,P,D]
         z = np.empty((H * H, D))
         z[perm] = out.reshape(-1, D)
         x = x + z[:N]
         if c["ffn"]:
-            x = _ffn64(x, st, p, c["ffn_act"])
+            x = _ffn64(x, st, p, c["ffn_act"], lowp)
         if taps is not None:
             taps["cr_msa.rep"] = rep
             taps["cr_msa.out"] = x
@@ -205,13 +277,15 @@ def forward_f64(x, state, cfg=None, taps=None):
 
 
 # --------------------------------------------------------------------------- eager-equivalent torch/CPU port
-def forward_eager(x, state, cfg=None, grad=False, drop=None):
+def forward_eager(x, state, cfg=None, grad=False, drop=None, autocast=None):
     """torch fp32 CPU port issuing the reference's aten op sequence; x: (N, D)
     torch tensor or array -> torch (N, D).  Used as the timed CPU baseline.
     grad=True: float64 leaves with requires_grad (x and every parameter) and a recorded graph -- torch autograd
     then yields the reference's gradients (the oracle of the backward, row f2); returns (y, x_leaf, params).
     drop = (p, {layer: keep mask [rows, D]}): train-mode proj_drop (rmsa.py:132) with GIVEN masks (layer index, or
-    "cr_msa"), i.e. nn.Dropout's arithmetic x * keep / (1 - p) without its random number generator."""
+    "cr_msa"), i.e. nn.Dropout's arithmetic x * keep / (1 - p) without its random number generator.
+    autocast = torch.bfloat16 / torch.float16: the whole sequence under torch.autocast('cpu', dtype), i.e. the
+    reference's --amp forward (main.py:101-102,439) with torch's CPU autocast policy."""
     import contextlib
     import torch
     import torch.nn.functional as F
@@ -282,7 +356,8 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None):
         return out[:, :-add] if add > 0 else out
 
     use_pos = c["pos"] in ("peg", "ppeg")
-    with (contextlib.nullcontext() if grad else torch.no_grad()):
+    amp = contextlib.nullcontext() if autocast is None else torch.autocast("cpu", dtype=autocast)
+    with (contextlib.nullcontext() if grad else torch.no_grad()), amp:
         if use_pos and c["pos_pos"] == -1:
             x = pos_embed(x)
         for li in range(c["n_layers"] - 1):

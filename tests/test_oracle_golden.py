@@ -7,7 +7,7 @@ import pytest
 from conftest import golden_names, load_golden, synth_case
 from oracle import rrt_oracle as O
 
-SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G8", "G11", "G13"))   # G8/G11/G13 = RRTMIL goldens
+SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G8", "G11", "G13", "G15", "G16"))   # G8/G11/G13 = RRTMIL goldens; G15 / G16: below
          and int(load_golden(n)["n"]) <= 4096]
 LARGE = ["G3_d512_n9000", "G5_d512_n9000_c1_sc"]
 
@@ -80,3 +80,106 @@ def test_mil_f64_truth_matches_reference(name):
     assert np.abs(attn - g["attn"][0]).max() <= 1e-7          # softmax weights ~ 1/N
     if "attn_raw" in g:
         assert np.abs(raw - g["attn_raw"][0]).max() <= 2e-5
+
+
+# ------------------------------------------------------------------ G15: the reference's own gradients (row f2)
+def grad_fixture(name):
+    """{'dx' | parameter name: (rows or None, values, float64 checksums)} + names the reference left without a gradient"""
+    g = load_golden(name)
+    out = {}
+    for key in g:
+        if not key.endswith("__sums"):
+            continue
+        base = key[:-len("__sums")]
+        if base + "__full" in g:
+            out[base] = (None, g[base + "__full"], g[key])
+        else:
+            out[base] = (g[base + "__rows"], g[base + "__vals"], g[key])
+    none = bytes(g["none"]).decode().split("\n") if g["none"].size else []
+    return g, out, none
+
+
+def grad_compare(got, entry, tol, what, floor=0.0):
+    """per-tensor bound: max error <= tol * that tensor's own largest entry (checksum[2]); floor only for tensors
+    the caller knows to be zero up to rounding"""
+    rows, vals, sums = entry
+    got = np.asarray(got, dtype=np.float64)
+    pick = got if rows is None else got.reshape(got.shape[0], -1)[rows]
+    scale = max(float(sums[2]), floor, 1e-30)
+    err = np.abs(pick.reshape(vals.shape) - vals).max() / scale
+    assert np.isfinite(got).all(), what
+    assert err <= tol, f"{what}: max error {err:.2e} of the tensor's own largest entry {sums[2]:.3e}"
+    # whole-tensor checksums (sum and sum of squares) catch errors outside the sampled rows
+    assert abs(got.sum() - sums[0]) <= 50 * tol * max(sums[1], floor), what
+    assert abs((got * got).sum() - sums[3]) <= 50 * tol * max(sums[3], floor * floor), what
+
+
+@pytest.mark.parametrize("name", golden_names("G15"))
+def test_eager_port_gradients_match_reference(name):
+    """The backward oracle (torch autograd over the eager port, float64 leaves) against the gradients the real
+    reference produced (its own modules cast to float64, tools/make_golden_grad_amp.py): every parameter and dL/dx,
+    each within 1e-6 of ITS OWN largest entry; parameters the reference leaves without a gradient get none here."""
+    import torch
+    from rrt_mil_amd import synth
+    g, fx, none = grad_fixture(name)
+    cfg, N = g["cfg"], int(g["n"])
+    tag = name[len("G15_grad_"):]
+    st = synth.encoder_state(**{k: v for k, v in cfg.items() if k in __import__("conftest").STATE_KEYS})
+    x = synth.bag(N, cfg["mlp_dim"], tag="train/" + tag)
+    G = synth.normal("train/G/" + tag, (N, cfg["mlp_dim"]))
+    y, x_leaf, params = O.forward_eager(x, st, cfg, grad=True)
+    (y * torch.from_numpy(G).double()).sum().backward()
+    grad_compare(x_leaf.grad.numpy(), fx["dx"], 1e-6, "dx")
+    for pname, p in params.items():
+        if pname in none:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, pname
+            continue
+        key = "p_" + pname.replace(".", "_")
+        zero = pname.endswith("pe.bias")                 # Identity 2: exactly zero up to rounding
+        grad_compare(p.grad.numpy(), fx[key], 1e-6, pname, floor=1e-6 if zero else 0.0)
+    assert set("p_" + n.replace(".", "_") for n in params if n not in none) | {"dx"} == set(fx)
+
+
+# ------------------------------------------------------------------ G16: the reference under autocast (bf16 / fp16)
+@pytest.mark.parametrize("name", golden_names("G16"))
+def test_eager_port_autocast_matches_reference(name):
+    """forward_eager(autocast=dtype) = the same aten op sequence under torch.autocast('cpu', dtype) against the real
+    reference under the same context.  Same ops, same torch build: bit-identical here; the bound leaves room for one
+    low-precision rounding flip per row on a host with a different BLAS split."""
+    import torch
+    g = load_golden(name)
+    x, st, cfg = synth_case(g)
+    dt = {"torch.bfloat16": torch.bfloat16, "torch.float16": torch.float16}[bytes(g["dtype"]).decode()]
+    y = O.forward_eager(x, st, cfg, autocast=dt).numpy()
+    d = np.abs(y[g["rows"]].astype(np.float64) - g["y_rows"])
+    fp32_dist = float(g["dist_fp32"][0])
+    assert d.max() <= 0.25 * fp32_dist and d.mean() <= 1e-5, (d.max(), d.mean(), fp32_dist)
+    # and the autocast run really differs from the fp32 run by the recorded distance
+    d32 = np.abs(g["y_rows"].astype(np.float64) - g["y32_rows"])
+    assert d32.max() <= fp32_dist + 1e-7 and d32.max() >= 0.2 * fp32_dist
+
+
+@pytest.mark.parametrize("name,attn", [("G16_amp_bf16_d512_n1000", False), ("G16_amp_bf16_d512_n1000", True),
+                                       ("G16_amp_f16_d512_n1000", True), ("G16_amp_bf16_d512_n3000_k21_c5", True)])
+def test_lowp_restatement_is_autocast_class(name, attn):
+    """The float64 restatement of the HIP path's reduced modes (explicit bf16 / fp16 rounding of the GEMM operands,
+    and of Q~ / K / P / V in the region attention) sits at least as close to the fp32 reference as the reference's
+    own autocast run does, and within 1.25x that distance of the autocast run itself."""
+    g = load_golden(name)
+    x, st, cfg = synth_case(g)
+    dtype = "bf16" if "bf16" in name else "f16"
+    y = O.forward_f64(x, st, cfg, lowp=O.LowP(dtype, attn=attn))[g["rows"]]
+    to_fp32 = np.abs(y - g["y32_rows"])
+    to_amp = np.abs(y - g["y_rows"])
+    amp_to_fp32 = np.abs(g["y_rows"].astype(np.float64) - g["y32_rows"])
+    assert to_fp32.mean() <= amp_to_fp32.mean() and to_fp32.max() <= 1.1 * amp_to_fp32.max(), (to_fp32.max(), amp_to_fp32.max())
+    assert to_amp.max() <= 1.25 * amp_to_fp32.max() and to_amp.mean() <= 1.25 * amp_to_fp32.mean()
+    assert to_fp32.max() > 1e-6        # the rounding points really are on
+
+
+def test_round_lowp():
+    import torch
+    a = np.concatenate([np.linspace(-3, 3, 10001), [0.0, 1e-30, -1e-30, 65504.0, 1e5, 2.0 ** -24, 1.00390625, 1.01171875]])
+    t = torch.from_numpy(a.astype(np.float32))
+    assert np.array_equal(O.round_lowp(a, "bf16"), t.to(torch.bfloat16).double().numpy())
+    assert np.array_equal(O.round_lowp(a, "f16"), t.to(torch.float16).double().numpy())

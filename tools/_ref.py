@@ -1,7 +1,7 @@
 """Container-only helper: import the real reference (/root/reference) as an oracle.
 
 Never imported by the product, the tests or bench.py -- /root/reference does not
-exist on the GPU box.  Used by tools/make_golden.py and tools/check_oracle.py.
+exist on the GPU box.  Used by tools/make_golden.py and tools/make_golden_grad_amp.py.
 `timm` is absent from this image; the two symbols the reference imports from it
 are stubbed (neither executes on the default path) -- SURVEY.md Appendix A.
 """
