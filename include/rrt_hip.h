@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 13
+#define RRT_ABI_VERSION 14
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -285,8 +285,8 @@ int rrt_executor_forward(rrt_executor *ex, const rrt_encoder_weights *w, const r
                          int32_t n_bags, void *stream);
 int rrt_executor_destroy(rrt_executor *ex);
 
-/* ---- row f2 building blocks: backward stages (training is not assembled yet; these are parity-tested
- * on their own) ----
+/* ---- row f2 building blocks: backward stages (assembled by rrt_encoder_backward_f32 below; parity-tested
+ * on their own as well) ----
  * nn.Linear backward for Y[M,N] = X[M,K] . W[N,K]^T + b:  dX[M,K] = dY . W,  dW[N,K] = dY^T . X,
  * db[N] = column sums of dY.  Any of dX / dW / db may be NULL.  N must be a multiple of 32 when dX is
  * requested (it is the reduction length of that product). */
@@ -318,6 +318,10 @@ int rrt_linear_backward_f32(const float *dY, const float *X, const float *W, flo
  * drop_p / drop_seed: the train-mode proj_drop of every InnerAttention (rmsa.py:70,132; p = drop_out): a stateless
  * mask, element kept iff hash(seed, layer, index) >= p * 2^32, kept values scaled by 1/(1-p); the backward call
  * must receive the same (drop_p, drop_seed) as its forward.  drop_p = 0: no dropout.
+ * branch_scale (HOST pointer, may be NULL = all ones): stochastic depth, TransLayer.drop_path (rrt.py:102,125,129;
+ * timm's DropPath at batch size 1 keeps or drops a whole residual branch): 2 * (RRT_MAX_RMSA_LAYERS + 1) multipliers,
+ * first the attention branches (index n_rmsa_layers = CR-MSA's), then the FFN branches in the same order; each is
+ * 1 (drop_path = 0), 1 / keep_prob (kept) or 0 (dropped).  The caller draws them; forward and backward get the same.
  * Gradients mirror the parameters: norm = [2, dim] (d gamma then d beta); pe bias gradients are exactly zero and
  * are not written.  NULL gradient pointers are not allowed for parameters the model has. */
 typedef struct rrt_attn_grads {
@@ -343,12 +347,13 @@ int rrt_encoder_train_sizes(const rrt_encoder_desc *desc, int64_t n_tokens, size
 /* y = RRTEncoder(x) (eval-equivalent arithmetic), intermediates kept in the caller-owned stash */
 int rrt_encoder_forward_train_f32(const rrt_encoder_desc *desc, const rrt_encoder_weights *w, const float *x,
                                   float *y, int64_t n_tokens, void *stash, size_t stash_bytes,
-                                  float drop_p, uint64_t drop_seed, void *stream);
+                                  float drop_p, uint64_t drop_seed, const float *branch_scale, void *stream);
 /* given dy = dL/dy: every parameter gradient and (optional) dx = dL/dx.  x and the stash are those of the forward. */
 int rrt_encoder_backward_f32(const rrt_encoder_desc *desc, const rrt_encoder_weights *w, const float *x,
                              const float *dy, const void *stash, size_t stash_bytes,
                              const rrt_encoder_grads *grads, float *dx, int64_t n_tokens, void *workspace,
-                             size_t workspace_bytes, float drop_p, uint64_t drop_seed, void *stream);
+                             size_t workspace_bytes, float drop_p, uint64_t drop_seed,
+                             const float *branch_scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -277,13 +277,15 @@ def forward_f64(x, state, cfg=None, taps=None, lowp=None):
 
 
 # --------------------------------------------------------------------------- eager-equivalent torch/CPU port
-def forward_eager(x, state, cfg=None, grad=False, drop=None, autocast=None):
+def forward_eager(x, state, cfg=None, grad=False, drop=None, autocast=None, branch=None):
     """torch fp32 CPU port issuing the reference's aten op sequence; x: (N, D)
     torch tensor or array -> torch (N, D).  Used as the timed CPU baseline.
     grad=True: float64 leaves with requires_grad (x and every parameter) and a recorded graph -- torch autograd
     then yields the reference's gradients (the oracle of the backward, row f2); returns (y, x_leaf, params).
     drop = (p, {layer: keep mask [rows, D]}): train-mode proj_drop (rmsa.py:132) with GIVEN masks (layer index, or
     "cr_msa"), i.e. nn.Dropout's arithmetic x * keep / (1 - p) without its random number generator.
+    branch = {(layer index | "cr_msa", "attn" | "ffn"): multiplier}: stochastic depth with GIVEN draws -- timm's
+    DropPath at batch 1 multiplies a whole residual branch by 0 or 1 / keep_prob (rrt.py:102,125,129).
     autocast = torch.bfloat16 / torch.float16: the whole sequence under torch.autocast('cpu', dtype), i.e. the
     reference's --amp forward (main.py:101-102,439) with torch's CPU autocast policy."""
     import contextlib
@@ -331,12 +333,15 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None, autocast=None):
         o = (attn @ v).transpose(1, 2).reshape(B_, P, D)
         return proj_drop(F.linear(o, st[pfx + "proj.weight"], st[pfx + "proj.bias"]), key)
 
+    def bm(key, kind):
+        return 1.0 if branch is None else float(branch.get((key, kind), 1.0))
+
     def ffn(t, pfx, key=None):                                               # modules/rrt.py:25-41,127-129
         u = F.layer_norm(t, (D,), st[pfx + "norm2.weight"], st[pfx + "norm2.bias"], 1e-5)
         h = F.linear(u, st[pfx + "mlp.fc1.weight"], st[pfx + "mlp.fc1.bias"])
         h = F.gelu(h) if c["ffn_act"] == "gelu" else F.relu(h)
         h = proj_drop(h, ("ffn1", key))                                      # Mlp.drop after the activation ...
-        return t + proj_drop(F.linear(h, st[pfx + "mlp.fc2.weight"], st[pfx + "mlp.fc2.bias"]), ("ffn2", key))  # ... and after fc2
+        return t + bm(key, "ffn") * proj_drop(F.linear(h, st[pfx + "mlp.fc2.weight"], st[pfx + "mlp.fc2.bias"]), ("ffn2", key))  # ... and after fc2
 
     def pos_embed(t):                                                        # modules/emb_position.py:24-82
         Hh = int(np.ceil(np.sqrt(N)))
@@ -371,7 +376,7 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None, autocast=None):
             z = unpart(inner(part(u, H, s), p + "attn.attn.", c["n_heads"], c["epeg_k"], li), H, s)
             if add > 0:
                 z = z[:, :-add]
-            x = x + z
+            x = x + bm(li, "attn") * z
             if c["ffn"]:
                 x = ffn(x, p, li)
         if c["cr_msa"]:
@@ -398,7 +403,7 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None, autocast=None):
             z = unpart(o, H, s)
             if add > 0:
                 z = z[:, :-add]
-            x = x + z
+            x = x + bm("cr_msa", "attn") * z
             if c["ffn"]:
                 x = ffn(x, p, "cr_msa")
         if c["all_shortcut"]:

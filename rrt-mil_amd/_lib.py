@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _f32p = C.POINTER(C.c_float)
 
@@ -131,10 +131,11 @@ SIGNATURES = {
                                           C.POINTER(C.c_size_t)]),
     "rrt_encoder_forward_train_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p,
                                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_float,
-                                                C.c_uint64, C.c_void_p]),
+                                                C.c_uint64, C.POINTER(C.c_float), C.c_void_p]),
     "rrt_encoder_backward_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_size_t, C.POINTER(EncoderGrads), C.c_void_p, C.c_int64,
-                                           C.c_void_p, C.c_size_t, C.c_float, C.c_uint64, C.c_void_p]),
+                                           C.c_void_p, C.c_size_t, C.c_float, C.c_uint64, C.POINTER(C.c_float),
+                                           C.c_void_p]),
     "rrt_linear_act_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                         C.c_void_p]),
 }

@@ -938,7 +938,7 @@ Stash carve_stash(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const
 
 struct BwdWs {
   float *dx2, *dxa, *dxb, *dz, *dO, *dqkv, *lnpart, *attnpart, *dWd, *dC, *dlg, *Cw, *d_rep2, *d_rep_o,
-      *d_rep_qkv, *d_rep, *rows, *dxpart, *th, *dhid, *dvphi, *w1t, *tnscratch, *fh, *fdh, *fdu;
+      *d_rep_qkv, *d_rep, *rows, *dxpart, *th, *dhid, *dvphi, *w1t, *tnscratch, *fh, *fdh, *fdu, *attnpart_cr;
   char *lin, *pegws;
   size_t bytes;
 };
@@ -989,7 +989,9 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
       const size_t a2 = linear_bwd_workspace((int)Np8, (int)k, (int)(D / 4));
       w.tnscratch = take((a1 > a2 ? a1 : a2) / sizeof(float));
     }
-    if (!w.attnpart) w.attnpart = take(attn_bwd_workspace((int)k, (int)R8, (int)D, d.crmsa_heads, 0) / sizeof(float));
+    // attnpart is shared by the R-MSA layers' and CR-MSA's attention backward: the larger of the two geometries
+    // (a small bag's R-MSA partials can be smaller than what CR-MSA's 64-token regions need)
+    w.attnpart_cr = take(attn_bwd_workspace((int)k, (int)R8, (int)D, d.crmsa_heads, 0) / sizeof(float));
     const size_t l3 = linear_bwd_workspace((int)(k * R8), 3 * (int)D, (int)D);
     if (l3 > lin) lin = l3;
   }
@@ -1057,14 +1059,29 @@ int make_drop(float p, DropCfg* d) {
   return RRT_OK;
 }
 constexpr int DROP_LAYER_CRMSA = 100;
+// stochastic depth (TransLayer.drop_path, rrt.py:102,125,129): per-call multipliers of the residual branches,
+// host array [2][RRT_MAX_RMSA_LAYERS + 1] = {attention branches, FFN branches}, index n_rmsa_layers = CR-MSA's
+struct Branch {
+  float attn[RRT_MAX_RMSA_LAYERS + 1], ffn[RRT_MAX_RMSA_LAYERS + 1];
+};
+int make_branch(const float* bs, Branch* b) {
+  for (int i = 0; i <= RRT_MAX_RMSA_LAYERS; ++i) {
+    b->attn[i] = bs ? bs[i] : 1.0f;
+    b->ffn[i] = bs ? bs[RRT_MAX_RMSA_LAYERS + 1 + i] : 1.0f;
+    if (!(b->attn[i] >= 0.f) || !(b->ffn[i] >= 0.f)) return RRT_E_INVALID;
+  }
+  return RRT_OK;
+}
 }  // namespace
 
 int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encoder_weights* w, const float* x,
                                   float* y, int64_t n_tokens, void* stash, size_t stash_bytes, float drop_p,
-                                  uint64_t drop_seed, void* stream) {
+                                  uint64_t drop_seed, const float* branch_scale, void* stream) {
   if (!desc || !w || !x || !y || x == y) return RRT_E_INVALID;
   DropCfg dc{};
   if (make_drop(drop_p, &dc)) return RRT_E_INVALID;
+  Branch br{};
+  if (make_branch(branch_scale, &br)) return RRT_E_INVALID;
   rrt_grid g{}, g8{};
   int rc = check_train(desc, n_tokens, &g, &g8);
   if (rc) return rc;
@@ -1109,8 +1126,10 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     e2.bias = lw.fc2_b;
     e2.resid = xi;
     e2.g = gid;
+    const float bsf = br.ffn[idx < RRT_MAX_RMSA_LAYERS ? idx : desc->n_rmsa_layers];
     e2.drop_thresh = dc.thresh;
-    e2.drop_scale = dc.scale;
+    e2.drop_scale = dc.scale * bsf;
+    e2.drop_on = dc.thresh || bsf != 1.0f;
     e2.drop_seed = dc.seed(drop_seed, 201 + 2 * idx);
     return (int)launch_linear(s.hscr, lw.fc2_w, s.xf[idx], (int)N, D, desc->ffn_hidden, e2, st);
   };
@@ -1144,9 +1163,10 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     ep2.resid = xin;
     ep2.g = gd;
     ep2.drop_thresh = dc.thresh;
-    ep2.drop_scale = dc.scale;
+    ep2.drop_scale = dc.scale * br.attn[li];
+    ep2.drop_on = dc.thresh || br.attn[li] != 1.0f;
     ep2.drop_seed = dc.seed(drop_seed, li);
-    ep2.prec = dc.thresh ? RRT_COMPUTE_F32 : desc->compute;      // the dropout epilogue exists in fp32 only
+    ep2.prec = ep2.drop_on ? RRT_COMPUTE_F32 : desc->compute;      // the dropout epilogue exists in fp32 only
     RRT_TRY(launch_linear(s.o[li], lw.proj_w, s.xout[li], gd.Np, D, D, ep2, st));
     xin = s.xout[li];
     if (desc->ffn) {
@@ -1186,10 +1206,13 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     RRT_TRY(launch_region_attention(s.rep_qkv, nullptr, s.rep_o, k, R8, D, desc->crmsa_heads, 0, st));
     LinearEpilogue ep2{};
     ep2.bias = cw.proj_b;
+    // CR-MSA's branch is linear in rep2 (dispatch = sum_n wdisp * rep2): its stochastic-depth multiplier rides here
+    const float bsc = br.attn[desc->n_rmsa_layers];
     ep2.drop_thresh = dc.thresh;
-    ep2.drop_scale = dc.scale;
+    ep2.drop_scale = dc.scale * bsc;
+    ep2.drop_on = dc.thresh || bsc != 1.0f;
     ep2.drop_seed = dc.seed(drop_seed, DROP_LAYER_CRMSA);
-    ep2.prec = dc.thresh ? RRT_COMPUTE_F32 : desc->compute;
+    ep2.prec = ep2.drop_on ? RRT_COMPUTE_F32 : desc->compute;
     RRT_TRY(launch_linear(s.rep_o, cw.proj_w, s.rep2, k * R8, D, D, ep2, st));
     if (desc->ffn) {
       // CR-MSA's TransLayer: x1 + dispatch -> xcr, FFN -> xf, then the shortcut, then the final LayerNorm
@@ -1211,10 +1234,12 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
 int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_weights* w, const float* x,
                              const float* dy, const void* stash, size_t stash_bytes, const rrt_encoder_grads* gr,
                              float* dx, int64_t n_tokens, void* workspace, size_t workspace_bytes, float drop_p,
-                             uint64_t drop_seed, void* stream) {
+                             uint64_t drop_seed, const float* branch_scale, void* stream) {
   if (!desc || !w || !x || !dy || !gr) return RRT_E_INVALID;
   DropCfg dc{};
   if (make_drop(drop_p, &dc)) return RRT_E_INVALID;
+  Branch br{};
+  if (make_branch(branch_scale, &br)) return RRT_E_INVALID;
   rrt_grid g{}, g8{};
   int rc = check_train(desc, n_tokens, &g, &g8);
   if (rc) return rc;
@@ -1246,8 +1271,9 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
                                        dc.seed(drop_seed, 200 + 2 * idx), dc.scale, st);
     if (fe != hipSuccess) return (int)fe;
     const float* dyf = cur;                        // d(fc2 output): the residual's gradient through the second mask
-    if (dc.thresh) {
-      fe = launch_copy_drop_mask(cur, b.fdu, (size_t)N * D, dc.thresh, dc.seed(drop_seed, 201 + 2 * idx), dc.scale, st);
+    const float bsf = br.ffn[idx < RRT_MAX_RMSA_LAYERS ? idx : desc->n_rmsa_layers];
+    if (dc.thresh || bsf != 1.0f) {
+      fe = launch_copy_drop_mask(cur, b.fdu, (size_t)N * D, dc.thresh, dc.seed(drop_seed, 201 + 2 * idx), dc.scale * bsf, st);
       if (fe != hipSuccess) return (int)fe;
       dyf = b.fdu;
     }
@@ -1294,10 +1320,11 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     float* dx1 = (cur == b.dxa) ? b.dxb : b.dxa;
     RRT_TRY(launch_crmsa_tokdot(up, nullptr, nullptr, nullptr, s.rep2, b.dWd, D, k, gd8, st));
     RRT_TRY(launch_crmsa_wsum(up, s.wdisp, b.d_rep2, D, k, gd8, st));
-    RRT_TRY(launch_apply_drop_mask(b.d_rep2, k * R8, D, dc.thresh, dc.seed(drop_seed, DROP_LAYER_CRMSA), dc.scale, st));
+    RRT_TRY(launch_apply_drop_mask(b.d_rep2, k * R8, D, dc.thresh, dc.seed(drop_seed, DROP_LAYER_CRMSA),
+                                   dc.scale * br.attn[L], st));
     RRT_TRY(launch_linear_backward(b.d_rep2, s.rep_o, cw.proj_w, b.d_rep_o, cg.proj_w, cg.proj_b, k * R8, D, D, desc->compute,
                                    b.lin, st));
-    RRT_TRY(launch_attention_backward(s.rep_qkv, nullptr, s.rep_o, b.d_rep_o, b.d_rep_qkv, nullptr, b.attnpart, k,
+    RRT_TRY(launch_attention_backward(s.rep_qkv, nullptr, s.rep_o, b.d_rep_o, b.d_rep_qkv, nullptr, b.attnpart_cr, k,
                                       R8, D, desc->crmsa_heads, 0, st));
     RRT_TRY(launch_linear_backward(b.d_rep_qkv, s.rep, cw.qkv_w, b.d_rep, cg.qkv_w, cg.qkv_b, k * R8, 3 * D, D, desc->compute,
                                    b.lin, st));
@@ -1339,7 +1366,7 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
       rc = ffn_backward(lw, lg, s.xout[li], li);
       if (rc) return rc;
     }
-    RRT_TRY(launch_partition_rows(cur, b.dz, D, gd, dc.thresh, dc.seed(drop_seed, li), dc.scale, st));
+    RRT_TRY(launch_partition_rows(cur, b.dz, D, gd, dc.thresh, dc.seed(drop_seed, li), dc.scale * br.attn[li], st));
     RRT_TRY(launch_linear_backward(b.dz, s.o[li], lw.proj_w, b.dO, lg.proj_w, lg.proj_b, gd.Np, D, D, desc->compute, b.lin, st));
     RRT_TRY(launch_attention_backward(s.qkv[li], desc->epeg ? lw.pe_w : nullptr, s.o[li], b.dO, b.dqkv,
                                       desc->epeg ? lg.pe_w : nullptr, b.attnpart, gd.rs * gd.rs, gd.P, D,

@@ -33,6 +33,7 @@ struct LinearEpilogue {
   // values are scaled by drop_scale = 1 / (1 - p); mask index = A-row * N + column (common.h rrt_drop_keep)
   unsigned drop_thresh, drop_seed;
   float drop_scale;
+  bool drop_on;          // selects the dropout epilogue (drop_thresh may be 0: a pure branch multiplier, stochastic depth)
   // un-partition + residual (used when resid != null): C row = token, A row = slot
   const float* resid;
   GridDev g;

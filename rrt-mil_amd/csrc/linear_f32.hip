@@ -653,7 +653,7 @@ RRT_TRACE_DEFINE_READER(rrt_debug_trace_linear)
 hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
                          const LinearEpilogue& ep, hipStream_t st) {
   const bool u = ep.resid != nullptr;
-  if (ep.drop_thresh && (ep.prec != PREC_F32 || ep.act)) return hipErrorInvalidValue;   // dropout: fp32 training only
+  if (ep.drop_on && (ep.prec != PREC_F32 || ep.act)) return hipErrorInvalidValue;   // dropout: fp32 training only
   const Cfg c = choose(M, N);
 #define RRT_CASE(MT_, NT_)                                                                          \
   if (c.mt == MT_ && c.nt == NT_) {                                                                 \
@@ -662,7 +662,7 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
     return RRT_MODES(MT_, NT_, PREC_F32);                                                           \
   }
 #define RRT_MODES(MT_, NT_, P_)                                                                     \
-  (ep.drop_thresh ? (u ? launch_cfg<MT_, NT_, MODE_UNPART_DROP, PREC_F32>(A, B, C, M, N, K, c.cap, ep, st)  \
+  (ep.drop_on ? (u ? launch_cfg<MT_, NT_, MODE_UNPART_DROP, PREC_F32>(A, B, C, M, N, K, c.cap, ep, st)  \
                        : launch_cfg<MT_, NT_, MODE_DROP, PREC_F32>(A, B, C, M, N, K, c.cap, ep, st))        \
    : u ? launch_cfg<MT_, NT_, MODE_UNPART, P_>(A, B, C, M, N, K, c.cap, ep, st)                      \
      : ep.act ? launch_cfg<MT_, NT_, MODE_ACT, P_>(A, B, C, M, N, K, c.cap, ep, st)                 \

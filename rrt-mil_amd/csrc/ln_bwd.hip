@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void partition_rows_kernel(const float* __rest
     const int t = slot_to_token(slot, g);
     for (int c = lane * 4; c < dim; c += 256) {
       float4 v = t < g.L ? *(const float4*)(src + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (thresh) {       // adjoint of the forward's dropout on this layer's proj output (same mask)
+      if (thresh || scale != 1.0f) {       // adjoint of the forward's dropout / branch multiplier on this layer's proj output (same mask)
         const unsigned long long i = (unsigned long long)slot * dim + c;
         v.x = rrt_drop_keep(seed, i, thresh) ? v.x * scale : 0.f;
         v.y = rrt_drop_keep(seed, i + 1, thresh) ? v.y * scale : 0.f;
@@ -213,7 +213,7 @@ hipError_t launch_act_backward(float* dh, const float* hpre, size_t n, int act, 
 
 hipError_t launch_apply_drop_mask(float* buf, int rows, int cols, unsigned drop_thresh, unsigned drop_seed,
                                   float drop_scale, hipStream_t st) {
-  if (!drop_thresh) return hipSuccess;
+  if (!drop_thresh && drop_scale == 1.0f) return hipSuccess;
   const size_t n = (size_t)rows * cols;
   apply_drop_mask_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(buf, buf, n, drop_thresh, drop_seed,
                                                                             drop_scale);

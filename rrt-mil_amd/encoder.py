@@ -6,9 +6,12 @@ forward.  The parameter holders are real nn.LayerNorm / nn.Linear / nn.Conv2d
 sub-modules under the reference's names (so ``.apply(initialize_weights)``,
 optimizers and checkpoints behave identically); the forward itself is ONE call
 into librrt_hip.so (rrt_encoder_forward_f32, include/rrt_hip.h) per bag on the
-current HIP stream.  There is no PyTorch/CPU fallback: CPU tensors, training-mode
-dropout and the reference's ablation branches raise.
+current HIP stream.  With gradients enabled and something to differentiate the call goes
+through a torch.autograd.Function over rrt_encoder_forward_train_f32 /
+rrt_encoder_backward_f32 (train() adds proj dropout and stochastic depth, eval() does not).
+There is no PyTorch/CPU fallback: CPU tensors and configurations outside the HIP path raise.
 """
+import warnings
 import ctypes as C
 import math
 
@@ -138,8 +141,6 @@ class TransLayer(nn.Module):
                  region_size=0, min_region_num=0, min_region_ratio=0, qkv_bias=True, crmsa_k=3,
                  epeg_k=15, **kwargs):
         super().__init__()
-        if drop_path > 0.:
-            raise NotImplementedError("drop_path > 0 (training-only stochastic depth) is not on the HIP path")
         self.norm = norm_layer(dim)
         self.norm2 = norm_layer(dim) if ffn else nn.Identity()
         common = dict(dim=dim, num_heads=head, drop=drop_out, region_num=n_region, head_dim=dim // head,
@@ -153,7 +154,10 @@ class TransLayer(nn.Module):
             raise NotImplementedError("attn='ntrans' (Nystrom ablation) is out of scope")
         else:
             raise NotImplementedError
+        # timm's DropPath (rrt.py:102) holds no parameters: at batch size 1 it keeps or drops a whole residual
+        # branch; the draw happens in RRTEncoder._branch_scales and rides into the kernels as a multiplier
         self.drop_path = nn.Identity()
+        self.drop_path_p = float(drop_path)
         self.ffn = ffn
         act_layer = nn.GELU if ffn_act == 'gelu' else nn.ReLU
         self.mlp = (Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop_out)
@@ -179,15 +183,20 @@ class _EncoderFunction(torch.autograd.Function):
         y = torch.empty_like(x2d)
         w = enc._weights()
         # train-mode proj_drop: a stateless mask keyed by a seed drawn from torch's CPU generator (so
-        # torch.manual_seed reproduces a run); the backward regenerates the same mask from (p, seed)
+        # torch.manual_seed reproduces a run); the backward regenerates the same mask from (p, seed).
+        # eval() with gradients enabled (fine-tuning with frozen dropout, saliency maps): same graph, no dropout
         drop_p = float(enc.drop_out) if enc.training else 0.0
         seed = enc._next_drop_seed() if drop_p > 0 else 0
+        branch = enc._branch_scales()
         with torch.cuda.device(x2d.device):
             rc = lib.rrt_encoder_forward_train_f32(C.byref(enc._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
-                                                   stash.data_ptr(), stash.numel(), drop_p, seed,
+                                                   stash.data_ptr(), stash.numel(), drop_p, seed, branch,
                                                    torch.cuda.current_stream(x2d.device).cuda_stream)
         _lib.check(rc, "rrt_encoder_forward_train_f32")
-        ctx.enc, ctx.stash, ctx.ws_bytes, ctx.drop, ctx.compute = enc, stash, ws_b.value, (drop_p, seed), enc._desc.compute
+        ctx.enc, ctx.stash, ctx.ws_bytes, ctx.drop, ctx.compute = enc, stash, ws_b.value, (drop_p, seed, branch), enc._desc.compute
+        # the backward reads the parameters through their live pointers: an in-place update between forward and
+        # backward (optimizer.step() before a second backward through a retained graph) must not go unnoticed
+        ctx.versions = [(p_.data_ptr(), p_._version) for p_ in params]
         ctx.save_for_backward(x2d)
         return y
 
@@ -196,6 +205,10 @@ class _EncoderFunction(torch.autograd.Function):
         lib = _lib.load()
         enc = ctx.enc
         (x2d,) = ctx.saved_tensors
+        if ctx.versions != [(p_.data_ptr(), p_._version) for p_ in enc.parameters()]:
+            raise RuntimeError("RRTEncoder: a parameter was modified in place (or replaced) between this forward and "
+                               "its backward; the backward kernels read the live weights, so the gradients would be "
+                               "wrong -- run the forward again")
         n, dev = x2d.shape[0], x2d.device
         dy = dy.contiguous().float()
         grads, gstruct = enc._grad_buffers(dev)
@@ -207,7 +220,8 @@ class _EncoderFunction(torch.autograd.Function):
             rc = lib.rrt_encoder_backward_f32(C.byref(enc._desc), C.byref(w), x2d.data_ptr(), dy.data_ptr(),
                                               ctx.stash.data_ptr(), ctx.stash.numel(), C.byref(gstruct),
                                               dx.data_ptr() if dx is not None else None, n, ws.data_ptr(), ws.numel(),
-                                              ctx.drop[0], ctx.drop[1], torch.cuda.current_stream(dev).cuda_stream)
+                                              ctx.drop[0], ctx.drop[1], ctx.drop[2],
+                                              torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "rrt_encoder_backward_f32")
         return (None, dx) + tuple(grads)      # (the stash lives as long as the graph node: retain_graph works)
 
@@ -256,8 +270,11 @@ class RRTEncoder(nn.Module):
             ffn_act=_lib.ACT_GELU if ffn_act == 'gelu' else _lib.ACT_RELU, ffn_hidden=int(mlp_dim * mlp_ratio),
             pos={'peg': _lib.POS_PEG, 'ppeg': _lib.POS_PPEG}.get(pos, _lib.POS_NONE), pos_pos=pos_pos, peg_k=peg_k,
             peg_1d=int(bool(peg_1d)))
-        if self._desc.pos and pos_pos not in (-1, 0):
-            self._desc.pos = _lib.POS_NONE       # the reference only applies pos_embedding at pos_pos -1 / 0 (rrt.py:181-187)
+        if self._desc.pos and (pos_pos not in (-1, 0) or (pos_pos == 0 and n_layers - 1 < 2)):
+            # the reference only applies pos_embedding before the first layer (pos_pos = -1) or before layer index 1
+            # (pos_pos = 0, which needs a second R-MSA layer: the default `--pos ppeg` run with n_layers = 2 never
+            # reaches it, rrt.py:181-187): the stage is absent from the kernels and its parameters get no gradient
+            self._desc.pos = _lib.POS_NONE
         # None: exact fp32 unless the call runs under torch autocast (then bf16/fp16 MFMA operands in
         # the Linear layers, like the reference's --amp path); or force torch.float32/bfloat16/float16
         self.compute_dtype = None
@@ -271,7 +288,8 @@ class RRTEncoder(nn.Module):
         if t is None:
             return None
         if t.dtype != torch.float32 or not t.is_contiguous():
-            raise _lib.RRTHipError("parameters must be contiguous fp32 (bf16 configs: not built yet)")
+            raise _lib.RRTHipError("parameters must be contiguous fp32 tensors (bf16 / fp16 arithmetic is selected by "
+                                   "torch.autocast or compute_dtype, not by casting the module)")
         return t.data_ptr()
 
     def _attn_weights(self, layer):
@@ -373,9 +391,10 @@ class RRTEncoder(nn.Module):
                     by_name[f"pos_embedding.{name}.bias"] = gb
                     gs.pos_b[i] = gb.data_ptr()
         elif not isinstance(self.pos_embedding, nn.Identity):
-            # constructed but never applied (pos_pos outside {-1, 0}): zero gradients, as autograd would leave None
-            for name, prm in self.pos_embedding.named_parameters():
-                by_name["pos_embedding." + name] = torch.zeros_like(prm)
+            # constructed but never applied: no gradient, exactly as the reference's autograd leaves None (an
+            # optimizer then skips these parameters instead of decaying them)
+            for name, _ in self.pos_embedding.named_parameters():
+                by_name["pos_embedding." + name] = None
         # the struct holds raw pointers: the caller keeps `grads` alive through the C call and then hands the
         # tensors to autograd as their ONLY owner -- AccumulateGrad then adopts them instead of cloning (an extra
         # reference here cost ~20 device copies per step)
@@ -408,17 +427,16 @@ class RRTEncoder(nn.Module):
             x2d = x2d.float()        # e.g. the bf16 output of an autocast patch_to_emb; HBM tensors stay fp32
         if x2d.dtype != torch.float32:
             raise NotImplementedError(f"unsupported bag dtype {x2d.dtype}")
-        if self.training and self.drop_out > 0:
-            raise NotImplementedError("training-mode forward (proj dropout p=%.2f + autograd) is not built; "
-                                      "call .eval()" % self.drop_out)
-        if torch.is_grad_enabled() and (x2d.requires_grad or any(p.requires_grad for p in self.parameters())):
-            # inference path: no autograd graph is recorded
-            pass
         x2d = x2d.contiguous()
         n, d = x2d.shape
         if d != self.final_dim:
             raise ValueError(f"expected feature dim {self.final_dim}, got {d}")
         y = out if out is not None else torch.empty_like(x2d)
+        if self._stochastic():
+            # train() without a graph (torch.no_grad(): MC dropout, EMA / teacher forwards, frozen models): the
+            # reference still applies proj dropout and stochastic depth; same kernels as the training forward, the
+            # stash is scratch
+            return self._forward_bag_stochastic(x2d, y)
         ws = self._workspace(n, x2d.device)
         w = self._weights()
         self._desc.compute = self._compute_mode()
@@ -427,6 +445,58 @@ class RRTEncoder(nn.Module):
             rc = lib.rrt_encoder_forward_f32(C.byref(self._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
                                              ws.data_ptr(), ws.numel(), stream)
         _lib.check(rc, "rrt_encoder_forward_f32")
+        return y
+
+    def _stochastic(self):
+        return self.training and (self.drop_out > 0 or any(l.drop_path_p > 0 for l in self._trans_layers()))
+
+    def _trans_layers(self):
+        layers = list(self.layers.children())
+        if self._desc.cr_msa:
+            layers.append(self.cr_msa)
+        return layers
+
+    def _branch_scales(self):
+        """Stochastic depth for this call (timm DropPath at batch 1, rrt.py:102,125,129): one multiplier per residual
+        branch -- 1 / keep_prob if the branch is kept, 0 if dropped, 1 outside train() -- as the host float array
+        rrt_encoder_forward_train_f32 takes (NULL when there is nothing to draw).  ``drop_path_draws`` (a list of
+        multipliers, attention branches then FFN branches) pins them (tests)."""
+        if not self.training or not any(l.drop_path_p > 0 for l in self._trans_layers()):
+            return None
+        n = _lib.RRT_MAX_RMSA_LAYERS + 1
+        arr = (C.c_float * (2 * n))(*([1.0] * (2 * n)))
+        layers = list(self.layers.children())
+        slots = [(i, l) for i, l in enumerate(layers)] + ([(len(layers), self.cr_msa)] if self._desc.cr_msa else [])
+        fixed = getattr(self, "drop_path_draws", None)
+        k = 0
+        for part in (0, 1):                      # 0: attention branches, 1: FFN branches (ffn=True only)
+            for idx, layer in slots:
+                if part == 1 and not layer.ffn:
+                    continue
+                keep = 1.0 - layer.drop_path_p
+                if fixed is not None:
+                    m = float(fixed[k])
+                else:
+                    m = (1.0 / keep if keep > 0 else 1.0) if float(torch.rand(())) < keep else 0.0
+                arr[part * n + idx] = m
+                k += 1
+        return arr
+
+    def _forward_bag_stochastic(self, x2d, y):
+        lib = _lib.load()
+        self._desc.compute = self._compute_mode()
+        stash_b, ws_b = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.rrt_encoder_train_sizes(C.byref(self._desc), x2d.shape[0], C.byref(stash_b), C.byref(ws_b)),
+                   "rrt_encoder_train_sizes")
+        stash = torch.empty(stash_b.value, dtype=torch.uint8, device=x2d.device)
+        w = self._weights()
+        drop_p = float(self.drop_out)
+        with torch.cuda.device(x2d.device):
+            rc = lib.rrt_encoder_forward_train_f32(C.byref(self._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(),
+                                                   x2d.shape[0], stash.data_ptr(), stash.numel(), drop_p,
+                                                   self._next_drop_seed() if drop_p > 0 else 0, self._branch_scales(),
+                                                   torch.cuda.current_stream(x2d.device).cuda_stream)
+        _lib.check(rc, "rrt_encoder_forward_train_f32")
         return y
 
     # ------------------------------------------------------------------ batch of independent bags
@@ -465,8 +535,8 @@ class RRTEncoder(nn.Module):
         lib = _lib.load()
         if not bags:
             return []
-        if self.training and self.drop_out > 0:
-            raise NotImplementedError("training-mode forward is not built; call .eval()")
+        if self._stochastic():          # train() under no_grad: dropout / stochastic depth per bag, one bag at a time
+            return [self.forward_bag(b[0]).unsqueeze(0) if b.dim() == 3 else self.forward_bag(b) for b in bags]
         dev = bags[0].device
         xs = []
         for b in bags:
@@ -504,11 +574,25 @@ class RRTEncoder(nn.Module):
         return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
     def _wants_grad(self, x):
-        """Training path (stash + autograd node) only in train() mode with gradients enabled and something to
-        differentiate; eval() forwards never record a graph (the reference's validation loops run under
-        torch.no_grad() anyway)."""
-        return (self.training and torch.is_grad_enabled()
-                and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
+        """Autograd path (stash + graph node) whenever gradients are enabled and there is something to
+        differentiate -- in train() and in eval() alike, as the reference records a graph in both (eval() only
+        switches dropout / stochastic depth off).  Inference proper runs under torch.no_grad(), like the
+        reference's validation loops.  In eval() a configuration the backward kernels do not cover falls back
+        to the inference path with a warning (its output carries no graph); in train() it raises."""
+        if not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return False
+        if self.training:
+            return True
+        n = x.shape[-2] if x.dim() in (2, 3) else x.shape[-1] * x.shape[-2]
+        a, b = C.c_size_t(), C.c_size_t()
+        if _lib.load().rrt_encoder_train_sizes(C.byref(self._desc), int(n), C.byref(a), C.byref(b)) == 0:
+            return True
+        if not getattr(self, "_warned_detached", False):
+            self._warned_detached = True
+            warnings.warn("RRTEncoder.eval() called with gradients enabled on a configuration the backward kernels "
+                          "do not cover: running the inference path, the output is detached from the graph "
+                          "(wrap inference in torch.no_grad() to silence this)", RuntimeWarning, stacklevel=3)
+        return False
 
     def forward(self, x):
         if self._wants_grad(x):

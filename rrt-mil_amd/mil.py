@@ -110,6 +110,11 @@ class RRTMIL(nn.Module):
         self.pool_fn = DAttention(self.online_encoder.final_dim, da_act, gated=da_gated, bias=da_bias,
                                   dropout=da_dropout)
         self.predictor = nn.Linear(self.online_encoder.final_dim, n_classes)
+        if self.patch_to_emb[0].out_features != self.online_encoder.final_dim:
+            # the reference hard-codes Linear(input_dim, 512) in front of an encoder of width mlp_dim
+            # (rrt.py:208,219) and dies with a shape error in the first LayerNorm otherwise
+            raise ValueError(f"patch_to_emb emits 512 features but the encoder was built with mlp_dim="
+                             f"{self.online_encoder.final_dim} (the reference fails on this combination too)")
         self.apply(initialize_weights)
 
         self._act_name = act.lower() if act.lower() in ("relu", "gelu") else "none"
@@ -154,8 +159,9 @@ class RRTMIL(nn.Module):
         if not x2d.is_cuda:
             raise _lib.RRTHipError("rrt_mil_amd.RRTMIL runs on MI355X only: move the bag to a 'cuda' (HIP) "
                                    "device; there is no CPU fallback")
-        if self.training and (self.online_encoder.drop_out > 0 or isinstance(self.dp, nn.Dropout)):
-            raise NotImplementedError("training-mode forward (dropout + autograd) is not built; call .eval()")
+        if self.training and (isinstance(self.dp, nn.Dropout) or self.online_encoder._stochastic()):
+            raise NotImplementedError("forward_bag is the one-call inference entry (no dropout inside); in train() "
+                                      "call the module itself: forward() applies the dropouts and records a graph")
         if x2d.dtype in (torch.bfloat16, torch.float16):
             x2d = x2d.float()
         if x2d.dtype != torch.float32:
@@ -180,12 +186,16 @@ class RRTMIL(nn.Module):
         return (logits, attn) if return_attn else logits
 
     def forward(self, x, return_attn=False, no_norm=False):
-        if (self.training and torch.is_grad_enabled()
-                and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
-            # training: the encoder is the HIP autograd Function (forward with stash + backward kernels); the
-            # thin layers around it (patch_to_emb, Dropout, DAttention, predictor) are torch ops under autograd
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # a graph is wanted (training, or eval()-mode fine-tuning / attribution): the encoder is the HIP
+            # autograd Function (forward with stash + backward kernels); the thin layers around it (patch_to_emb,
+            # Dropout, DAttention, predictor) are torch ops under autograd
             return self._forward_layers(x, return_attn, no_norm)
         with torch.no_grad():
+            if self.training and (isinstance(self.dp, nn.Dropout) or self.online_encoder._stochastic()
+                                  or any(isinstance(m, nn.Dropout) for m in self.pool_fn.modules())):
+                # train() without a graph: the reference still applies its dropouts
+                return self._forward_layers(x, return_attn, no_norm)
             return self._forward_infer(x, return_attn, no_norm)
 
     def _forward_infer(self, x, return_attn=False, no_norm=False):

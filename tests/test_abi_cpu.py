@@ -114,12 +114,17 @@ def test_cpu_tensor_and_ablations_raise():
 
 def test_pos_state_dict_surface():
     """pos='ppeg' / 'peg' (modules/emb_position.py:24-82): pos_embedding.proj{,1,2} depth-wise convs."""
-    for cfg in (dict(mlp_dim=64, pos='ppeg', pos_pos=-1), dict(mlp_dim=64, pos='peg', peg_k=5, peg_1d=True, peg_bias=False)):
+    for cfg in (dict(mlp_dim=64, pos='ppeg', pos_pos=-1), dict(mlp_dim=64, pos='peg', pos_pos=-1, peg_k=5, peg_1d=True, peg_bias=False)):
         enc = RRTEncoder(**cfg)
         st = synth.encoder_state(**cfg)
         enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
         assert enc._desc.pos == (_lib.POS_PPEG if cfg['pos'] == 'ppeg' else _lib.POS_PEG)
     assert RRTEncoder(mlp_dim=64, pos='peg', peg_k=5, peg_1d=True).pos_embedding.proj.weight.shape == (64, 1, 5, 1)
+    # pos_pos = 0 applies the stage before layer index 1 (rrt.py:185): with the default n_layers = 2 there is no such
+    # layer -- the reference's default `--pos ppeg` run never executes it; the parameters exist, the stage does not
+    assert RRTEncoder(mlp_dim=64, pos='ppeg')._desc.pos == _lib.POS_NONE
+    assert RRTEncoder(mlp_dim=64, pos='ppeg', n_layers=3)._desc.pos == _lib.POS_PPEG
+    assert len(RRTEncoder(mlp_dim=64, pos='ppeg').pos_embedding.state_dict()) == 6
 
 
 def test_ffn_state_dict_surface():

@@ -27,6 +27,17 @@ def _need_gpu():
     _lib.load()   # fails loudly if librrt_hip.so is not built
 
 
+@pytest.fixture(autouse=True)
+def _inference_runs_without_a_graph(request):
+    """The reference's validation loops run under torch.no_grad() (main.py val loop); with gradients enabled a forward
+    records a graph (eval() too) and takes the training kernels.  Inference tests therefore run under no_grad; the
+    tests of the backward (names with backward / train / gradients / learns) keep gradients on."""
+    name = request.node.name
+    grad = any(k in name for k in ("backward", "train", "gradients", "learns"))
+    with torch.set_grad_enabled(grad):
+        yield
+
+
 def _cmp(got, ref, tol, what):
     err = np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()
     assert np.isfinite(got).all(), f"{what}: non-finite output"
@@ -521,7 +532,8 @@ def test_rrtmil_fails_loudly():
     mil = mil.to("cuda:0")
     with pytest.raises(ValueError):
         mil.forward_bag(torch.zeros(10, 96, device="cuda:0"))
-    out = mil.train()(torch.randn(1, 10, 64, device="cuda:0"))          # training records a graph (row f2)
+    with torch.enable_grad():
+        out = mil.train()(torch.randn(1, 10, 64, device="cuda:0"))      # training records a graph (row f2)
     assert out.grad_fn is not None and out.shape == (1, 2)
     with pytest.raises(NotImplementedError):                            # the one-call inference path refuses train mode
         mil.forward_bag(torch.zeros(10, 64, device="cuda:0"))
@@ -936,8 +948,17 @@ def test_encoder_backward_matches_autograd(case):
             assert float(prm.grad.abs().max()) == 0.0 and float(ref.abs().max()) < 1e-6     # Identity 2
             continue
         rel(prm.grad.cpu().numpy(), ref.numpy().reshape(prm.shape), name)
-    # eval() never records a graph
-    assert enc.eval()(xd.unsqueeze(0)).grad_fn is None
+    # eval() with gradients enabled records a graph too (the reference does: fine-tuning with dropout frozen,
+    # attribution); under torch.no_grad() it is the inference path
+    enc.eval()
+    enc.zero_grad(set_to_none=True)
+    ye = enc(xd.unsqueeze(0)).squeeze(0)
+    assert ye.grad_fn is not None
+    if case == "c16_n2600":
+        (ye * dev(G)).sum().backward()
+        rel(enc.cr_msa.attn.attn.qkv.weight.grad.cpu().numpy(), params["cr_msa.attn.attn.qkv.weight"].grad.numpy(), "eval-mode graph")
+    with torch.no_grad():
+        assert enc(xd.unsqueeze(0)).grad_fn is None
     if case == "default_n1500":
         # a second backward through a retained graph gives the same gradients again (accumulated: x2)
         enc.train()
@@ -1040,6 +1061,104 @@ def test_encoder_backward_with_dropout(case, p):
     assert not torch.equal(y1, y2)
     enc.eval()
     assert torch.equal(enc(xd.unsqueeze(0)), enc(xd.unsqueeze(0)))
+
+
+@pytest.mark.parametrize("case,draws", [("default_n1500", [1 / 0.7, 0.0]), ("default_n1500", [0.0, 1 / 0.7]),
+                                        ("ffn_gelu_n1200", [1 / 0.7, 0.0, 0.0, 1 / 0.7]),
+                                        ("nsclc_layers3_n900", [0.0, 1 / 0.7, 1 / 0.7])])
+def test_encoder_backward_with_drop_path(case, draws):
+    """drop_path > 0 (TransLayer.drop_path, rrt.py:102,125,129: timm's DropPath keeps or drops a whole residual branch
+    at batch size 1, kept branches scaled by 1 / keep_prob): with the draws pinned, forward and every gradient against
+    the float64 oracle given the same multipliers (together with proj dropout); unpinned, the draws follow
+    Bernoulli(keep_prob) and eval() ignores them."""
+    from hip_util import DEV, dev, dropout_keep
+    from rrt_mil_amd import RRTEncoder
+    N, cfg = TRAIN_CASES[case]
+    D, p = cfg["mlp_dim"], 0.1
+    st = synth.encoder_state(**{k: v for k, v in cfg.items() if k in ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k",
+                                                                      "cr_msa", "crmsa_k", "qkv_bias", "ffn", "mlp_ratio")})
+    x = synth.bag(N, D, tag="train/" + case)
+    G = synth.normal("train/G/" + case, (N, D))
+    seed = 0x0F1E_2D3C_4B5A
+    H, _, _ = O.grid(N, cfg.get("region_num", 8))
+    n_layers = cfg.get("n_layers", 2) - 1
+    masks = {li: dropout_keep(seed, li, H * H, D, p) for li in range(n_layers)}
+    masks["cr_msa"] = dropout_keep(seed, 100, cfg.get("crmsa_k", 3) * 64, D, p)
+    keys = list(range(n_layers)) + ["cr_msa"]
+    if cfg.get("ffn"):
+        hid = int(D * cfg.get("mlp_ratio", 4.0))
+        for key, idx in [(li, li) for li in range(n_layers)] + [("cr_msa", 8)]:
+            masks[("ffn1", key)] = dropout_keep(seed, 200 + 2 * idx, N, hid, p)
+            masks[("ffn2", key)] = dropout_keep(seed, 201 + 2 * idx, N, D, p)
+    order = [(k, "attn") for k in keys] + ([(k, "ffn") for k in keys] if cfg.get("ffn") else [])
+    assert len(order) == len(draws)
+    branch = dict(zip(order, draws))
+    y64, x_leaf, params = O.forward_eager(x, st, cfg, grad=True, drop=(p, masks), branch=branch)
+    (y64 * torch.from_numpy(G).double()).sum().backward()
+    enc = RRTEncoder(drop_out=p, drop_path=0.3, **cfg)
+    enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    enc = enc.to(DEV).train()
+    enc.drop_seed, enc.drop_path_draws = seed, draws
+    xd = dev(x).requires_grad_(True)
+    y = enc(xd.unsqueeze(0)).squeeze(0)
+    _cmp(y.detach().cpu().numpy(), y64.detach().numpy(), 2e-4, case + " forward with drop_path")
+    (y * dev(G)).sum().backward()
+    torch.cuda.synchronize()
+    top = max(float(v.grad.abs().max()) for v in params.values() if v.grad is not None)
+    for name, got, ref in [("dx", xd.grad, x_leaf.grad)] + [(n_, p_.grad, params[n_].grad.reshape(p_.shape))
+                                                            for n_, p_ in enc.named_parameters()
+                                                            if not n_.endswith("pe.bias")]:
+        ref = ref.numpy().astype(np.float64)
+        # a dropped branch leaves its parameters with an exactly zero gradient
+        err = np.abs(got.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-6 * top)
+        assert err <= 2e-3, f"{case} {name}: {err:.2e}"
+    dropped = [k for k, m in branch.items() if m == 0.0 and k[1] == "attn" and k[0] != "cr_msa"]
+    for li, _ in dropped:
+        assert float(enc.layers[li].attn.attn.qkv.weight.grad.abs().max()) == 0.0
+    # unpinned: draws are Bernoulli(keep) / keep from torch's CPU generator; eval() has none
+    enc.drop_path_draws = None
+    torch.manual_seed(7)
+    seen = [tuple(enc._branch_scales()) for _ in range(200)]
+    vals = np.array([s_[0] for s_ in seen])
+    assert set(np.round(vals, 4)) == {0.0, round(1 / 0.7, 4)} and abs((vals > 0).mean() - 0.7) < 0.12
+    enc.eval()
+    assert enc._branch_scales() is None
+    with torch.no_grad():
+        assert torch.equal(enc(xd.unsqueeze(0)), enc(xd.unsqueeze(0)))
+
+
+def test_train_mode_without_graph_and_stale_weights():
+    """train() under torch.no_grad() (MC dropout, EMA / teacher forwards) applies proj dropout like the reference
+    (rmsa.py:132) -- with the seed pinned it equals the oracle given the same masks -- and a parameter changed in
+    place between a forward and its backward is refused (the backward kernels read the live weights)."""
+    from hip_util import DEV, dev, dropout_keep
+    from rrt_mil_amd import RRTEncoder
+    N, cfg = TRAIN_CASES["default_n1500"]
+    st = synth.encoder_state(mlp_dim=512, epeg_k=15, crmsa_k=3)
+    x = synth.bag(N, 512, tag="train/default_n1500")
+    p, seed = 0.1, 0x5EED
+    H, _, _ = O.grid(N, 8)
+    masks = {0: dropout_keep(seed, 0, H * H, 512, p), "cr_msa": dropout_keep(seed, 100, 3 * 64, 512, p)}
+    ref = O.forward_eager(torch.from_numpy(x).double(), {k: torch.from_numpy(v).double() for k, v in st.items()}, cfg,
+                          drop=(p, masks)).numpy()
+    enc = RRTEncoder(drop_out=p, **cfg)
+    enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    enc = enc.to(DEV).train()
+    xd = dev(x)
+    with torch.no_grad():
+        enc.drop_seed = seed
+        y = enc(xd.unsqueeze(0)).squeeze(0)
+        assert y.grad_fn is None
+        _cmp(y.cpu().numpy(), ref, 2e-4, "train() forward under no_grad")
+        enc.drop_seed = None
+        assert not torch.equal(enc(xd.unsqueeze(0)), enc(xd.unsqueeze(0)))
+        outs = enc.forward_bags([xd, xd[:700]])
+        assert outs[0].shape == xd.shape and not torch.equal(outs[0], y)
+    y = enc(xd.unsqueeze(0))
+    with torch.no_grad():
+        enc.norm.weight.mul_(1.5)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        y.sum().backward()
 
 
 def test_rrtmil_learns_synthetic_task():

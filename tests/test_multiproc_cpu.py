@@ -69,3 +69,40 @@ def test_assignment_is_balanced_and_deterministic():
     assert sharding.assign_bags([30000] * 8, 8) == [[i] for i in range(8)]
     from oracle import rrt_oracle
     assert sharding.bag_cost(9000) == rrt_oracle.flops_per_bag(9000)
+
+
+def _run_bench(*argv):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                         timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout            # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_self_spawns_ranks_like_the_driver_invokes_it():
+    """`python bench.py --gpus 2 ...` with NO torch.distributed environment (the driver's SCALE command shape): bench.py
+    re-executes itself under torch.distributed.run, every rank runs the rank program (config 4: the 64-bag mix split
+    by sharding.assign_bags), rank 0 prints one JSON line.  --stub-cpu swaps the GPU workload for a CPU stand-in over
+    gloo; everything else (spawn, sharding, barrier, MAX over ranks, the record) is the code the GPUs run."""
+    from rrt_mil_amd import sharding
+    rec = _run_bench("--gpus", "2", "--stub-cpu", "--steps", "3", "--warmup", "1", "--config", "4")
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "strong"
+    assert rec["unit"] == "slides/s" and rec["higher_is_better"] is True and rec["value"] > 0
+    assert rec["config"]["bags_per_step"] == 64 and rec["config"]["baseline_config_index"] == 4
+    sizes = [int(v) for v in np.random.RandomState(2021).randint(3000, 15001, size=64)]
+    want = sharding.assign_bags(sizes, 2, region_num=8, epeg_k=21, crmsa_k=5)
+    assert rec["config"]["bags_this_rank"] == len(want[0])
+    assert abs(rec["value"] - 64 * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-3
+
+
+def test_bench_single_rank_and_weak_scaling_record():
+    rec1 = _run_bench("--stub-cpu", "--steps", "2", "--warmup", "0", "--config", "3")
+    assert rec1["n_gpus"] == 1 and rec1["scaling"] == "weak" and rec1["config"]["n_tokens"] == 30000
+    rec2 = _run_bench("--gpus", "2", "--stub-cpu", "--steps", "2", "--warmup", "0", "--config", "3")
+    assert rec2["n_gpus"] == 2 and rec2["config"]["bags_per_step"] == 2 * rec1["config"]["bags_per_step"]
