@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 14
+#define RRT_ABI_VERSION 15
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -37,8 +37,13 @@ enum {
  * fp32 on the fp32 matrix cores (the default; what the <=1e-3 fp32 parity claim is made on).
  * BF16 / F16 round the two MFMA operands to bf16 / fp16 and accumulate in fp32 -- the
  * autocast-class numerics of the reference's --amp path (main.py:101-102,439); LayerNorm,
- * softmax, attention, residuals and all intermediates in HBM stay fp32 in every mode. */
+ * softmax statistics, residuals and the residual stream in HBM stay fp32 in every mode. */
 enum { RRT_COMPUTE_F32 = 0, RRT_COMPUTE_BF16 = 1, RRT_COMPUTE_F16 = 2 };
+/* In BF16 / F16 on regions of 17..208 tokens with head dim 64 the R-MSA layers run on 16-bit data end to end
+ * (rrt_ln_partition16 -> rrt_rmsa_fused16 -> rrt_linear16_f32 below): the LayerNorm output, the weights and the
+ * attention output live in HBM in 16 bits, and Q~, K, V and the softmax probabilities go to the matrix cores in 16
+ * bits too (fp32 accumulation, fp32 softmax statistics) -- what autocast does to nn.Linear, q k^T and attn v.
+ * The residual stream x / x1 / y, LayerNorm, CR-MSA's logits / combine / dispatch stay fp32. */
 enum { RRT_POS_NONE = 0, RRT_POS_PEG = 1, RRT_POS_PPEG = 2 };
 
 /* Elementwise activations of the caller-side layers (patch_to_emb, DAttention). */
@@ -190,6 +195,23 @@ int rrt_region_attention_f32(const float *qkv, const float *pe_w, float *o,
 int rrt_rmsa_fused_f32(const float *u, const float *qkv_w, const float *qkv_b, const float *pe_w,
                        float *o, int32_t n_regions, int32_t P, int32_t dim, int32_t heads,
                        int32_t epeg_k, int32_t compute, void *stream);
+
+/* 16-bit operand stages of the reduced-precision modes (compute = RRT_COMPUTE_BF16 / F16 selects the element type;
+ * uint16_t* = raw bf16 / fp16 bits, round-to-nearest-even):
+ *  cast16        : dst[i] = (16-bit) src[i], n % 4 == 0 (the nn.Linear weights, once per forward);
+ *  ln_partition16: rrt_ln_partition_f32 with the normalised rows rounded to 16 bits (what autocast feeds nn.Linear);
+ *  linear16      : C fp32 [M, N] = A16 [M, K] . B16 [N, K]^T + bias; with resid != NULL the un-partition + residual
+ *                  epilogue of rrt_linear_unpartition_residual_f32 (M = H*H of g); K % 64 == 0, M >= 128;
+ *  rmsa_fused16  : rrt_rmsa_fused_f32 on 16-bit u / qkv_w, attention operands in 16 bits, o in 16 bits
+ *                  (rmsa.py:100-122 under autocast); head dim 64, 16 < P <= 208. */
+int rrt_cast16(const float *src, uint16_t *dst, int64_t n, int32_t compute, void *stream);
+int rrt_ln_partition16(const float *x, const float *gamma, const float *beta, uint16_t *u, int64_t L,
+                       int32_t dim, const rrt_grid *g, int32_t compute, void *stream);
+int rrt_linear16_f32(const uint16_t *A, const uint16_t *B, const float *bias, const float *resid, float *C,
+                     int64_t M, int32_t N, int32_t K, const rrt_grid *g, int32_t compute, void *stream);
+int rrt_rmsa_fused16(const uint16_t *u, const uint16_t *qkv_w, const float *qkv_b, const float *pe_w,
+                     uint16_t *o, int32_t n_regions, int32_t P, int32_t dim, int32_t heads, int32_t epeg_k,
+                     int32_t compute, void *stream);
 
 /* CR-MSA (rmsa.py:303-335), three kernels around the inner MSA (g8 = the 8x8 grid):
  *  logits  : LayerNorm statistics mean_rstd [L,2] and logits [Np8, k] in region-major order

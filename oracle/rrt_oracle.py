@@ -146,8 +146,9 @@ def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None, lowp=None, attn_low
             qt = q.copy()
             for t in range(epeg_k):
                 qt += w[None, :, t, None, None] * qp[:, :, t:t + P, :]
-        S = attn_lowp.r(qt) @ attn_lowp.r(k).transpose(0, 1, 3, 2)
-        e = np.exp(S - S.max(-1, keepdims=True))
+        # (the kernels fold log2(e) into the stencil taps, round Q~ log2(e) and exponentiate with exp2)
+        S = attn_lowp.r(qt * 1.4426950408889634) @ attn_lowp.r(k).transpose(0, 1, 3, 2)
+        e = np.exp2(S - S.max(-1, keepdims=True))
         O = (attn_lowp.r(e) @ attn_lowp.r(v)) / e.sum(-1, keepdims=True)
         O = O.transpose(0, 2, 1, 3).reshape(B_, P, D)
         Wp = st[pfx + "proj.weight"].astype(np.float64)

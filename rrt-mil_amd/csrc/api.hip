@@ -27,6 +27,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Workspace {
   float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *v8, *hid;
   float *ffn_ln, *ffn_hid, *xp;
+  uint16_t* w16;     // reduced-precision modes: 16-bit copies of the R-MSA layers' qkv / proj weights (4 D^2 per layer)
   size_t bytes;
 };
 
@@ -47,6 +48,9 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     w.qkv = take(Np * 3 * D);
     w.xa = take((size_t)N * D);
     if (d.n_rmsa_layers > 1 || d.ffn) w.xb = take((size_t)N * D);
+    // carved in every mode (2 MB per layer at D = 512): the size must not depend on desc.compute, which callers
+    // flip between calls on one workspace
+    w.w16 = (uint16_t*)take((size_t)d.n_rmsa_layers * 2 * D * D);
   }
   if (d.ffn) {
     if (!w.xa) w.xa = take((size_t)N * D);
@@ -282,6 +286,26 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
     rc = pos_embed();
     if (rc) return rc;
   }
+  // Reduced-precision modes on regions the 16-bit fused kernel covers: every tensor that is only a matrix-core
+  // operand (LayerNorm output u, the weights, the attention output O) lives in HBM in 16 bits.  The weights are
+  // cast once per call (one launch for all layers; the ABI is stateless, so nothing is cached across calls).
+  bool lowp16 = false;
+  if (desc->n_rmsa_layers > 0 && desc->compute != RRT_COMPUTE_F32) {
+    const GridDev gd = to_dev(g);
+    lowp16 = rmsa_fused16_supported(gd.P, D, desc->n_heads, desc->epeg ? desc->epeg_k : 0) &&
+             rmsa_fused_supported_rows(gd.Np, D) && D % 64 == 0;
+    if (lowp16) {
+      Cast16Jobs jobs{};
+      for (int li = 0; li < desc->n_rmsa_layers; ++li) {
+        const rrt_attn_weights& lw = w->rmsa[li];
+        if (!lw.qkv_w || !lw.proj_w) return RRT_E_INVALID;
+        uint16_t* base = ws.w16 + (size_t)li * 4 * D * D;
+        jobs.src[jobs.count] = lw.qkv_w; jobs.dst[jobs.count] = base; jobs.n4[jobs.count++] = (size_t)3 * D * D / 4;
+        jobs.src[jobs.count] = lw.proj_w; jobs.dst[jobs.count] = base + (size_t)3 * D * D; jobs.n4[jobs.count++] = (size_t)D * D / 4;
+      }
+      RRT_TRY(launch_cast16(jobs, desc->compute, st));
+    }
+  }
   // ---- R-MSA TransLayers: x = x + unpart(InnerAttention(part(pad(LN(x)))))  (rrt.py:117-125)
   for (int li = 0; li < desc->n_rmsa_layers; ++li) {
     if (li == 1 && desc->pos && desc->pos_pos == 0) {
@@ -294,8 +318,36 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
     const GridDev gd = to_dev(g);
     // without FFN the layers ping-pong xa / xb; with it attention writes xa and the FFN writes xb
     float* xout = desc->ffn ? ws.xa : ((li & 1) ? ws.xb : ws.xa);
-    RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, ws.uo, D, gd, st));
     const int ek = desc->epeg ? desc->epeg_k : 0;
+    if (lowp16) {
+      // u (16-bit) in the uo buffer, O (16-bit) in the qkv buffer; qkv, scores and probabilities never leave the CU
+      uint16_t* u16 = (uint16_t*)ws.uo;
+      uint16_t* o16 = (uint16_t*)ws.qkv;
+      const uint16_t* wq16 = ws.w16 + (size_t)li * 4 * D * D;
+      RRT_TRY(launch_ln_partition16(xin, lw.norm_w, lw.norm_b, u16, D, gd, desc->compute, st));
+      rrt_phase_gate* const gt16 = (gate && gd.P > 112) ? gate : nullptr;
+      if (gt16 && gt16->armed) RRT_TRY(hipStreamWaitEvent(st, gt16->done, 0));
+      if (li == 0) RRT_MARK(RRT_EV_LN_PARTITION);
+      RRT_TRY(launch_rmsa_fused16(u16, wq16, lw.qkv_b, desc->epeg ? lw.pe_w : nullptr, o16, gd.rs * gd.rs, gd.P, D,
+                                  desc->n_heads, ek, desc->compute, st));
+      if (gt16) { RRT_TRY(hipEventRecord(gt16->done, st)); gt16->armed = true; }
+      if (li == 0) { RRT_MARK(RRT_EV_QKV); RRT_MARK(RRT_EV_ATTN); }
+      LinearEpilogue ep{};
+      ep.prec = desc->compute;
+      ep.bias = lw.proj_b;
+      ep.resid = xin;
+      ep.g = gd;
+      RRT_TRY(launch_linear16(o16, wq16 + (size_t)3 * D * D, xout, gd.Np, D, D, ep, st));
+      if (li == 0) RRT_MARK(RRT_EV_PROJ);
+      xin = xout;
+      if (desc->ffn) {
+        rc = ffn_block(lw, xout, ws.xb);
+        if (rc) return rc;
+        xin = ws.xb;
+      }
+      continue;
+    }
+    RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, ws.uo, D, gd, st));
     const bool fused = rmsa_fused_supported(gd.P, D, desc->n_heads, ek) && rmsa_fused_supported_rows(gd.Np, D);
     // the gate only pays for launches that fill the matrix pipes of the whole chip on their own: the fused
     // kernel on regions of >= 113 tokens (measured on the configs[4] mix: gating small or unfused bags costs 5 %)
@@ -495,6 +547,50 @@ int rrt_rmsa_fused_f32(const float* u, const float* qkv_w, const float* qkv_b, c
     return unsupported("rmsa_fused: needs head dim 64, 48 < P <= 208, epeg_k <= 63 (use linear + region_attention)");
   return (int)launch_rmsa_fused(u, qkv_w, qkv_b, pe_w, o, n_regions, P, dim, heads, ek, compute,
                                 (hipStream_t)stream);
+}
+
+// ---- 16-bit operand stages of the reduced-precision modes (cast16.hip, linear_f32.hip IN16, rmsa_fused16.hip)
+int rrt_cast16(const float* src, uint16_t* dst, int64_t n, int32_t compute, void* stream) {
+  if (!src || !dst || n <= 0 || n % 4) return RRT_E_INVALID;
+  if (compute != RRT_COMPUTE_BF16 && compute != RRT_COMPUTE_F16) return unsupported("cast16: compute must be BF16 or F16");
+  Cast16Jobs jobs{};
+  jobs.src[0] = src; jobs.dst[0] = dst; jobs.n4[0] = (size_t)n / 4; jobs.count = 1;
+  return (int)launch_cast16(jobs, compute, (hipStream_t)stream);
+}
+
+int rrt_ln_partition16(const float* x, const float* gamma, const float* beta, uint16_t* u, int64_t L, int32_t dim,
+                       const rrt_grid* g, int32_t compute, void* stream) {
+  if (!x || !gamma || !beta || !u || !g || L != g->L || dim <= 0 || dim % 4) return RRT_E_INVALID;
+  if (dim > 2048) return unsupported("dim > 2048");
+  if (compute != RRT_COMPUTE_BF16 && compute != RRT_COMPUTE_F16) return unsupported("compute must be BF16 or F16");
+  return (int)launch_ln_partition16(x, gamma, beta, u, dim, to_dev(*g), compute, (hipStream_t)stream);
+}
+
+int rrt_linear16_f32(const uint16_t* A, const uint16_t* B, const float* bias, const float* resid, float* C, int64_t M,
+                     int32_t N, int32_t K, const rrt_grid* g, int32_t compute, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (resid && !g)) return RRT_E_INVALID;
+  if (K % 64) return unsupported("linear16: K must be a multiple of 64");
+  if (compute != RRT_COMPUTE_BF16 && compute != RRT_COMPUTE_F16) return unsupported("compute must be BF16 or F16");
+  LinearEpilogue ep{};
+  ep.prec = compute;
+  ep.bias = bias;
+  if (resid) {
+    ep.resid = resid;
+    ep.g = to_dev(*g);
+    if (M != ep.g.Np) return RRT_E_INVALID;
+  }
+  return (int)launch_linear16(A, B, C, (int)M, N, K, ep, (hipStream_t)stream);
+}
+
+int rrt_rmsa_fused16(const uint16_t* u, const uint16_t* qkv_w, const float* qkv_b, const float* pe_w, uint16_t* o,
+                     int32_t n_regions, int32_t P, int32_t dim, int32_t heads, int32_t epeg_k, int32_t compute,
+                     void* stream) {
+  if (!u || !qkv_w || !o || n_regions <= 0 || P <= 0 || dim <= 0 || heads <= 0) return RRT_E_INVALID;
+  if (compute != RRT_COMPUTE_BF16 && compute != RRT_COMPUTE_F16) return unsupported("compute must be BF16 or F16");
+  const int ek = pe_w ? epeg_k : 0;
+  if (!rmsa_fused16_supported(P, dim, heads, ek) || !rmsa_fused_supported_rows((long)n_regions * P, dim))
+    return unsupported("rmsa_fused16: needs head dim 64, 16 < P <= 208, epeg_k <= 63");
+  return (int)launch_rmsa_fused16(u, qkv_w, qkv_b, pe_w, o, n_regions, P, dim, heads, ek, compute, (hipStream_t)stream);
 }
 
 int rrt_crmsa_logits_f32(const float* x1, const float* gamma, const float* beta, const float* phi,

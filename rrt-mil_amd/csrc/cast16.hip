@@ -1,0 +1,122 @@
+// cast16.hip -- producers of the 16-bit GEMM operands of the reduced-precision modes (bf16 / fp16).
+//
+// In RRT_COMPUTE_BF16 / F16 every tensor that is consumed ONLY as a matrix-core operand lives in HBM in
+// 16 bits: half the bytes over HBM / L2 / LDS-DMA and no conversion inside the GEMM loops (the round-1
+// kernels moved fp32 and rounded after LDS -- the same values, twice the traffic and twice the DMA issue).
+//   * cast16_kernel       : the nn.Linear weights of the R-MSA layers (qkv.weight, proj.weight), once per call;
+//   * ln_partition16_kernel: LayerNorm + zero-pad + region_partition (modules/rrt.py:121-123,
+//                            modules/rmsa.py:199-200,28-39) with the normalised rows rounded to 16 bits -- exactly
+//                            what torch.autocast feeds nn.Linear (LayerNorm runs in fp32, Linear casts its input).
+// Rounding is round-to-nearest-even (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32).
+#include "internal.h"
+
+namespace {
+
+template <int PREC>
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  if constexpr (PREC == 1) {
+    typedef __bf16 v4 __attribute__((ext_vector_type(4)));
+    v4 r;
+    r[0] = (__bf16)a; r[1] = (__bf16)b; r[2] = (__bf16)c; r[3] = (__bf16)d;
+    return __builtin_bit_cast(uint2, r);
+  } else {
+    typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+    v4 r;
+    r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d;
+    return __builtin_bit_cast(uint2, r);
+  }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void cast16_kernel(Cast16Jobs jobs) {
+  const int j = blockIdx.y;
+  const float4* src = (const float4*)jobs.src[j];
+  uint2* dst = (uint2*)jobs.dst[j];
+  const size_t n4 = jobs.n4[j];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = src[i];
+    dst[i] = pack4<PREC>(v.x, v.y, v.z, v.w);
+  }
+}
+
+template <int NV, int PREC>   // float4 per lane: supports dim <= NV*256
+__global__ __launch_bounds__(256) void ln_partition16_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             uint16_t* __restrict__ u, int dim, GridDev g) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);   // padded-grid token index
+  if (t >= g.Np) return;
+  uint16_t* dst = u + (size_t)token_to_slot(t, g) * dim;
+  if (t >= g.L) {   // pad row: exact zeros (they are NOT layer-normed in the reference)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      int c = (v * 64 + lane) * 4;
+      if (c < dim) *(uint2*)(dst + c) = make_uint2(0u, 0u);
+    }
+    return;
+  }
+  const float* src = x + (size_t)t * dim;
+  float4 r[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int c = (v * 64 + lane) * 4;
+    r[v] = (c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sum += (r[v].x + r[v].y) + (r[v].z + r[v].w);
+  }
+  const float inv_d = 1.0f / (float)dim;
+  const float mean = wave_sum(sum) * inv_d;
+  float sq = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int c = (v * 64 + lane) * 4;
+    if (c < dim) {
+      float a = r[v].x - mean, b = r[v].y - mean, cc = r[v].z - mean, d = r[v].w - mean;
+      sq += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int c = (v * 64 + lane) * 4;
+    if (c < dim) {
+      float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
+      *(uint2*)(dst + c) = pack4<PREC>((r[v].x - mean) * rstd * gm.x + bt.x, (r[v].y - mean) * rstd * gm.y + bt.y,
+                                       (r[v].z - mean) * rstd * gm.z + bt.z, (r[v].w - mean) * rstd * gm.w + bt.w);
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_cast16(const Cast16Jobs& jobs, int prec, hipStream_t st) {
+  if (jobs.count <= 0) return hipSuccess;
+  if (prec != 1 && prec != 2) return hipErrorInvalidValue;
+  size_t mx = 0;
+  for (int j = 0; j < jobs.count; ++j) mx = jobs.n4[j] > mx ? jobs.n4[j] : mx;
+  size_t blocks = (mx + 256 * 4 - 1) / (256 * 4);           // ~4 float4 per thread
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;
+  dim3 grid((unsigned)blocks, jobs.count);
+  if (prec == 1) cast16_kernel<1><<<grid, 256, 0, st>>>(jobs);
+  else cast16_kernel<2><<<grid, 256, 0, st>>>(jobs);
+  return hipGetLastError();
+}
+
+hipError_t launch_ln_partition16(const float* x, const float* gamma, const float* beta, uint16_t* u, int dim,
+                                 const GridDev& g, int prec, hipStream_t st) {
+  if (prec != 1 && prec != 2) return hipErrorInvalidValue;
+  dim3 grid((g.Np + 3) / 4), block(256);
+#define RRT_LNP16(NV)                                                                               \
+  do {                                                                                              \
+    if (prec == 1) ln_partition16_kernel<NV, 1><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);  \
+    else ln_partition16_kernel<NV, 2><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);           \
+  } while (0)
+  if (dim <= 256) RRT_LNP16(1);
+  else if (dim <= 512) RRT_LNP16(2);
+  else if (dim <= 1024) RRT_LNP16(4);
+  else RRT_LNP16(8);
+#undef RRT_LNP16
+  return hipGetLastError();
+}

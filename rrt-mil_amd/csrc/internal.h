@@ -41,6 +41,25 @@ struct LinearEpilogue {
 hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
                          const LinearEpilogue& ep, hipStream_t st);
 
+// ---- 16-bit operand path of the reduced-precision modes (cast16.hip, linear_f32.hip IN16, rmsa_fused16.hip)
+constexpr int CAST16_MAX_JOBS = 2 * RRT_MAX_RMSA_LAYERS;
+struct Cast16Jobs {
+  const float* src[CAST16_MAX_JOBS];
+  uint16_t* dst[CAST16_MAX_JOBS];
+  size_t n4[CAST16_MAX_JOBS];       // float4 groups (element count / 4)
+  int count;
+};
+hipError_t launch_cast16(const Cast16Jobs& jobs, int prec, hipStream_t st);
+hipError_t launch_ln_partition16(const float* x, const float* gamma, const float* beta, uint16_t* u, int dim,
+                                 const GridDev& g, int prec, hipStream_t st);
+hipError_t launch_linear16(const void* A16, const void* B16, float* C, int M, int N, int K, const LinearEpilogue& ep,
+                           hipStream_t st);
+// fused R-MSA core on 16-bit operands: U16 [n_regions*P, D], Wqkv16 [3D, D] -> O16 [n_regions*P, D]
+bool rmsa_fused16_supported(int P, int D, int heads, int epeg_k);
+hipError_t launch_rmsa_fused16(const uint16_t* U16, const uint16_t* Wqkv16, const float* bqkv, const float* pe_w,
+                               uint16_t* O16, int n_regions, int P, int D, int heads, int epeg_k, int prec,
+                               hipStream_t st);
+
 hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o, int n_regions,
                                    int P, int dim, int heads, int epeg_k, hipStream_t st);
 

@@ -388,12 +388,21 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
 // (measured: ~10 us per tile that two co-resident blocks hit in lockstep).  Here the loader waves
 // own every DMA and every vmcnt wait; the compute waves never wait on vector memory, so their
 // stores drain underneath the next tile's MFMAs.  One s_barrier per K tile, shared by all 6 waves.
-template <int MT, int NT, int MODE, int PREC>
-__global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restrict__ A,
-                                                           const float* __restrict__ B,
+// IN16: A and B already hold 16-bit operands in HBM (bf16 / fp16 per PREC; cast16.hip produces them): a K tile is
+// 64 elements = the same 128-byte rows, so the staging ring, the XOR swizzle and the DMA schedule are byte for byte
+// those of the fp32 form; a 16-byte LDS slot is one 16x16x32 MFMA operand (k = 8 lg .. 8 lg + 7 of a 32-wide
+// sub-tile) and nothing is converted in the loop.
+template <int MT, int NT, int MODE, int PREC, bool IN16 = false>
+__global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restrict__ Av,
+                                                           const void* __restrict__ Bv,
                                                            float* __restrict__ C, int M, int N, int K,
                                                            int tiles_n, int ntiles, LinearEpilogue ep) {
+  static_assert(!IN16 || PREC != PREC_F32, "16-bit operands need a 16-bit MFMA");
   constexpr int BM = 16 * MT, BN = 64 * NT;
+  constexpr int ES = IN16 ? 2 : 4;                       // bytes per operand element in HBM
+  constexpr int BKE = 128 / ES;                          // elements per K tile (BK floats = 128 bytes either way)
+  const char* const A = (const char*)Av;
+  const char* const B = (const char*)Bv;
   constexpr int STAGE = (BM + BN) * BK;
   constexpr int NA = BM / 8, NB = BN / 8;                // DMA wave-instructions per A / B tile
   constexpr int LA = (NA + 1) / 2, LB = NB / 2;          // per loader wave
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
     first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   if (first >= ntiles) return;
-  const int nk = K / BK;
+  const int nk = K / BKE;
   RRT_TRACE_INIT(blockIdx.x * 6 + wave);
   RRT_TRACE_MARK();                                   // [1] entry
 
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
         int row = S >> 3, p = S & 7;
         int gr = m0 + row;
         gr = gr < M ? gr : M - 1;
-        aoff[qi] = (unsigned)(gr - m0) * (unsigned)K * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+        aoff[qi] = (unsigned)(gr - m0) * (unsigned)K * (unsigned)ES + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
       }
 #pragma unroll
       for (int qi = 0; qi < LB; ++qi) {
@@ -433,10 +442,10 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
         int row = S >> 3, p = S & 7;
         int gr = n0 + row;
         gr = gr < N ? gr : N - 1;
-        boff[qi] = (unsigned)(gr - n0) * (unsigned)K * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+        boff[qi] = (unsigned)(gr - n0) * (unsigned)K * (unsigned)ES + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
       }
     };
-    auto stage = [&](const float* abase, const float* bbase, unsigned buf) {
+    auto stage = [&](const char* abase, const char* bbase, unsigned buf) {
 #pragma unroll
       for (int qi = 0; qi < LA; ++qi)
         if (qi * 2 + lw < NA) dma16s(abase, aoff[qi], buf + (qi * 2 + lw) * 1024);
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
     int tile = first;
     int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     tile_offsets(tm * BM, tn * BN);
-    stage(A + (size_t)tm * BM * K, B + (size_t)tn * BN * K, lds_b);
+    stage(A + (size_t)tm * BM * K * ES, B + (size_t)tn * BN * K * ES, lds_b);
     RRT_TRACE_MARK();                                 // loader [2] first stage issued
     int it = 0;
     for (; tile < ntiles; tile += G) {
@@ -459,10 +468,10 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
         if (kt == 0 || kt == 8) RRT_TRACE_MARK();     // loader: barrier passed
         const unsigned nxt = lds_b + ((it + 1) & 1) * STAGE * 4;
         if (kt + 1 < nk) {
-          stage(A + (size_t)tm * BM * K + (kt + 1) * BK, B + (size_t)tn * BN * K + (kt + 1) * BK, nxt);
+          stage(A + ((size_t)tm * BM * K + (size_t)(kt + 1) * BKE) * ES, B + ((size_t)tn * BN * K + (size_t)(kt + 1) * BKE) * ES, nxt);
         } else if (ntile < ntiles) {
           tile_offsets(ntm * BM, ntn * BN);
-          stage(A + (size_t)ntm * BM * K, B + (size_t)ntn * BN * K, nxt);
+          stage(A + (size_t)ntm * BM * K * ES, B + (size_t)ntn * BN * K * ES, nxt);
         }
       }
       tm = ntm;
@@ -529,6 +538,27 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
               }
         }
+      } else if constexpr (IN16) {
+        using F = Frag8<PREC>;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          typename F::type a8[MT], b8[NT];
+          const int cslot = 4 * kk + lg;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int row = wave * (16 * NT) + j * 16 + lr;
+            b8[j] = *(const typename F::type*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int row = i * 16 + lr;
+            a8[i] = *(const typename F::type*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(b8[j], a8[i], acc[i][j]);
+        }
       } else {
         using F = Frag8<PREC>;
         typename F::type a8[MT], b8[NT];
@@ -586,6 +616,24 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const float* __restri
   }
   // the block's last tile has no successor to hide behind
   if (have_prev) store_all_slices<MT, NT, MODE>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
+}
+
+template <int MT, int NT, int MODE, int PREC>
+hipError_t launch_cfg16(const void* A, const void* B, float* C, int M, int N, int K, int grid_cap,
+                        const LinearEpilogue& ep, hipStream_t st) {
+  constexpr int BM = 16 * MT, BN = 64 * NT;
+  constexpr int LDS_BYTES = 2 * (BM + BN) * BK * 4;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int ntiles = tiles_m * tiles_n;
+  const int grid = ntiles < grid_cap ? ntiles : grid_cap;
+  auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true>;
+  if (LDS_BYTES > 64 * 1024) {
+    static OncePerDevice once;
+    if (once.first())
+      (void)hipFuncSetAttribute((const void*)kws, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  }
+  kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
+  return hipGetLastError();
 }
 
 template <int MT, int NT, int MODE, int PREC>
@@ -649,6 +697,41 @@ Cfg choose(int M, int N) {
 #ifdef RRT_TRACE
 RRT_TRACE_DEFINE_READER(rrt_debug_trace_linear)
 #endif
+
+// C[M,N] fp32 = A16[M,K] . B16[N,K]^T with the operands already in 16 bits (ep.prec = 1 bf16 / 2 fp16); the
+// epilogues are the fp32 kernel's.  K % 64 == 0; the warp-specialised large-tile kernel only (the callers are the
+// R-MSA projections of the reduced-precision path: M = Np >= 3136 rows).
+hipError_t launch_linear16(const void* A, const void* B, float* C, int M, int N, int K, const LinearEpilogue& ep,
+                           hipStream_t st) {
+  if ((ep.prec != PREC_BF16 && ep.prec != PREC_F16) || K % 64 || ep.drop_on) return hipErrorInvalidValue;
+  const bool u = ep.resid != nullptr;
+  Cfg best{9, 1, 512};
+  {
+    static const Cfg cands[] = {{9, 1, 512}, {8, 1, 512}, {9, 2, 512}, {8, 2, 512}, {9, 2, 256}, {8, 2, 256}};
+    long best_cost = -1;
+    for (const Cfg& c : cands) {
+      long tiles = (long)((M + 16 * c.mt - 1) / (16 * c.mt)) * ((N + 64 * c.nt - 1) / (64 * c.nt));
+      long grid = tiles < c.cap ? tiles : c.cap;
+      long cost = ((tiles + grid - 1) / grid) * ((grid + 255) / 256) * c.mt * c.nt;
+      if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
+    }
+  }
+  const Cfg c = best;
+#define RRT_MODES16(MT_, NT_, P_)                                                                  \
+  (u ? launch_cfg16<MT_, NT_, MODE_UNPART, P_>(A, B, C, M, N, K, c.cap, ep, st)                    \
+     : ep.act ? launch_cfg16<MT_, NT_, MODE_ACT, P_>(A, B, C, M, N, K, c.cap, ep, st)              \
+              : launch_cfg16<MT_, NT_, MODE_PLAIN, P_>(A, B, C, M, N, K, c.cap, ep, st))
+#define RRT_CASE16(MT_, NT_)                                                                       \
+  if (c.mt == MT_ && c.nt == NT_)                                                                  \
+    return ep.prec == PREC_BF16 ? RRT_MODES16(MT_, NT_, PREC_BF16) : RRT_MODES16(MT_, NT_, PREC_F16);
+  RRT_CASE16(9, 1);
+  RRT_CASE16(8, 1);
+  RRT_CASE16(9, 2);
+  RRT_CASE16(8, 2);
+#undef RRT_CASE16
+#undef RRT_MODES16
+  return hipErrorInvalidValue;
+}
 
 hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
                          const LinearEpilogue& ep, hipStream_t st) {

@@ -1,0 +1,420 @@
+// rmsa_fused16.hip -- the fused R-MSA core (rmsa_fused.hip) for the reduced-precision modes, on 16-bit data end to end.
+//
+// Replaces InnerAttention.forward up to (not including) proj, modules/rmsa.py:100-122, under the reference's --amp
+// path (main.py:101-102,439: nn.Linear, q k^T and attn v run in bf16 / fp16 under autocast).  One block per
+// (region, head), 8 waves:
+//   phase 1  C[P x 192] = U16_r[P x D] . W16_h[192 x D]^T on the 16-bit matrix cores (v_mfma_f32_16x16x32_bf16/f16,
+//            fp32 accumulate).  U16 (LayerNorm output, cast16.hip) and W16 arrive in 16 bits: a K tile is 64
+//            elements = 128-byte rows, so the LDS image, the XOR swizzle and the DMA addressing are those of the
+//            fp32 kernel with half the bytes per element, and a 16-byte LDS slot IS one MFMA operand -- nothing is
+//            converted in the loop.  With MFMAs 16x faster than fp32 the loop is bound by how fast 1-KiB DMA pieces
+//            can be issued, so FOUR loader waves (one per SIMD, next to the four compute waves) feed the ring.
+//   phase 2  accumulators (+bias, q*scale) -> LDS: Q as fp32 (the EPEG stencil runs in fp32), K as 16-bit rows,
+//            V as its 16-bit TRANSPOSE with the keys of each 32-key block permuted into MFMA operand order
+//            (pos = 32 b + 8 g + 4 h + r for key = 32 b + 16 h + 4 g + r), so that the P.V operand is one
+//            ds_read_b128 and P^T never leaves the registers it was computed in;
+//   phase 3  EPEG sliding-window stencil over the fp32 Q tile (as in rmsa_fused.hip), x log2(e), rounded ONCE to
+//            16 bits into the Q~ tile that overwrites Q;
+//   phase 4  S^T = K Q~^T (scores transposed: lane = query, registers = keys), row softmax in fp32 registers,
+//            O^T = V^T P^T with V^T rows taken in the order d = 4 a + c so that a lane ends up with 16 consecutive
+//            head-dim columns of ITS query: two 16-byte stores per lane, 128 contiguous bytes per query row.
+// Rounding points (restated in oracle/rrt_oracle.py::forward_f64(lowp=...)): U, W (inputs); Q~ * log2 e, K, V,
+// exp2(S - max) (operands of the two attention products); O (output).  Accumulation, bias, scale, stencil, softmax
+// statistics and normalisation are fp32.
+// LDS: max(2 x (16 MT + 192) x 128 B ring, Q 16 MT x 256 B + K 16 MT x 128 B + V^T 64 x 512 B) = 86 KiB at MT = 9.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "internal.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int BN = 3 * HD;          // q | k | v columns of one head
+constexpr int ROWB = 128;           // bytes of one staged row = 64 16-bit elements = one K tile
+constexpr int VT_PITCH = 512;       // bytes per V^T row: 32 x 16-byte slots (keys <= 256), XOR-swizzled over 16
+constexpr float NEG_BIG = -3.0e38f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int PREC>
+struct H16;
+template <>
+struct H16<1> {
+  typedef __bf16 frag __attribute__((ext_vector_type(8)));
+  typedef __bf16 v4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 elem;
+  static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct H16<2> {
+  typedef _Float16 frag __attribute__((ext_vector_type(8)));
+  typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 elem;
+  static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <int PREC>
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  typename H16<PREC>::v4 r;
+  using E = typename H16<PREC>::elem;
+  r[0] = (E)a; r[1] = (E)b; r[2] = (E)c; r[3] = (E)d;
+  return __builtin_bit_cast(uint2, r);
+}
+template <int PREC>
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  typename H16<PREC>::v2 r;
+  using E = typename H16<PREC>::elem;
+  r[0] = (E)a; r[1] = (E)b;
+  return __builtin_bit_cast(unsigned, r);
+}
+template <int PREC>
+__device__ __forceinline__ typename H16<PREC>::frag pack8(const f32x4& a, const f32x4& b) {
+  typename H16<PREC>::frag r;
+  using E = typename H16<PREC>::elem;
+  r[0] = (E)a[0]; r[1] = (E)a[1]; r[2] = (E)a[2]; r[3] = (E)a[3];
+  r[4] = (E)b[0]; r[5] = (E)b[1]; r[6] = (E)b[2]; r[7] = (E)b[3];
+  return r;
+}
+
+// value of the lane whose index differs in bit 0 (DPP quad_perm [1,0,3,2]; no LDS round trip)
+__device__ __forceinline__ float swap_lane1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+
+template <int MT, int PREC>
+__global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __restrict__ U,
+                                                              const uint16_t* __restrict__ W,
+                                                              const float* __restrict__ bqkv,
+                                                              const float* __restrict__ pe_w,
+                                                              uint16_t* __restrict__ O, int n_rows, int P, int D,
+                                                              int heads_rt, int epeg_k, float q_scale) {
+  using H = H16<PREC>;
+  using Frag = typename H::frag;
+  constexpr int BM = 16 * MT;
+  constexpr int MTP = (MT + 1) & ~1;                 // key tiles rounded up to whole 32-key MFMA blocks
+  constexpr int STAGE_B = (BM + BN) * ROWB;          // bytes per pipeline stage
+  constexpr int NA = BM / 8, NB = BN / 8;            // 1-KiB DMA pieces (8 rows) per A / B stage
+  constexpr int LA = (NA + 3) / 4, LB = NB / 4;      // per loader wave
+  constexpr int NT = 3;                              // 16-column tiles per compute wave (4 x 48 = 192)
+  constexpr int QF_B = BM * 256, KS_B = BM * ROWB;   // fp32 Q tile, 16-bit K tile
+  static_assert(16 * MTP * 2 <= VT_PITCH, "V^T row");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const QF = smem;                             // fp32 Q [BM][64], slot XOR (row & 15); later Q~ 16-bit rows
+  char* const KS = smem + QF_B;                      // K [BM] x 128 B, slot XOR ((row >> 1) & 7)
+  char* const VT = smem + QF_B + KS_B;               // V^T [64] x 512 B, slot XOR ((d >> 2) & 15)
+  char* const QT = smem;                             // Q~ [BM] x 128 B (phase 3 writes it over Q)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const unsigned lds_b = lds_addr_of(smem);
+  // XCD-aware block -> (region, head) map (as rmsa_fused.hip): the 8 head-blocks of a region sit on ONE XCD so
+  // that the region's U panel is fetched from HBM once and served to the other heads from that XCD's L2
+  int head, reg;
+  {
+    const int b = blockIdx.x;
+    const int n_regions = gridDim.x / heads_rt;
+    const int full = (n_regions >> 3) * 8 * heads_rt;
+    if (b < full) {
+      const int xcd = b & 7, idx = b >> 3;
+      const int grp = idx / heads_rt;
+      reg = grp * 8 + xcd;
+      head = idx - grp * heads_rt;
+    } else {
+      const int rem = b - full;
+      reg = (n_regions >> 3) * 8 + rem / heads_rt;
+      head = rem % heads_rt;
+    }
+  }
+  const int row0 = reg * P;
+  const int nk = D / 64;
+
+  // ================================================================== phase 1: projection
+  if (wave >= 4) {
+    const int lw = wave - 4;
+    unsigned aoff[LA], boff[LB];
+#pragma unroll
+    for (int qi = 0; qi < LA; ++qi) {
+      const int row = (qi * 4 + lw) * 8 + (lane >> 3), p = lane & 7;
+      int gr = row0 + row;
+      gr = gr < n_rows ? gr : n_rows - 1;          // rows past the last region: re-read (finite, never used)
+      aoff[qi] = (unsigned)gr * (unsigned)D * 2u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int qi = 0; qi < LB; ++qi) {
+      const int row = (qi * 4 + lw) * 8 + (lane >> 3), p = lane & 7;   // row in [0,192): row / 64 picks q / k / v
+      const int wr = (row >> 6) * D + head * HD + (row & 63);
+      boff[qi] = (unsigned)wr * (unsigned)D * 2u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+    }
+    auto stage = [&](int kt, unsigned buf) {
+      const char* ub = (const char*)U + kt * ROWB;
+      const char* wb = (const char*)W + kt * ROWB;
+#pragma unroll
+      for (int qi = 0; qi < LA; ++qi)
+        if (qi * 4 + lw < NA) dma16s(ub, aoff[qi], buf + (qi * 4 + lw) * 1024);
+#pragma unroll
+      for (int qi = 0; qi < LB; ++qi) dma16s(wb, boff[qi], buf + BM * ROWB + (qi * 4 + lw) * 1024);
+    };
+    stage(0, lds_b);
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_vm0();
+      __syncthreads();                              // publishes K tile kt
+      if (kt + 1 < nk) stage(kt + 1, lds_b + ((kt + 1) & 1) * STAGE_B);
+    }
+    __syncthreads();                                // "the staging ring is dead"
+    if (MT & 1) {
+      // odd tile count: the second half of the last 32-key block has no keys; its V^T columns meet P = 0 in the
+      // MFMA and must hold finite numbers -> zeros.  256 loader threads = 64 rows x 4 groups of 4 positions.
+      const int t2 = tid - 256, dd = t2 >> 2, g = t2 & 3;
+      const int slot = 4 * (MT >> 1) + g;           // pos = 32 b + 8 g + 4 .. + 7, b = (MT - 1) / 2
+      *(uint2*)(VT + dd * VT_PITCH + ((slot ^ ((dd >> 2) & 15)) << 4) + 8) = make_uint2(0u, 0u);
+    }
+  } else {
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();
+      const char* As = smem + (kt & 1) * STAGE_B;
+      const char* Bs = As + BM * ROWB;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        Frag a8[MT], b8[NT];
+        const int cslot = 4 * kk + lg;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wave * (16 * NT) + j * 16 + lr;
+          b8[j] = *(const Frag*)(Bs + row * ROWB + ((cslot ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = i * 16 + lr;
+          a8[i] = *(const Frag*)(As + row * ROWB + ((cslot ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = H::mfma(b8[j], a8[i], acc[i][j]);
+      }
+    }
+    // ================================================================ phase 2: Q (fp32), K, V^T (16-bit) -> LDS
+    __syncthreads();                                // every wave is done with the staging ring
+    // transposed accumulators: reg r of lane (lr, lg) is C[m = 16 i + lr][n = 48 wave + 16 j + 4 lg + r]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = wave * (16 * NT) + j * 16 + 4 * lg;        // 0..191, multiple of 4
+      const int c = n >> 6, d = n & 63;                         // q / k / v and the head-dim column
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bqkv) b = *(const float4*)(bqkv + c * D + head * HD + d);
+      if (c == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = i * 16 + lr;
+          *(float4*)(QF + m * 256 + (((d >> 2) ^ (m & 15)) << 4)) =
+              make_float4((acc[i][j][0] + b.x) * q_scale, (acc[i][j][1] + b.y) * q_scale,
+                          (acc[i][j][2] + b.z) * q_scale, (acc[i][j][3] + b.w) * q_scale);
+        }
+      } else if (c == 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = i * 16 + lr;
+          *(uint2*)(KS + m * ROWB + (((d >> 3) ^ ((m >> 1) & 7)) << 4) + ((d & 4) << 1)) =
+              pack4<PREC>(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w);
+        }
+      } else {
+        // V^T: neighbouring lanes hold neighbouring tokens (m, m + 1) of the same 4 columns; they trade halves so
+        // that each writes two dwords = the token PAIR of two columns (even lane: d, d + 1; odd lane: d + 2, d + 3)
+        const bool odd = lr & 1;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
+          const float r0 = swap_lane1(odd ? v0 : v2), r1 = swap_lane1(odd ? v1 : v3);
+          const unsigned w0 = odd ? pack2<PREC>(r0, v2) : pack2<PREC>(v0, r0);
+          const unsigned w1 = odd ? pack2<PREC>(r1, v3) : pack2<PREC>(v1, r1);
+          const int dd = d + (odd ? 2 : 0);
+          const int pos = 32 * (i >> 1) + 8 * (lr >> 2) + 4 * (i & 1) + (lr & 2);   // of the pair's first token
+          const int col = ((pos >> 3) << 4) | ((pos & 7) << 1);                      // slot * 16 + byte within
+          *(unsigned*)(VT + dd * VT_PITCH + ((((col >> 4) ^ ((dd >> 2) & 15)) << 4) | (col & 15))) = w0;
+          *(unsigned*)(VT + (dd + 1) * VT_PITCH + ((((col >> 4) ^ (((dd + 1) >> 2) & 15)) << 4) | (col & 15))) = w1;
+        }
+      }
+    }
+  }
+  __syncthreads();                                  // Q / K / V^T tiles complete
+
+  // ================================================================== phase 3: EPEG stencil -> Q~ (16-bit)
+  // thread = (fp32 slot s of 16 = 4 head-dim columns, run g of RUN consecutive query rows); all 8 waves
+  {
+    constexpr int RUN = (BM + 31) / 32;
+    const int half = epeg_k >> 1;
+    const float* w = pe_w + head * epeg_k;          // taps come from global (L1-resident, <= 63 floats)
+    auto tap = [&](int t) {                         // log2(e) * (w[t] + [t == half]); 0 outside [0, k)
+      float wt = (t >= 0 && t < epeg_k) ? w[t] : 0.f;
+      if (t == half) wt += 1.0f;
+      return wt * LOG2E;
+    };
+    const int s = tid & 15, g = tid >> 4;
+    const int r0 = g * RUN;
+    float4 out[RUN];
+#pragma unroll
+    for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < BM) {
+      const int lo = max(r0 - half, 0), hi = min(r0 + RUN - 1 + half, P - 1);   // rows outside [0, P): zero padding
+      float wr[RUN];
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) wr[o] = tap(lo - r0 - o + half);
+      for (int rr = lo; rr <= hi; ++rr) {
+        const float4 v = *(const float4*)(QF + rr * 256 + ((s ^ (rr & 15)) << 4));
+        const float wnext = tap(rr + 1 - r0 + half);
+#pragma unroll
+        for (int o = 0; o < RUN; ++o) {
+          out[o].x += wr[o] * v.x; out[o].y += wr[o] * v.y; out[o].z += wr[o] * v.z; out[o].w += wr[o] * v.w;
+        }
+#pragma unroll
+        for (int o = RUN - 1; o > 0; --o) wr[o] = wr[o - 1];
+        wr[0] = wnext;
+      }
+    }
+    __syncthreads();                                // all reads of Q done
+    if (r0 < BM) {
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) {
+        const int m = r0 + o;
+        if (m < BM)
+          *(uint2*)(QT + m * ROWB + (((s >> 1) ^ ((m >> 1) & 7)) << 4) + ((s & 1) << 3)) =
+              pack4<PREC>(out[o].x, out[o].y, out[o].z, out[o].w);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ================================================================== phase 4: attention from LDS
+  for (int t = wave; t < MT; t += 8) {
+    const int i0 = t * 16;
+    if (i0 >= P) break;
+    Frag bq[2];
+    {
+      const int m = i0 + lr;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) bq[kk] = *(const Frag*)(QT + m * ROWB + (((4 * kk + lg) ^ ((m >> 1) & 7)) << 4));
+    }
+    f32x4 s[MTP];
+#pragma unroll
+    for (int jt = 0; jt < MTP; ++jt) s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      Frag a[MT];
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) {
+        const int row = jt * 16 + lr;
+        a[jt] = *(const Frag*)(KS + row * ROWB + (((4 * kk + lg) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) s[jt] = H::mfma(a[jt], bq[kk], s[jt]);
+    }
+    // s[jt][r] = log2e * score(query i0 + lr, key 16 jt + 4 lg + r)
+    float cmax = NEG_BIG;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;       // keys past the region
+        cmax = fmaxf(cmax, s[jt][r]);
+      }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    float psum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[jt][r] - cmax);
+        s[jt][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    const float inv = 1.0f / psum;                  // of THIS lane's query (lr): the four lg lanes agree
+    // O^T = V^T P^T: A = V^T rows d = 4 a + c (a = lr), B = P^T straight from the score registers
+    f32x4 oacc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < MTP / 2; ++b) {
+      const Frag pb = pack8<PREC>(s[2 * b], s[2 * b + 1]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dd = 4 * lr + c;
+        const Frag vf = *(const Frag*)(VT + dd * VT_PITCH + (((4 * b + lg) ^ lr) << 4));
+        oacc[c] = H::mfma(vf, pb, oacc[c]);
+      }
+    }
+    // oacc[c][r] = O[query i0 + lr][d = 16 lg + 4 r + c]
+    const int i = i0 + lr;
+    if (i < P) {
+      uint4 lo, hi;
+      uint2 q0 = pack4<PREC>(oacc[0][0] * inv, oacc[1][0] * inv, oacc[2][0] * inv, oacc[3][0] * inv);
+      uint2 q1 = pack4<PREC>(oacc[0][1] * inv, oacc[1][1] * inv, oacc[2][1] * inv, oacc[3][1] * inv);
+      uint2 q2 = pack4<PREC>(oacc[0][2] * inv, oacc[1][2] * inv, oacc[2][2] * inv, oacc[3][2] * inv);
+      uint2 q3 = pack4<PREC>(oacc[0][3] * inv, oacc[1][3] * inv, oacc[2][3] * inv, oacc[3][3] * inv);
+      lo = make_uint4(q0.x, q0.y, q1.x, q1.y);
+      hi = make_uint4(q2.x, q2.y, q3.x, q3.y);
+      uint16_t* dst = O + (size_t)(row0 + i) * D + head * HD + 16 * lg;
+      *(uint4*)dst = lo;
+      *(uint4*)(dst + 8) = hi;
+    }
+  }
+}
+
+template <int MT, int PREC>
+hipError_t launch_mt(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
+                     int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
+  constexpr int BM = 16 * MT;
+  constexpr size_t RING = (size_t)2 * (BM + BN) * ROWB, TILES = (size_t)BM * (256 + ROWB) + 64 * VT_PITCH;
+  constexpr size_t LDS = RING > TILES ? RING : TILES;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  auto kern = rmsa_fused16_kernel<MT, PREC>;
+  static OncePerDevice once;
+  if (once.first())
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+  const float q_scale = 1.0f / sqrtf((float)HD);
+  kern<<<dim3(heads * n_regions), dim3(512), LDS, st>>>(U, W, bqkv, pe_w, O, n_regions * P, P, D, heads,
+                                                       pe_w ? epeg_k : 0, q_scale);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool rmsa_fused16_supported(int P, int D, int heads, int epeg_k) {
+  static const bool off = getenv("RRT_NO_FUSED16") != nullptr;
+  if (off) return false;
+  // one block holds a whole region (P <= 208 -> MT <= 13); 64-element K tiles; 32-bit DMA byte offsets
+  return heads > 0 && D == heads * HD && D % 64 == 0 && P > 16 && P <= 208 && epeg_k >= 0 && epeg_k <= 63;
+}
+
+hipError_t launch_rmsa_fused16(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w,
+                               uint16_t* O, int n_regions, int P, int D, int heads, int epeg_k, int prec,
+                               hipStream_t st) {
+  if (prec != 1 && prec != 2) return hipErrorInvalidValue;
+#define RRT_FUSED16(MT_)                                                                                \
+  return prec == 1 ? launch_mt<MT_, 1>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st)          \
+                   : launch_mt<MT_, 2>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st);
+  if (P > 176) { RRT_FUSED16(13) }
+  if (P > 144) { RRT_FUSED16(11) }
+  if (P > 128) { RRT_FUSED16(9) }
+  if (P > 112) { RRT_FUSED16(8) }
+  if (P > 96) { RRT_FUSED16(7) }
+  if (P > 64) { RRT_FUSED16(6) }
+  if (P > 32) { RRT_FUSED16(4) }
+  RRT_FUSED16(2)
+#undef RRT_FUSED16
+}

@@ -860,6 +860,174 @@ def test_region_attention_backward(R, P, D, heads, ek):
         assert np.abs(tb.grad.numpy()).max() < 1e-9 * R * P          # Identity 2: the bias gradient is zero
 
 
+# ------------------------------------------------------------------ 16-bit operand path of the bf16 / fp16 modes
+_DT16 = {1: torch.bfloat16, 2: torch.float16}
+
+
+def _to16(a, compute):
+    """fp32 numpy -> device int16 tensor holding the bf16 / fp16 bits (RNE), and the rounded values as float64"""
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(_DT16[compute])
+    return t.view(torch.int16).to("cuda:0"), t.double().numpy()
+
+
+def _from16(bits, compute):
+    return bits.view(_DT16[compute]).double().cpu().numpy()
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+def test_cast16_and_ln_partition16(compute):
+    """cast16 is torch's round-to-nearest-even cast bit for bit; ln_partition16 is the fp32 LayerNorm + pad + partition
+    stage with its rows rounded once (a value that sits next to a rounding boundary may land on the other side of it
+    than the float64 restatement: at most one 16-bit ulp, on a small fraction of the elements)."""
+    from hip_util import dev, p, stream
+    lib = _lib.load()
+    w = synth.uniform("c16/w", (1536, 512), -1, 1) * np.exp(synth.uniform("c16/e", (1536, 512), -12, 4))
+    out = torch.empty((1536, 512), dtype=torch.int16, device="cuda:0")
+    wd = dev(w)                                   # (device buffers are kept alive across the asynchronous call)
+    _lib.check(lib.rrt_cast16(p(wd), p(out), w.size, compute, stream()), "cast16")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), torch.from_numpy(w).to(_DT16[compute]).view(torch.int16))
+    for L, rn, D in ((9000, 8, 512), (700, 8, 128), (30000, 16, 512)):
+        x = synth.bag(L, D, tag="lnp16")
+        gm, bt = 1.0 + synth.uniform("lnp16/g", (D,), -0.3, 0.3), synth.uniform("lnp16/b", (D,), -0.2, 0.2)
+        g = _lib.region_grid(L, rn)
+        u = torch.full((g.H * g.H, D), 0x7FC0, dtype=torch.int16, device="cuda:0")
+        xd, gd_, bd_ = dev(x), dev(gm), dev(bt)
+        _lib.check(lib.rrt_ln_partition16(p(xd), p(gd_), p(bd_), p(u), L, D, g, compute, stream()), "lnp16")
+        torch.cuda.synchronize()
+        got = _from16(u, compute)
+        x64 = x.astype(np.float64)
+        ln = (x64 - x64.mean(-1, keepdims=True)) / np.sqrt(x64.var(-1, keepdims=True) + 1e-5) * gm + bt
+        ref = np.zeros((g.H * g.H, D))
+        ref[:L] = ln
+        ref = O.round_lowp(ref[O.partition_index(g.H, g.s)], "bf16" if compute == 1 else "f16")
+        ulp = 2.0 ** (-7 if compute == 1 else -10)
+        diff = np.abs(got - ref)
+        assert (diff <= ulp * np.maximum(np.abs(ref), 1e-3)).all()
+        assert (diff > 0).mean() < 0.01
+        assert (got[np.abs(ref).sum(-1) == 0] == 0).all()          # pad slots: exact zeros
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(9216, 512, 512), (9216, 1536, 512), (3136, 512, 512), (1000, 192, 128), (9216, 512, 1024)])
+def test_linear16(M, N, K, compute):
+    """C = A16 . B16^T + bias on operands that ARE 16-bit in HBM: against the float64 product of exactly those values
+    (only the fp32 accumulation differs)."""
+    from hip_util import dev, p, stream
+    lib = _lib.load()
+    A16, A = _to16(synth.normal(f"l16/A{M}x{K}", (M, K)), compute)
+    B16, B = _to16(synth.uniform(f"l16/B{N}x{K}", (N, K), -1, 1) / np.sqrt(K), compute)
+    bias = synth.uniform("l16/b", (N,), -0.1, 0.1)
+    C_ = torch.full((M, N), float("nan"), device="cuda:0")
+    bd_ = dev(bias)
+    _lib.check(lib.rrt_linear16_f32(p(A16), p(B16), p(bd_), None, p(C_), M, N, K, None, compute, stream()), "linear16")
+    torch.cuda.synchronize()
+    _cmp(C_.cpu().numpy(), A @ B.T + bias, 2e-5, f"linear16 {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("L,rn", [(9000, 8), (30000, 16), (3000, 8)])
+def test_linear16_unpartition_residual(L, rn):
+    from hip_util import dev, p, stream
+    lib = _lib.load()
+    D = 512
+    g = _lib.region_grid(L, rn)
+    Np = g.H * g.H
+    A16, A = _to16(synth.normal("l16u/A", (Np, D)), 1)
+    B16, B = _to16(synth.uniform("l16u/B", (D, D), -1, 1) / np.sqrt(D), 1)
+    bias, resid = synth.uniform("l16u/b", (D,), -0.1, 0.1), synth.bag(L, D, tag="l16u/r")
+    out = torch.full((L, D), float("nan"), device="cuda:0")
+    bd_, rd_ = dev(bias), dev(resid)
+    _lib.check(lib.rrt_linear16_f32(p(A16), p(B16), p(bd_), p(rd_), p(out), Np, D, D, g, 1, stream()), "linear16 unpart")
+    torch.cuda.synchronize()
+    z = np.empty((Np, D))
+    z[O.partition_index(g.H, g.s)] = A @ B.T + bias
+    _cmp(out.cpu().numpy(), resid + z[:L], 2e-5, "linear16 un-partition + residual")
+
+
+def _fused16_ref(u, w, b, pe_w, R, P, D, heads, ek, dt):
+    """float64 restatement of rmsa_fused16's rounding points on the given (already 16-bit) u, w: -> O (unrounded)"""
+    st = {"qkv.weight": w, "proj.weight": np.eye(D), "proj.bias": np.zeros(D)}
+    if b is not None:
+        st["qkv.bias"] = b
+    if pe_w is not None:
+        st["pe.weight"] = pe_w.reshape(heads, 1, ek, 1)
+
+    class NoRound:                                 # u / w are exact already; O is compared before its rounding
+        r = staticmethod(lambda a: a)
+    return O._inner_attention64(u.reshape(R, P, D), st, "", heads, ek, None, NoRound, O.LowP(dt, True)).reshape(R * P, D)
+
+
+@pytest.mark.parametrize("R,P,D,heads,ek,compute", [(64, 144, 512, 8, 15, 1), (64, 144, 512, 8, 15, 2), (9, 121, 512, 8, 15, 1),
+                                                    (5, 196, 512, 8, 21, 1), (7, 169, 512, 8, 15, 1), (3, 100, 512, 8, 9, 1),
+                                                    (12, 81, 512, 8, 15, 1), (20, 49, 512, 8, 15, 1), (6, 25, 512, 8, 15, 1),
+                                                    (4, 64, 256, 4, 0, 1), (3, 208, 512, 8, 63, 1), (2, 130, 1024, 16, 15, 2),
+                                                    (256, 121, 512, 8, 15, 1)])
+def test_rmsa_fused16(R, P, D, heads, ek, compute):
+    """The 16-bit fused R-MSA kernel against a float64 restatement with the SAME rounding points (Q~ log2e, K, V and
+    exp2(S - max) rounded to 16 bits; everything else exact), on inputs that are exactly representable: what is left
+    is fp32 accumulation order and values that sit on a rounding boundary."""
+    from hip_util import dev, p, stream
+    lib = _lib.load()
+    dt = "bf16" if compute == 1 else "f16"
+    u16, u = _to16(synth.normal(f"f16/u{R}x{P}", (R * P, D)), compute)
+    w16, w = _to16(synth.uniform("f16/w", (3 * D, D), -1, 1) / np.sqrt(D) * 1.5, compute)
+    b = synth.uniform("f16/b", (3 * D,), -0.2, 0.2)
+    pe = synth.uniform("f16/pe", (heads, ek), -0.3, 0.3) if ek else None
+    o16 = torch.full((R * P, D), 0x7FC0, dtype=torch.int16, device="cuda:0")
+    bd_, ped_ = dev(b), (dev(pe) if ek else None)
+    _lib.check(lib.rrt_rmsa_fused16(p(u16), p(w16), p(bd_), p(ped_), p(o16), R, P, D, heads, ek, compute, stream()),
+               "rmsa_fused16")
+    torch.cuda.synchronize()
+    got = _from16(o16, compute)
+    Rr = min(R, 8)                                                # float64 restatement of the first regions
+    ref = _fused16_ref(u[:Rr * P], w, b, pe, Rr, P, D, heads, ek, dt)
+    got = got[:ref.shape[0]]
+    assert np.isfinite(_from16(o16, compute)).all()
+    ulp = 2.0 ** (-8 if compute == 1 else -11)                    # half a 16-bit ulp, relative
+    err = np.abs(got - ref)
+    scale = np.abs(ref).max()
+    # the final rounding of O accounts for <= ulp * |O|; rounding-boundary flips of individual probabilities / Q~
+    # entries add a little on top
+    assert (err <= 1.01 * ulp * np.abs(ref) + 4e-3 * ulp * 256 * scale).all(), (err.max(), scale)
+    assert err.mean() <= 0.6 * ulp * np.abs(ref).mean() + 1e-6
+
+
+@pytest.mark.parametrize("name,dt", [("G16_amp_bf16_d512_n9000", torch.bfloat16), ("G16_amp_bf16_d512_n1000", torch.bfloat16),
+                                     ("G16_amp_f16_d512_n1000", torch.float16), ("G16_amp_bf16_d512_n9000_c1_sc", torch.bfloat16),
+                                     ("G16_amp_bf16_d512_n3000_k21_c5", torch.bfloat16),
+                                     ("G16_amp_bf16_d512_n15000_k21_c5", torch.bfloat16),
+                                     ("G16_amp_bf16_d512_n30000_rn16", torch.bfloat16)])
+def test_encoder_amp_against_restatement_and_reference_autocast(name, dt):
+    """BASELINE configs[2..4] arithmetic.  (1) TIGHT: the HIP encoder under autocast against the float64 restatement of
+    its own rounding points (oracle forward_f64(lowp=...)): a mis-rounded or skipped stage shows up here.
+    (2) The reference's own autocast run (G16 fixtures: the real reference under torch.autocast('cpu', dtype)): the
+    HIP result is at least as close to the fp32 reference as that run is, and within 1.25x that distance of it."""
+    from hip_util import encoder_from_state, dev
+    g = load_golden(name)
+    x, st, cfg = synth_case(g)
+    N = int(g["n"])
+    enc = encoder_from_state(st, cfg)
+    with torch.autocast("cuda", dtype=dt):
+        y = enc(dev(x).unsqueeze(0)).squeeze(0)
+    torch.cuda.synchronize()
+    assert y.dtype == torch.float32
+    y = y.cpu().numpy().astype(np.float64)
+    rows = g["rows"]
+    H, s_, _ = O.grid(N, cfg.get("region_num", 8))
+    fused16 = 16 < s_ * s_ <= 208
+    if N <= 9000:
+        ref = O.forward_f64(x, st, cfg, lowp=O.LowP("bf16" if dt == torch.bfloat16 else "f16", attn=fused16))
+        d = np.abs(y - ref)
+        tol = (6e-4, 3e-5) if dt == torch.bfloat16 else (1e-4, 5e-6)
+        assert d.max() <= tol[0] and d.mean() <= tol[1], (d.max(), d.mean())
+    to_fp32 = np.abs(y[rows] - g["y32_rows"])
+    to_amp = np.abs(y[rows] - g["y_rows"])
+    amp_to_fp32 = np.abs(g["y_rows"].astype(np.float64) - g["y32_rows"])
+    assert to_fp32.mean() <= amp_to_fp32.mean() and to_fp32.max() <= 1.1 * amp_to_fp32.max(), (to_fp32.max(), amp_to_fp32.max())
+    assert to_amp.max() <= 1.25 * amp_to_fp32.max() and to_amp.mean() <= 1.25 * amp_to_fp32.mean()
+    assert to_fp32.max() > 1e-6
+
+
 # ------------------------------------------------------------------ row f2: training (forward + backward end to end)
 TRAIN_CASES = {
     "crmsa_only_n700": (700, dict(mlp_dim=512, n_layers=1, crmsa_k=3)),
