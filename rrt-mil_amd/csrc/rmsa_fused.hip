@@ -80,6 +80,9 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   constexpr int NA = BM / 8, NB = BN / 8;          // DMA wave-instructions per A / B stage
   constexpr int LA = (NA + 1) / 2, LB = NB / 2;    // per loader wave
   constexpr int NT = 3;                            // 16-column tiles per compute wave (4 x 48 = 192)
+  constexpr int LDS_MAIN = (2 * STAGE > 3 * TILE ? 2 * STAGE : 3 * TILE) * 4;   // bytes: staging ring / Q, K, V tiles
+  constexpr int RUN = (BM * 16 + 383) / 384;       // query rows per stencil thread: 6 for BM = 144
+  constexpr int TAP_OFF = 12 + RUN - 1;            // tap t lives at taps[t + TAP_OFF]; taps[12..] is 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = (float*)smem;
   float* Qs = lds;                                 // after phase 1 (aliases the staging ring)
@@ -114,6 +117,16 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   }
   const int row0 = reg * P;                        // first token row of this region
   const int nk = D / BK;
+  // EPEG taps as the stencil wants them -- log2(e) * (w[t] + [t == k/2]), zero outside [0, k) -- in a 128-entry LDS
+  // table behind the tiles (index t + TAP_OFF).  (Fetching w[t] from global inside the stencil loop put one
+  // dependent vector load on every source row: the trace showed 9.2K cycles for a phase with ~2K cycles of work.)
+  float* const taps = (float*)(smem + LDS_MAIN);
+  if (tid < 128) {
+    const int t = tid - TAP_OFF;
+    float wt = (pe_w != nullptr && t >= 0 && t < epeg_k) ? pe_w[head * epeg_k + t] : 0.f;
+    if (t == (epeg_k >> 1)) wt += 1.0f;
+    taps[tid] = wt * LOG2E;
+  }
   RRT_TRACE_INIT(blockIdx.x * 6 + wave);
   RRT_TRACE_MARK();                                 // [1] entry
 
@@ -239,37 +252,46 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     // In place: every thread first gathers its outputs in registers, a barrier retires all reads of
     // the Q tile, then Q~ is written over it.  (A separate Q~ buffer + tap table cost 37.4 KB more
     // LDS; at 108 KiB a proj tile of another bag (52 KiB) can share the CU: 108 + 52 = 160 KiB.)
-    constexpr int RUN = (BM * 16 + 383) / 384;      // 6 for BM = 144
+    static_assert(RUN - 1 <= TAP_OFF && (TAP_OFF - (RUN - 1)) % 4 == 0 && 2 * RUN + 90 < 128, "tap table range / alignment");
     const int half = epeg_k >> 1;
-    const float* w = pe_w + head * epeg_k;          // taps come from global (L1-resident, <= 63 floats)
-    auto tap = [&](int t) {                         // log2(e) * (w[t] + [t == half]); 0 outside [0, k)
-      float wt = (t >= 0 && t < epeg_k) ? w[t] : 0.f;
-      if (t == half) wt += 1.0f;
-      return wt * LOG2E;
-    };
     const int s = tid & 15, g = tid >> 4;
     const int r0 = g * RUN;
     float4 out[RUN];
 #pragma unroll
     for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 < BM) {
-      // source rows r0 - half .. r0 + RUN - 1 + half, clipped to the region [0, P) (zero padding)
-      const int lo = max(r0 - half, 0), hi = min(r0 + RUN - 1 + half, P - 1);
-      // wr[o] = weight of source row rr for output row r0+o = tap(rr - r0 - o + half); stepping rr
-      // shifts the window by one: one tap fetch per source row instead of RUN
-      float wr[RUN];
+      // source row j of the run (j = 0 .. RUN + k - 2, row r0 - k/2 + j) meets output o with tap t = j - o: the RUN
+      // weights slide by one per source row.  Four rows per trip, their loads issued together (a row per trip was
+      // a chain of dependent LDS round trips); rows outside the region [0, P) read as zero (zero padding), taps
+      // outside [0, k) are zero in the table.
+      const int nsrc = RUN + 2 * half;
+      // taps tp[j0 - RUN + 1 .. j0 + 3] of a four-row group: one broadcast read (the address is the same in every
+      // lane), then compile-time indices -- row u meets output o with T[u + RUN - 1 - o]
+      constexpr int NTV = (RUN + 3 + 3) / 4;
+      const float4* tp4 = (const float4*)(taps + TAP_OFF - (RUN - 1));
+      for (int j0 = 0; j0 < nsrc; j0 += 4) {
+        float4 v[4];
+        float T[4 * NTV];
 #pragma unroll
-      for (int o = 0; o < RUN; ++o) wr[o] = tap(lo - r0 - o + half);
-      for (int rr = lo; rr <= hi; ++rr) {
-        const float4 v = *(const float4*)(Qs + rr * HD + ((s ^ (rr & 15)) << 2));
-        const float wnext = tap(rr + 1 - r0 + half);
-#pragma unroll
-        for (int o = 0; o < RUN; ++o) {
-          out[o].x += wr[o] * v.x; out[o].y += wr[o] * v.y; out[o].z += wr[o] * v.z; out[o].w += wr[o] * v.w;
+        for (int q = 0; q < NTV; ++q) {
+          const float4 t4 = tp4[(j0 >> 2) + q];
+          T[4 * q] = t4.x; T[4 * q + 1] = t4.y; T[4 * q + 2] = t4.z; T[4 * q + 3] = t4.w;
         }
 #pragma unroll
-        for (int o = RUN - 1; o > 0; --o) wr[o] = wr[o - 1];
-        wr[0] = wnext;
+        for (int u = 0; u < 4; ++u) {
+          const int rr = r0 - half + j0 + u;
+          const bool ok = rr >= 0 && rr < P;
+          const int rc = ok ? rr : 0;
+          v[u] = *(const float4*)(Qs + rc * HD + ((s ^ (rc & 15)) << 2));
+          if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int o = 0; o < RUN; ++o) {
+            const float wt = T[u + RUN - 1 - o];
+            out[o].x += wt * v[u].x; out[o].y += wt * v[u].y; out[o].z += wt * v[u].z; out[o].w += wt * v[u].w;
+          }
       }
     }
     __syncthreads();                                // all reads of Q done
@@ -379,7 +401,7 @@ hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const
                      int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
   constexpr int BM = 16 * MT;
   constexpr size_t STG = (size_t)2 * (BM + BN) * BK * 4, QKV = (size_t)3 * BM * HD * 4;
-  constexpr size_t LDS = (STG > QKV ? STG : QKV);   // staging ring, then the Q/K/V tiles (Q~ in place)
+  constexpr size_t LDS = (STG > QKV ? STG : QKV) + 512;   // staging ring, then the Q/K/V tiles (Q~ in place); tap table
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = rmsa_fused_kernel<MT, PREC>;
   static OncePerDevice once;

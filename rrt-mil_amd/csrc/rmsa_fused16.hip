@@ -12,7 +12,9 @@
 //   phase 2  accumulators (+bias, q*scale) -> LDS: Q as fp32 (the EPEG stencil runs in fp32), K as 16-bit rows,
 //            V as its 16-bit TRANSPOSE with the keys of each 32-key block permuted into MFMA operand order
 //            (pos = 32 b + 8 g + 4 h + r for key = 32 b + 16 h + 4 g + r), so that the P.V operand is one
-//            ds_read_b128 and P^T never leaves the registers it was computed in;
+//            ds_read_b128 and P^T never leaves the registers it was computed in.  (The V column tiles are
+//            accumulated with the MFMA operand roles NOT swapped, so a lane holds four consecutive tokens of one
+//            column: V^T goes out as 8-byte stores, no cross-lane shuffle.);
 //   phase 3  EPEG sliding-window stencil over the fp32 Q tile (as in rmsa_fused.hip), x log2(e), rounded ONCE to
 //            16 bits into the Q~ tile that overwrites Q;
 //   phase 4  S^T = K Q~^T (scores transposed: lane = query, registers = keys), row softmax in fp32 registers,
@@ -21,7 +23,7 @@
 // Rounding points (restated in oracle/rrt_oracle.py::forward_f64(lowp=...)): U, W (inputs); Q~ * log2 e, K, V,
 // exp2(S - max) (operands of the two attention products); O (output).  Accumulation, bias, scale, stencil, softmax
 // statistics and normalisation are fp32.
-// LDS: max(2 x (16 MT + 192) x 128 B ring, Q 16 MT x 256 B + K 16 MT x 128 B + V^T 64 x 512 B) = 86 KiB at MT = 9.
+// LDS: max(3 x (16 MT + 192) x 128 B ring, Q 16 MT x 256 B + K 16 MT x 128 B + V^T 64 x 512 B) = 126 KiB at MT = 9.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -82,9 +84,14 @@ __device__ __forceinline__ typename H16<PREC>::frag pack8(const f32x4& a, const 
   return r;
 }
 
-// value of the lane whose index differs in bit 0 (DPP quad_perm [1,0,3,2]; no LDS round trip)
-__device__ __forceinline__ float swap_lane1(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+// XOR key of the 16-byte slots of V^T row d: injective over the 16 rows a wave WRITES together (d = 16 w + lr: bits
+// 1..0 = lr >> 2, bits 3..2 = (lr & 3) ^ (w & 3)) and over the 16 rows it READS together (d = 4 lr + c: lr ^ 4 c)
+__device__ __forceinline__ int vt_swz(int d) { return ((d >> 2) ^ ((d & 3) << 2)) & 15; }
+
+// wait until at most N of this wave's vector-memory operations (the LDS-DMA pieces) are still in flight
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int MT, int PREC>
@@ -104,6 +111,10 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
   constexpr int NT = 3;                              // 16-column tiles per compute wave (4 x 48 = 192)
   constexpr int QF_B = BM * 256, KS_B = BM * ROWB;   // fp32 Q tile, 16-bit K tile
   static_assert(16 * MTP * 2 <= VT_PITCH, "V^T row");
+  constexpr int RING_B = 3 * STAGE_B, TILES_B = QF_B + KS_B + 64 * VT_PITCH;
+  constexpr int LDS_MAIN = RING_B > TILES_B ? RING_B : TILES_B;
+  constexpr int RUN = (BM + 31) / 32;                // query rows per stencil thread (512 threads = 32 runs x 16 slots)
+  constexpr int TAP_OFF = 12 + RUN - 1;              // tap t lives at taps[t + TAP_OFF]; taps[12..] is 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const QF = smem;                             // fp32 Q [BM][64], slot XOR (row & 15); later Q~ 16-bit rows
   char* const KS = smem + QF_B;                      // K [BM] x 128 B, slot XOR ((row >> 1) & 7)
@@ -135,8 +146,21 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
   }
   const int row0 = reg * P;
   const int nk = D / 64;
+  // EPEG taps as the stencil wants them -- log2(e) * (w[t] + [t == k/2]), zero outside [0, k) -- in a 128-entry LDS
+  // table behind the tiles (index t + TAP_OFF): no global load inside the stencil loop
+  float* const taps = (float*)(smem + LDS_MAIN);
+  if (tid < 128) {
+    const int t = tid - TAP_OFF;
+    float wt = (pe_w != nullptr && t >= 0 && t < epeg_k) ? pe_w[head * epeg_k + t] : 0.f;
+    if (t == (epeg_k >> 1)) wt += 1.0f;
+    taps[tid] = wt * LOG2E;
+  }
+  RRT_TRACE_INIT(blockIdx.x * 8 + wave);
+  RRT_TRACE_MARK();                                 // [1] entry
 
   // ================================================================== phase 1: projection
+  // 3-stage ring: stage kt + 2 is issued while stage kt + 1 lands and stage kt feeds the MFMAs (with two stages the
+  // loop period was DMA issue + landing latency, 1550 cycles per K tile against 920 of MFMA)
   if (wave >= 4) {
     const int lw = wave - 4;
     unsigned aoff[LA], boff[LB];
@@ -162,37 +186,67 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
 #pragma unroll
       for (int qi = 0; qi < LB; ++qi) dma16s(wb, boff[qi], buf + BM * ROWB + (qi * 4 + lw) * 1024);
     };
+    const bool full = (LA - 1) * 4 + lw < NA;       // this loader issues LA (else LA - 1) A pieces per stage
     stage(0, lds_b);
+    if (nk > 1) stage(1, lds_b + STAGE_B);
+    RRT_TRACE_MARK();                               // loader [2] first stages issued
+    int slot = 2;                                   // ring slot of stage kt + 2
     for (int kt = 0; kt < nk; ++kt) {
-      wait_vm0();
-      __syncthreads();                              // publishes K tile kt
-      if (kt + 1 < nk) stage(kt + 1, lds_b + ((kt + 1) & 1) * STAGE_B);
+      if (kt + 1 < nk) {                            // stage kt landed; stage kt + 1 may still be in flight
+        if (full) wait_vmcnt<LA + LB>(); else wait_vmcnt<LA - 1 + LB>();
+      } else {
+        wait_vm0();
+      }
+      if (kt == 0 || kt == 4) RRT_TRACE_MARK();     // loader [3,5] K tile 0 / 4 landed
+      __syncthreads();                              // publishes K tile kt; everyone is done with tile kt - 1
+      if (kt + 2 < nk) stage(kt + 2, lds_b + slot * STAGE_B);
+      slot = slot == 2 ? 0 : slot + 1;
+      if (kt == 0 || kt == 4) RRT_TRACE_MARK();     // loader [4,6] next stage issued
     }
     __syncthreads();                                // "the staging ring is dead"
+    RRT_TRACE_MARK();                               // loader [7]
     if (MT & 1) {
       // odd tile count: the second half of the last 32-key block has no keys; its V^T columns meet P = 0 in the
       // MFMA and must hold finite numbers -> zeros.  256 loader threads = 64 rows x 4 groups of 4 positions.
       const int t2 = tid - 256, dd = t2 >> 2, g = t2 & 3;
-      const int slot = 4 * (MT >> 1) + g;           // pos = 32 b + 8 g + 4 .. + 7, b = (MT - 1) / 2
-      *(uint2*)(VT + dd * VT_PITCH + ((slot ^ ((dd >> 2) & 15)) << 4) + 8) = make_uint2(0u, 0u);
+      const int vslot = 4 * (MT >> 1) + g;          // pos = 32 b + 8 g + 4 .. + 7, b = (MT - 1) / 2
+      *(uint2*)(VT + dd * VT_PITCH + ((vslot ^ vt_swz(dd)) << 4) + 8) = make_uint2(0u, 0u);
     }
   } else {
+    // Wave w owns ONE 16-column tile of each of Q, K and V (W_h rows 16 w .., 64 + 16 w .., 128 + 16 w ..): the four
+    // waves do the same work in phase 2.  Q and K tiles are accumulated with the operand roles swapped (A slot = W
+    // fragment): reg r of lane (lr, lg) is C[token 16 i + lr][d = 16 w + 4 lg + r] -- four consecutive columns of a
+    // token row, what the row-major Q / K images want.  The V tile keeps the roles (A slot = U fragment): reg r is
+    // V[token 16 i + 4 lg + r][d = 16 w + lr] -- four consecutive TOKENS of one column, what V^T wants.
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias of this lane's columns: lands under the K loop
+    const int dq = 16 * wave + 4 * lg;              // first of the lane's 4 Q / K columns
+    const int dv = 16 * wave + lr;                  // the lane's V column
+    float4 bq4 = make_float4(0.f, 0.f, 0.f, 0.f), bk4 = bq4;
+    float bv1 = 0.f;
+    if (bqkv) {
+      bq4 = *(const float4*)(bqkv + head * HD + dq);
+      bk4 = *(const float4*)(bqkv + D + head * HD + dq);
+      bv1 = bqkv[2 * D + head * HD + dv];
+    }
+    int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();
-      const char* As = smem + (kt & 1) * STAGE_B;
+      if (kt == 0 || kt == 1 || kt == 4) RRT_TRACE_MARK();   // compute [2,3,4] barrier kt passed
+      const char* As = smem + slot * STAGE_B;
       const char* Bs = As + BM * ROWB;
+      slot = slot == 2 ? 0 : slot + 1;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         Frag a8[MT], b8[NT];
         const int cslot = 4 * kk + lg;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const int row = wave * (16 * NT) + j * 16 + lr;
+          const int row = 64 * j + 16 * wave + lr;
           b8[j] = *(const Frag*)(Bs + row * ROWB + ((cslot ^ ((row >> 1) & 7)) << 4));
         }
 #pragma unroll
@@ -201,87 +255,78 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
           a8[i] = *(const Frag*)(As + row * ROWB + ((cslot ^ ((row >> 1) & 7)) << 4));
         }
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = H::mfma(b8[j], a8[i], acc[i][j]);
+        for (int i = 0; i < MT; ++i) {
+          acc[i][0] = H::mfma(b8[0], a8[i], acc[i][0]);
+          acc[i][1] = H::mfma(b8[1], a8[i], acc[i][1]);
+          acc[i][2] = H::mfma(a8[i], b8[2], acc[i][2]);
+        }
       }
     }
+    RRT_TRACE_MARK();                               // compute [5] last projection MFMA issued
     // ================================================================ phase 2: Q (fp32), K, V^T (16-bit) -> LDS
     __syncthreads();                                // every wave is done with the staging ring
-    // transposed accumulators: reg r of lane (lr, lg) is C[m = 16 i + lr][n = 48 wave + 16 j + 4 lg + r]
+    RRT_TRACE_MARK();                               // compute [6]
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = wave * (16 * NT) + j * 16 + 4 * lg;        // 0..191, multiple of 4
-      const int c = n >> 6, d = n & 63;                         // q / k / v and the head-dim column
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bqkv) b = *(const float4*)(bqkv + c * D + head * HD + d);
-      if (c == 0) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int m = i * 16 + lr;
-          *(float4*)(QF + m * 256 + (((d >> 2) ^ (m & 15)) << 4)) =
-              make_float4((acc[i][j][0] + b.x) * q_scale, (acc[i][j][1] + b.y) * q_scale,
-                          (acc[i][j][2] + b.z) * q_scale, (acc[i][j][3] + b.w) * q_scale);
-        }
-      } else if (c == 1) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int m = i * 16 + lr;
-          *(uint2*)(KS + m * ROWB + (((d >> 3) ^ ((m >> 1) & 7)) << 4) + ((d & 4) << 1)) =
-              pack4<PREC>(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w);
-        }
-      } else {
-        // V^T: neighbouring lanes hold neighbouring tokens (m, m + 1) of the same 4 columns; they trade halves so
-        // that each writes two dwords = the token PAIR of two columns (even lane: d, d + 1; odd lane: d + 2, d + 3)
-        const bool odd = lr & 1;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
-          const float r0 = swap_lane1(odd ? v0 : v2), r1 = swap_lane1(odd ? v1 : v3);
-          const unsigned w0 = odd ? pack2<PREC>(r0, v2) : pack2<PREC>(v0, r0);
-          const unsigned w1 = odd ? pack2<PREC>(r1, v3) : pack2<PREC>(v1, r1);
-          const int dd = d + (odd ? 2 : 0);
-          const int pos = 32 * (i >> 1) + 8 * (lr >> 2) + 4 * (i & 1) + (lr & 2);   // of the pair's first token
-          const int col = ((pos >> 3) << 4) | ((pos & 7) << 1);                      // slot * 16 + byte within
-          *(unsigned*)(VT + dd * VT_PITCH + ((((col >> 4) ^ ((dd >> 2) & 15)) << 4) | (col & 15))) = w0;
-          *(unsigned*)(VT + (dd + 1) * VT_PITCH + ((((col >> 4) ^ (((dd + 1) >> 2) & 15)) << 4) | (col & 15))) = w1;
-        }
-      }
+    for (int i = 0; i < MT; ++i) {
+      const int m = i * 16 + lr;
+      *(float4*)(QF + m * 256 + (((dq >> 2) ^ (m & 15)) << 4)) =
+          make_float4((acc[i][0][0] + bq4.x) * q_scale, (acc[i][0][1] + bq4.y) * q_scale,
+                      (acc[i][0][2] + bq4.z) * q_scale, (acc[i][0][3] + bq4.w) * q_scale);
+      *(uint2*)(KS + m * ROWB + (((dq >> 3) ^ ((m >> 1) & 7)) << 4) + ((dq & 4) << 1)) =
+          pack4<PREC>(acc[i][1][0] + bk4.x, acc[i][1][1] + bk4.y, acc[i][1][2] + bk4.z, acc[i][1][3] + bk4.w);
+      // tokens 16 i + 4 lg + r, r = 0..3 -> positions 32 (i / 2) + 8 lg + 4 (i % 2) + r of V^T row dv: 8 bytes
+      const int vslot = 4 * (i >> 1) + lg;
+      *(uint2*)(VT + dv * VT_PITCH + ((vslot ^ vt_swz(dv)) << 4) + ((i & 1) << 3)) =
+          pack4<PREC>(acc[i][2][0] + bv1, acc[i][2][1] + bv1, acc[i][2][2] + bv1, acc[i][2][3] + bv1);
     }
   }
   __syncthreads();                                  // Q / K / V^T tiles complete
+  RRT_TRACE_MARK();                                 // compute [7] / loader [8]: tiles in LDS
 
   // ================================================================== phase 3: EPEG stencil -> Q~ (16-bit)
-  // thread = (fp32 slot s of 16 = 4 head-dim columns, run g of RUN consecutive query rows); all 8 waves
+  // thread = (fp32 slot s of 16 = 4 head-dim columns, run g of RUN consecutive query rows); all 8 waves.
+  // Source row j of a run (j = 0 .. RUN + k - 2, row r0 - k/2 + j) meets output o with tap t = j - o: the RUN
+  // weights slide by one per source row.  Rows are taken four at a time with their loads issued together (a row
+  // per trip was a chain of dependent LDS round trips: 5.5K cycles for ~1.5K of work); rows outside the region
+  // [0, P) read as zero (the EPEG convolution zero-pads at the region edge), taps outside [0, k) are zero in the
+  // table.
   {
-    constexpr int RUN = (BM + 31) / 32;
+    static_assert(RUN - 1 <= TAP_OFF && (TAP_OFF - (RUN - 1)) % 4 == 0 && 2 * RUN + 90 < 128, "tap table range / alignment");
     const int half = epeg_k >> 1;
-    const float* w = pe_w + head * epeg_k;          // taps come from global (L1-resident, <= 63 floats)
-    auto tap = [&](int t) {                         // log2(e) * (w[t] + [t == half]); 0 outside [0, k)
-      float wt = (t >= 0 && t < epeg_k) ? w[t] : 0.f;
-      if (t == half) wt += 1.0f;
-      return wt * LOG2E;
-    };
     const int s = tid & 15, g = tid >> 4;
     const int r0 = g * RUN;
     float4 out[RUN];
 #pragma unroll
     for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 < BM) {
-      const int lo = max(r0 - half, 0), hi = min(r0 + RUN - 1 + half, P - 1);   // rows outside [0, P): zero padding
-      float wr[RUN];
+      const int nsrc = RUN + 2 * half;
+      // taps tp[j0 - RUN + 1 .. j0 + 3] of a four-row group: one broadcast read (the address is the same in every
+      // lane), then compile-time indices -- row u meets output o with T[u + RUN - 1 - o]
+      constexpr int NTV = (RUN + 3 + 3) / 4;
+      const float4* tp4 = (const float4*)(taps + TAP_OFF - (RUN - 1));
+      for (int j0 = 0; j0 < nsrc; j0 += 4) {
+        float4 v[4];
+        float T[4 * NTV];
 #pragma unroll
-      for (int o = 0; o < RUN; ++o) wr[o] = tap(lo - r0 - o + half);
-      for (int rr = lo; rr <= hi; ++rr) {
-        const float4 v = *(const float4*)(QF + rr * 256 + ((s ^ (rr & 15)) << 4));
-        const float wnext = tap(rr + 1 - r0 + half);
-#pragma unroll
-        for (int o = 0; o < RUN; ++o) {
-          out[o].x += wr[o] * v.x; out[o].y += wr[o] * v.y; out[o].z += wr[o] * v.z; out[o].w += wr[o] * v.w;
+        for (int q = 0; q < NTV; ++q) {
+          const float4 t4 = tp4[(j0 >> 2) + q];
+          T[4 * q] = t4.x; T[4 * q + 1] = t4.y; T[4 * q + 2] = t4.z; T[4 * q + 3] = t4.w;
         }
 #pragma unroll
-        for (int o = RUN - 1; o > 0; --o) wr[o] = wr[o - 1];
-        wr[0] = wnext;
+        for (int u = 0; u < 4; ++u) {
+          const int rr = r0 - half + j0 + u;
+          const bool ok = rr >= 0 && rr < P;
+          const int rc = ok ? rr : 0;
+          v[u] = *(const float4*)(QF + rc * 256 + ((s ^ (rc & 15)) << 4));
+          if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int o = 0; o < RUN; ++o) {
+            const float wt = T[u + RUN - 1 - o];
+            out[o].x += wt * v[u].x; out[o].y += wt * v[u].y; out[o].z += wt * v[u].z; out[o].w += wt * v[u].w;
+          }
       }
     }
     __syncthreads();                                // all reads of Q done
@@ -296,6 +341,7 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
     }
   }
   __syncthreads();
+  RRT_TRACE_MARK();                                 // compute [8] / loader [9]: Q~ built
 
   // ================================================================== phase 4: attention from LDS
   for (int t = wave; t < MT; t += 8) {
@@ -321,15 +367,20 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
 #pragma unroll
       for (int jt = 0; jt < MT; ++jt) s[jt] = H::mfma(a[jt], bq[kk], s[jt]);
     }
+    RRT_TRACE_MARK();                               // tile: S^T issued
     // s[jt][r] = log2e * score(query i0 + lr, key 16 jt + 4 lg + r)
     float cmax = NEG_BIG;
 #pragma unroll
     for (int jt = 0; jt < MT; ++jt)
+      if ((jt + 1) * 16 > P) {                                    // (wave-uniform) tiles with keys past the region
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;       // keys past the region
-        cmax = fmaxf(cmax, s[jt][r]);
+        for (int r = 0; r < 4; ++r)
+          if (jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;
       }
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[jt][r]);
     cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
     cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
     float psum = 0.f;
@@ -344,6 +395,8 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
     psum += __shfl_xor(psum, 16);
     psum += __shfl_xor(psum, 32);
     const float inv = 1.0f / psum;                  // of THIS lane's query (lr): the four lg lanes agree
+    asm volatile("" :: "v"(inv));
+    RRT_TRACE_MARK();                               // tile: softmax done
     // O^T = V^T P^T: A = V^T rows d = 4 a + c (a = lr), B = P^T straight from the score registers
     f32x4 oacc[4];
 #pragma unroll
@@ -354,10 +407,11 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int dd = 4 * lr + c;
-        const Frag vf = *(const Frag*)(VT + dd * VT_PITCH + (((4 * b + lg) ^ lr) << 4));
+        const Frag vf = *(const Frag*)(VT + dd * VT_PITCH + (((4 * b + lg) ^ ((lr ^ (c << 2)) & 15)) << 4));
         oacc[c] = H::mfma(vf, pb, oacc[c]);
       }
     }
+    RRT_TRACE_MARK();                               // tile: PV issued
     // oacc[c][r] = O[query i0 + lr][d = 16 lg + 4 r + c]
     const int i = i0 + lr;
     if (i < P) {
@@ -372,6 +426,7 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
       *(uint4*)dst = lo;
       *(uint4*)(dst + 8) = hi;
     }
+    RRT_TRACE_MARK();                               // tile: O stored
   }
 }
 
@@ -379,8 +434,8 @@ template <int MT, int PREC>
 hipError_t launch_mt(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
                      int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
   constexpr int BM = 16 * MT;
-  constexpr size_t RING = (size_t)2 * (BM + BN) * ROWB, TILES = (size_t)BM * (256 + ROWB) + 64 * VT_PITCH;
-  constexpr size_t LDS = RING > TILES ? RING : TILES;
+  constexpr size_t RING = (size_t)3 * (BM + BN) * ROWB, TILES = (size_t)BM * (256 + ROWB) + 64 * VT_PITCH;
+  constexpr size_t LDS = (RING > TILES ? RING : TILES) + 512;          // + the EPEG tap table
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = rmsa_fused16_kernel<MT, PREC>;
   static OncePerDevice once;
@@ -393,6 +448,10 @@ hipError_t launch_mt(const uint16_t* U, const uint16_t* W, const float* bqkv, co
 }
 
 }  // namespace
+
+#ifdef RRT_TRACE
+RRT_TRACE_DEFINE_READER(rrt_debug_trace_fused16)
+#endif
 
 bool rmsa_fused16_supported(int P, int D, int heads, int epeg_k) {
   static const bool off = getenv("RRT_NO_FUSED16") != nullptr;
