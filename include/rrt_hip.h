@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 16
+#define RRT_ABI_VERSION 15
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -231,19 +231,6 @@ int rrt_crmsa_dispatch_ln_f32(const float *x1, const float *x0, const float *wdi
                               const float *rep2, const float *gamma,
                               const float *beta, float *y, int64_t L, int32_t dim, int32_t k,
                               const rrt_grid *g8, void *stream);
-/* Inference form of logits + combine: ONE pass over x1 with an online softmax over each region's tokens
- * (rmsa.py:303-316), then a chunk merge -> logits [Np8, k] (region-major), rep [k, R8, dim] and the regions'
- * (min, max) of the logits per representative, stats [R8, k, 2]; rrt_crmsa_dispatch_fly_ln_f32 forms the dispatch
- * weights minmax_p(Lg) * softmax_k(Lg) (rmsa.py:310-314,324-325) from logits + stats on the fly.  What
- * rrt_encoder_forward_f32 runs when phi is the [dim, k] matrix (the training forward keeps the three-kernel form,
- * whose stash the backward reads). */
-int rrt_crmsa_scan_workspace_size(int32_t dim, int32_t k, const rrt_grid *g8, size_t *bytes);
-int rrt_crmsa_scan_f32(const float *x1, const float *gamma, const float *beta, const float *phi, float *logits,
-                       float *rep, float *stats, int64_t L, int32_t dim, int32_t k, const rrt_grid *g8,
-                       void *workspace, size_t workspace_bytes, void *stream);
-int rrt_crmsa_dispatch_fly_ln_f32(const float *x1, const float *x0, const float *logits, const float *stats,
-                                  const float *rep2, const float *gamma, const float *beta, float *y, int64_t L,
-                                  int32_t dim, int32_t k, const rrt_grid *g8, void *stream);
 /* crmsa_mlp logits (rmsa.py:248-252, :305): logits[r, n] = sum_j tanh(hid[r, j]) * w2[n, j] */
 int rrt_crmsa_mlp_logits_f32(const float *hid, const float *w2, float *logits, int64_t rows,
                              int32_t hdim, int32_t k, void *stream);

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 16
+ABI_VERSION = 15
 
 _f32p = C.POINTER(C.c_float)
 
@@ -112,11 +112,6 @@ SIGNATURES = {
                                                           C.POINTER(Grid), C.c_void_p]),
     "rrt_crmsa_dispatch_ln_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32,
                                                               C.POINTER(Grid), C.c_void_p]),
-    "rrt_crmsa_scan_workspace_size": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(Grid), C.POINTER(C.c_size_t)]),
-    "rrt_crmsa_scan_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_void_p,
-                                                       C.c_size_t, C.c_void_p]),
-    "rrt_crmsa_dispatch_fly_ln_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid),
-                                                                   C.c_void_p]),
     "rrt_crmsa_mlp_logits_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "rrt_layernorm_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p]),
     "rrt_mil_workspace_size": (C.c_int, [C.POINTER(MilDesc), C.c_int64, C.POINTER(C.c_size_t)]),

@@ -2,7 +2,6 @@
 // carving and the launch sequence of one RRTEncoder forward (modules/rrt.py:165-202).
 #include <math.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 
 #include "internal.h"
@@ -28,7 +27,6 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Workspace {
   float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *v8, *hid;
   float *ffn_ln, *ffn_hid, *xp;
-  float *cr_part, *cr_stats;   // one-pass CR-MSA scan: chunk partials, region (min, max) per representative
   uint16_t* w16;     // reduced-precision modes: 16-bit copies of the R-MSA layers' qkv / proj weights (4 D^2 per layer)
   size_t bytes;
 };
@@ -72,9 +70,6 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     if (d.crmsa_mlp) {
       w.v8 = take(Np8 * D);
       w.hid = take(Np8 * (D / 4));
-    } else {
-      w.cr_part = take(crmsa_scan_workspace((int)D, (int)k, to_dev(g8)) / sizeof(float));
-      w.cr_stats = take(R8 * k * 2);
     }
   }
   if (d.pos) w.xp = take((size_t)N * D);
@@ -420,8 +415,6 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
   if (desc->crmsa_mlp ? (!w->phi0_w || !w->phi2_w) : !w->phi) return RRT_E_INVALID;
   const GridDev gd8 = to_dev(g8);
   const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
-  static const bool fly_off = getenv("RRT_NO_CRMSA_SCAN") != nullptr;
-  const bool fly = !desc->crmsa_mlp && !fly_off && D <= 1024;       // one-pass scan + dispatch weights on the fly
   if (desc->crmsa_mlp) {
     // MLP phi (rmsa.py:248-252,305): v = LN(x1) materialised in region-major order, hidden = v W1^T on
     // the matrix cores, logits = tanh(hidden) W2^T; the combine then runs on the normalised rows
@@ -431,9 +424,6 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
     RRT_TRY(launch_linear(ws.v8, w->phi0_w, ws.hid, gd8.Np, D / 4, D, ep, st));
     RRT_TRY(launch_crmsa_mlp_logits(ws.hid, w->phi2_w, ws.logits, gd8.Np, D / 4, k, st));
     RRT_TRY(launch_crmsa_combine(ws.v8, nullptr, nullptr, nullptr, ws.logits, ws.wdisp, ws.rep, D, k, gd8, st));
-  } else if (fly) {
-    // LN2 + logits + combine in one pass over x1 (online softmax over each region's tokens), chunk merge
-    RRT_TRY(launch_crmsa_scan(xin, cw.norm_w, cw.norm_b, w->phi, ws.logits, ws.rep, ws.cr_stats, ws.cr_part, D, k, gd8, st));
   } else {
     RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, ws.mean_rstd, ws.logits, D, k, gd8, st));
     RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, ws.mean_rstd, ws.logits, ws.wdisp, ws.rep, D, k,
@@ -452,17 +442,15 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
   if (desc->ffn) {
     // x2 = x1 + dispatch (no LayerNorm yet) -> FFN -> (+ shortcut) -> final LayerNorm.  xin is xb or the
     // caller's x: xa is free for x2, and xin is dead once the dispatch has read it.
-    if (fly) RRT_TRY(launch_crmsa_dispatch_fly_ln(xin, nullptr, ws.logits, ws.cr_stats, ws.rep2, nullptr, nullptr, ws.xa, D, k, gd8, st));
-    else RRT_TRY(launch_crmsa_dispatch_ln(xin, nullptr, ws.wdisp, ws.rep2, nullptr, nullptr, ws.xa, D, k, gd8, st));
+    RRT_TRY(launch_crmsa_dispatch_ln(xin, nullptr, ws.wdisp, ws.rep2, nullptr, nullptr, ws.xa, D, k, gd8, st));
     rc = ffn_block(cw, ws.xa, ws.xb);
     if (rc) return rc;
     RRT_TRY(launch_layernorm(ws.xb, x0, w->norm_w, w->norm_b, y, (int)N, D, st));
     RRT_MARK(RRT_EV_END);
     return RRT_OK;
   }
-  if (fly) RRT_TRY(launch_crmsa_dispatch_fly_ln(xin, x0, ws.logits, ws.cr_stats, ws.rep2, w->norm_w, w->norm_b, y, D, k, gd8, st));
-  else RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, ws.wdisp, ws.rep2, w->norm_w, w->norm_b, y, D, k,
-                                        gd8, st));
+  RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, ws.wdisp, ws.rep2, w->norm_w, w->norm_b, y, D, k,
+                                   gd8, st));
   RRT_MARK(RRT_EV_END);
 #undef RRT_TRY
 #undef RRT_MARK
@@ -631,32 +619,6 @@ int rrt_crmsa_dispatch_ln_f32(const float* x1, const float* x0, const float* wdi
   if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4 || dim > 2048) return unsupported("crmsa: k in [1,8], dim%4==0, dim<=2048");
   return (int)launch_crmsa_dispatch_ln(x1, x0, wdisp, rep2, gamma, beta, y, dim, k, to_dev(*g8),
                                        (hipStream_t)stream);
-}
-
-int rrt_crmsa_scan_workspace_size(int32_t dim, int32_t k, const rrt_grid* g8, size_t* bytes) {
-  if (!g8 || !bytes || dim <= 0 || k <= 0 || k > RRT_MAX_CRMSA_K) return RRT_E_INVALID;
-  *bytes = crmsa_scan_workspace(dim, k, to_dev(*g8));
-  return RRT_OK;
-}
-
-int rrt_crmsa_scan_f32(const float* x1, const float* gamma, const float* beta, const float* phi, float* logits,
-                       float* rep, float* stats, int64_t L, int32_t dim, int32_t k, const rrt_grid* g8,
-                       void* workspace, size_t workspace_bytes, void* stream) {
-  if (!x1 || !gamma || !beta || !phi || !logits || !rep || !stats || !g8 || L != g8->L) return RRT_E_INVALID;
-  if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4 || dim > 1024) return unsupported("crmsa scan: k in [1,8], dim%4==0, dim<=1024");
-  const GridDev gd = to_dev(*g8);
-  if (!workspace || workspace_bytes < crmsa_scan_workspace(dim, k, gd)) return RRT_E_WORKSPACE;
-  return (int)launch_crmsa_scan(x1, gamma, beta, phi, logits, rep, stats, (float*)workspace, dim, k, gd,
-                                (hipStream_t)stream);
-}
-
-int rrt_crmsa_dispatch_fly_ln_f32(const float* x1, const float* x0, const float* logits, const float* stats,
-                                  const float* rep2, const float* gamma, const float* beta, float* y, int64_t L,
-                                  int32_t dim, int32_t k, const rrt_grid* g8, void* stream) {
-  if (!x1 || !logits || !stats || !rep2 || !gamma || !beta || !y || !g8 || L != g8->L) return RRT_E_INVALID;
-  if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4 || dim > 2048) return unsupported("crmsa: k in [1,8], dim%4==0, dim<=2048");
-  return (int)launch_crmsa_dispatch_fly_ln(x1, x0, logits, stats, rep2, gamma, beta, y, dim, k, to_dev(*g8),
-                                           (hipStream_t)stream);
 }
 
 int rrt_crmsa_mlp_logits_f32(const float* hid, const float* w2, float* logits, int64_t rows, int32_t hdim,

@@ -278,233 +278,11 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Inference form of logits + combine: ONE pass over x1 (crmsa_scan_kernel) and a small merge.
-// A block owns a chunk of one region's tokens; a wave takes four rows at a time, normalises them in registers
-// (LN2), forms the k logits, and feeds the rows straight into the combine as an ONLINE softmax over the region's
-// tokens -- running max m[n], normaliser l[n] and the weighted row sum acc[n][:] = sum_p exp(Lg[n,p] - m[n]) v_p
-// (pad tokens: v = 0 and Lg = 0, so they count in l and add no row, exactly like the reference's zero rows after
-// LayerNorm).  x1 is read once; the [R, k, P, D] temporaries of the reference and the second pass of
-// crmsa_combine_kernel do not exist.  The block's four waves merge through 8 KiB of LDS; chunk partials
-// (m, l, min, row) go to `part`, crmsa_merge_kernel folds the chunks of a region into rep [k, R, D] and the
-// region statistics (min, max) the dispatch weights need.
-constexpr int SCAN_RW = 4;                 // rows in flight per wave
-constexpr int SCAN_HDR = 4;                // floats in front of a partial row: m, l, min, (unused)
-
-template <int NV, int KK>   // KK >= k: representatives held in registers
-__global__ __launch_bounds__(256) void crmsa_scan_kernel(const float* __restrict__ x1,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta,
-                                                         const float* __restrict__ phi,
-                                                         float* __restrict__ logits, float* __restrict__ part,
-                                                         int dim, int k, int nch, int CH, GridDev g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* phi_t = (float*)smem;                    // [k][dim]
-  float* mrg = phi_t + (size_t)k * dim;           // [4 waves][SCAN_HDR + dim]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int n = 0; n < k; ++n)
-    for (int d = threadIdx.x; d < dim; d += 256) phi_t[n * dim + d] = phi[(size_t)d * k + n];
-  __syncthreads();
-  const int reg = blockIdx.x / nch, ch = blockIdx.x - reg * nch;
-  const int p_lo = ch * CH, p_hi = min(p_lo + CH, g.P);
-  const int ri = fdiv(reg, g.rs, g.inv_rs), rj = reg - ri * g.rs;
-  float4 gm[NV], bt[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int c = (v * 64 + lane) * 4;
-    gm[v] = c < dim ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    bt[v] = c < dim ? *(const float4*)(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  float m[KK], l[KK], mn[KK];
-  float4 acc[KK][NV];
-#pragma unroll
-  for (int n = 0; n < KK; ++n) {
-    m[n] = -3.0e38f; l[n] = 0.f; mn[n] = 3.0e38f;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) acc[n][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const float inv_d = 1.0f / (float)dim;
-  for (int p0 = p_lo + wave * SCAN_RW; p0 < p_hi; p0 += 4 * SCAN_RW) {
-    float4 r[SCAN_RW][NV];
-    bool real[SCAN_RW];
-    float sum[SCAN_RW];
-#pragma unroll
-    for (int i = 0; i < SCAN_RW; ++i) {
-      const int p = p0 + i;
-      const int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
-      const int t = (ri * g.s + pi) * g.H + rj * g.s + pj;
-      real[i] = p < p_hi && t < g.L;
-      sum[i] = 0.f;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int c = (v * 64 + lane) * 4;
-        r[i][v] = (real[i] && c < dim) ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        sum[i] += (r[i][v].x + r[i][v].y) + (r[i][v].z + r[i][v].w);
-      }
-    }
-    float mean[SCAN_RW], rstd[SCAN_RW];
-#pragma unroll
-    for (int i = 0; i < SCAN_RW; ++i) mean[i] = wave_sum(sum[i]) * inv_d;
-#pragma unroll
-    for (int i = 0; i < SCAN_RW; ++i) {
-      float sq = 0.f;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int c = (v * 64 + lane) * 4;
-        if (c < dim) {
-          const float a = r[i][v].x - mean[i], b = r[i][v].y - mean[i], cc = r[i][v].z - mean[i], d = r[i][v].w - mean[i];
-          sq += (a * a + b * b) + (cc * cc + d * d);
-        }
-      }
-      rstd[i] = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
-    }
-    // rows <- LN2(x1) (pad rows stay exact zeros: they are not layer-normed in the reference)
-#pragma unroll
-    for (int i = 0; i < SCAN_RW; ++i)
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        if (real[i]) {
-          r[i][v].x = (r[i][v].x - mean[i]) * rstd[i] * gm[v].x + bt[v].x;
-          r[i][v].y = (r[i][v].y - mean[i]) * rstd[i] * gm[v].y + bt[v].y;
-          r[i][v].z = (r[i][v].z - mean[i]) * rstd[i] * gm[v].z + bt[v].z;
-          r[i][v].w = (r[i][v].w - mean[i]) * rstd[i] * gm[v].w + bt[v].w;
-        }
-      }
-#pragma unroll
-    for (int n = 0; n < KK; ++n) {
-      if (n >= k) break;
-      float a[SCAN_RW];
-#pragma unroll
-      for (int i = 0; i < SCAN_RW; ++i) a[i] = 0.f;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int c = (v * 64 + lane) * 4;
-        if (c < dim) {
-          const float4 ph = *(const float4*)(phi_t + n * dim + c);
-#pragma unroll
-          for (int i = 0; i < SCAN_RW; ++i)
-            a[i] += (r[i][v].x * ph.x + r[i][v].y * ph.y) + (r[i][v].z * ph.z + r[i][v].w * ph.w);
-        }
-      }
-      float lgv[SCAN_RW], top = m[n];
-#pragma unroll
-      for (int i = 0; i < SCAN_RW; ++i) {
-        lgv[i] = real[i] ? wave_sum(a[i]) : 0.f;             // wave-uniform; pad tokens: exactly 0
-        if (p0 + i < p_hi) {
-          if (lane == 0) logits[((size_t)reg * g.P + p0 + i) * k + n] = lgv[i];
-          top = fmaxf(top, lgv[i]);
-          mn[n] = fminf(mn[n], lgv[i]);
-        }
-      }
-      if (top > m[n]) {                                        // (wave-uniform) new running max: rescale
-        const float sc = __expf(m[n] - top);
-        l[n] *= sc;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) { acc[n][v].x *= sc; acc[n][v].y *= sc; acc[n][v].z *= sc; acc[n][v].w *= sc; }
-        m[n] = top;
-      }
-#pragma unroll
-      for (int i = 0; i < SCAN_RW; ++i)
-        if (p0 + i < p_hi) {
-          const float e = __expf(lgv[i] - m[n]);
-          l[n] += e;
-#pragma unroll
-          for (int v = 0; v < NV; ++v) {
-            acc[n][v].x += e * r[i][v].x; acc[n][v].y += e * r[i][v].y;
-            acc[n][v].z += e * r[i][v].z; acc[n][v].w += e * r[i][v].w;
-          }
-        }
-    }
-  }
-  // merge the four waves, one representative at a time (8 KiB of LDS): partial = (m, l, min | row)
-  const int stride = SCAN_HDR + dim;
-  for (int n = 0; n < k; ++n) {
-    float* mine = mrg + wave * stride;
-    float mm = 0.f, ll = 0.f, mi = 0.f;
-    float4 row[NV];
-#pragma unroll
-    for (int q = 0; q < KK; ++q)
-      if (q == n) {
-        mm = m[q]; ll = l[q]; mi = mn[q];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) row[v] = acc[q][v];
-      }
-    if (lane == 0) { mine[0] = mm; mine[1] = ll; mine[2] = mi; }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int c = (v * 64 + lane) * 4;
-      if (c < dim) *(float4*)(mine + SCAN_HDR + c) = row[v];
-    }
-    __syncthreads();
-    float* out = part + ((size_t)(reg * nch + ch) * k + n) * stride;
-    const float M = fmaxf(fmaxf(mrg[0], mrg[stride]), fmaxf(mrg[2 * stride], mrg[3 * stride]));
-    float sc[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) sc[w] = mrg[w * stride + 1] > 0.f ? __expf(mrg[w * stride] - M) : 0.f;   // idle wave: l = 0
-    if (threadIdx.x == 0) {
-      out[0] = M;
-      out[1] = (sc[0] * mrg[1] + sc[1] * mrg[stride + 1]) + (sc[2] * mrg[2 * stride + 1] + sc[3] * mrg[3 * stride + 1]);
-      out[2] = fminf(fminf(mrg[2], mrg[stride + 2]), fminf(mrg[2 * stride + 2], mrg[3 * stride + 2]));
-      out[3] = 0.f;
-    }
-    for (int c = threadIdx.x * 4; c < dim; c += 1024) {
-      const float4 a0 = *(const float4*)(mrg + SCAN_HDR + c), a1 = *(const float4*)(mrg + stride + SCAN_HDR + c);
-      const float4 a2 = *(const float4*)(mrg + 2 * stride + SCAN_HDR + c), a3 = *(const float4*)(mrg + 3 * stride + SCAN_HDR + c);
-      float4 o;
-      o.x = (sc[0] * a0.x + sc[1] * a1.x) + (sc[2] * a2.x + sc[3] * a3.x);
-      o.y = (sc[0] * a0.y + sc[1] * a1.y) + (sc[2] * a2.y + sc[3] * a3.y);
-      o.z = (sc[0] * a0.z + sc[1] * a1.z) + (sc[2] * a2.z + sc[3] * a3.z);
-      o.w = (sc[0] * a0.w + sc[1] * a1.w) + (sc[2] * a2.w + sc[3] * a3.w);
-      *(float4*)(out + SCAN_HDR + c) = o;
-    }
-    __syncthreads();
-  }
-}
-
-// rep[n, reg, :] = sum_c exp(m_c - M) row_c / sum_c exp(m_c - M) l_c ; stats[reg][n] = (region min, region max) of the logits
-__global__ __launch_bounds__(128) void crmsa_merge_kernel(const float* __restrict__ part, float* __restrict__ rep,
-                                                          float* __restrict__ stats, int dim, int k, int nch, int R) {
-  const int reg = blockIdx.x / k, n = blockIdx.x - reg * k;
-  const int stride = SCAN_HDR + dim;
-  const float* base = part + ((size_t)reg * nch * k + n) * stride;
-  float M = -3.0e38f, mi = 3.0e38f;
-  for (int c = 0; c < nch; ++c) {
-    const float* pc = base + (size_t)c * k * stride;
-    if (pc[1] > 0.f) M = fmaxf(M, pc[0]);
-    mi = fminf(mi, pc[2]);
-  }
-  float L = 0.f;
-  for (int c = 0; c < nch; ++c) {
-    const float* pc = base + (size_t)c * k * stride;
-    if (pc[1] > 0.f) L += __expf(pc[0] - M) * pc[1];
-  }
-  const float inv = 1.0f / L;
-  for (int col = threadIdx.x * 4; col < dim; col += 512) {
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < nch; ++c) {
-      const float* pc = base + (size_t)c * k * stride;
-      if (pc[1] > 0.f) {
-        const float sc = __expf(pc[0] - M);
-        const float4 a = *(const float4*)(pc + SCAN_HDR + col);
-        o.x += sc * a.x; o.y += sc * a.y; o.z += sc * a.z; o.w += sc * a.w;
-      }
-    }
-    *(float4*)(rep + ((size_t)n * R + reg) * dim + col) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
-  }
-  if (threadIdx.x == 0) {
-    stats[((size_t)reg * k + n) * 2] = mi;
-    stats[((size_t)reg * k + n) * 2 + 1] = M;
-  }
-}
-
-// WFLY: `wdisp` holds the raw logits [Np8, k] and `stats` the regions' (min, max) per representative; the dispatch
-// weight minmax_p(Lg) * softmax_k(Lg) (rmsa.py:310-314,324-325) is formed here instead of being stored and re-read
-template <int NV, bool CRMSA, bool WFLY = false>
+template <int NV, bool CRMSA>
 __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
     const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ wdisp,
     const float* __restrict__ rep2, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ y, int L, int dim, int k, GridDev g,
-    const float* __restrict__ stats = nullptr) {
+    const float* __restrict__ beta, float* __restrict__ y, int L, int dim, int k, GridDev g) {
   constexpr int RW = RW_DISPATCH;
   const int lane = threadIdx.x & 63;
   const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
@@ -532,27 +310,10 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
       const int slot = token_to_slot(t, g);
       const int reg = fdiv(slot, g.P, g.inv_P);
       const float* wd = wdisp + (size_t)slot * k;
-      float wfly[KMAX];
-      if (WFLY) {
-        float lgv[KMAX], mxk = -3.0e38f, se = 0.f;
-#pragma unroll
-        for (int n = 0; n < KMAX; ++n)
-          if (n < k) { lgv[n] = wd[n]; mxk = fmaxf(mxk, lgv[n]); }
-#pragma unroll
-        for (int n = 0; n < KMAX; ++n)
-          if (n < k) { wfly[n] = __expf(lgv[n] - mxk); se += wfly[n]; }
-        const float inv = 1.0f / se;
-#pragma unroll
-        for (int n = 0; n < KMAX; ++n)
-          if (n < k) {
-            const float lo = stats[((size_t)reg * k + n) * 2], hi = stats[((size_t)reg * k + n) * 2 + 1];
-            wfly[n] = (lgv[n] - lo) / (hi - lo + 1e-8f) * (wfly[n] * inv);
-          }
-      }
 #pragma unroll
       for (int n = 0; n < KMAX; ++n)
         if (n < k) {
-          const float w = WFLY ? wfly[n] : wd[n];
+          const float w = wd[n];
           const float* rp = rep2 + ((size_t)n * R + reg) * dim;
 #pragma unroll
           for (int v = 0; v < NV; ++v) {
@@ -644,14 +405,14 @@ __global__ __launch_bounds__(256) void crmsa_mlp_logits_kernel(const float* __re
     }
 }
 
-template <bool CRMSA, bool WFLY = false>
+template <bool CRMSA>
 hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
                            const float* rep2, const float* gamma, const float* beta, float* y, int L,
-                           int dim, int k, const GridDev& g, hipStream_t st, const float* stats = nullptr) {
+                           int dim, int k, const GridDev& g, hipStream_t st) {
   dim3 grid((L + 4 * RW_DISPATCH - 1) / (4 * RW_DISPATCH)), block(256);
-#define RRT_DISPATCH(NV)                                                                          \
-  crmsa_dispatch_ln_kernel<NV, CRMSA, WFLY><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, \
-                                                                    beta, y, L, dim, k, g, stats)
+#define RRT_DISPATCH(NV)                                                                    \
+  crmsa_dispatch_ln_kernel<NV, CRMSA><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, \
+                                                              beta, y, L, dim, k, g)
   if (dim <= 256) RRT_DISPATCH(1);
   else if (dim <= 512) RRT_DISPATCH(2);
   else if (dim <= 1024) RRT_DISPATCH(4);
@@ -690,48 +451,6 @@ hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   kern<<<grid, block, lds, st>>>(x1, gamma, beta, mean_rstd, logits, wdisp, rep, dim, k, g8);
   return hipGetLastError();
-}
-
-// one-pass logits + combine (inference): `part` = crmsa_scan_workspace bytes; logits [Np8, k] region-major,
-// rep [k, R, dim], stats [R, k, 2]
-int crmsa_scan_chunks(const GridDev& g8) {
-  const int R = g8.rs * g8.rs;
-  int nch = (256 + R - 1) / R;                                   // fill the chip: R * nch >= 256 blocks ...
-  const int cap = (g8.P + 4 * SCAN_RW - 1) / (4 * SCAN_RW);     // ... but at least one four-row trip per wave
-  if (nch > cap) nch = cap;
-  return nch < 1 ? 1 : nch;
-}
-size_t crmsa_scan_workspace(int dim, int k, const GridDev& g8) {
-  return (size_t)g8.rs * g8.rs * crmsa_scan_chunks(g8) * k * (SCAN_HDR + dim) * sizeof(float);
-}
-hipError_t launch_crmsa_scan(const float* x1, const float* gamma, const float* beta, const float* phi,
-                             float* logits, float* rep, float* stats, float* part, int dim, int k,
-                             const GridDev& g8, hipStream_t st) {
-  const int R = g8.rs * g8.rs, nch = crmsa_scan_chunks(g8), CH = (g8.P + nch - 1) / nch;
-  const size_t lds = ((size_t)dim * k + 4 * (SCAN_HDR + dim)) * sizeof(float);
-  if (lds > 64 * 1024) return hipErrorInvalidValue;              // dim <= 2048 at k = 8 is 80 KiB: not reached (dim <= 1024 here)
-  dim3 grid(R * nch), block(256);
-#define RRT_SCAN(NV)                                                                                                   \
-  do {                                                                                                                 \
-    if (k <= 2) crmsa_scan_kernel<NV, 2><<<grid, block, lds, st>>>(x1, gamma, beta, phi, logits, part, dim, k, nch, CH, g8);      \
-    else if (k <= 4) crmsa_scan_kernel<NV, 4><<<grid, block, lds, st>>>(x1, gamma, beta, phi, logits, part, dim, k, nch, CH, g8); \
-    else crmsa_scan_kernel<NV, 8><<<grid, block, lds, st>>>(x1, gamma, beta, phi, logits, part, dim, k, nch, CH, g8);             \
-  } while (0)
-  if (dim <= 256) RRT_SCAN(1);
-  else if (dim <= 512) RRT_SCAN(2);
-  else if (dim <= 1024) RRT_SCAN(4);
-  else return hipErrorInvalidValue;
-#undef RRT_SCAN
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  crmsa_merge_kernel<<<dim3(R * k), 128, 0, st>>>(part, rep, stats, dim, k, nch, R);
-  return hipGetLastError();
-}
-
-hipError_t launch_crmsa_dispatch_fly_ln(const float* x1, const float* x0, const float* logits, const float* stats,
-                                        const float* rep2, const float* gamma, const float* beta, float* y, int dim,
-                                        int k, const GridDev& g8, hipStream_t st) {
-  return launch_dispatch<true, true>(x1, x0, logits, rep2, gamma, beta, y, g8.L, dim, k, g8, st, stats);
 }
 
 hipError_t launch_crmsa_mlp_logits(const float* hid, const float* w2, float* logits, int rows, int hdim,

@@ -76,15 +76,6 @@ hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float*
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
                                 const float* mean_rstd, const float* logits, float* wdisp,
                                 float* rep, int dim, int k, const GridDev& g8, hipStream_t st);
-// inference: logits + combine in one pass over x1 (online softmax over each region's tokens) + chunk merge
-size_t crmsa_scan_workspace(int dim, int k, const GridDev& g8);
-hipError_t launch_crmsa_scan(const float* x1, const float* gamma, const float* beta, const float* phi,
-                             float* logits, float* rep, float* stats, float* part, int dim, int k,
-                             const GridDev& g8, hipStream_t st);
-// dispatch + LayerNorm with the dispatch weights formed from logits [Np8, k] and the regions' (min, max) stats [R, k, 2]
-hipError_t launch_crmsa_dispatch_fly_ln(const float* x1, const float* x0, const float* logits, const float* stats,
-                                        const float* rep2, const float* gamma, const float* beta, float* y, int dim,
-                                        int k, const GridDev& g8, hipStream_t st);
 // mean_rstd == nullptr: x1 is LN(x1) already, region-major [Np8, dim] (crmsa_mlp path)
 hipError_t launch_crmsa_mlp_logits(const float* hid, const float* w2, float* logits, int rows, int hdim,
                                    int k, hipStream_t st);

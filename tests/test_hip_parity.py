@@ -169,8 +169,7 @@ def test_region_attention_online_softmax_rescale():
     _cmp(got, _attn_ref(qkv, None, R, P, D, heads, 0), 3e-5, "online softmax rescale")
 
 
-@pytest.mark.parametrize("L,D,k", [(9000, 512, 3), (300, 64, 3), (3000, 512, 5), (50, 512, 1), (9000, 512, 8),
-                                   (30000, 512, 3), (1, 512, 3), (65, 1024, 2), (15000, 256, 5)])
+@pytest.mark.parametrize("L,D,k", [(9000, 512, 3), (300, 64, 3), (3000, 512, 5), (50, 512, 1), (9000, 512, 8)])
 def test_crmsa_stages(L, D, k):
     from hip_util import dev, p, stream, DEV
     lib = _lib.load()
@@ -221,27 +220,6 @@ def test_crmsa_stages(L, D, k):
     mu = x2.mean(-1, keepdims=True)
     ref = (x2 - mu) / np.sqrt(((x2 - mu) ** 2).mean(-1, keepdims=True) + 1e-5) * gm3 + bt3
     _cmp(y.cpu().numpy(), ref, 2e-5, "crmsa dispatch + LN")
-    # the inference form: ONE pass over x1 (online softmax over each region's tokens + chunk merge), and the dispatch
-    # weights formed from logits + region (min, max) inside the dispatch kernel
-    if D <= 1024:
-        need = C.c_size_t()
-        _lib.check(lib.rrt_crmsa_scan_workspace_size(D, k, C.byref(g8), C.byref(need)), "scan workspace")
-        wsb = torch.full((max(need.value, 4) // 4,), float("nan"), device=DEV)
-        lg2 = torch.full((Np8, k), float("nan"), device=DEV)
-        rep_b = torch.full((k, R8, D), float("nan"), device=DEV)
-        stats = torch.full((R8, k, 2), float("nan"), device=DEV)
-        y2 = torch.full((L, D), float("nan"), device=DEV)
-        _lib.check(lib.rrt_crmsa_scan_f32(p(d_x1), p(d_gm), p(d_bt), p(d_phi), p(lg2), p(rep_b), p(stats), L, D, k,
-                                          C.byref(g8), p(wsb), wsb.numel() * 4, stream()), "scan")
-        _lib.check(lib.rrt_crmsa_dispatch_fly_ln_f32(p(d_x1), p(d_x0), p(lg2), p(stats), p(d_rep2), p(d_gm3), p(d_bt3),
-                                                     p(y2), L, D, k, C.byref(g8), stream()), "dispatch (weights on the fly)")
-        torch.cuda.synchronize()
-        _cmp(lg2.cpu().numpy().reshape(R8, P8, k).transpose(0, 2, 1), Lg, 2e-5, "scan logits")
-        _cmp(rep_b.cpu().numpy(), (Cw @ V).transpose(1, 0, 2), 2e-5, "scan combine")
-        st_ = stats.cpu().numpy()
-        _cmp(st_[..., 0], mn[..., 0], 2e-5, "region min")
-        _cmp(st_[..., 1], mx[..., 0], 2e-5, "region max")
-        _cmp(y2.cpu().numpy(), ref, 2e-5, "dispatch (weights on the fly) + LN")
 
 
 # ------------------------------------------------------------------ whole path
