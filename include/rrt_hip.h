@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 15
+#define RRT_ABI_VERSION 16
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -45,6 +45,7 @@ enum { RRT_COMPUTE_F32 = 0, RRT_COMPUTE_BF16 = 1, RRT_COMPUTE_F16 = 2 };
  * bits too (fp32 accumulation, fp32 softmax statistics) -- what autocast does to nn.Linear, q k^T and attn v.
  * The residual stream x / x1 / y, LayerNorm, CR-MSA's logits / combine / dispatch stay fp32. */
 enum { RRT_POS_NONE = 0, RRT_POS_PEG = 1, RRT_POS_PPEG = 2 };
+enum { RRT_EPEG_ATTN = 0, RRT_EPEG_VALUE_BF = 1, RRT_EPEG_VALUE_AF = 2 };
 
 /* Elementwise activations of the caller-side layers (patch_to_emb, DAttention). */
 enum { RRT_ACT_NONE = 0, RRT_ACT_RELU = 1, RRT_ACT_GELU = 2, RRT_ACT_TANH = 3, RRT_ACT_SIGMOID = 4 };
@@ -85,11 +86,15 @@ typedef struct rrt_encoder_desc {
   int32_t pos_pos;         /* -1: before the first layer; 0: before layer index 1 (needs n_layers >= 3), rrt.py:181-187 */
   int32_t peg_k;           /* odd, <= 11 */
   int32_t peg_1d;          /* 1: (k, 1) kernels (peg_1d / conv_1d) */
+  /* EPEG ablations (rmsa.py:76-85,106-129; inference only, unfused path): */
+  int32_t epeg_2d;         /* 1: k x k kernel -- over the score map ('attn') or over v's sqrt(P) x sqrt(P) image ('value_*') */
+  int32_t epeg_type;       /* RRT_EPEG_ATTN (default) / RRT_EPEG_VALUE_BF / RRT_EPEG_VALUE_AF */
 } rrt_encoder_desc;
 
 /* One TransLayer's parameters: InnerAttention, modules/rmsa.py:57-89 (+ the optional FFN).  Row-major, fp32.
  * qkv_w [3*dim, dim], qkv_b [3*dim] or NULL, proj_w [dim, dim], proj_b [dim],
- * pe_w [heads, epeg_k] or NULL, pe_b [heads] or NULL. */
+ * pe_w [heads, epeg_k] or NULL, pe_b [heads] or NULL (epeg_2d: pe_w [heads, k, k]; epeg_type value_*:
+ * pe_w [dim, k] or [dim, k, k], pe_b [dim] -- the value variants READ the bias, it is added to v / x). */
 typedef struct rrt_attn_weights {
   const float *norm_w, *norm_b;   /* the owning TransLayer's LayerNorm, modules/rrt.py:47 */
   const float *qkv_w, *qkv_b;

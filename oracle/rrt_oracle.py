@@ -72,7 +72,7 @@ _DEFAULTS = dict(mlp_dim=512, region_num=8, n_layers=2, n_heads=8, epeg=True, ep
                  region_size=0, min_region_num=0, min_region_ratio=0.0, qkv_bias=True,
                  cr_msa=True, crmsa_k=3, all_shortcut=False, crmsa_mlp=False, crmsa_heads=8,
                  epeg_bias=True, ffn=False, ffn_act="gelu", mlp_ratio=4.0, pos="none", pos_pos=0, peg_k=7,
-                 peg_1d=False, peg_bias=True)
+                 peg_1d=False, peg_bias=True, epeg_2d=False, epeg_type="attn")
 
 
 def _cfg(cfg):
@@ -122,9 +122,56 @@ class LowP:
         return round_lowp(a, self.dtype)
 
 
-def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None, lowp=None, attn_lowp=None):
-    """x: [B_, P, D] -> [B_, P, D]   (modules/rmsa.py:91-134, 'attn' EPEG only)."""
+def _conv_dw64(img, w, b, two_d):
+    """depth-wise Conv2d, zero padded: img [B, C, H, W], w [C, 1, k, kw] (kw = k or 1), b [C] or None"""
+    k, kw = w.shape[2], w.shape[3]
+    ph, pw = k // 2, (kw // 2 if two_d else 0)
+    Hh, Ww = img.shape[2], img.shape[3]
+    pad = np.pad(img, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
+    out = np.zeros_like(img)
+    for a in range(k):
+        for bb in range(kw):
+            out += w[None, :, 0, a, bb, None, None] * pad[:, :, a:a + Hh, bb:bb + Ww]
+    if b is not None:
+        out += b[None, :, None, None]
+    return out
+
+
+def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None, lowp=None, attn_lowp=None, epeg_2d=False,
+                       epeg_type="attn"):
+    """x: [B_, P, D] -> [B_, P, D]   (modules/rmsa.py:91-134; the default 1-D 'attn' EPEG and, in exact arithmetic
+    only, the epeg_2d / epeg_type = value_bf / value_af ablations of :76-85,:106-129)."""
     B_, P, D = x.shape
+    variant = (pfx + "pe.weight" in st) and (epeg_2d or epeg_type != "attn")
+    if variant:
+        assert lowp is None or attn_lowp is None
+        hd = D // heads
+        W = st[pfx + "qkv.weight"].astype(np.float64)
+        xx, WW = (x, W) if lowp is None else (lowp.r(x), lowp.r(W))
+        qkv = xx @ WW.T
+        if pfx + "qkv.bias" in st:
+            qkv = qkv + st[pfx + "qkv.bias"].astype(np.float64)
+        qkv = qkv.reshape(B_, P, 3, heads, hd).transpose(2, 0, 3, 1, 4)
+        q, k, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]                    # [B_,h,P,hd]
+        pw = st[pfx + "pe.weight"].astype(np.float64)
+        pb = st[pfx + "pe.bias"].astype(np.float64) if pfx + "pe.bias" in st else None
+        S = q @ k.transpose(0, 1, 3, 2)
+        if epeg_type == "attn":                                             # rmsa.py:106-108, k x k kernel
+            S = S + _conv_dw64(S, pw, pb, True)
+        A = _softmax64(S, -1)
+        s_ = int(np.ceil(np.sqrt(P)))
+        if epeg_type != "attn":                                             # rmsa.py:114-118 / :124-129
+            img = v.transpose(0, 3, 1, 2).reshape(B_, D, s_, s_)            # channel c = d * h + head
+            pe = _conv_dw64(img, pw, pb, epeg_2d)
+        if epeg_type == "value_bf":
+            v = v + pe.reshape(B_, heads, hd, P).transpose(0, 1, 3, 2)
+        O = (A @ v).transpose(0, 2, 1, 3).reshape(B_, P, D)
+        if epeg_type == "value_af":
+            O = O + pe.reshape(B_, D, P).transpose(0, 2, 1)
+        Wp = st[pfx + "proj.weight"].astype(np.float64)
+        if lowp is not None:
+            O, Wp = lowp.r(O), lowp.r(Wp)
+        return O @ Wp.T + st[pfx + "proj.bias"].astype(np.float64)
     hd = D // heads
     W = st[pfx + "qkv.weight"].astype(np.float64)
     if lowp is not None:                                                    # GEMM operands in 16 bits
@@ -233,7 +280,8 @@ def forward_f64(x, state, cfg=None, taps=None, lowp=None):
         up = np.concatenate([u, np.zeros((add, D))], 0)                     # pad rows are exact zeros (T5)
         perm = partition_index(H, s)
         U = up[perm].reshape(-1, s * s, D)
-        Z = _inner_attention64(U, st, p + "attn.attn.", c["n_heads"], c["epeg_k"], taps, lowp, attn_lowp)
+        Z = _inner_attention64(U, st, p + "attn.attn.", c["n_heads"], c["epeg_k"], taps, lowp, attn_lowp,
+                               c["epeg_2d"], c["epeg_type"])
         z = np.empty((H * H, D))
         z[perm] = Z.reshape(-1, D)
         x = x + z[:N]
@@ -326,12 +374,23 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None, autocast=None, bran
         q, k, v = qkv[0], qkv[1], qkv[2]
         q = q * (hd ** -0.5)
         attn = q @ k.transpose(-2, -1)
-        if pfx + "pe.weight" in st:
-            pe = F.conv2d(attn, st[pfx + "pe.weight"], st.get(pfx + "pe.bias"),
-                          padding=(epeg_k // 2, 0), groups=heads)
+        has_pe = pfx + "pe.weight" in st
+        et = c["epeg_type"] if has_pe else None
+        pad = (epeg_k // 2, epeg_k // 2) if c["epeg_2d"] else (epeg_k // 2, 0)
+        if et == "attn":                                                     # rmsa.py:106-108
+            pe = F.conv2d(attn, st[pfx + "pe.weight"], st.get(pfx + "pe.bias"), padding=pad, groups=heads)
             attn = attn + pe
         attn = attn.softmax(dim=-1)
+        s_ = int(np.ceil(np.sqrt(P)))
+        if et == "value_bf":                                                 # rmsa.py:114-118
+            pe = F.conv2d(v.permute(0, 3, 1, 2).reshape(B_, D, s_, s_), st[pfx + "pe.weight"], st.get(pfx + "pe.bias"),
+                          padding=pad, groups=D)
+            v = v + pe.reshape(B_, heads, hd, P).permute(0, 1, 3, 2)
         o = (attn @ v).transpose(1, 2).reshape(B_, P, D)
+        if et == "value_af":                                                 # rmsa.py:124-129
+            pe = F.conv2d(v.permute(0, 3, 1, 2).reshape(B_, D, s_, s_), st[pfx + "pe.weight"], st.get(pfx + "pe.bias"),
+                          padding=pad, groups=D)
+            o = o + pe.reshape(B_, D, P).transpose(-1, -2)
         return proj_drop(F.linear(o, st[pfx + "proj.weight"], st[pfx + "proj.bias"]), key)
 
     def bm(key, kind):

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _f32p = C.POINTER(C.c_float)
 
@@ -28,7 +28,8 @@ class EncoderDesc(C.Structure):
                 ("cr_msa", C.c_int32), ("crmsa_k", C.c_int32), ("crmsa_heads", C.c_int32),
                 ("crmsa_mlp", C.c_int32), ("all_shortcut", C.c_int32), ("compute", C.c_int32),
                 ("ffn", C.c_int32), ("ffn_act", C.c_int32), ("ffn_hidden", C.c_int32),
-                ("pos", C.c_int32), ("pos_pos", C.c_int32), ("peg_k", C.c_int32), ("peg_1d", C.c_int32)]
+                ("pos", C.c_int32), ("pos_pos", C.c_int32), ("peg_k", C.c_int32), ("peg_1d", C.c_int32),
+                ("epeg_2d", C.c_int32), ("epeg_type", C.c_int32)]
 
 
 class AttnWeights(C.Structure):
@@ -148,6 +149,7 @@ SIGNATURES = {
 
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
 POS_NONE, POS_PEG, POS_PPEG = 0, 1, 2
+EPEG_ATTN, EPEG_VALUE_BF, EPEG_VALUE_AF = 0, 1, 2
 
 # stage-boundary event slots of rrt_encoder_forward_events_f32 (enum in include/rrt_hip.h)
 EV_START, EV_LN_PARTITION, EV_QKV, EV_ATTN, EV_PROJ, EV_CR_COMBINE, EV_CR_INNER, EV_END, EV_COUNT = range(9)

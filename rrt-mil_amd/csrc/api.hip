@@ -27,6 +27,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Workspace {
   float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *v8, *hid;
   float *ffn_ln, *ffn_hid, *xp;
+  float* pe_out;     // value-EPEG ablation: the conv's output [Np, D]
   uint16_t* w16;     // reduced-precision modes: 16-bit copies of the R-MSA layers' qkv / proj weights (4 D^2 per layer)
   size_t bytes;
 };
@@ -51,6 +52,7 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     // carved in every mode (2 MB per layer at D = 512): the size must not depend on desc.compute, which callers
     // flip between calls on one workspace
     w.w16 = (uint16_t*)take((size_t)d.n_rmsa_layers * 2 * D * D);
+    if (d.epeg && d.epeg_type != RRT_EPEG_ATTN) w.pe_out = take(Np * D);
   }
   if (d.ffn) {
     if (!w.xa) w.xa = take((size_t)N * D);
@@ -85,6 +87,8 @@ int check_desc(const rrt_encoder_desc* d, int64_t N) {
   if (d->n_rmsa_layers > 0) {
     if (d->n_heads <= 0 || d->dim % d->n_heads != 0) return unsupported("n_heads must divide dim");
     if (d->epeg && (d->epeg_k <= 0 || d->epeg_k % 2 == 0)) return unsupported("epeg_k must be odd");
+    if (d->epeg_type < RRT_EPEG_ATTN || d->epeg_type > RRT_EPEG_VALUE_AF) return unsupported("epeg_type must be attn / value_bf / value_af");
+    if (d->epeg && (d->epeg_2d || d->epeg_type != RRT_EPEG_ATTN) && d->epeg_k > 63) return unsupported("epeg ablations: epeg_k <= 63");
     if (d->region_size <= 0 && d->region_num <= 0) return unsupported("region_num must be positive");
   }
   if (d->cr_msa) {
@@ -289,8 +293,10 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
   // Reduced-precision modes on regions the 16-bit fused kernel covers: every tensor that is only a matrix-core
   // operand (LayerNorm output u, the weights, the attention output O) lives in HBM in 16 bits.  The weights are
   // cast once per call (one launch for all layers; the ABI is stateless, so nothing is cached across calls).
+  // EPEG ablations (epeg_2d, epeg_type = value_*): unfused path with their own kernels (epeg_variants.hip)
+  const bool epeg_variant = desc->epeg && (desc->epeg_2d || desc->epeg_type != RRT_EPEG_ATTN);
   bool lowp16 = false;
-  if (desc->n_rmsa_layers > 0 && desc->compute != RRT_COMPUTE_F32) {
+  if (desc->n_rmsa_layers > 0 && desc->compute != RRT_COMPUTE_F32 && !epeg_variant) {
     const GridDev gd = to_dev(g);
     lowp16 = rmsa_fused16_supported(gd.P, D, desc->n_heads, desc->epeg ? desc->epeg_k : 0) &&
              rmsa_fused_supported_rows(gd.Np, D) && D % 64 == 0;
@@ -348,6 +354,44 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
       continue;
     }
     RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, ws.uo, D, gd, st));
+    if (epeg_variant) {
+      if (!lw.pe_w) return RRT_E_INVALID;
+      const int nreg = gd.rs * gd.rs;
+      {
+        LinearEpilogue ep{};
+        ep.prec = desc->compute;
+        ep.bias = lw.qkv_b;
+        ep.q_cols = D;
+        ep.q_scale = 1.0f / sqrtf((float)(D / desc->n_heads));
+        RRT_TRY(launch_linear(ws.uo, lw.qkv_w, ws.qkv, gd.Np, 3 * D, D, ep, st));
+      }
+      if (desc->epeg_type == RRT_EPEG_ATTN) {           // epeg_2d: k x k stencil over the score map
+        if (attn_scoremap_lds(gd.P, desc->epeg_k) > 160 * 1024)
+          return unsupported("epeg_2d: the [P, P] score map of a region must fit the CU's LDS (regions of <= ~180 tokens)");
+        RRT_TRY(launch_attn_scoremap(ws.qkv, lw.pe_w, ws.uo, nreg, gd.P, D, desc->n_heads, desc->epeg_k, st));
+      } else {
+        RRT_TRY(launch_value_pe(ws.qkv, lw.pe_w, lw.pe_b, ws.pe_out, nreg, gd.P, gd.s, D, desc->n_heads, desc->epeg_k,
+                                desc->epeg_2d, st));
+        if (desc->epeg_type == RRT_EPEG_VALUE_BF)       // v += pe before attn @ v (rmsa.py:114-118)
+          RRT_TRY(launch_add_cols(ws.qkv + 2 * D, ws.pe_out, (size_t)gd.Np, D, 3 * D, st));
+        RRT_TRY(launch_region_attention(ws.qkv, nullptr, ws.uo, nreg, gd.P, D, desc->n_heads, 0, st));
+        if (desc->epeg_type == RRT_EPEG_VALUE_AF)       // x += pe after it (rmsa.py:124-129)
+          RRT_TRY(launch_add_cols(ws.uo, ws.pe_out, (size_t)gd.Np, D, D, st));
+      }
+      LinearEpilogue ep{};
+      ep.prec = desc->compute;
+      ep.bias = lw.proj_b;
+      ep.resid = xin;
+      ep.g = gd;
+      RRT_TRY(launch_linear(ws.uo, lw.proj_w, xout, gd.Np, D, D, ep, st));
+      xin = xout;
+      if (desc->ffn) {
+        rc = ffn_block(lw, xout, ws.xb);
+        if (rc) return rc;
+        xin = ws.xb;
+      }
+      continue;
+    }
     const bool fused = rmsa_fused_supported(gd.P, D, desc->n_heads, ek) && rmsa_fused_supported_rows(gd.Np, D);
     // the gate only pays for launches that fill the matrix pipes of the whole chip on their own: the fused
     // kernel on regions of >= 113 tokens (measured on the configs[4] mix: gating small or unfused bags costs 5 %)
@@ -1109,6 +1153,8 @@ int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8)
   int rc = check_desc(d, N);
   if (rc) return rc;
   if (d->dim > 1024) return unsupported("training: dim > 1024");
+  if (d->epeg && d->n_rmsa_layers > 0 && (d->epeg_2d || d->epeg_type != RRT_EPEG_ATTN))
+    return unsupported("training: the EPEG ablations (epeg_2d, epeg_type = value_*) are inference-only on the HIP path");
   memset(g, 0, sizeof(*g));
   if (d->n_rmsa_layers > 0) {
     rc = rrt_region_grid(N, d->region_num, d->region_size, d->min_region_num, d->min_region_ratio, g);

@@ -70,6 +70,14 @@ hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqk
                              float* O, int n_regions, int P, int D, int heads, int epeg_k, int prec,
                              hipStream_t st);
 
+// EPEG ablations (epeg_variants.hip): 2-D 'attn' EPEG over the score map; value EPEG over v's token image
+size_t attn_scoremap_lds(int P, int k);
+hipError_t launch_attn_scoremap(const float* qkv, const float* pe_w, float* o, int n_regions, int P, int dim, int heads,
+                                int k, hipStream_t st);
+hipError_t launch_value_pe(const float* qkv, const float* w, const float* bias, float* pe, int n_regions, int P, int s,
+                           int dim, int heads, int k, int two_d, hipStream_t st);
+hipError_t launch_add_cols(float* dst, const float* src, size_t rows, int dim, int ld, hipStream_t st);
+
 hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float* beta,
                                const float* phi, float* mean_rstd, float* logits, int dim, int k,
                                const GridDev& g8, hipStream_t st);

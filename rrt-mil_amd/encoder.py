@@ -39,9 +39,8 @@ class InnerAttention(nn.Module):
     def __init__(self, dim, head_dim=None, num_heads=8, qkv_bias=True, proj_drop=0., epeg=True,
                  epeg_k=15, epeg_2d=False, epeg_bias=True, epeg_type='attn', **_ignored):
         super().__init__()
-        if epeg and (epeg_2d or epeg_type != 'attn'):
-            raise NotImplementedError("only the default 1-D 'attn' EPEG is on the HIP path "
-                                      "(epeg_2d / epeg_type='value_*' are reference ablations)")
+        if epeg_type not in ('attn', 'value_bf', 'value_af'):
+            raise NotImplementedError(f"epeg_type={epeg_type!r}")
         head_dim = head_dim or dim // num_heads
         if head_dim * num_heads != dim:
             raise NotImplementedError("head_dim * num_heads must equal dim")
@@ -50,9 +49,12 @@ class InnerAttention(nn.Module):
         self.qkv = nn.Linear(dim, head_dim * num_heads * 3, bias=qkv_bias)
         self.proj = nn.Linear(head_dim * num_heads, dim)
         self.proj_drop_p = proj_drop
-        self.epeg_k = epeg_k
-        self.pe = (nn.Conv2d(num_heads, num_heads, (epeg_k, 1), padding=(epeg_k // 2, 0),
-                             groups=num_heads, bias=epeg_bias) if epeg else None)
+        self.epeg_k, self.epeg_2d, self.epeg_type = epeg_k, bool(epeg_2d), epeg_type
+        # modules/rmsa.py:74-87: the conv runs over the score map ('attn': one channel per head) or over v's token
+        # image ('value_*': one channel per feature), with a (k, 1) or -- epeg_2d -- a k x k kernel
+        ch = num_heads if epeg_type == 'attn' else head_dim * num_heads
+        ks, pad = (epeg_k, epeg_k // 2) if epeg_2d else ((epeg_k, 1), (epeg_k // 2, 0))
+        self.pe = nn.Conv2d(ch, ch, ks, padding=pad, groups=ch, bias=epeg_bias) if epeg else None
 
     def extra_repr(self):
         return f'dim={self.dim}, num_heads={self.num_heads}'
@@ -269,7 +271,9 @@ class RRTEncoder(nn.Module):
             compute=_lib.COMPUTE_F32, ffn=int(bool(ffn)),
             ffn_act=_lib.ACT_GELU if ffn_act == 'gelu' else _lib.ACT_RELU, ffn_hidden=int(mlp_dim * mlp_ratio),
             pos={'peg': _lib.POS_PEG, 'ppeg': _lib.POS_PPEG}.get(pos, _lib.POS_NONE), pos_pos=pos_pos, peg_k=peg_k,
-            peg_1d=int(bool(peg_1d)))
+            peg_1d=int(bool(peg_1d)), epeg_2d=int(bool(kwargs.get('epeg_2d', False))),
+            epeg_type={'attn': _lib.EPEG_ATTN, 'value_bf': _lib.EPEG_VALUE_BF,
+                       'value_af': _lib.EPEG_VALUE_AF}[kwargs.get('epeg_type', 'attn')])
         if self._desc.pos and (pos_pos not in (-1, 0) or (pos_pos == 0 and n_layers - 1 < 2)):
             # the reference only applies pos_embedding before the first layer (pos_pos = -1) or before layer index 1
             # (pos_pos = 0, which needs a second R-MSA layer: the default `--pos ppeg` run with n_layers = 2 never

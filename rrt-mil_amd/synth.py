@@ -42,7 +42,7 @@ def normal(name: str, shape, dtype=np.float32) -> np.ndarray:
 def encoder_state_shapes(mlp_dim=512, n_layers=2, n_heads=8, epeg=True, epeg_k=15,
                          cr_msa=True, crmsa_k=3, crmsa_mlp=False, qkv_bias=True,
                          epeg_bias=True, ffn=False, mlp_ratio=4., pos='none', peg_k=7, peg_1d=False,
-                         peg_bias=True, **_unused):
+                         peg_bias=True, epeg_2d=False, epeg_type='attn', **_unused):
     """Ordered {state_dict key: shape} of the default-path RRTEncoder."""
     D = mlp_dim
     sh = {"norm.weight": (D,), "norm.bias": (D,)}
@@ -53,10 +53,11 @@ def encoder_state_shapes(mlp_dim=512, n_layers=2, n_heads=8, epeg=True, epeg_k=1
             sh[prefix + "qkv.bias"] = (3 * D,)
         sh[prefix + "proj.weight"] = (D, D)
         sh[prefix + "proj.bias"] = (D,)
-        if with_pe:
-            sh[prefix + "pe.weight"] = (n_heads, 1, epeg_k, 1)
+        if with_pe:                    # modules/rmsa.py:74-87: channels = heads ('attn') or features ('value_*')
+            ch = n_heads if epeg_type == 'attn' else D
+            sh[prefix + "pe.weight"] = (ch, 1, epeg_k, epeg_k if epeg_2d else 1)
             if epeg_bias:
-                sh[prefix + "pe.bias"] = (n_heads,)
+                sh[prefix + "pe.bias"] = (ch,)
 
     def mlp(prefix):                       # TransLayer(ffn=True): norm2 + Mlp, modules/rrt.py:25-41,48,106
         if ffn:
@@ -107,7 +108,7 @@ def encoder_state(**cfg):
             b = 1.0 / np.sqrt(shape[2] * shape[3])
             out[k] = uniform(k, shape, -b, b)
         elif k.endswith("pe.weight"):
-            b = 1.0 / np.sqrt(shape[2])
+            b = 1.0 / np.sqrt(shape[2] * shape[3])
             out[k] = uniform(k, shape, -b, b)
         elif k.endswith("pe.bias"):
             out[k] = uniform(k, shape, -0.25, 0.25)

@@ -28,7 +28,8 @@ def golden_names(prefix=""):
 
 
 STATE_KEYS = ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k", "cr_msa", "crmsa_k",
-              "crmsa_mlp", "qkv_bias", "epeg_bias", "ffn", "mlp_ratio", "pos", "peg_k", "peg_1d", "peg_bias")
+              "crmsa_mlp", "qkv_bias", "epeg_bias", "ffn", "mlp_ratio", "pos", "peg_k", "peg_1d", "peg_bias",
+              "epeg_2d", "epeg_type")
 
 
 def synth_case(g):

@@ -106,10 +106,22 @@ def test_cpu_tensor_and_ablations_raise():
     enc = RRTEncoder(mlp_dim=64).eval()
     with pytest.raises(_lib.RRTHipError):
         enc(torch.zeros(1, 10, 64))
-    for kw in (dict(pos='sincos'), dict(attn='ntrans'), dict(epeg_2d=True),
-               dict(epeg_type='value_bf'), dict(region_attn='ntrans')):
+    for kw in (dict(pos='sincos'), dict(attn='ntrans'), dict(region_attn='ntrans'), dict(epeg_type='value_xx')):
         with pytest.raises(NotImplementedError):
             RRTEncoder(mlp_dim=64, **kw)
+
+
+def test_epeg_ablation_state_dict_surface():
+    """epeg_2d / epeg_type = value_bf / value_af (modules/rmsa.py:74-87): the conv's channels and kernel shape."""
+    for kw, shape, desc in ((dict(epeg_2d=True), (8, 1, 15, 15), (1, _lib.EPEG_ATTN)),
+                            (dict(epeg_type='value_bf'), (64, 1, 15, 1), (0, _lib.EPEG_VALUE_BF)),
+                            (dict(epeg_type='value_af', epeg_2d=True, epeg_k=5), (64, 1, 5, 5), (1, _lib.EPEG_VALUE_AF))):
+        enc = RRTEncoder(mlp_dim=64, **kw)
+        assert enc.layers[0].attn.attn.pe.weight.shape == shape
+        assert (enc._desc.epeg_2d, enc._desc.epeg_type) == desc
+        st = synth.encoder_state(mlp_dim=64, **kw)
+        enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+        assert enc.cr_msa.attn.attn.pe is None
 
 
 def test_pos_state_dict_surface():

@@ -24,7 +24,8 @@ os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(8)
 
 STATE_KEYS = ("mlp_dim", "n_layers", "n_heads", "epeg", "epeg_k", "cr_msa", "crmsa_k",
-              "crmsa_mlp", "qkv_bias", "epeg_bias", "ffn", "mlp_ratio", "pos", "peg_k", "peg_1d", "peg_bias")
+              "crmsa_mlp", "qkv_bias", "epeg_bias", "ffn", "mlp_ratio", "pos", "peg_k", "peg_1d", "peg_bias",
+              "epeg_2d", "epeg_type")
 
 
 def run_ref(N, cfg, hooks=False, tag="bag"):

@@ -1,6 +1,6 @@
 """Generate the round-2 fixtures from the REAL reference (build container only):
 
-    python tools/make_golden_grad_amp.py [G15|G16]
+    python tools/make_golden_grad_amp.py [G15|G16|G17]
 
 G15_grad_*   parameter / input gradients of the reference RRTEncoder in .train() mode with drop_out = 0
              (main.py:466-467 ``loss.backward()``): loss = <y, G>, G closed-form.  The reference module is cast
@@ -13,6 +13,9 @@ G16_amp_*    the reference forward under ``torch.autocast('cpu', dtype=torch.bfl
              the reference, so the CPU autocast policy is what can be pinned: Linear / matmul / conv2d / einsum
              run in the low-precision dtype and hand it on to softmax; LayerNorm and the residual stream stay
              fp32).  Stored next to the fp32 output of the same case.
+
+G17_epeg_*   the reference forward with the EPEG ablations (epeg_2d, epeg_type = value_bf / value_af,
+             modules/rmsa.py:76-85,106-129), fp32 eval.
 
 Only arrays are written (inputs regenerate from rrt-mil_amd/synth.py).
 """
@@ -142,6 +145,38 @@ def gen_amp(only=None):
         print(f"   autocast vs fp32: max {d.max():.3e} mean {d.mean():.3e}")
 
 
+# G17: the EPEG ablations (row f4): epeg_2d and epeg_type = value_bf / value_af (modules/rmsa.py:76-85,106-129)
+EPEG_CASES = {
+    "attn2d_d64_n300": (300, dict(mlp_dim=64, epeg_k=15, crmsa_k=3, epeg_2d=True)),
+    "attn2d_d512_n1000_k9": (1000, dict(mlp_dim=512, epeg_k=9, crmsa_k=3, epeg_2d=True)),
+    "attn2d_d512_n9000": (9000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, epeg_2d=True)),
+    "valuebf_d64_n300": (300, dict(mlp_dim=64, epeg_k=15, crmsa_k=3, epeg_type="value_bf")),
+    "valuebf_d512_n9000": (9000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, epeg_type="value_bf")),
+    "valuebf2d_d512_n3000_k5": (3000, dict(mlp_dim=512, epeg_k=5, crmsa_k=3, epeg_type="value_bf", epeg_2d=True)),
+    "valueaf_d64_n700_l3": (700, dict(mlp_dim=64, epeg_k=9, crmsa_k=3, epeg_type="value_af", n_layers=3)),
+    "valueaf_d512_n9000": (9000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, epeg_type="value_af")),
+    "valueaf2d_d512_n1000_nobias": (1000, dict(mlp_dim=512, epeg_k=7, crmsa_k=1, epeg_type="value_af", epeg_2d=True,
+                                               epeg_bias=False)),
+}
+
+
+def gen_epeg(only=None):
+    for tag, (N, cfg) in EPEG_CASES.items():
+        if only and only not in tag:
+            continue
+        D = cfg["mlp_dim"]
+        state = synth.encoder_state(**{k: v for k, v in cfg.items() if k in STATE_KEYS})
+        enc = build_reference_encoder(state, **cfg)
+        x = synth.bag(N, D)
+        with torch.no_grad():
+            y = enc(torch.from_numpy(x).unsqueeze(0)).squeeze(0).numpy()
+        if N <= 700:
+            save("G17_epeg_" + tag, cfg=cfg_array(cfg), n=np.array(N), y=y)
+        else:
+            rows = np.unique(np.concatenate([np.arange(0, N, max(1, N // 120)), [N - 1]]))
+            save("G17_epeg_" + tag, cfg=cfg_array(cfg), n=np.array(N), rows=rows, y_rows=y[rows], y_sums=checksums(y))
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else ""
     sub = sys.argv[2] if len(sys.argv) > 2 else None
@@ -150,3 +185,5 @@ if __name__ == "__main__":
         gen_grad(sub)
     if which in ("", "G16"):
         gen_amp(sub)
+    if which in ("", "G17"):
+        gen_epeg(sub)
