@@ -236,7 +236,8 @@ class EncoderWorkload:
         cfg = self.cfg = CONFIGS[args.config]
         self.dev, self.n, self.enc_cfg = dev, cfg["n"], cfg["enc"]
         self.dtype = args.dtype or cfg["dtype"]
-        self.compute = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f16": _lib.COMPUTE_F16}[self.dtype]
+        self.compute = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f16": _lib.COMPUTE_F16,
+                        "f32x3": _lib.COMPUTE_F32X3}[self.dtype]
         self.S = S = max(1, args.streams)
         self.units_global = world * S
         self.scaling = "weak"
@@ -255,7 +256,8 @@ class EncoderWorkload:
             mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in mst.items()}, strict=True)
             self.mil = mil.to(dev)
             self.enc = self.mil.online_encoder
-            self.enc.compute_dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[self.dtype]
+            self.enc.compute_dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16,
+                                      "f32x3": "f32x3"}[self.dtype]
             self.bags = [torch.from_numpy(synth.bag(self.n, cfg["input_dim"], tag=f"bench/mil/r{rank}/b{i}",
                                                     nonneg=True)).to(dev) for i in range(4)]
             self.mdesc, self.mw = self.mil._mil_desc(cfg["input_dim"]), self.mil._mil_weights()
@@ -341,9 +343,16 @@ class EncoderWorkload:
         rec = {}
         flops, g = fused_flops(self.n, self.enc_cfg)
         peak = PEAK_TFLOPS["bf16" if self.dtype in ("bf16", "f16") else "f32"]
+        if self.dtype == "f32x3":
+            # projection: 3 bf16 MFMAs per product; attention: fp32 MFMA.  The roofline of THIS arithmetic is the sum of
+            # the two parts' matrix-pipe times; `peak` = algorithmic FLOPs over that time
+            f_proj, f_attn = 2.0 * g.Np * 1536 * DIM, 4.0 * g.Np * g.P * DIM
+            peak = round(flops / (3.0 * f_proj / PEAK_TFLOPS["bf16"] + f_attn / PEAK_TFLOPS["f32"]), 1)
         iso_ms = self.isolated_fused_ms()
         kernel = (f"rmsa_fused_kernel (R-MSA per (region, head): qkv projection {g.P}x192x512 + EPEG + softmax(QK^T)V "
-                  f"from LDS; {2.0 * g.Np * 1536 * DIM / 1e9:.2f} + {4.0 * g.Np * g.P * DIM / 1e9:.2f} GFLOP), {self.dtype} operands")
+                  f"from LDS; {2.0 * g.Np * 1536 * DIM / 1e9:.2f} + {4.0 * g.Np * g.P * DIM / 1e9:.2f} GFLOP), {self.dtype} operands"
+                  + (" (projection: fp32 emulated by 3 bf16 MFMAs per product; attention: fp32 MFMA; peak = FLOPs over "
+                     "3 x projection / 2.5 PFLOP/s + attention / 157.3 TFLOP/s)" if self.dtype == "f32x3" else ""))
         if self.mil is None:
             ms = float(np.mean([self.hev.elapsed_ms(a, b) for a, b in self.ev_pairs]))
             ach = flops / (ms * 1e-3) / 1e12
@@ -439,7 +448,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS),
                     help="index into BASELINE.json configs (default 1: the config the metric is quoted on)")
-    ap.add_argument("--dtype", choices=("f32", "bf16", "f16"), default=None, help="override the config's arithmetic")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f16", "f32x3"), default=None,
+                    help="override the config's arithmetic (f32x3: the two big projections emulated in fp32 on the bf16 "
+                         "matrix cores, RRT_COMPUTE_F32X3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational extra records of the default run")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("RRT_BENCH_STREAMS", "2")),
@@ -555,7 +566,33 @@ def extras(wl, dev):
     out["amp_bf16"] = {"value": round(S * 40 / (time.perf_counter() - ta), 2), "unit": "slides/s", "n_gpus": 1,
                        "note": "rank 0 only, 40 steps after the timed region; RRT_COMPUTE_BF16 (bf16 operands on the "
                                "matrix cores, fp32 accumulate; `--config 3` / `--dtype bf16` give the full record)"}
+    # fp32 EMULATED on the bf16 matrix cores for the two big projections (RRT_COMPUTE_F32X3; ~1e-6 from the exact path)
+    y_exact = wl.outs[0].clone()
+    wl.enc._desc.compute = _lib.COMPUTE_F32X3
+    for i in range(10):
+        wl.step(i, False)
+    torch.cuda.synchronize()
+    tb = time.perf_counter()
+    for i in range(40):
+        wl.step(i, False)
+    torch.cuda.synchronize()
+    tb = time.perf_counter() - tb
     wl.enc._desc.compute = _lib.COMPUTE_F32
+    wl.step(39, False)                        # the same bags through the exact path: outs[0] of both modes side by side
+    torch.cuda.synchronize()
+    y_x3 = y_exact                            # (outs[0] after the timed region held the exact result of another bag)
+    wl.enc._desc.compute = _lib.COMPUTE_F32X3
+    wl.step(39, False)
+    torch.cuda.synchronize()
+    y_x3 = wl.outs[0].clone()
+    wl.enc._desc.compute = _lib.COMPUTE_F32
+    wl.step(39, False)
+    torch.cuda.synchronize()
+    out["f32x3"] = {"value": round(S * 40 / tb, 2), "unit": "slides/s", "n_gpus": 1,
+                    "max_abs_vs_exact_f32": float((y_x3 - wl.outs[0]).abs().max()),
+                    "note": "rank 0 only, 40 steps after the timed region; RRT_COMPUTE_F32X3: qkv / proj GEMMs of the R-MSA "
+                            "layers as three bf16 MFMAs per product on (hi, lo) bf16 operand pairs, fp32 accumulate; attention, "
+                            "LayerNorm, CR-MSA exact fp32 (`--dtype f32x3` gives the full record)"}
 
     # the whole slide classifier of BASELINE configs[2] (C16-R50 shape) through the one-call path (row f1), fp32,
     # one bag in flight

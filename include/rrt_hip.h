@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 16
+#define RRT_ABI_VERSION 17
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -38,7 +38,12 @@ enum {
  * BF16 / F16 round the two MFMA operands to bf16 / fp16 and accumulate in fp32 -- the
  * autocast-class numerics of the reference's --amp path (main.py:101-102,439); LayerNorm,
  * softmax statistics, residuals and the residual stream in HBM stay fp32 in every mode. */
-enum { RRT_COMPUTE_F32 = 0, RRT_COMPUTE_BF16 = 1, RRT_COMPUTE_F16 = 2 };
+enum { RRT_COMPUTE_F32 = 0, RRT_COMPUTE_BF16 = 1, RRT_COMPUTE_F16 = 2, RRT_COMPUTE_F32X3 = 3 };
+/* F32X3 (inference): the qkv and proj GEMMs of the R-MSA layers -- 84 % of the FLOPs -- EMULATED in fp32 on the bf16
+ * matrix cores: each fp32 operand is carried as a (hi, lo) pair of bf16 values (16 significant bits) and a product is
+ * three bf16 MFMAs with fp32 accumulation, hi.hi + hi.lo + lo.hi.  Attention, LayerNorm, CR-MSA and every other GEMM
+ * are the F32 path's.  Measured distance to the F32 path on the encoder output: ~1e-6; regions of 49..144
+ * tokens with head dim 64, anything else silently takes the exact F32 kernels. */
 /* In BF16 / F16 on regions of 17..208 tokens with head dim 64 the R-MSA layers run on 16-bit data end to end
  * (rrt_ln_partition16 -> rrt_rmsa_fused16 -> rrt_linear16_f32 below): the LayerNorm output, the weights and the
  * attention output live in HBM in 16 bits, and Q~, K, V and the softmax probabilities go to the matrix cores in 16
@@ -217,6 +222,21 @@ int rrt_linear16_f32(const uint16_t *A, const uint16_t *B, const float *bias, co
 int rrt_rmsa_fused16(const uint16_t *u, const uint16_t *qkv_w, const float *qkv_b, const float *pe_w,
                      uint16_t *o, int32_t n_regions, int32_t P, int32_t dim, int32_t heads, int32_t epeg_k,
                      int32_t compute, void *stream);
+
+/* RRT_COMPUTE_F32X3 stages.  A "split image" of a row-major fp32 array holds, per 32 consecutive elements, 32 bf16 hi
+ * values then 32 bf16 lo values (128 bytes; hi = bf16(x), lo = bf16(x - hi)) -- 4 bytes per element like the original.
+ *  cast_split        : dst = split image of src, n % 32 == 0 (the weights, once per forward);
+ *  ln_partition_split: rrt_ln_partition_f32 with the rows written as a split image;
+ *  linear_split      : C fp32 [M, N] = A . B^T + bias from split images of A [M, K] and B [N, K]; with resid != NULL
+ *                      the un-partition + residual epilogue (M = H*H of g); K % 32 == 0;
+ *  rmsa_fused_x3     : rrt_rmsa_fused_f32 on split images of u / qkv_w, o written as a split image; 48 < P <= 144. */
+int rrt_cast_split(const float *src, void *dst, int64_t n, void *stream);
+int rrt_ln_partition_split(const float *x, const float *gamma, const float *beta, void *u, int64_t L,
+                           int32_t dim, const rrt_grid *g, void *stream);
+int rrt_linear_split_f32(const void *A, const void *B, const float *bias, const float *resid, float *C,
+                         int64_t M, int32_t N, int32_t K, const rrt_grid *g, void *stream);
+int rrt_rmsa_fused_x3(const void *u, const void *qkv_w, const float *qkv_b, const float *pe_w, void *o,
+                      int32_t n_regions, int32_t P, int32_t dim, int32_t heads, int32_t epeg_k, void *stream);
 
 /* CR-MSA (rmsa.py:303-335), three kernels around the inner MSA (g8 = the 8x8 grid):
  *  logits  : LayerNorm statistics mean_rstd [L,2] and logits [Np8, k] in region-major order

@@ -122,6 +122,27 @@ class LowP:
         return round_lowp(a, self.dtype)
 
 
+def split_hi_lo(a):
+    """fp32 value -> (hi, lo) bf16 pair of RRT_COMPUTE_F32X3: hi = bf16(x), lo = bf16(x - hi) (as float64 arrays)."""
+    a32 = np.ascontiguousarray(a, dtype=np.float32).astype(np.float64)
+    hi = round_lowp(a32, "bf16")
+    lo = round_lowp((a32 - hi).astype(np.float32), "bf16")
+    return hi, lo
+
+
+def split_matmul_t(A, B):
+    """A . B^T as the F32X3 kernels form it: three products of the (hi, lo) parts, the lo.lo term dropped."""
+    ah, al = split_hi_lo(A)
+    bh, bl = split_hi_lo(B)
+    return ah @ bh.T + ah @ bl.T + al @ bh.T
+
+
+class SplitX3:
+    """forward_f64(lowp=SplitX3()): the rounding points of RRT_COMPUTE_F32X3 -- the qkv and proj GEMMs of the R-MSA
+    layers on (hi, lo) bf16 operand pairs; everything else exact."""
+    dtype, attn = "split", False
+
+
 def _conv_dw64(img, w, b, two_d):
     """depth-wise Conv2d, zero padded: img [B, C, H, W], w [C, 1, k, kw] (kw = k or 1), b [C] or None"""
     k, kw = w.shape[2], w.shape[3]
@@ -174,9 +195,14 @@ def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None, lowp=None, attn_low
         return O @ Wp.T + st[pfx + "proj.bias"].astype(np.float64)
     hd = D // heads
     W = st[pfx + "qkv.weight"].astype(np.float64)
-    if lowp is not None:                                                    # GEMM operands in 16 bits
-        x, W = lowp.r(x), lowp.r(W)
-    qkv = x @ W.T
+    x3 = isinstance(lowp, SplitX3)
+    if x3:
+        qkv = split_matmul_t(x.reshape(-1, D), W).reshape(B_, P, 3 * D)
+        lowp = None
+    else:
+        if lowp is not None:                                                # GEMM operands in 16 bits
+            x, W = lowp.r(x), lowp.r(W)
+        qkv = x @ W.T
     if pfx + "qkv.bias" in st:
         qkv = qkv + st[pfx + "qkv.bias"].astype(np.float64)
     qkv = qkv.reshape(B_, P, 3, heads, hd).transpose(2, 0, 3, 1, 4)       # [3,B_,h,P,hd]
@@ -218,6 +244,8 @@ def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None, lowp=None, attn_low
     Wp = st[pfx + "proj.weight"].astype(np.float64)
     if taps is not None:
         taps[pfx + "proj_in"] = O
+    if x3:
+        return split_matmul_t(O.reshape(-1, D), Wp).reshape(B_, P, D) + st[pfx + "proj.bias"].astype(np.float64)
     if lowp is not None:
         O, Wp = lowp.r(O), lowp.r(Wp)
     out = O @ Wp.T + st[pfx + "proj.bias"].astype(np.float64)
@@ -264,6 +292,7 @@ def forward_f64(x, state, cfg=None, taps=None, lowp=None):
     lowp: None (exact) or a LowP -- the rounding points of the HIP path's bf16 / fp16 modes."""
     c = _cfg(cfg)
     attn_lowp = lowp if (lowp is not None and lowp.attn) else None
+    lowp_small = None if isinstance(lowp, SplitX3) else lowp       # F32X3 touches the R-MSA layers' two projections only
     st = state
     x = np.asarray(x, dtype=np.float64)
     N, D = x.shape
@@ -286,7 +315,7 @@ def forward_f64(x, state, cfg=None, taps=None, lowp=None):
         z[perm] = Z.reshape(-1, D)
         x = x + z[:N]
         if c["ffn"]:
-            x = _ffn64(x, st, p, c["ffn_act"], lowp)
+            x = _ffn64(x, st, p, c["ffn_act"], lowp_small)
         if taps is not None:
             taps[p + "out"] = x
     if c["cr_msa"]:
@@ -300,7 +329,7 @@ def forward_f64(x, state, cfg=None, taps=None, lowp=None):
         V = vp[perm].reshape(-1, s * s, D)                                   # [R,P,D]
         if c["crmsa_mlp"]:
             W1 = st[p + "attn.phi.0.weight"].astype(np.float64)
-            h1 = np.tanh(V @ W1.T) if lowp is None else np.tanh(lowp.r(V) @ lowp.r(W1).T)
+            h1 = np.tanh(V @ W1.T) if lowp_small is None else np.tanh(lowp_small.r(V) @ lowp_small.r(W1).T)
             Lg = (h1 @ st[p + "attn.phi.2.weight"].astype(np.float64).T).transpose(0, 2, 1)
         else:
             Lg = (V @ st[p + "attn.phi"].astype(np.float64)).transpose(0, 2, 1)   # [R,k,P]
@@ -310,13 +339,13 @@ def forward_f64(x, state, cfg=None, taps=None, lowp=None):
         Mm = (Lg - mn) / (mx - mn + 1e-8)
         rep = (Cw @ V).transpose(1, 0, 2)                                    # [k,R,D]
         # (the representatives' 64-token attention stays in fp32 in every mode: only its GEMM operands round)
-        rep2 = _inner_attention64(rep, st, p + "attn.attn.", c["crmsa_heads"], 0, taps, lowp, None)
+        rep2 = _inner_attention64(rep, st, p + "attn.attn.", c["crmsa_heads"], 0, taps, lowp_small, None)
         out = np.einsum("rnp,nrd->rpd", Mm * Dw, rep2)                       # [R,P,D]
         z = np.empty((H * H, D))
         z[perm] = out.reshape(-1, D)
         x = x + z[:N]
         if c["ffn"]:
-            x = _ffn64(x, st, p, c["ffn_act"], lowp)
+            x = _ffn64(x, st, p, c["ffn_act"], lowp_small)
         if taps is not None:
             taps["cr_msa.rep"] = rep
             taps["cr_msa.out"] = x

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _f32p = C.POINTER(C.c_float)
 
@@ -107,6 +107,11 @@ SIGNATURES = {
     "rrt_linear16_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_int32,
                                                       C.c_void_p]),
     "rrt_rmsa_fused16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
+    "rrt_cast_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rrt_ln_partition_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                         C.POINTER(Grid), C.c_void_p]),
+    "rrt_linear_split_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_void_p]),
+    "rrt_rmsa_fused_x3": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p]),
     "rrt_crmsa_logits_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32,
                                                          C.POINTER(Grid), C.c_void_p]),
     "rrt_crmsa_combine_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32,
@@ -147,7 +152,7 @@ SIGNATURES = {
                                                         C.c_void_p]),
 }
 
-COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32X3 = 0, 1, 2, 3
 POS_NONE, POS_PEG, POS_PPEG = 0, 1, 2
 EPEG_ATTN, EPEG_VALUE_BF, EPEG_VALUE_AF = 0, 1, 2
 

@@ -51,7 +51,7 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     if (d.n_rmsa_layers > 1 || d.ffn) w.xb = take((size_t)N * D);
     // carved in every mode (2 MB per layer at D = 512): the size must not depend on desc.compute, which callers
     // flip between calls on one workspace
-    w.w16 = (uint16_t*)take((size_t)d.n_rmsa_layers * 2 * D * D);
+    w.w16 = (uint16_t*)take((size_t)d.n_rmsa_layers * 4 * D * D);     // (F32X3: (hi, lo) pairs = 4 bytes per weight)
     if (d.epeg && d.epeg_type != RRT_EPEG_ATTN) w.pe_out = take(Np * D);
   }
   if (d.ffn) {
@@ -107,7 +107,7 @@ int check_desc(const rrt_encoder_desc* d, int64_t N) {
     if (d->pos_pos != -1 && d->pos_pos != 0) return unsupported("pos_pos must be -1 or 0");
   }
   if (N > (int64_t)4000000) return unsupported("bag larger than 4e6 tokens");
-  if (d->compute < 0 || d->compute > 2) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16");
+  if (d->compute < 0 || d->compute > RRT_COMPUTE_F32X3) return unsupported("compute must be RRT_COMPUTE_F32/BF16/F16/F32X3");
   return RRT_OK;
 }
 
@@ -210,12 +210,17 @@ struct rrt_phase_gate {
   bool armed;
 };
 
-static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weights* w, const float* x,
+static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_weights* w, const float* x,
                            float* y, int64_t n_tokens, void* workspace, size_t workspace_bytes,
                            void* stream, void** events, rrt_phase_gate* gate = nullptr) {
-  if (!desc || !w || !x || !y || x == y) return RRT_E_INVALID;
-  int rc = check_desc(desc, n_tokens);
+  if (!desc_in || !w || !x || !y || x == y) return RRT_E_INVALID;
+  int rc = check_desc(desc_in, n_tokens);
   if (rc) return rc;
+  // RRT_COMPUTE_F32X3 concerns the R-MSA layers' two big projections (below); every other GEMM of the call is exact fp32
+  rrt_encoder_desc dloc = *desc_in;
+  const bool want_x3 = dloc.compute == RRT_COMPUTE_F32X3;
+  if (want_x3) dloc.compute = RRT_COMPUTE_F32;
+  const rrt_encoder_desc* const desc = &dloc;
   hipStream_t st = (hipStream_t)stream;
   const int D = desc->dim;
   const int64_t N = n_tokens;
@@ -312,6 +317,24 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
       RRT_TRY(launch_cast16(jobs, desc->compute, st));
     }
   }
+  // RRT_COMPUTE_F32X3: the qkv and proj GEMMs of the R-MSA layers emulated in fp32 on the bf16 matrix cores (operands
+  // as (hi, lo) bf16 pairs, three MFMAs per product; rmsa_fused_x3.hip, cast16.hip); attention and everything else as F32
+  bool x3 = false;
+  if (want_x3 && desc->n_rmsa_layers > 0 && !epeg_variant) {
+    const GridDev gd = to_dev(g);
+    x3 = rmsa_fused_x3_supported(gd.P, D, desc->n_heads, desc->epeg ? desc->epeg_k : 0) && rmsa_fused_supported_rows(gd.Np, D);
+    if (x3) {
+      Cast16Jobs jobs{};
+      for (int li = 0; li < desc->n_rmsa_layers; ++li) {
+        const rrt_attn_weights& lw = w->rmsa[li];
+        if (!lw.qkv_w || !lw.proj_w) return RRT_E_INVALID;
+        uint16_t* base = ws.w16 + (size_t)li * 8 * D * D;          // 4 D^2 weights x 2 bf16
+        jobs.src[jobs.count] = lw.qkv_w; jobs.dst[jobs.count] = base; jobs.n4[jobs.count++] = (size_t)3 * D * D / 4;
+        jobs.src[jobs.count] = lw.proj_w; jobs.dst[jobs.count] = base + (size_t)6 * D * D; jobs.n4[jobs.count++] = (size_t)D * D / 4;
+      }
+      RRT_TRY(launch_cast_split(jobs, st));
+    }
+  }
   // ---- R-MSA TransLayers: x = x + unpart(InnerAttention(part(pad(LN(x)))))  (rrt.py:117-125)
   for (int li = 0; li < desc->n_rmsa_layers; ++li) {
     if (li == 1 && desc->pos && desc->pos_pos == 0) {
@@ -344,6 +367,31 @@ static int encoder_forward(const rrt_encoder_desc* desc, const rrt_encoder_weigh
       ep.resid = xin;
       ep.g = gd;
       RRT_TRY(launch_linear16(o16, wq16 + (size_t)3 * D * D, xout, gd.Np, D, D, ep, st));
+      if (li == 0) RRT_MARK(RRT_EV_PROJ);
+      xin = xout;
+      if (desc->ffn) {
+        rc = ffn_block(lw, xout, ws.xb);
+        if (rc) return rc;
+        xin = ws.xb;
+      }
+      continue;
+    }
+    if (x3) {
+      // u and O as split images (4 bytes per element: the uo / qkv buffers as they are)
+      const uint16_t* wq = ws.w16 + (size_t)li * 8 * D * D;
+      RRT_TRY(launch_ln_partition_split(xin, lw.norm_w, lw.norm_b, ws.uo, D, gd, st));
+      rrt_phase_gate* const gt3 = (gate && gd.P > 112) ? gate : nullptr;
+      if (gt3 && gt3->armed) RRT_TRY(hipStreamWaitEvent(st, gt3->done, 0));
+      if (li == 0) RRT_MARK(RRT_EV_LN_PARTITION);
+      RRT_TRY(launch_rmsa_fused_x3(ws.uo, wq, lw.qkv_b, desc->epeg ? lw.pe_w : nullptr, ws.qkv, gd.rs * gd.rs, gd.P, D,
+                                   desc->n_heads, ek, st));
+      if (gt3) { RRT_TRY(hipEventRecord(gt3->done, st)); gt3->armed = true; }
+      if (li == 0) { RRT_MARK(RRT_EV_QKV); RRT_MARK(RRT_EV_ATTN); }
+      LinearEpilogue ep{};
+      ep.bias = lw.proj_b;
+      ep.resid = xin;
+      ep.g = gd;
+      RRT_TRY(launch_linear_split(ws.qkv, wq + (size_t)6 * D * D, xout, gd.Np, D, D, ep, st));
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;
       if (desc->ffn) {
@@ -635,6 +683,46 @@ int rrt_rmsa_fused16(const uint16_t* u, const uint16_t* qkv_w, const float* qkv_
   if (!rmsa_fused16_supported(P, dim, heads, ek) || !rmsa_fused_supported_rows((long)n_regions * P, dim))
     return unsupported("rmsa_fused16: needs head dim 64, 16 < P <= 208, epeg_k <= 63");
   return (int)launch_rmsa_fused16(u, qkv_w, qkv_b, pe_w, o, n_regions, P, dim, heads, ek, compute, (hipStream_t)stream);
+}
+
+// ---- RRT_COMPUTE_F32X3 stages: fp32 as (hi, lo) bf16 pairs (cast16.hip), three bf16 MFMAs per product
+int rrt_cast_split(const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0 || n % 32) return RRT_E_INVALID;
+  Cast16Jobs jobs{};
+  jobs.src[0] = src; jobs.dst[0] = (uint16_t*)dst; jobs.n4[0] = (size_t)n / 4; jobs.count = 1;
+  return (int)launch_cast_split(jobs, (hipStream_t)stream);
+}
+
+int rrt_ln_partition_split(const float* x, const float* gamma, const float* beta, void* u, int64_t L, int32_t dim,
+                           const rrt_grid* g, void* stream) {
+  if (!x || !gamma || !beta || !u || !g || L != g->L || dim <= 0 || dim % 32) return RRT_E_INVALID;
+  if (dim > 2048) return unsupported("dim > 2048");
+  return (int)launch_ln_partition_split(x, gamma, beta, u, dim, to_dev(*g), (hipStream_t)stream);
+}
+
+int rrt_linear_split_f32(const void* A, const void* B, const float* bias, const float* resid, float* C, int64_t M,
+                         int32_t N, int32_t K, const rrt_grid* g, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (resid && !g)) return RRT_E_INVALID;
+  if (K % 32) return unsupported("linear_split: K must be a multiple of 32");
+  LinearEpilogue ep{};
+  ep.bias = bias;
+  if (resid) {
+    ep.resid = resid;
+    ep.g = to_dev(*g);
+    if (M != ep.g.Np) return RRT_E_INVALID;
+  }
+  hipError_t e = launch_linear_split(A, B, C, (int)M, N, K, ep, (hipStream_t)stream);
+  if (e == hipErrorInvalidValue) return unsupported("linear_split: needs M large enough for 128-row tiles");
+  return (int)e;
+}
+
+int rrt_rmsa_fused_x3(const void* u, const void* qkv_w, const float* qkv_b, const float* pe_w, void* o,
+                      int32_t n_regions, int32_t P, int32_t dim, int32_t heads, int32_t epeg_k, void* stream) {
+  if (!u || !qkv_w || !o || n_regions <= 0 || P <= 0 || dim <= 0 || heads <= 0) return RRT_E_INVALID;
+  const int ek = pe_w ? epeg_k : 0;
+  if (!rmsa_fused_x3_supported(P, dim, heads, ek) || !rmsa_fused_supported_rows((long)n_regions * P, dim))
+    return unsupported("rmsa_fused_x3: needs head dim 64, 48 < P <= 144, epeg_k <= 63");
+  return (int)launch_rmsa_fused_x3(u, qkv_w, qkv_b, pe_w, o, n_regions, P, dim, heads, ek, (hipStream_t)stream);
 }
 
 int rrt_crmsa_logits_f32(const float* x1, const float* gamma, const float* beta, const float* phi,
@@ -1152,6 +1240,7 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
 int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8) {
   int rc = check_desc(d, N);
   if (rc) return rc;
+  if (d->compute == RRT_COMPUTE_F32X3) return unsupported("training: RRT_COMPUTE_F32X3 is an inference mode (train in F32 or under autocast)");
   if (d->dim > 1024) return unsupported("training: dim > 1024");
   if (d->epeg && d->n_rmsa_layers > 0 && (d->epeg_2d || d->epeg_type != RRT_EPEG_ATTN))
     return unsupported("training: the EPEG ablations (epeg_2d, epeg_type = value_*) are inference-only on the HIP path");

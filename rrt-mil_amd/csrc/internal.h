@@ -52,6 +52,16 @@ struct Cast16Jobs {
 hipError_t launch_cast16(const Cast16Jobs& jobs, int prec, hipStream_t st);
 hipError_t launch_ln_partition16(const float* x, const float* gamma, const float* beta, uint16_t* u, int dim,
                                  const GridDev& g, int prec, hipStream_t st);
+// RRT_COMPUTE_F32X3: fp32 as (hi, lo) bf16 pairs, 32-element groups [32 hi | 32 lo] (cast16.hip); jobs.dst = byte images
+hipError_t launch_cast_split(const Cast16Jobs& jobs, hipStream_t st);
+hipError_t launch_ln_partition_split(const float* x, const float* gamma, const float* beta, void* u, int dim,
+                                     const GridDev& g, hipStream_t st);
+// C fp32 = A . B^T on split images of A [M, K] and B [N, K] (3 bf16 MFMAs per product: hi.hi + hi.lo + lo.hi)
+hipError_t launch_linear_split(const void* Asplit, const void* Bsplit, float* C, int M, int N, int K,
+                               const LinearEpilogue& ep, hipStream_t st);
+bool rmsa_fused_x3_supported(int P, int D, int heads, int epeg_k);
+hipError_t launch_rmsa_fused_x3(const void* Usplit, const void* Wsplit, const float* bqkv, const float* pe_w,
+                                void* Osplit, int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st);
 hipError_t launch_linear16(const void* A16, const void* B16, float* C, int M, int N, int K, const LinearEpilogue& ep,
                            hipStream_t st);
 // fused R-MSA core on 16-bit operands: U16 [n_regions*P, D], Wqkv16 [3D, D] -> O16 [n_regions*P, D]

@@ -44,7 +44,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // operand precision of the MFMA (accumulation and everything around it stay fp32)
-enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_SPLIT = 3 };   // SPLIT: operands are (hi, lo) bf16 images, cast16.hip
 
 template <int PREC>
 struct Frag8;
@@ -538,6 +538,30 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
               }
         }
+      } else if constexpr (PREC == PREC_SPLIT) {
+        // fp32 emulated on the bf16 matrix cores: a = ah + al, b = bh + bl (bf16 each), a.b ~ ah.bh + ah.bl + al.bh
+        // (the dropped al.bl term is 2^-16 of the product).  A tile row = [32 hi | 32 lo]: slots 0..3 / 4..7.
+        bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wave * (16 * NT) + j * 16 + lr, f = (row >> 1) & 7;
+          bh[j] = *(const bf16x8*)(Bs + row * BK + ((lg ^ f) << 2));
+          bl[j] = *(const bf16x8*)(Bs + row * BK + (((4 + lg) ^ f) << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = i * 16 + lr, f = (row >> 1) & 7;
+          ah[i] = *(const bf16x8*)(As + row * BK + ((lg ^ f) << 2));
+          al[i] = *(const bf16x8*)(As + row * BK + (((4 + lg) ^ f) << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+          }
       } else if constexpr (IN16) {
         using F = Frag8<PREC>;
 #pragma unroll
@@ -658,14 +682,18 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
       return hipGetLastError();
     }
   }
-  auto kern = linear_kernel<MT, NT, MODE, PREC>;
-  if (LDS_BYTES > 64 * 1024) {
-    static OncePerDevice once;
-    if (once.first())
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if constexpr (PREC == PREC_SPLIT) {
+    return hipErrorInvalidValue;          // the split form exists in the warp-specialised kernel only
+  } else {
+    auto kern = linear_kernel<MT, NT, MODE, PREC>;
+    if (LDS_BYTES > 64 * 1024) {
+      static OncePerDevice once;
+      if (once.first())
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }
+    kern<<<dim3(grid), dim3(256), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
+    return hipGetLastError();
   }
-  kern<<<dim3(grid), dim3(256), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
-  return hipGetLastError();
 }
 
 struct Cfg { int mt, nt, cap; };
@@ -697,6 +725,25 @@ Cfg choose(int M, int N) {
 #ifdef RRT_TRACE
 RRT_TRACE_DEFINE_READER(rrt_debug_trace_linear)
 #endif
+
+// C[M,N] fp32 = A . B^T on (hi, lo) bf16 images of A and B (RRT_COMPUTE_F32X3, cast16.hip); epilogues as fp32
+hipError_t launch_linear_split(const void* A, const void* B, float* C, int M, int N, int K, const LinearEpilogue& ep,
+                               hipStream_t st) {
+  if (K % 32 || ep.drop_on || ep.act) return hipErrorInvalidValue;
+  const bool u = ep.resid != nullptr;
+  const Cfg c = choose(M, N);
+  if (c.mt < 8) return hipErrorInvalidValue;      // the warp-specialised kernel only (M >= 128-row tiles)
+#define RRT_SPLIT_CASE(MT_, NT_)                                                                                  \
+  if (c.mt == MT_ && c.nt == NT_)                                                                                 \
+    return u ? launch_cfg<MT_, NT_, MODE_UNPART, PREC_SPLIT>((const float*)A, (const float*)B, C, M, N, K, c.cap, ep, st) \
+             : launch_cfg<MT_, NT_, MODE_PLAIN, PREC_SPLIT>((const float*)A, (const float*)B, C, M, N, K, c.cap, ep, st);
+  RRT_SPLIT_CASE(9, 1);
+  RRT_SPLIT_CASE(8, 1);
+  RRT_SPLIT_CASE(9, 2);
+  RRT_SPLIT_CASE(8, 2);
+#undef RRT_SPLIT_CASE
+  return hipErrorInvalidValue;
+}
 
 // C[M,N] fp32 = A16[M,K] . B16[N,K]^T with the operands already in 16 bits (ep.prec = 1 bf16 / 2 fp16); the
 // epilogues are the fp32 kernel's.  K % 64 == 0; the warp-specialised large-tile kernel only (the callers are the

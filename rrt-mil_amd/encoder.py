@@ -279,8 +279,9 @@ class RRTEncoder(nn.Module):
             # (pos_pos = 0, which needs a second R-MSA layer: the default `--pos ppeg` run with n_layers = 2 never
             # reaches it, rrt.py:181-187): the stage is absent from the kernels and its parameters get no gradient
             self._desc.pos = _lib.POS_NONE
-        # None: exact fp32 unless the call runs under torch autocast (then bf16/fp16 MFMA operands in
-        # the Linear layers, like the reference's --amp path); or force torch.float32/bfloat16/float16
+        # None: exact fp32 unless the call runs under torch autocast (then bf16 / fp16 arithmetic like the
+        # reference's --amp path); or force torch.float32 / bfloat16 / float16, or "f32x3" (inference: the two big
+        # projections emulated in fp32 on the bf16 matrix cores, ~1e-6 from the exact path, include/rrt_hip.h)
         self.compute_dtype = None
         self._ws = None           # cached workspace tensor (grown on demand, per device)
         if need_init:
@@ -419,7 +420,7 @@ class RRTEncoder(nn.Module):
         if dt is None and torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
         return {None: _lib.COMPUTE_F32, torch.float32: _lib.COMPUTE_F32, torch.bfloat16: _lib.COMPUTE_BF16,
-                torch.float16: _lib.COMPUTE_F16}[dt]
+                torch.float16: _lib.COMPUTE_F16, "f32x3": _lib.COMPUTE_F32X3}[dt]
 
     def forward_bag(self, x2d, out=None):
         """One bag: x2d (N, D) fp32 device tensor -> (N, D).  Enqueued on the current stream."""
