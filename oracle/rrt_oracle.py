@@ -138,8 +138,8 @@ def split_matmul_t(A, B):
 
 
 class SplitX3:
-    """forward_f64(lowp=SplitX3()): the rounding points of RRT_COMPUTE_F32X3 -- the qkv and proj GEMMs of the R-MSA
-    layers on (hi, lo) bf16 operand pairs; everything else exact."""
+    """forward_f64(lowp=SplitX3()): the rounding points of RRT_COMPUTE_F32X3 -- the qkv / proj GEMMs and the two
+    attention products of the R-MSA layers on (hi, lo) bf16 operand pairs; everything else exact."""
     dtype, attn = "split", False
 
 
@@ -207,6 +207,29 @@ def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None, lowp=None, attn_low
         qkv = qkv + st[pfx + "qkv.bias"].astype(np.float64)
     qkv = qkv.reshape(B_, P, 3, heads, hd).transpose(2, 0, 3, 1, 4)       # [3,B_,h,P,hd]
     q, k, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]
+    if x3:
+        # RRT_COMPUTE_F32X3 attention: Q~ log2(e), K, V and exp2(S - max) as (hi, lo) pairs, three products each
+        qt = q
+        if pfx + "pe.weight" in st:
+            w = st[pfx + "pe.weight"].astype(np.float64).reshape(heads, epeg_k)
+            half = epeg_k // 2
+            qp = np.pad(q, ((0, 0), (0, 0), (half, half), (0, 0)))
+            qt = q.copy()
+            for t in range(epeg_k):
+                qt += w[None, :, t, None, None] * qp[:, :, t:t + P, :]
+        qh, ql = split_hi_lo(qt * 1.4426950408889634)
+        kh, kl = split_hi_lo(k)
+        vh, vl = split_hi_lo(v)
+        kT = lambda a: a.transpose(0, 1, 3, 2)
+        S = qh @ kT(kh) + qh @ kT(kl) + ql @ kT(kh)
+        e = np.exp2(S - S.max(-1, keepdims=True))
+        eh, el = split_hi_lo(e)
+        O = (eh @ vh + eh @ vl + el @ vh) / e.sum(-1, keepdims=True)
+        O = O.transpose(0, 2, 1, 3).reshape(B_, P, D)
+        Wp = st[pfx + "proj.weight"].astype(np.float64)
+        if taps is not None:
+            taps[pfx + "proj_in"] = O
+        return split_matmul_t(O.reshape(-1, D), Wp).reshape(B_, P, D) + st[pfx + "proj.bias"].astype(np.float64)
     if attn_lowp is not None:
         # the kernels' form (DESIGN.md identities 1, 2): Q~ = Q + T Q built in fp32, then Q~, K, V and the
         # unnormalised probabilities exp(S - max) go to the matrix cores in 16 bits; the row sum is taken over the

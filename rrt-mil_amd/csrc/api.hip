@@ -711,9 +711,7 @@ int rrt_linear_split_f32(const void* A, const void* B, const float* bias, const 
     ep.g = to_dev(*g);
     if (M != ep.g.Np) return RRT_E_INVALID;
   }
-  hipError_t e = launch_linear_split(A, B, C, (int)M, N, K, ep, (hipStream_t)stream);
-  if (e == hipErrorInvalidValue) return unsupported("linear_split: needs M large enough for 128-row tiles");
-  return (int)e;
+  return (int)launch_linear_split(A, B, C, (int)M, N, K, ep, (hipStream_t)stream);
 }
 
 int rrt_rmsa_fused_x3(const void* u, const void* qkv_w, const float* qkv_b, const float* pe_w, void* o,

@@ -731,8 +731,17 @@ hipError_t launch_linear_split(const void* A, const void* B, float* C, int M, in
                                hipStream_t st) {
   if (K % 32 || ep.drop_on || ep.act) return hipErrorInvalidValue;
   const bool u = ep.resid != nullptr;
-  const Cfg c = choose(M, N);
-  if (c.mt < 8) return hipErrorInvalidValue;      // the warp-specialised kernel only (M >= 128-row tiles)
+  Cfg c{9, 1, 512};                                // the warp-specialised kernel's tile shapes only
+  {
+    static const Cfg cands[] = {{9, 1, 512}, {8, 1, 512}, {9, 2, 512}, {8, 2, 512}, {9, 2, 256}, {8, 2, 256}};
+    long best_cost = -1;
+    for (const Cfg& q : cands) {
+      long tiles = (long)((M + 16 * q.mt - 1) / (16 * q.mt)) * ((N + 64 * q.nt - 1) / (64 * q.nt));
+      long grid = tiles < q.cap ? tiles : q.cap;
+      long cost = ((tiles + grid - 1) / grid) * ((grid + 255) / 256) * q.mt * q.nt;
+      if (best_cost < 0 || cost < best_cost) { c = q; best_cost = cost; }
+    }
+  }
 #define RRT_SPLIT_CASE(MT_, NT_)                                                                                  \
   if (c.mt == MT_ && c.nt == NT_)                                                                                 \
     return u ? launch_cfg<MT_, NT_, MODE_UNPART, PREC_SPLIT>((const float*)A, (const float*)B, C, M, N, K, c.cap, ep, st) \

@@ -13,8 +13,11 @@
 //            elements = the fp32 kernels' 128-byte K tile, so the LDS ring, the XOR swizzle and the DMA addressing are
 //            unchanged; slots 0..3 / 4..7 of a tile row are the hi / lo MFMA operands.  The loop is then bound by
 //            LDS-DMA bandwidth like the 16-bit kernel's: four loader waves, 3-stage ring (rmsa_fused16.hip);
-//   phases 2-4  fp32, as rmsa_fused.hip: Q / K / V tiles (fp32) -> EPEG stencil in place -> softmax(Q~ K^T) V on the
-//            fp32 matrix cores (scores and probabilities keep full fp32 products: 16 % of the FLOPs);
+//   phase 2  accumulators (+bias, q*scale) -> LDS: Q in fp32 (the EPEG stencil runs in fp32), K as two 16-bit row images
+//            (hi, lo), V as two TRANSPOSED 16-bit images with the keys in MFMA operand order (rmsa_fused16.hip's layout);
+//   phase 3  EPEG stencil in fp32, x log2(e), Q~ written as (hi, lo) row images over Q;
+//   phase 4  S^T = K Q~^T and O^T = V^T P^T as three bf16 MFMAs per product (P split in registers), softmax statistics
+//            in fp32 -- the attention's matrix-pipe time drops 5x like the projection's;
 //   output   O in the split layout, the A operand of the proj GEMM (linear_ws_kernel PREC_SPLIT).
 // One wave owns one 16-column tile of each of Q, K and V (balanced phase 2).  MT <= 9 (regions of <= 144 tokens:
 // 204 VGPRs at two waves per SIMD); larger regions keep the exact fp32 kernel.
@@ -28,6 +31,7 @@ namespace {
 constexpr int HD = 64;
 constexpr int BN = 3 * HD;
 constexpr int ROWB = 128;           // bytes of one staged row = one K tile of 32 elements (hi | lo)
+constexpr int VT_PITCH = 512;       // bytes per V^T row: 32 x 16-byte slots, XOR-swizzled (rmsa_fused16.hip)
 constexpr float NEG_BIG = -3.0e38f;
 constexpr float LOG2E = 1.4426950408889634f;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -48,6 +52,24 @@ __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2
   lo = __builtin_bit_cast(uint2, l);
 }
 
+__device__ __forceinline__ int vt_swz(int d) { return ((d >> 2) ^ ((d & 3) << 2)) & 15; }
+
+// 8 floats -> (hi, lo) bf16x8 fragments
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (__bf16)a[e];
+    lo[e] = (__bf16)(a[e] - (float)hi[e]);
+    hi[4 + e] = (__bf16)b[e];
+    lo[4 + e] = (__bf16)(b[e] - (float)hi[4 + e]);
+  }
+}
+__device__ __forceinline__ f32x4 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+
 template <int MT>
 __global__ __launch_bounds__(512, 2) void rmsa_fused_x3_kernel(const char* __restrict__ U, const char* __restrict__ W,
                                                                const float* __restrict__ bqkv,
@@ -59,16 +81,21 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused_x3_kernel(const char* __res
   constexpr int NA = BM / 8, NB = BN / 8;
   constexpr int LA = (NA + 3) / 4, LB = NB / 4;
   constexpr int NT = 3;
-  constexpr int TILE = BM * HD;                        // floats of one Q / K / V tile
-  constexpr int RING_B = 3 * STAGE_B, TILES_B = 3 * TILE * 4;
+  constexpr int MTP = (MT + 1) & ~1;                   // key tiles rounded up to whole 32-key MFMA blocks
+  constexpr int QF_B = BM * 256, KP_B = BM * ROWB;     // fp32 Q tile; one 16-bit plane of K (or of Q~)
+  constexpr int RING_B = 3 * STAGE_B, TILES_B = QF_B + 2 * KP_B + 2 * 64 * VT_PITCH;
   constexpr int LDS_MAIN = RING_B > TILES_B ? RING_B : TILES_B;
   constexpr int RUN = (BM + 31) / 32;
   constexpr int TAP_OFF = 12 + RUN - 1;
+  static_assert(16 * MTP * 2 <= VT_PITCH, "V^T row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Qs = (float*)smem;                            // fp32 tiles alias the dead staging ring
-  float* Ks = Qs + TILE;
-  float* Vs = Qs + 2 * TILE;
-  float* Qt = Qs;
+  float* Qs = (float*)smem;                            // fp32 Q [BM][64] (aliases the dead staging ring)
+  char* const QTH = smem;                              // Q~ hi / lo [BM] x 128 B, written over Q after the stencil
+  char* const QTL = smem + KP_B;
+  char* const KH = smem + QF_B;                        // K hi / lo [BM] x 128 B, slot XOR ((row >> 1) & 7)
+  char* const KL = KH + KP_B;
+  char* const VTH = KL + KP_B;                         // V^T hi / lo [64] x 512 B, slot XOR vt_swz(d)
+  char* const VTL = VTH + 64 * VT_PITCH;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -142,17 +169,28 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused_x3_kernel(const char* __res
       slot = slot == 2 ? 0 : slot + 1;
     }
     __syncthreads();                                // "the staging ring is dead"
+    if (MT & 1) {                                   // the keyless half of the last 32-key block: finite (zero) V^T columns
+      const int t2 = tid - 256, dd = t2 >> 2, g = t2 & 3;
+      const int vslot = 4 * (MT >> 1) + g;
+      const int off = dd * VT_PITCH + ((vslot ^ vt_swz(dd)) << 4) + 8;
+      *(uint2*)(VTH + off) = make_uint2(0u, 0u);
+      *(uint2*)(VTL + off) = make_uint2(0u, 0u);
+    }
   } else {
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int dq = 16 * wave + 4 * lg;              // first of the lane's 4 columns in each of its Q / K / V tiles
-    float4 b4[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-      b4[j] = bqkv ? *(const float4*)(bqkv + j * D + head * HD + dq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int dq = 16 * wave + 4 * lg;              // first of the lane's 4 Q / K columns
+    const int dv = 16 * wave + lr;                  // the lane's V column
+    float4 bq4 = make_float4(0.f, 0.f, 0.f, 0.f), bk4 = bq4;
+    float bv1 = 0.f;
+    if (bqkv) {
+      bq4 = *(const float4*)(bqkv + head * HD + dq);
+      bk4 = *(const float4*)(bqkv + D + head * HD + dq);
+      bv1 = bqkv[2 * D + head * HD + dv];
+    }
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();
@@ -172,29 +210,33 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused_x3_kernel(const char* __res
         ah[i] = *(const bf16x8*)(As + row * ROWB + ((lg ^ f) << 4));
         al[i] = *(const bf16x8*)(As + row * ROWB + (((4 + lg) ^ f) << 4));
       }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-        }
-    }
-    // ================================================================ phase 2: Q / K / V tiles (fp32) -> LDS
-    __syncthreads();                                // every wave is done with the staging ring
-    // transposed accumulators: reg r of lane (lr, lg) is C[m = 16 i + lr][tile j, column dq + r]
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float sc = j == 0 ? q_scale : 1.0f;
-      float* dstm = j == 0 ? Qs : (j == 1 ? Ks : Vs);
+      // Q and K tiles with the operand roles swapped (a lane ends up with 4 consecutive columns of a token row), the
+      // V tile with the roles kept (4 consecutive TOKENS of one column: what V^T wants)
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int m = i * 16 + lr;
-        *(float4*)(dstm + m * HD + (((dq >> 2) ^ (m & 15)) << 2)) =
-            make_float4((acc[i][j][0] + b4[j].x) * sc, (acc[i][j][1] + b4[j].y) * sc,
-                        (acc[i][j][2] + b4[j].z) * sc, (acc[i][j][3] + b4[j].w) * sc);
+        acc[i][0] = mfma3(bh[0], bl[0], ah[i], al[i], acc[i][0]);
+        acc[i][1] = mfma3(bh[1], bl[1], ah[i], al[i], acc[i][1]);
+        acc[i][2] = mfma3(ah[i], al[i], bh[2], bl[2], acc[i][2]);
       }
+    }
+    // ================================================================ phase 2: Q (fp32), K and V^T as (hi, lo) images
+    __syncthreads();                                // every wave is done with the staging ring
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = i * 16 + lr;
+      *(float4*)((char*)Qs + m * 256 + (((dq >> 2) ^ (m & 15)) << 4)) =
+          make_float4((acc[i][0][0] + bq4.x) * q_scale, (acc[i][0][1] + bq4.y) * q_scale,
+                      (acc[i][0][2] + bq4.z) * q_scale, (acc[i][0][3] + bq4.w) * q_scale);
+      uint2 hi, lo;
+      split4(acc[i][1][0] + bk4.x, acc[i][1][1] + bk4.y, acc[i][1][2] + bk4.z, acc[i][1][3] + bk4.w, hi, lo);
+      const int koff = m * ROWB + (((dq >> 3) ^ ((m >> 1) & 7)) << 4) + ((dq & 4) << 1);
+      *(uint2*)(KH + koff) = hi;
+      *(uint2*)(KL + koff) = lo;
+      // tokens 16 i + 4 lg + r -> positions 32 (i / 2) + 8 lg + 4 (i % 2) + r of V^T row dv
+      split4(acc[i][2][0] + bv1, acc[i][2][1] + bv1, acc[i][2][2] + bv1, acc[i][2][3] + bv1, hi, lo);
+      const int voff = dv * VT_PITCH + (((4 * (i >> 1) + lg) ^ vt_swz(dv)) << 4) + ((i & 1) << 3);
+      *(uint2*)(VTH + voff) = hi;
+      *(uint2*)(VTL + voff) = lo;
     }
   }
   __syncthreads();                                  // Q / K / V tiles complete
@@ -242,42 +284,44 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused_x3_kernel(const char* __res
 #pragma unroll
       for (int o = 0; o < RUN; ++o) {
         const int m = r0 + o;
-        if (m < BM) *(float4*)(Qt + m * HD + ((s ^ (m & 15)) << 2)) = out[o];
+        if (m < BM) {
+          uint2 hi, lo;
+          split4(out[o].x, out[o].y, out[o].z, out[o].w, hi, lo);
+          const int qoff = m * ROWB + (((s >> 1) ^ ((m >> 1) & 7)) << 4) + ((s & 1) << 3);
+          *(uint2*)(QTH + qoff) = hi;
+          *(uint2*)(QTL + qoff) = lo;
+        }
       }
     }
   }
   __syncthreads();
 
-  // ================================================================== phase 4: attention from LDS (fp32 MFMA)
+  // ================================================================== phase 4: attention from LDS (split operands)
   for (int t = wave; t < MT; t += 8) {
     const int i0 = t * 16;
     if (i0 >= P) break;
-    float4 bq[4];
+    bf16x8 bqh[2], bql[2];
     {
       const int m = i0 + lr;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) bq[c] = *(const float4*)(Qt + m * HD + (((4 * c + lg) ^ (m & 15)) << 2));
+      for (int kk = 0; kk < 2; ++kk) {
+        const int off = m * ROWB + (((4 * kk + lg) ^ ((m >> 1) & 7)) << 4);
+        bqh[kk] = *(const bf16x8*)(QTH + off);
+        bql[kk] = *(const bf16x8*)(QTL + off);
+      }
     }
-    f32x4 s[MT];
+    f32x4 s[MTP];
 #pragma unroll
-    for (int jt = 0; jt < MT; ++jt) s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int jt = 0; jt < MTP; ++jt) s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float4 a[MT];
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int jt = 0; jt < MT; ++jt) {
         const int row = jt * 16 + lr;
-        a[jt] = *(const float4*)(Ks + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+        const int off = row * ROWB + (((4 * kk + lg) ^ ((row >> 1) & 7)) << 4);
+        s[jt] = mfma3(*(const bf16x8*)(KH + off), *(const bf16x8*)(KL + off), bqh[kk], bql[kk], s[jt]);
       }
-#pragma unroll
-      for (int jt = 0; jt < MT; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].x, bq[c].x, s[jt], 0, 0, 0);
-#pragma unroll
-      for (int jt = 0; jt < MT; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].y, bq[c].y, s[jt], 0, 0, 0);
-#pragma unroll
-      for (int jt = 0; jt < MT; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].z, bq[c].z, s[jt], 0, 0, 0);
-#pragma unroll
-      for (int jt = 0; jt < MT; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jt].w, bq[c].w, s[jt], 0, 0, 0);
-    }
+    // s[jt][r] = log2e * score(query i0 + lr, key 16 jt + 4 lg + r)
     float cmax = NEG_BIG;
 #pragma unroll
     for (int jt = 0; jt < MT; ++jt) {
@@ -302,35 +346,35 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused_x3_kernel(const char* __res
       }
     psum += __shfl_xor(psum, 16);
     psum += __shfl_xor(psum, 32);
-    const float inv = 1.0f / psum;
+    const float inv = 1.0f / psum;                  // of THIS lane's query (lr)
+    // O^T = V^T P^T: A = V^T rows d = 4 a + c (a = lr), B = P^T straight from the score registers, both as (hi, lo)
     f32x4 oacc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int jt = 0; jt < MT; ++jt)
+    for (int b = 0; b < MTP / 2; ++b) {
+      bf16x8 ph, pl;
+      split8(s[2 * b], s[2 * b + 1], ph, pl);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = jt * 16 + 4 * lg + r;
-        const float4 v = *(const float4*)(Vs + row * HD + ((lr ^ (row & 15)) << 2));
-        const float p = s[jt][r];
-        oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.x, oacc[0], 0, 0, 0);
-        oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.y, oacc[1], 0, 0, 0);
-        oacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.z, oacc[2], 0, 0, 0);
-        oacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.w, oacc[3], 0, 0, 0);
+      for (int c = 0; c < 4; ++c) {
+        const int dd = 4 * lr + c;
+        const int off = dd * VT_PITCH + (((4 * b + lg) ^ ((lr ^ (c << 2)) & 15)) << 4);
+        oacc[c] = mfma3(*(const bf16x8*)(VTH + off), *(const bf16x8*)(VTL + off), ph, pl, oacc[c]);
       }
-    // O row (row0 + i), columns head * 64 + 4 lr .. + 3, as (hi, lo) quads of the split image
+    }
+    // oacc[c][r] = O[query i0 + lr][d = 16 lg + 4 r + c]: 16 consecutive columns -> 16 hi + 16 lo values of the split image
+    const int i = i0 + lr;
+    if (i < P) {
+      uint2 h[4], l[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float ir = __shfl(inv, 4 * lg + r);
-      const int i = i0 + 4 * lg + r;
-      if (i < P) {
-        uint2 hi, lo;
-        split4(oacc[0][r] * ir, oacc[1][r] * ir, oacc[2][r] * ir, oacc[3][r] * ir, hi, lo);
-        const int c = head * HD + (lr << 2);
-        char* dst = O + (size_t)(row0 + i) * D * 4 + (c >> 5) * 128 + (c & 31) * 2;
-        *(uint2*)dst = hi;
-        *(uint2*)(dst + 64) = lo;
-      }
+      for (int r = 0; r < 4; ++r)
+        split4(oacc[0][r] * inv, oacc[1][r] * inv, oacc[2][r] * inv, oacc[3][r] * inv, h[r], l[r]);
+      const int c0 = head * HD + 16 * lg;
+      char* dst = O + (size_t)(row0 + i) * D * 4 + (c0 >> 5) * 128 + (c0 & 31) * 2;
+      *(uint4*)dst = make_uint4(h[0].x, h[0].y, h[1].x, h[1].y);
+      *(uint4*)(dst + 16) = make_uint4(h[2].x, h[2].y, h[3].x, h[3].y);
+      *(uint4*)(dst + 64) = make_uint4(l[0].x, l[0].y, l[1].x, l[1].y);
+      *(uint4*)(dst + 80) = make_uint4(l[2].x, l[2].y, l[3].x, l[3].y);
     }
   }
 }
@@ -339,7 +383,7 @@ template <int MT>
 hipError_t launch_mt(const char* U, const char* W, const float* bqkv, const float* pe_w, char* O, int n_regions, int P,
                      int D, int heads, int epeg_k, hipStream_t st) {
   constexpr int BM = 16 * MT;
-  constexpr size_t RING = (size_t)3 * (BM + BN) * ROWB, TILES = (size_t)3 * BM * HD * 4;
+  constexpr size_t RING = (size_t)3 * (BM + BN) * ROWB, TILES = (size_t)BM * 512 + 2 * 64 * VT_PITCH;
   constexpr size_t LDS = (RING > TILES ? RING : TILES) + 512;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = rmsa_fused_x3_kernel<MT>;

@@ -1111,10 +1111,12 @@ def test_rmsa_fused_x3(R, P, D, heads, ek):
     Rr = min(R, 8)
     got = _from_split(o, (R * P, D))[:Rr * P]
     assert np.isfinite(_from_split(o, (R * P, D))).all()
-    qkv = O.split_matmul_t(u[:Rr * P], w) + b
-    qkv[:, :D] *= (D // heads) ** -0.5
-    ref = _attn_ref(qkv, pe, Rr, P, D, heads, ek)
-    _cmp(got, ref, 4e-5, "fused_x3 vs its restatement")             # (the output itself is stored as hi + lo: 2^-16)
+    st = {"qkv.weight": w, "qkv.bias": b, "proj.weight": np.eye(D), "proj.bias": np.zeros(D)}
+    if ek:
+        st["pe.weight"] = pe.reshape(heads, 1, ek, 1)
+    taps = {}
+    O._inner_attention64(u[:Rr * P].reshape(Rr, P, D), st, "", heads, ek, taps, O.SplitX3(), None)
+    _cmp(got, taps["proj_in"].reshape(Rr * P, D), 4e-5, "fused_x3 vs its restatement")   # (O itself is stored as hi + lo)
     qkv_e = u[:Rr * P].astype(np.float64) @ w.astype(np.float64).T + b
     qkv_e[:, :D] *= (D // heads) ** -0.5
     err = np.abs(got - _attn_ref(qkv_e, pe, Rr, P, D, heads, ek))
