@@ -58,7 +58,8 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA
 # HBM-side bytes of the dominant kernel per launch at the north star from rocprofv3 --pmc (separate FETCH_SIZE
 # and WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction)
 TRAFFIC_BYTES_PER_LAUNCH = {("f32", 9000): 88.0e6,      # profiles/r02_a_pmc_f32.txt  (2 x 33967.5 KiB + 18432 KiB)
-                            ("bf16", 9000): 31.7e6}     # profiles/r02_a_pmc_bf16.txt (2 x 10876.6 KiB +  9216 KiB)
+                            ("bf16", 9000): 31.7e6,     # profiles/r02_a_pmc_bf16.txt (2 x 10876.6 KiB +  9216 KiB)
+                            ("f32x3", 9000): 88.0e6}    # profiles/r02_b_pmc_f32x3.txt (2 x 33959.8 KiB + 18432 KiB)
 
 CONFIGS = {
     0: dict(kind="encoder", n=512, dtype="f32", enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8),
