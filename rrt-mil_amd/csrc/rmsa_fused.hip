@@ -81,6 +81,12 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   constexpr int LA = (NA + 1) / 2, LB = NB / 2;    // per loader wave
   constexpr int NT = 3;                            // 16-column tiles per compute wave (4 x 48 = 192)
   constexpr int LDS_MAIN = (2 * STAGE > 3 * TILE ? 2 * STAGE : 3 * TILE) * 4;   // bytes: staging ring / Q, K, V tiles
+  // MT = 4 m + 1 tiles (9, 13) on four SIMDs leave one tile over: the SIMD that takes it whole finishes a tile after
+  // the others (traced: 10.6 K of a block's 170 K cycles).  It is shared out instead: waves 0..3 (one per SIMD) each
+  // run it against a quarter of the keys and the partial (max, sum, O) are merged like an online softmax.
+  constexpr bool SPLIT_LAST = MT == 9;             // (MT = 13 has no LDS left for the partials)
+  constexpr int QT_MAX = MT / 4 + 1;               // key tiles of the largest quarter
+  constexpr int PART_F = 16 * HD + 32;             // floats of one wave's partial: O [16][64], max [16], sum [16]
   constexpr int RUN = (BM * 16 + 383) / 384;       // query rows per stencil thread: 6 for BM = 144
   constexpr int TAP_OFF = 12 + RUN - 1;            // tap t lives at taps[t + TAP_OFF]; taps[12..] is 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     if (pass == 2) t = (wave == 2 || wave == 3) ? wave + 8 : MT;
     const int i0 = t * 16;
     if (t >= MT || i0 >= P) break;
+    if (SPLIT_LAST && t == MT - 1) break;          // the last tile is shared out below
     float4 bq[4];
     {
       const int m = i0 + lr;
@@ -394,6 +401,109 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     }
     RRT_TRACE_MARK();                               // tile: O stored
   }
+  if constexpr (SPLIT_LAST) {
+    float* const scratch = (float*)(smem + LDS_MAIN + 512);     // 4 x PART_F floats behind the tap table
+    constexpr int T = MT - 1, i0 = T * 16;
+    if (wave < 4) {
+      const int j_lo = wave * (MT / 4) + (wave < MT % 4 ? wave : MT % 4);   // MT % 4 == 1: wave 0 takes the extra tile
+      const int nj = MT / 4 + (wave < MT % 4 ? 1 : 0);
+      float4 bq[4];
+      {
+        const int m = i0 + lr;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bq[c] = *(const float4*)(Qt + m * HD + (((4 * c + lg) ^ (m & 15)) << 2));
+      }
+      f32x4 s[QT_MAX];
+#pragma unroll
+      for (int jj = 0; jj < QT_MAX; ++jj) s[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float4 a[QT_MAX];
+#pragma unroll
+        for (int jj = 0; jj < QT_MAX; ++jj) {
+          const int row = (j_lo + (jj < nj ? jj : 0)) * 16 + lr;
+          a[jj] = *(const float4*)(Ks + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+        }
+#pragma unroll
+        for (int jj = 0; jj < QT_MAX; ++jj) s[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].x, bq[c].x, s[jj], 0, 0, 0);
+#pragma unroll
+        for (int jj = 0; jj < QT_MAX; ++jj) s[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].y, bq[c].y, s[jj], 0, 0, 0);
+#pragma unroll
+        for (int jj = 0; jj < QT_MAX; ++jj) s[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].z, bq[c].z, s[jj], 0, 0, 0);
+#pragma unroll
+        for (int jj = 0; jj < QT_MAX; ++jj) s[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].w, bq[c].w, s[jj], 0, 0, 0);
+      }
+      float cmax = NEG_BIG;
+#pragma unroll
+      for (int jj = 0; jj < QT_MAX; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (jj >= nj || (j_lo + jj) * 16 + 4 * lg + r >= P) s[jj][r] = NEG_BIG;   // outside the quarter / the region
+          cmax = fmaxf(cmax, s[jj][r]);
+        }
+      cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+      cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+      float psum = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < QT_MAX; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[jj][r] - cmax);
+          s[jj][r] = p;
+          psum += p;
+        }
+      psum += __shfl_xor(psum, 16);
+      psum += __shfl_xor(psum, 32);
+      f32x4 oacc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < QT_MAX; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (j_lo + (jj < nj ? jj : 0)) * 16 + 4 * lg + r;
+          const float4 v = *(const float4*)(Vs + row * HD + ((lr ^ (row & 15)) << 2));
+          const float p = s[jj][r];                 // 0 for tiles outside the quarter
+          oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.x, oacc[0], 0, 0, 0);
+          oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.y, oacc[1], 0, 0, 0);
+          oacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.z, oacc[2], 0, 0, 0);
+          oacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.w, oacc[3], 0, 0, 0);
+        }
+      // partial of this quarter: O [query 4 lg + r][d = 4 lr + c] unnormalised, the query's max and sum
+      float* mine = scratch + wave * PART_F;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *(float4*)(mine + (4 * lg + r) * HD + 4 * lr) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+      if (lg == 0) {
+        mine[16 * HD + lr] = cmax;
+        mine[16 * HD + 16 + lr] = psum;
+      }
+    }
+    __syncthreads();
+    if (wave < 4) {
+      // merge: thread = (query q, four columns); 256 threads cover the 16 x 64 tile
+      const int t4 = threadIdx.x, q = t4 >> 4, col = (t4 & 15) * 4;
+      float m4[4], l4[4], M = NEG_BIG;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        m4[w] = scratch[w * PART_F + 16 * HD + q];
+        l4[w] = scratch[w * PART_F + 16 * HD + 16 + q];
+        M = fmaxf(M, m4[w]);
+      }
+      float L = 0.f;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float sc = __builtin_amdgcn_exp2f(m4[w] - M);
+        L += sc * l4[w];
+        const float4 a = *(const float4*)(scratch + w * PART_F + q * HD + col);
+        o.x += sc * a.x; o.y += sc * a.y; o.z += sc * a.z; o.w += sc * a.w;
+      }
+      const float inv = 1.0f / L;
+      if (i0 + q < P)
+        *(float4*)(O + (size_t)(row0 + i0 + q) * D + head * HD + col) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+    }
+  }
 }
 
 template <int MT, int PREC>
@@ -401,7 +511,8 @@ hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const
                      int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
   constexpr int BM = 16 * MT;
   constexpr size_t STG = (size_t)2 * (BM + BN) * BK * 4, QKV = (size_t)3 * BM * HD * 4;
-  constexpr size_t LDS = (STG > QKV ? STG : QKV) + 512;   // staging ring, then the Q/K/V tiles (Q~ in place); tap table
+  // staging ring, then the Q/K/V tiles (Q~ in place); tap table; partials of the shared-out last tile (MT = 9)
+  constexpr size_t LDS = (STG > QKV ? STG : QKV) + 512 + (MT == 9 ? 4 * (16 * HD + 32) * 4 : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = rmsa_fused_kernel<MT, PREC>;
   static OncePerDevice once;
