@@ -30,6 +30,8 @@ Besides the contract fields the JSON line carries
   cpu_baseline -- the oracle's eager torch-CPU port of the reference op sequence
                   (oracle/rrt_oracle.py::forward_eager) timed on this box's host cores over a bounded sample
                   of the same workload (rank 0, N=1 only).
+--dtype overrides a config's arithmetic (f32 | bf16 | f16 | f32x3 = fp32 in / out with the big products emulated on the bf16
+matrix cores, RRT_COMPUTE_F32X3); the default run also reports bf16 and f32x3 as extra records (`amp_bf16`, `f32x3`).
 --stub-cpu replaces the GPU workload by a tiny CPU one over gloo: the rank logic (spawn, sharding, barrier,
 MAX over ranks, the JSON line) then runs without a GPU -- tests/test_multiproc_cpu.py drives it.
 """
