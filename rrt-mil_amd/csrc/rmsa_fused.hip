@@ -84,6 +84,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   // MT = 4 m + 1 tiles (9, 13) on four SIMDs leave one tile over: the SIMD that takes it whole finishes a tile after
   // the others (traced: 10.6 K of a block's 170 K cycles).  It is shared out instead: waves 0..3 (one per SIMD) each
   // run it against a quarter of the keys and the partial (max, sum, O) are merged like an online softmax.
+  constexpr bool PIPE = PREC == PREC_F32 && MT <= 11;   // software-pipelined projection loop (phase 1)
   constexpr bool SPLIT_LAST = MT == 9;             // (MT = 13 has no LDS left for the partials)
   constexpr int QT_MAX = MT / 4 + 1;               // key tiles of the largest quarter
   constexpr int PART_F = 16 * HD + 32;             // floats of one wave's partial: O [16][64], max [16], sum [16]
@@ -163,10 +164,24 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
       for (int qi = 0; qi < LB; ++qi) dma16s(Wqkv + kt * BK, boff[qi], buf + BM * BK * 4 + (qi * 2 + lw) * 1024);
     };
     stage(0, lds_b);
-    for (int kt = 0; kt < nk; ++kt) {
+    if constexpr (PIPE) {
+      // fp32: the compute waves pass barrier B_kt in the MIDDLE of k tile kt, once both halves of stage kt are in
+      // their registers -- so stage kt + 1 is published (and its first fragments fetched) half a tile before it is
+      // needed, and buffer kt & 1 is free for stage kt + 2 from that point on
       wait_vm0();
-      __syncthreads();                              // publishes K tile kt
-      if (kt + 1 < nk) stage(kt + 1, lds_b + ((kt + 1) & 1) * STAGE * 4);
+      __syncthreads();                              // publishes K tile 0
+      if (nk > 1) stage(1, lds_b + STAGE * 4);
+      for (int kt = 0; kt < nk; ++kt) {
+        wait_vm0();                                 // K tile kt + 1 has landed
+        __syncthreads();                            // B_kt
+        if (kt + 2 < nk) stage(kt + 2, lds_b + (kt & 1) * STAGE * 4);
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        wait_vm0();
+        __syncthreads();                            // publishes K tile kt
+        if (kt + 1 < nk) stage(kt + 1, lds_b + ((kt + 1) & 1) * STAGE * 4);
+      }
     }
   } else {
     f32x4 acc[MT][NT];
@@ -174,12 +189,74 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (PIPE) {
+      // Software pipeline over half k tiles (16 columns = one float4 slot per lane group, 4 MFMA k steps): the
+      // fragments of the next half are always in flight under the 108 MFMAs of the current one.  With one compute
+      // wave per SIMD nothing else covers an LDS round trip: fetching a stage's first fragments right after its
+      // barrier left the matrix pipe idle ~580 of every 7.5 K cycles (traced).
+      float4 af0[MT], bf0[NT], af1[MT], bf1[NT];
+      auto fetch = [&](const float* As, int kk, float4 (&af)[MT], float4 (&bf)[NT]) {
+        const float* Bs = As + BM * BK;
+        const int cslot = 4 * kk + lg;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          int row = wave * (16 * NT) + j * 16 + lr;
+          bf[j] = *(const float4*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          int row = i * 16 + lr;
+          af[i] = *(const float4*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+        }
+      };
+      auto mma = [&](const float4 (&af)[MT], const float4 (&bf)[NT]) {
+#pragma unroll
+        for (int comp = 0; comp < 4; ++comp)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const float a = comp == 0 ? af[i].x : comp == 1 ? af[i].y : comp == 2 ? af[i].z : af[i].w;
+              const float b = comp == 0 ? bf[j].x : comp == 1 ? bf[j].y : comp == 2 ? bf[j].z : bf[j].w;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
+            }
+      };
+      __syncthreads();                              // K tile 0 published
+      RRT_TRACE_MARK();                             // [2]
+      fetch(lds, 0, af0, bf0);
+      // one LDS read behind each of the first MT + NT MFMAs of a half, the rest of the MFMAs after them: a wave
+      // issues in order, so a bunch of 12 reads between two MFMA runs drains the matrix pipe while the four waves'
+      // reads queue up at the LDS (traced: ~770 cycles per bunch); issued in the shadow of an MFMA they are free
+      auto interleave = [&]() {
+#pragma unroll
+        for (int q = 0; q < MT + NT; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT - (MT + NT), 0);
+      };
+      for (int kt = 0; kt < nk; ++kt) {
+        const float* As = lds + (kt & 1) * STAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(As, 1, af1, bf1);
+        mma(af0, bf0);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                            // B_kt: stage kt is in registers everywhere, stage kt + 1 published
+        if (kt == 0 || kt == 7) RRT_TRACE_MARK();   // [3,4] B_0, B_7
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(lds + ((kt + 1) & 1) * STAGE, 0, af0, bf0);   // (after the last tile: a stale stage, never used)
+        mma(af1, bf1);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();
       if (kt == 0 || kt == 1 || kt == 8) RRT_TRACE_MARK();   // [2,3,4] barrier kt passed
       const float* As = lds + (kt & 1) * STAGE;
       const float* Bs = As + BM * BK;
-      if constexpr (PREC == PREC_F32) {
+      if constexpr (PREC == PREC_F32) {              // MT = 13: no registers for a second fragment set
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           float4 af[MT], bf[NT];
@@ -225,6 +302,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(b8[j], a8[i], acc[i][j]);
       }
+    }
     }
     RRT_TRACE_MARK();                               // [5] last projection MFMA issued
     // ================================================================ phase 2: Q / K / V tiles -> LDS
@@ -478,8 +556,10 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
         mine[16 * HD + lr] = cmax;
         mine[16 * HD + 16 + lr] = psum;
       }
+      RRT_TRACE_MARK();                             // quarter of the shared-out tile done
     }
     __syncthreads();
+    RRT_TRACE_MARK();                               // partials published
     if (wave < 4) {
       // merge: thread = (query q, four columns); 256 threads cover the 16 x 64 tile
       const int t4 = threadIdx.x, q = t4 >> 4, col = (t4 & 15) * 4;
@@ -502,6 +582,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
       const float inv = 1.0f / L;
       if (i0 + q < P)
         *(float4*)(O + (size_t)(row0 + i0 + q) * D + head * HD + col) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+      RRT_TRACE_MARK();                             // merged tile stored
     }
   }
 }

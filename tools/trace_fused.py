@@ -22,18 +22,20 @@ raw.rrt_debug_trace_fused(None, 0, 1)
 call()
 raw.rrt_debug_trace_fused(buf.ctypes.data, buf.nbytes, 0)
 t = buf.reshape(WAVES, EV)
-idx = np.arange(WAVES)
-live = t[:, 1] > 0
-for role, sel in (("compute wave 0 (3 query tiles)", live & (idx % 6 == 0)), ("compute waves 1-3 (2 tiles)", live & (idx % 6 > 0) & (idx % 6 < 4)), ("loader", live & (idx % 6 >= 4))):
-    ts = t[sel][:, 1:].astype(np.int64)
+NW = 6                                            # waves per block (RRT_TRACE_INIT(blockIdx.x * 6 + wave))
+nb = (t[:, 1] > 0).sum() // NW
+tb = t[:nb * NW].reshape(nb, NW, EV)[:, :, 1:].astype(np.int64)
+t0 = np.where(tb[:, :, 0] > 0, tb[:, :, 0], np.iinfo(np.int64).max).min(1)          # first wave entry of the block
+first = tb[:, :, 0].min(1) <= np.percentile(tb[:, :, 0].min(1), 45)                     # first-round blocks (2 per CU)
+for w in range(NW):
+    ts = tb[:, w, :]
     nev = int((ts > 0).sum(1).max())
+    rel = ts[:, :nev] - t0[:, None]
     ok = (ts[:, :nev] > 0).all(1)
-    ts = ts[ok][:, :nev]
-    print(f"== {role}: {ok.sum()} waves, {nev} events")
-    d = np.diff(ts, axis=1)
-    for i in range(nev - 1):
-        x = d[:, i]
-        print(f"   ev{i + 1:02d}->ev{i + 2:02d}  median {np.median(x):8.0f}  p10 {np.percentile(x, 10):8.0f}  p90 {np.percentile(x, 90):8.0f}")
-    life = ts[:, -1] - ts[:, 0]
-    print(f"   lifetime median {np.median(life):.0f} p10 {np.percentile(life, 10):.0f} p90 {np.percentile(life, 90):.0f}")
-print("compute: 1 entry | 2,3,4 barrier kt=0,1,8 | 5 last proj MFMA | 6 QKV in LDS | 7 Q~ built | per tile: S^T issued, softmax done, PV issued, O stored")
+    print(f"== wave {w}: {nev} events; time since the block's first wave entered (median | first-round blocks | step)")
+    prev = None
+    for i in range(nev):
+        m = np.median(rel[ok, i]); m1 = np.median(rel[ok & first, i])
+        print(f"   ev{i + 1:02d}  {m:9.0f}  {m1:9.0f}  {'' if prev is None else f'+{m - prev:.0f}'}")
+        prev = m
+print("marks: 1 entry | 2 K tile 0 published | 3,4 B_0, B_7 | 5 last proj MFMA | 6 QKV in LDS | 7 Q~ built | per tile: S^T issued, softmax done, PV issued, O stored | quarter done | partials published | merged")
