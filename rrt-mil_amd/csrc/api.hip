@@ -451,7 +451,8 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       // O goes to the qkv workspace (first Np*D floats), u stays in uo.
       RRT_TRY(launch_rmsa_fused(ws.uo, lw.qkv_w, lw.qkv_b, desc->epeg ? lw.pe_w : nullptr, ws.qkv,
                                 gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, desc->compute, st));
-      if (gt) { RRT_TRY(hipEventRecord(gt->done, st)); gt->armed = true; }
+      static const bool gate_proj = getenv("RRT_GATE_PROJ") != nullptr;
+      if (gt && !gate_proj) { RRT_TRY(hipEventRecord(gt->done, st)); gt->armed = true; }
       if (li == 0) { RRT_MARK(RRT_EV_QKV); RRT_MARK(RRT_EV_ATTN); }
       LinearEpilogue ep{};
       ep.prec = desc->compute;
@@ -459,6 +460,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       ep.resid = xin;
       ep.g = gd;
       RRT_TRY(launch_linear(ws.qkv, lw.proj_w, xout, gd.Np, D, D, ep, st));
+      if (gt && gate_proj) { RRT_TRY(hipEventRecord(gt->done, st)); gt->armed = true; }
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;
       if (desc->ffn) {

@@ -125,6 +125,31 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 
 #define LN_EPS 1e-5f
 
+// ---- lane ^ 16 / lane ^ 32 reductions on the VALU ------------------------------------------------
+// gfx950 v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two registers.  __shfl_xor lowers to
+// ds_bpermute_b32, which queues in the LDS pipe behind every wave's fragment reads (traced in the attention phases: a
+// softmax with six dependent bpermutes took 3.5 K cycles next to ~1.5 K of VALU work).
+static __device__ __forceinline__ float max_xor16(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static __device__ __forceinline__ float max_xor32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static __device__ __forceinline__ float sum_xor16(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+static __device__ __forceinline__ float sum_xor32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // ---- optional in-kernel timeline tracing (tools/build_ablation.sh trace -DRRT_TRACE) ------------
 // Per wave: up to RRT_TRACE_EV 64-bit shader-clock stamps + HW_ID/XCC_ID, written to a device
 // symbol that tools/trace_attn.py reads back.  Compiled out of the product build.

@@ -34,6 +34,7 @@ constexpr int BN = 3 * HD;          // q | k | v columns of one head
 constexpr float NEG_BIG = -3.0e38f;
 constexpr float LOG2E = 1.4426950408889634f;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
@@ -68,7 +69,7 @@ struct Frag8<PREC_F16> {
 };
 
 template <int MT, int PREC>
-__global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restrict__ U,
+__global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restrict__ U,
                                                             const float* __restrict__ Wqkv,
                                                             const float* __restrict__ bqkv,
                                                             const float* __restrict__ pe_w,
@@ -78,17 +79,16 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   constexpr int STAGE = (BM + BN) * BK;            // floats per pipeline stage
   constexpr int TILE = BM * HD;                    // floats of one Q / K / V tile
   constexpr int NA = BM / 8, NB = BN / 8;          // DMA wave-instructions per A / B stage
-  constexpr int LA = (NA + 1) / 2, LB = NB / 2;    // per loader wave
+  constexpr int LA = (NA + 3) / 4, LB = NB / 4;    // per loader wave (four of them)
   constexpr int NT = 3;                            // 16-column tiles per compute wave (4 x 48 = 192)
   constexpr int LDS_MAIN = (2 * STAGE > 3 * TILE ? 2 * STAGE : 3 * TILE) * 4;   // bytes: staging ring / Q, K, V tiles
-  // MT = 4 m + 1 tiles (9, 13) on four SIMDs leave one tile over: the SIMD that takes it whole finishes a tile after
-  // the others (traced: 10.6 K of a block's 170 K cycles).  It is shared out instead: waves 0..3 (one per SIMD) each
-  // run it against a quarter of the keys and the partial (max, sum, O) are merged like an online softmax.
+#ifdef RRT_NOPIPE
+  constexpr bool PIPE = false;
+#else
   constexpr bool PIPE = PREC == PREC_F32 && MT <= 11;   // software-pipelined projection loop (phase 1)
-  constexpr bool SPLIT_LAST = MT == 9;             // (MT = 13 has no LDS left for the partials)
-  constexpr int QT_MAX = MT / 4 + 1;               // key tiles of the largest quarter
-  constexpr int PART_F = 16 * HD + 32;             // floats of one wave's partial: O [16][64], max [16], sum [16]
-  constexpr int RUN = (BM * 16 + 383) / 384;       // query rows per stencil thread: 6 for BM = 144
+#endif
+  constexpr bool SPLIT_LAST = MT == 9;             // nine tiles on eight waves: the ninth is shared out (phase 4)
+  constexpr int RUN = (BM * 16 + 511) / 512;       // query rows per stencil thread: 5 for BM = 144
   constexpr int TAP_OFF = 12 + RUN - 1;            // tap t lives at taps[t + TAP_OFF]; taps[12..] is 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = (float*)smem;
@@ -128,13 +128,18 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   // table behind the tiles (index t + TAP_OFF).  (Fetching w[t] from global inside the stencil loop put one
   // dependent vector load on every source row: the trace showed 9.2K cycles for a phase with ~2K cycles of work.)
   float* const taps = (float*)(smem + LDS_MAIN);
+  float* const bias_l = taps + 128;                // q | k | v bias of this head (192 floats), read in phase 2
+  if (tid >= 128 && tid < 128 + BN) {
+    const int n = tid - 128;
+    bias_l[n] = bqkv ? bqkv[(n >> 6) * D + head * HD + (n & 63)] : 0.f;
+  }
   if (tid < 128) {
     const int t = tid - TAP_OFF;
     float wt = (pe_w != nullptr && t >= 0 && t < epeg_k) ? pe_w[head * epeg_k + t] : 0.f;
     if (t == (epeg_k >> 1)) wt += 1.0f;
     taps[tid] = wt * LOG2E;
   }
-  RRT_TRACE_INIT(blockIdx.x * 6 + wave);
+  RRT_TRACE_INIT(blockIdx.x * 8 + wave);
   RRT_TRACE_MARK();                                 // [1] entry
 
   // ================================================================== phase 1: projection
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     unsigned aoff[LA], boff[LB];
 #pragma unroll
     for (int qi = 0; qi < LA; ++qi) {
-      int S = (qi * 2 + lw) * 64 + lane;
+      int S = (qi * 4 + lw) * 64 + lane;
       int row = S >> 3, p = S & 7;
       int gr = row0 + row;
       gr = gr < n_rows ? gr : n_rows - 1;          // rows past the last region: re-read (never used)
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     }
 #pragma unroll
     for (int qi = 0; qi < LB; ++qi) {
-      int S = (qi * 2 + lw) * 64 + lane;
+      int S = (qi * 4 + lw) * 64 + lane;
       int row = S >> 3, p = S & 7;                  // row in [0,192): c = row/64 picks q / k / v
       int wr = (row >> 6) * D + head * HD + (row & 63);
       boff[qi] = (unsigned)wr * (unsigned)D * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
@@ -159,9 +164,9 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     auto stage = [&](int kt, unsigned buf) {
 #pragma unroll
       for (int qi = 0; qi < LA; ++qi)
-        if (qi * 2 + lw < NA) dma16s(U + kt * BK, aoff[qi], buf + (qi * 2 + lw) * 1024);
+        if (qi * 4 + lw < NA) dma16s(U + kt * BK, aoff[qi], buf + (qi * 4 + lw) * 1024);
 #pragma unroll
-      for (int qi = 0; qi < LB; ++qi) dma16s(Wqkv + kt * BK, boff[qi], buf + BM * BK * 4 + (qi * 2 + lw) * 1024);
+      for (int qi = 0; qi < LB; ++qi) dma16s(Wqkv + kt * BK, boff[qi], buf + BM * BK * 4 + (qi * 4 + lw) * 1024);
     };
     stage(0, lds_b);
     if constexpr (PIPE) {
@@ -312,8 +317,7 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     for (int j = 0; j < NT; ++j) {
       const int n = wave * (16 * NT) + j * 16 + 4 * lg;        // 0..191, multiple of 4
       const int c = n >> 6, d = n & 63;                         // q / k / v and the head-dim column
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bqkv) b = *(const float4*)(bqkv + c * D + head * HD + d);
+      const float4 b = *(const float4*)(bias_l + n);   // (a global load here sat on the critical path between two phases)
       const float sc = c == 0 ? q_scale : 1.0f;
       float* dstm = c == 0 ? Qs : (c == 1 ? Ks : Vs);
 #pragma unroll
@@ -331,18 +335,17 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   RRT_TRACE_MARK();                                 // [6] Q/K/V in LDS
 
   // ================================================================== phase 3: EPEG stencil -> Q~
-  // thread = (slot s of 16, run g of RUN consecutive query rows); all 6 waves take part
+  // thread = (slot s of 16, run g of RUN consecutive query rows); all eight waves take part
   {
     // In place: every thread first gathers its outputs in registers, a barrier retires all reads of
-    // the Q tile, then Q~ is written over it.  (A separate Q~ buffer + tap table cost 37.4 KB more
-    // LDS; at 108 KiB a proj tile of another bag (52 KiB) can share the CU: 108 + 52 = 160 KiB.)
+    // the Q tile, then Q~ is written over it.
     static_assert(RUN - 1 <= TAP_OFF && (TAP_OFF - (RUN - 1)) % 4 == 0 && 2 * RUN + 90 < 128, "tap table range / alignment");
     const int half = epeg_k >> 1;
     const int s = tid & 15, g = tid >> 4;
     const int r0 = g * RUN;
-    float4 out[RUN];
+    f32x2 out[RUN][2];                              // packed pairs: v_pk_fma_f32 does two lanes' worth per issue slot
 #pragma unroll
-    for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = 0; o < RUN; ++o) out[o][0] = out[o][1] = (f32x2){0.f, 0.f};
     if (r0 < BM) {
       // source row j of the run (j = 0 .. RUN + k - 2, row r0 - k/2 + j) meets output o with tap t = j - o: the RUN
       // weights slide by one per source row.  Four rows per trip, their loads issued together (a row per trip was
@@ -370,12 +373,16 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
           if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) {
+          const f32x2 lo = {v[u].x, v[u].y}, hi = {v[u].z, v[u].w};
 #pragma unroll
           for (int o = 0; o < RUN; ++o) {
             const float wt = T[u + RUN - 1 - o];
-            out[o].x += wt * v[u].x; out[o].y += wt * v[u].y; out[o].z += wt * v[u].z; out[o].w += wt * v[u].w;
+            const f32x2 w2 = {wt, wt};
+            out[o][0] = __builtin_elementwise_fma(w2, lo, out[o][0]);
+            out[o][1] = __builtin_elementwise_fma(w2, hi, out[o][1]);
           }
+        }
       }
     }
     __syncthreads();                                // all reads of Q done
@@ -383,7 +390,8 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
 #pragma unroll
       for (int o = 0; o < RUN; ++o) {
         const int m = r0 + o;
-        if (m < BM) *(float4*)(Qt + m * HD + ((s ^ (m & 15)) << 2)) = out[o];
+        if (m < BM)
+          *(float4*)(Qt + m * HD + ((s ^ (m & 15)) << 2)) = make_float4(out[o][0][0], out[o][0][1], out[o][1][0], out[o][1][1]);
       }
     }
   }
@@ -391,16 +399,217 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
   RRT_TRACE_MARK();                                 // [7] Q~ built
 
   // ================================================================== phase 4: attention from LDS
-  // all six waves (the loaders are idle now).  Tile -> wave schedule balanced per SIMD (waves 4, 5 share
-  // SIMDs 0, 1 with waves 0, 1): tiles 0..5 -> waves 0..5; 6, 7 -> waves 2, 3; 8, 9 -> waves 4, 5;
-  // 10, 11 -> waves 2, 3 again; 12 -> wave 0.
-  for (int pass = 0; pass < 3; ++pass) {
-    int t = wave;
-    if (pass == 1) t = wave >= 2 ? wave + 4 : (wave == 0 ? 12 : MT);
-    if (pass == 2) t = (wave == 2 || wave == 3) ? wave + 8 : MT;
+  // All eight waves, two per SIMD (wave w and w + 4), a 16-query tile each per pass: tile t -> wave t % 8.  One wave
+  // per SIMD left every LDS round trip and the whole softmax exposed (traced: 13.5 K cycles per tile for 9.2 K of
+  // MFMA); two waves with a tile each keep the matrix pipe ~100 % busy between them (18.2 K cycles for two tiles).
+  if constexpr (SPLIT_LAST) {
+    // MT = 8 + 1: eight whole tiles, one per wave, and the ninth SHARED OUT by key tile -- wave w also runs the
+    // ninth tile's queries against key tile w (wave 0: and key tile 8), inside its own MFMA streams: the K and V
+    // fragments are the ones its own tile needs anyway, so the extra costs 32 MFMAs and no LDS traffic.  The nine
+    // partial (max, sum, O) are merged like an online softmax.  (As a separate stage -- four key quarters on four
+    // waves, before or after the whole tiles -- the same work ran latency-bound: 8.8 K cycles for 2.3 K of MFMA.)
+    // Wave w visits the key tiles in the order w, w + 1, ... (mod MT) so that "its" key tile is at a compile-time
+    // position of the unrolled loops.
+    constexpr int XT = MT - 1;
+    // partial O of key tile w: over wave w's OWN Q~ rows (tile w of the Q~ image, dead once its fragments are in
+    // registers -- nobody else reads them); key tile 8's and the (max, sum) pairs behind the tap / bias tables
+    float* const pstat = (float*)(smem + LDS_MAIN + 1280);      // [MT][32]: max [16], sum [16]
+    float* const plast = pstat + MT * 32;                       // [16][HD]
+    const int i0 = wave * 16;
+    int tk[MT];                                                  // key tile at position j (scalar registers)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) tk[j] = j + wave < MT ? j + wave : j + wave - MT;
+    float4 bq[4], bx[4];
+    {
+      const int m = i0 + lr, mx = XT * 16 + lr;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bq[c] = *(const float4*)(Qt + m * HD + (((4 * c + lg) ^ lr) << 2));
+        bx[c] = *(const float4*)(Qt + mx * HD + (((4 * c + lg) ^ lr) << 2));
+      }
+    }
+    f32x4 s[MT], sx = {0.f, 0.f, 0.f, 0.f}, sy = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MT; ++j) s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float4 a[MT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) a[j] = *(const float4*)(Ks + (tk[j] * 16 + lr) * HD + (((4 * c + lg) ^ lr) << 2));
+#pragma unroll
+      for (int comp = 0; comp < 4; ++comp) {
+        const float qb = comp == 0 ? bq[c].x : comp == 1 ? bq[c].y : comp == 2 ? bq[c].z : bq[c].w;
+        const float xb = comp == 0 ? bx[c].x : comp == 1 ? bx[c].y : comp == 2 ? bx[c].z : bx[c].w;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          const float ka = comp == 0 ? a[j].x : comp == 1 ? a[j].y : comp == 2 ? a[j].z : a[j].w;
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka, qb, s[j], 0, 0, 0);
+          if (j == 0) sx = __builtin_amdgcn_mfma_f32_16x16x4f32(ka, xb, sx, 0, 0, 0);
+        }
+      }
+    }
+    if (wave == 0) {                                             // key tile 8 of the shared-out tile
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 a8 = *(const float4*)(Ks + (XT * 16 + lr) * HD + (((4 * c + lg) ^ lr) << 2));
+        sy = __builtin_amdgcn_mfma_f32_16x16x4f32(a8.x, bx[c].x, sy, 0, 0, 0);
+        sy = __builtin_amdgcn_mfma_f32_16x16x4f32(a8.y, bx[c].y, sy, 0, 0, 0);
+        sy = __builtin_amdgcn_mfma_f32_16x16x4f32(a8.z, bx[c].z, sy, 0, 0, 0);
+        sy = __builtin_amdgcn_mfma_f32_16x16x4f32(a8.w, bx[c].w, sy, 0, 0, 0);
+      }
+    }
+    RRT_TRACE_MARK();                               // tile: S^T issued
+    // fp32 MFMA and the vector ALU are the same lanes on this chip (measured, tools/ubench/mfma_valu_overlap.hip: no
+    // overlap, not even across waves), so every VALU instruction here is time taken from the matrix work: packed
+    // sub / add / mul, key masks only when the region does not fill its tiles.
+    float cmax = NEG_BIG, xmax = NEG_BIG, ymax = NEG_BIG;
+    if (P < BM) {
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (tk[j] * 16 + 4 * lg + r >= P) s[j][r] = NEG_BIG;   // keys past the region
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (tk[0] * 16 + 4 * lg + r >= P) sx[r] = NEG_BIG;
+        if (XT * 16 + 4 * lg + r >= P) sy[r] = NEG_BIG;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[j][r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xmax = fmaxf(xmax, sx[r]);
+      ymax = fmaxf(ymax, sy[r]);
+    }
+    cmax = max_xor32(max_xor16(cmax));
+    xmax = max_xor32(max_xor16(xmax));
+    ymax = max_xor32(max_xor16(ymax));
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const f32x4 c4 = {cmax, cmax, cmax, cmax};
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        f32x4 t = s[j] - c4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = __builtin_amdgcn_exp2f(t[r]);
+        s[j] = t;
+        acc4 += t;
+      }
+    }
+    float psum = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]), xsum = 0.f, ysum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sx[r] = __builtin_amdgcn_exp2f(sx[r] - xmax);
+      sy[r] = __builtin_amdgcn_exp2f(sy[r] - ymax);
+      xsum += sx[r];
+      ysum += sy[r];
+    }
+    psum = sum_xor32(sum_xor16(psum));
+    xsum = sum_xor32(sum_xor16(xsum));
+    ysum = sum_xor32(sum_xor16(ysum));
+    // normalised here, where a lane's 36 probabilities all belong to ITS query (lane & 15): the output tile holds
+    // query 4 lg + r in register r, and fetching that query's 1 / sum there is a general lane permute
+    {
+      const float inv = 1.0f / psum;
+      const f32x4 i4 = {inv, inv, inv, inv};
+#pragma unroll
+      for (int j = 0; j < MT; ++j) s[j] *= i4;
+    }
+    RRT_TRACE_MARK();                               // tile: softmax done
+    f32x4 oacc[4], ox[4], oy[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) oacc[c] = ox[c] = oy[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * lg + r;
+        const float4 v = *(const float4*)(Vs + (tk[j] * 16 + rr) * HD + ((lr ^ rr) << 2));
+        const float p = s[j][r];
+        oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.x, oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.y, oacc[1], 0, 0, 0);
+        oacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.z, oacc[2], 0, 0, 0);
+        oacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.w, oacc[3], 0, 0, 0);
+        if (j == 0) {
+          const float px = sx[r];
+          ox[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, v.x, ox[0], 0, 0, 0);
+          ox[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, v.y, ox[1], 0, 0, 0);
+          ox[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, v.z, ox[2], 0, 0, 0);
+          ox[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, v.w, ox[3], 0, 0, 0);
+        }
+      }
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * lg + r;
+        const float4 v = *(const float4*)(Vs + (XT * 16 + rr) * HD + ((lr ^ rr) << 2));
+        const float py = sy[r];
+        oy[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(py, v.x, oy[0], 0, 0, 0);
+        oy[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(py, v.y, oy[1], 0, 0, 0);
+        oy[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(py, v.z, oy[2], 0, 0, 0);
+        oy[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(py, v.w, oy[3], 0, 0, 0);
+      }
+    }
+    RRT_TRACE_MARK();                               // tile: PV issued
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * lg + r;
+      if (i < P)
+        *(float4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+    }
+    // partials of the shared-out tile: O [query 4 lg + r][d = 4 lr + c] unnormalised, the query's max and sum
+    {
+      float* mine = Qt + wave * 16 * HD;            // slot = key tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *(float4*)(mine + (4 * lg + r) * HD + 4 * lr) = make_float4(ox[0][r], ox[1][r], ox[2][r], ox[3][r]);
+      if (lg == 0) {
+        pstat[wave * 32 + lr] = xmax;
+        pstat[wave * 32 + 16 + lr] = xsum;
+      }
+      if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *(float4*)(plast + (4 * lg + r) * HD + 4 * lr) = make_float4(oy[0][r], oy[1][r], oy[2][r], oy[3][r]);
+        if (lg == 0) {
+          pstat[XT * 32 + lr] = ymax;
+          pstat[XT * 32 + 16 + lr] = ysum;
+        }
+      }
+    }
+    RRT_TRACE_MARK();                               // tile: O and partials stored
+    __syncthreads();
+    RRT_TRACE_MARK();                               // partials published
+    {
+      // merge: thread = (query q, two columns); 512 threads cover the 16 x 64 tile
+      const int q = tid >> 5, col = (tid & 31) * 2;
+      float mw[MT], M = NEG_BIG;
+#pragma unroll
+      for (int w = 0; w < MT; ++w) {
+        mw[w] = pstat[w * 32 + q];
+        M = fmaxf(M, mw[w]);
+      }
+      float L = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < MT; ++w) {
+        const float sc = __builtin_amdgcn_exp2f(mw[w] - M);
+        L += sc * pstat[w * 32 + 16 + q];
+        const float2 a = *(const float2*)((w < XT ? Qt + w * 16 * HD : plast) + q * HD + col);
+        o0 += sc * a.x;
+        o1 += sc * a.y;
+      }
+      const float invL = 1.0f / L;
+      if (XT * 16 + q < P)
+        *(float2*)(O + (size_t)(row0 + XT * 16 + q) * D + head * HD + col) = make_float2(o0 * invL, o1 * invL);
+      RRT_TRACE_MARK();                             // merged tile stored
+    }
+  } else {
+  for (int t = wave; t < MT; t += 8) {
     const int i0 = t * 16;
-    if (t >= MT || i0 >= P) break;
-    if (SPLIT_LAST && t == MT - 1) break;          // the last tile is shared out below
+    if (i0 >= P) break;
     float4 bq[4];
     {
       const int m = i0 + lr;
@@ -429,28 +638,37 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     }
     RRT_TRACE_MARK();                               // tile: S^T issued
     float cmax = NEG_BIG;
+    if (P < BM) {
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;     // keys past the region
+    }
 #pragma unroll
     for (int jt = 0; jt < MT; ++jt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;       // keys past the region
-        cmax = fmaxf(cmax, s[jt][r]);
-      }
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-    float psum = 0.f;
+      for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[jt][r]);
+    cmax = max_xor32(max_xor16(cmax));
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const f32x4 c4 = {cmax, cmax, cmax, cmax};
 #pragma unroll
-    for (int jt = 0; jt < MT; ++jt)
+      for (int jt = 0; jt < MT; ++jt) {
+        f32x4 t = s[jt] - c4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[jt][r] - cmax);
-        s[jt][r] = p;
-        psum += p;
+        for (int r = 0; r < 4; ++r) t[r] = __builtin_amdgcn_exp2f(t[r]);
+        s[jt] = t;
+        acc4 += t;
       }
-    psum += __shfl_xor(psum, 16);
-    psum += __shfl_xor(psum, 32);
-    const float inv = 1.0f / psum;
-    asm volatile("" :: "v"(inv));
+    }
+    const float psum = sum_xor32(sum_xor16((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])));
+    {
+      const float inv = 1.0f / psum;                // applied where a lane's probabilities all belong to its query
+      const f32x4 i4 = {inv, inv, inv, inv};
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) s[jt] *= i4;
+    }
     RRT_TRACE_MARK();                               // tile: softmax done
     f32x4 oacc[4];
 #pragma unroll
@@ -470,120 +688,12 @@ __global__ __launch_bounds__(384, 1) void rmsa_fused_kernel(const float* __restr
     RRT_TRACE_MARK();                               // tile: PV issued
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float ir = __shfl(inv, 4 * lg + r);
       const int i = i0 + 4 * lg + r;
-      if (i < P) {
-        float4 out = make_float4(oacc[0][r] * ir, oacc[1][r] * ir, oacc[2][r] * ir, oacc[3][r] * ir);
-        *(float4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)) = out;
-      }
+      if (i < P)
+        *(float4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
     }
     RRT_TRACE_MARK();                               // tile: O stored
   }
-  if constexpr (SPLIT_LAST) {
-    float* const scratch = (float*)(smem + LDS_MAIN + 512);     // 4 x PART_F floats behind the tap table
-    constexpr int T = MT - 1, i0 = T * 16;
-    if (wave < 4) {
-      const int j_lo = wave * (MT / 4) + (wave < MT % 4 ? wave : MT % 4);   // MT % 4 == 1: wave 0 takes the extra tile
-      const int nj = MT / 4 + (wave < MT % 4 ? 1 : 0);
-      float4 bq[4];
-      {
-        const int m = i0 + lr;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bq[c] = *(const float4*)(Qt + m * HD + (((4 * c + lg) ^ (m & 15)) << 2));
-      }
-      f32x4 s[QT_MAX];
-#pragma unroll
-      for (int jj = 0; jj < QT_MAX; ++jj) s[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float4 a[QT_MAX];
-#pragma unroll
-        for (int jj = 0; jj < QT_MAX; ++jj) {
-          const int row = (j_lo + (jj < nj ? jj : 0)) * 16 + lr;
-          a[jj] = *(const float4*)(Ks + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
-        }
-#pragma unroll
-        for (int jj = 0; jj < QT_MAX; ++jj) s[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].x, bq[c].x, s[jj], 0, 0, 0);
-#pragma unroll
-        for (int jj = 0; jj < QT_MAX; ++jj) s[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].y, bq[c].y, s[jj], 0, 0, 0);
-#pragma unroll
-        for (int jj = 0; jj < QT_MAX; ++jj) s[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].z, bq[c].z, s[jj], 0, 0, 0);
-#pragma unroll
-        for (int jj = 0; jj < QT_MAX; ++jj) s[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].w, bq[c].w, s[jj], 0, 0, 0);
-      }
-      float cmax = NEG_BIG;
-#pragma unroll
-      for (int jj = 0; jj < QT_MAX; ++jj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (jj >= nj || (j_lo + jj) * 16 + 4 * lg + r >= P) s[jj][r] = NEG_BIG;   // outside the quarter / the region
-          cmax = fmaxf(cmax, s[jj][r]);
-        }
-      cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-      cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-      float psum = 0.f;
-#pragma unroll
-      for (int jj = 0; jj < QT_MAX; ++jj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[jj][r] - cmax);
-          s[jj][r] = p;
-          psum += p;
-        }
-      psum += __shfl_xor(psum, 16);
-      psum += __shfl_xor(psum, 32);
-      f32x4 oacc[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int jj = 0; jj < QT_MAX; ++jj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = (j_lo + (jj < nj ? jj : 0)) * 16 + 4 * lg + r;
-          const float4 v = *(const float4*)(Vs + row * HD + ((lr ^ (row & 15)) << 2));
-          const float p = s[jj][r];                 // 0 for tiles outside the quarter
-          oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.x, oacc[0], 0, 0, 0);
-          oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.y, oacc[1], 0, 0, 0);
-          oacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.z, oacc[2], 0, 0, 0);
-          oacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.w, oacc[3], 0, 0, 0);
-        }
-      // partial of this quarter: O [query 4 lg + r][d = 4 lr + c] unnormalised, the query's max and sum
-      float* mine = scratch + wave * PART_F;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *(float4*)(mine + (4 * lg + r) * HD + 4 * lr) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
-      if (lg == 0) {
-        mine[16 * HD + lr] = cmax;
-        mine[16 * HD + 16 + lr] = psum;
-      }
-      RRT_TRACE_MARK();                             // quarter of the shared-out tile done
-    }
-    __syncthreads();
-    RRT_TRACE_MARK();                               // partials published
-    if (wave < 4) {
-      // merge: thread = (query q, four columns); 256 threads cover the 16 x 64 tile
-      const int t4 = threadIdx.x, q = t4 >> 4, col = (t4 & 15) * 4;
-      float m4[4], l4[4], M = NEG_BIG;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        m4[w] = scratch[w * PART_F + 16 * HD + q];
-        l4[w] = scratch[w * PART_F + 16 * HD + 16 + q];
-        M = fmaxf(M, m4[w]);
-      }
-      float L = 0.f;
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float sc = __builtin_amdgcn_exp2f(m4[w] - M);
-        L += sc * l4[w];
-        const float4 a = *(const float4*)(scratch + w * PART_F + q * HD + col);
-        o.x += sc * a.x; o.y += sc * a.y; o.z += sc * a.z; o.w += sc * a.w;
-      }
-      const float inv = 1.0f / L;
-      if (i0 + q < P)
-        *(float4*)(O + (size_t)(row0 + i0 + q) * D + head * HD + col) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
-      RRT_TRACE_MARK();                             // merged tile stored
-    }
   }
 }
 
@@ -592,15 +702,16 @@ hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const
                      int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
   constexpr int BM = 16 * MT;
   constexpr size_t STG = (size_t)2 * (BM + BN) * BK * 4, QKV = (size_t)3 * BM * HD * 4;
-  // staging ring, then the Q/K/V tiles (Q~ in place); tap table; partials of the shared-out last tile (MT = 9)
-  constexpr size_t LDS = (STG > QKV ? STG : QKV) + 512 + (MT == 9 ? 4 * (16 * HD + 32) * 4 : 0);
+  // staging ring / Q, K, V; tap table (512 B) + bias (768 B); partials of the shared-out tile (MT = 9)
+  // staging ring / Q, K, V; tap table (512 B) + bias (768 B); shared-out tile (MT = 9): (max, sum) pairs + one partial O
+  constexpr size_t LDS = (STG > QKV ? STG : QKV) + 1280 + (MT == 9 ? MT * 32 * 4 + 16 * HD * 4 : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = rmsa_fused_kernel<MT, PREC>;
   static OncePerDevice once;
   if (once.first())
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
   const float q_scale = 1.0f / sqrtf((float)HD);
-  kern<<<dim3(heads * n_regions), dim3(384), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D, heads,
+  kern<<<dim3(heads * n_regions), dim3(512), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D, heads,
                                                       pe_w ? epeg_k : 0, q_scale);
   return hipGetLastError();
 }

@@ -22,7 +22,7 @@ raw.rrt_debug_trace_fused(None, 0, 1)
 call()
 raw.rrt_debug_trace_fused(buf.ctypes.data, buf.nbytes, 0)
 t = buf.reshape(WAVES, EV)
-NW = 6                                            # waves per block (RRT_TRACE_INIT(blockIdx.x * 6 + wave))
+NW = 8                                            # waves per block (RRT_TRACE_INIT(blockIdx.x * 8 + wave))
 nb = (t[:, 1] > 0).sum() // NW
 tb = t[:nb * NW].reshape(nb, NW, EV)[:, :, 1:].astype(np.int64)
 t0 = np.where(tb[:, :, 0] > 0, tb[:, :, 0], np.iinfo(np.int64).max).min(1)          # first wave entry of the block
