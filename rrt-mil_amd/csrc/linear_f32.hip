@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
 // 64 elements = the same 128-byte rows, so the staging ring, the XOR swizzle and the DMA schedule are byte for byte
 // those of the fp32 form; a 16-byte LDS slot is one 16x16x32 MFMA operand (k = 8 lg .. 8 lg + 7 of a 32-wide
 // sub-tile) and nothing is converted in the loop.
-template <int MT, int NT, int MODE, int PREC, bool IN16 = false>
+template <int MT, int NT, int MODE, int PREC, bool IN16 = false, bool DEFER = true>
 __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restrict__ Av,
                                                            const void* __restrict__ Bv,
                                                            float* __restrict__ C, int M, int N, int K,
@@ -483,8 +483,11 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
   // -------------------------------------------------------------------- compute waves
   const int lr = lane & 15, lg = lane >> 4;
   int it = 0;
-  // deferred epilogue state: the previous tile's accumulators, bias and origin
-  f32x4 prev[MT][NT];
+  // deferred epilogue state: the previous tile's accumulators, bias and origin.  DEFER = false (the launcher picks it
+  // when no block gets a second tile): the tile is stored straight from its accumulators -- 36 registers fewer at
+  // MT = 9, which is what lets two blocks share a CU (traced at M = 9216, N = 512: with 142 registers the blocks ran
+  // one per CU, two rounds of 49 K cycles for 37 K of MFMA each)
+  f32x4 prev[DEFER ? MT : 1][NT];
   float pbias[NT][4];
   int pm0 = 0, pn0 = 0;
   bool have_prev = false;
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int kt = 0; kt < nk; ++kt, ++it) {
+    auto kstep = [&](int kt) {
       __syncthreads();
       if (kt == 0 || kt == 1 || kt == 8 || kt == 9) RRT_TRACE_MARK();   // compute: barrier kt passed
       const float* As = lds + (it & 1) * STAGE;
@@ -605,14 +608,23 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
       }
       // one 16-row slice of the PREVIOUS tile per K iteration (behind this iteration's MFMAs)
       // (static register indexing: always slice 0, then rotate the remaining slices down)
-      if (have_prev && kt < MT) {
-        store_slice<MT, NT, MODE, 0>(prev, pbias, C, M, N, pm0 + kt * 16, pn0, wave, lr, lg, ep);
+      if constexpr (DEFER) {
+        if (have_prev && kt < MT) {
+          store_slice<MT, NT, MODE, 0>(prev, pbias, C, M, N, pm0 + kt * 16, pn0, wave, lr, lg, ep);
 #pragma unroll
-        for (int i = 0; i + 1 < MT; ++i)
+          for (int i = 0; i + 1 < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) prev[i][j] = prev[i + 1][j];
+            for (int j = 0; j < NT; ++j) prev[i][j] = prev[i + 1][j];
+        }
       }
+        };
+    for (int kt = 0; kt < nk; ++kt, ++it) kstep(kt);
+    if constexpr (!DEFER) {
+      RRT_TRACE_MARK();                               // compute: last MFMA of the tile issued
+      store_all_slices<MT, NT, MODE>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep);
+      RRT_TRACE_MARK();
     }
+    if constexpr (DEFER) {
     if (have_prev)                        // K shorter than MT iterations: flush what is left
       for (int i = nk; i < MT; ++i) {
         store_slice<MT, NT, MODE, 0>(prev, pbias, C, M, N, pm0 + i * 16, pn0, wave, lr, lg, ep);
@@ -637,9 +649,18 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
     pn0 = n0;
     have_prev = true;
     RRT_TRACE_MARK();
+    }
   }
   // the block's last tile has no successor to hide behind
-  if (have_prev) store_all_slices<MT, NT, MODE>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
+  if constexpr (DEFER)
+    if (have_prev) store_all_slices<MT, NT, MODE>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
+}
+
+template <typename KernT>
+void allow_lds(KernT kern, int lds_bytes) {          // > 64 KiB of dynamic LDS needs the attribute (once per kernel per device)
+  static OncePerDevice once;
+  if (lds_bytes > 64 * 1024 && once.first())
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 }
 
 template <int MT, int NT, int MODE, int PREC>
@@ -650,13 +671,15 @@ hipError_t launch_cfg16(const void* A, const void* B, float* C, int M, int N, in
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
   const int grid = ntiles < grid_cap ? ntiles : grid_cap;
-  auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true>;
-  if (LDS_BYTES > 64 * 1024) {
-    static OncePerDevice once;
-    if (once.first())
-      (void)hipFuncSetAttribute((const void*)kws, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (ntiles <= grid) {                                // no block gets a second tile: nothing to defer
+    auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true, false>;
+    allow_lds(kws, LDS_BYTES);
+    kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
+  } else {
+    auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true, true>;
+    allow_lds(kws, LDS_BYTES);
+    kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
   }
-  kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
   return hipGetLastError();
 }
 
@@ -669,16 +692,18 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
   const int grid = ntiles < grid_cap ? ntiles : grid_cap;
-  if constexpr (MT >= 8) {
+  if constexpr (MT >= 6) {
     static const bool use_ws = getenv("RRT_LINEAR_NO_WS") == nullptr;
     if (use_ws) {
-      auto kws = linear_ws_kernel<MT, NT, MODE, PREC>;
-      if (LDS_BYTES > 64 * 1024) {
-        static OncePerDevice once;
-        if (once.first())
-          (void)hipFuncSetAttribute((const void*)kws, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (ntiles <= grid) {                            // no block gets a second tile: nothing to defer
+        auto kws = linear_ws_kernel<MT, NT, MODE, PREC, false, false>;
+        allow_lds(kws, LDS_BYTES);
+        kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
+      } else {
+        auto kws = linear_ws_kernel<MT, NT, MODE, PREC, false, true>;
+        allow_lds(kws, LDS_BYTES);
+        kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
       }
-      kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
       return hipGetLastError();
     }
   }
@@ -810,6 +835,7 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
   RRT_CASE(8, 1);
   RRT_CASE(9, 2);
   RRT_CASE(8, 2);
+  RRT_CASE(6, 1);
   RRT_CASE(4, 1);
   RRT_CASE(2, 1);
 #undef RRT_CASE

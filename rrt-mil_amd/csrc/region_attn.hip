@@ -206,8 +206,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
     for (int jt = 0; jt < TC; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[jt][r]);
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    cmax = max_xor32(max_xor16(cmax));             // VALU lane swaps (common.h), not ds_bpermute
     asm volatile("" :: "v"(cmax));
     RRT_TRACE_MARK();                                 // [6+5c] scores complete + row max reduced
     const float m_new = fmaxf(m_run, cmax);
@@ -258,8 +257,7 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
   }
   if (!active) return;
   RRT_TRACE_MARK();                                   // last PV MFMAs issued
-  float l_tot = l_run + __shfl_xor(l_run, 16);
-  l_tot += __shfl_xor(l_tot, 32);
+  const float l_tot = sum_xor32(sum_xor16(l_run));
   const float inv = 1.0f / l_tot;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {

@@ -28,6 +28,12 @@
 
 namespace {
 
+#ifdef RRT_NT_STORE
+#define RRT_STORE_O(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define RRT_STORE_O(ptr, val) (*(ptr) = (val))
+#endif
+
 constexpr int BK = 32;
 constexpr int HD = 64;
 constexpr int BN = 3 * HD;          // q | k | v columns of one head
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * lg + r;
       if (i < P)
-        *(float4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+        RRT_STORE_O((f32x4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)), ((f32x4){oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]}));
     }
     // partials of the shared-out tile: O [query 4 lg + r][d = 4 lr + c] unnormalised, the query's max and sum
     {
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
       }
       const float invL = 1.0f / L;
       if (XT * 16 + q < P)
-        *(float2*)(O + (size_t)(row0 + XT * 16 + q) * D + head * HD + col) = make_float2(o0 * invL, o1 * invL);
+        RRT_STORE_O((f32x2*)(O + (size_t)(row0 + XT * 16 + q) * D + head * HD + col), ((f32x2){o0 * invL, o1 * invL}));
       RRT_TRACE_MARK();                             // merged tile stored
     }
   } else {
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * lg + r;
       if (i < P)
-        *(float4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+        RRT_STORE_O((f32x4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)), ((f32x4){oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]}));
     }
     RRT_TRACE_MARK();                               // tile: O stored
   }

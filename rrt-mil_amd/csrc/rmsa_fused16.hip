@@ -381,8 +381,7 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
     for (int jt = 0; jt < MT; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[jt][r]);
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    cmax = max_xor32(max_xor16(cmax));             // VALU lane swaps (common.h), not ds_bpermute
     float psum = 0.f;
 #pragma unroll
     for (int jt = 0; jt < MT; ++jt)
@@ -392,8 +391,7 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
         s[jt][r] = p;
         psum += p;
       }
-    psum += __shfl_xor(psum, 16);
-    psum += __shfl_xor(psum, 32);
+    psum = sum_xor32(sum_xor16(psum));
     const float inv = 1.0f / psum;                  // of THIS lane's query (lr): the four lg lanes agree
     asm volatile("" :: "v"(inv));
     RRT_TRACE_MARK();                               // tile: softmax done

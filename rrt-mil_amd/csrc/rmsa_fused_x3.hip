@@ -333,8 +333,7 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused_x3_kernel(const char* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[jt][r]);
     }
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    cmax = max_xor32(max_xor16(cmax));             // VALU lane swaps (common.h), not ds_bpermute
     float psum = 0.f;
 #pragma unroll
     for (int jt = 0; jt < MT; ++jt)
@@ -344,8 +343,7 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused_x3_kernel(const char* __res
         s[jt][r] = p;
         psum += p;
       }
-    psum += __shfl_xor(psum, 16);
-    psum += __shfl_xor(psum, 32);
+    psum = sum_xor32(sum_xor16(psum));
     const float inv = 1.0f / psum;                  // of THIS lane's query (lr)
     // O^T = V^T P^T: A = V^T rows d = 4 a + c (a = lr), B = P^T straight from the score registers, both as (hi, lo)
     f32x4 oacc[4];
