@@ -283,11 +283,11 @@ class EncoderWorkload:
         # one event pair per launch of the dominant kernel in the timed region: every step, every stream
         self.ev_pairs = [(self.hev.create(), self.hev.create()) for _ in range(args.steps * S)]
         self.ev_arr = (C.c_void_p * _lib.EV_COUNT)()
-        # bags in flight on different streams share a phase gate: their MFMA-bound R-MSA cores take turns
-        # instead of time-slicing the matrix pipes, and the other bag's memory-bound kernels fill the gaps
-        # (pays at two bags in flight; with three or more, free-running streams are faster -- DESIGN.md §5)
+        # optional phase gate (RRT_BENCH_GATE=1): the bags' MFMA-bound R-MSA cores take turns instead of time-slicing.
+        # Off by default since round 2: with the denser kernels free-running streams are faster at every S
+        # (fp32 S=2: 4.53 k vs 4.40 k slides/s, bf16: 12.5 k vs 11.7 k -- DESIGN.md section 5)
         self.gate = C.c_void_p()
-        want_gate = (S == 2 or os.environ.get("RRT_BENCH_GATE") == "1") and os.environ.get("RRT_BENCH_GATE", "1") != "0"
+        want_gate = os.environ.get("RRT_BENCH_GATE") == "1"
         if want_gate and self.mil is None:
             _lib.check(self.lib.rrt_phase_gate_create(C.byref(self.gate)), "phase gate")
         self.extra = {}

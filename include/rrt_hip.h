@@ -160,9 +160,10 @@ int rrt_encoder_forward_events_f32(const rrt_encoder_desc *desc, const rrt_encod
                                    void **events);
 
 /* Concurrent forwards on several streams (one bag each): a phase gate shared by those calls keeps their
- * MFMA-bound R-MSA cores from co-running (two of them only time-slice the matrix pipes; one of them next to
- * another bag's memory-bound kernels overlaps well).  Host-side object, one host thread; the executor
- * below owns one.  events may be NULL (else as in rrt_encoder_forward_events_f32). */
+ * MFMA-bound R-MSA cores from co-running (they take turns instead of time-slicing the matrix pipes).  Optional:
+ * pass gate = NULL for free-running streams, which measure faster with the current kernels (the executor below
+ * gates only under RRT_GATE=1).  Host-side object, one host thread.  events may be NULL (else as in
+ * rrt_encoder_forward_events_f32). */
 typedef struct rrt_phase_gate rrt_phase_gate;
 int rrt_phase_gate_create(rrt_phase_gate **out);
 int rrt_phase_gate_destroy(rrt_phase_gate *gate);

@@ -1012,10 +1012,11 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
   for (int s = 0; s < S && e == hipSuccess; ++s) e = hipStreamWaitEvent(ex->streams[s], ex->fork, 0);
   int rc = (int)e;
   int64_t load[RRT_EXEC_MAX_STREAMS] = {0};
-  // phase gate: measured +1.5 % at two bags in flight (and the fused kernel then runs at its stand-alone
-  // speed); with three or more in flight free-running streams are faster (4.57 k vs 4.32 k slides/s)
-  static const bool gate_off = getenv("RRT_NO_GATE") != nullptr;
-  const bool gated = S == 2 && !gate_off;
+  // phase gate (the R-MSA cores of the bags in flight take turns): opt-in, RRT_GATE=1.  It paid +1.5 % at two bags in
+  // flight with the round-1 kernels; with the round-2 kernels free-running streams are faster at every S (configs[4]
+  // mix, bf16: 7.72 k vs 7.49 k slides/s; fp32: 3.74 k vs 3.68 k)
+  static const bool gate_on = getenv("RRT_GATE") != nullptr;
+  const bool gated = S == 2 && gate_on;
   for (int k = 0; k < n_bags && rc == RRT_OK; ++k) {
     const rrt_bag& b = bags[order[k]];
     int s = 0;

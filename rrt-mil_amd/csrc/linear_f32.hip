@@ -695,7 +695,8 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
   if constexpr (MT >= 6) {
     static const bool use_ws = getenv("RRT_LINEAR_NO_WS") == nullptr;
     if (use_ws) {
-      if (ntiles <= grid) {                            // no block gets a second tile: nothing to defer
+      static const bool force_defer = getenv("RRT_LINEAR_DEFER") != nullptr;   // tuning hook
+      if (ntiles <= grid && !force_defer) {            // no block gets a second tile: nothing to defer
         auto kws = linear_ws_kernel<MT, NT, MODE, PREC, false, false>;
         allow_lds(kws, LDS_BYTES);
         kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);

@@ -493,19 +493,16 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
     cmax = max_xor32(max_xor16(cmax));
     xmax = max_xor32(max_xor16(xmax));
     ymax = max_xor32(max_xor16(ymax));
-    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
-    {
-      const f32x4 c4 = {cmax, cmax, cmax, cmax};
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};              // four independent partial sums (plain scalar ops: the packed
+#pragma unroll                                       // forms cost more in register moves than they saved)
+    for (int j = 0; j < MT; ++j)
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        f32x4 t = s[j] - c4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = __builtin_amdgcn_exp2f(t[r]);
-        s[j] = t;
-        acc4 += t;
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[j][r] - cmax);
+        s[j][r] = e;
+        a4[r] += e;
       }
-    }
-    float psum = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]), xsum = 0.f, ysum = 0.f;
+    float psum = (a4[0] + a4[1]) + (a4[2] + a4[3]), xsum = 0.f, ysum = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       sx[r] = __builtin_amdgcn_exp2f(sx[r] - xmax);
@@ -516,37 +513,49 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
     psum = sum_xor32(sum_xor16(psum));
     xsum = sum_xor32(sum_xor16(xsum));
     ysum = sum_xor32(sum_xor16(ysum));
-    // normalised here, where a lane's 36 probabilities all belong to ITS query (lane & 15): the output tile holds
-    // query 4 lg + r in register r, and fetching that query's 1 / sum there is a general lane permute
+    // 1 / sum of query 4 lg + r for the output registers: a general lane permute (ds_bpermute), issued here and
+    // consumed after the P.V products -- its trip through the LDS queue is hidden behind them
+    float ir[4];
     {
       const float inv = 1.0f / psum;
-      const f32x4 i4 = {inv, inv, inv, inv};
 #pragma unroll
-      for (int j = 0; j < MT; ++j) s[j] *= i4;
+      for (int r = 0; r < 4; ++r) ir[r] = __shfl(inv, 4 * lg + r);
     }
     RRT_TRACE_MARK();                               // tile: softmax done
     f32x4 oacc[4], ox[4], oy[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) oacc[c] = ox[c] = oy[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      // V rows PD groups ahead of their four MFMAs (the compiler's own schedule fetched one group = 128 cycles ahead,
+      // less than an LDS round trip with eight waves reading)
+      constexpr int G = 4 * MT, PD = 5;
+      float4 vq[G];
+      auto vload = [&](int g) {
+        const int rr = 4 * lg + (g & 3);
+        return *(const float4*)(Vs + (tk[g >> 2] * 16 + rr) * HD + ((lr ^ rr) << 2));
+      };
 #pragma unroll
-    for (int j = 0; j < MT; ++j)
+      for (int g = 0; g < PD; ++g) vq[g] = vload(g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 4 * lg + r;
-        const float4 v = *(const float4*)(Vs + (tk[j] * 16 + rr) * HD + ((lr ^ rr) << 2));
-        const float p = s[j][r];
+      for (int g = 0; g < G; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + PD < G) vq[g + PD] = vload(g + PD);
+        const float4 v = vq[g];
+        const float p = s[g >> 2][g & 3];
         oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.x, oacc[0], 0, 0, 0);
         oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.y, oacc[1], 0, 0, 0);
         oacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.z, oacc[2], 0, 0, 0);
         oacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.w, oacc[3], 0, 0, 0);
-        if (j == 0) {
-          const float px = sx[r];
+        if (g < 4) {                                 // position 0 = key tile `wave`: the shared-out tile's partial
+          const float px = sx[g];
           ox[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, v.x, ox[0], 0, 0, 0);
           ox[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, v.y, ox[1], 0, 0, 0);
           ox[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, v.z, ox[2], 0, 0, 0);
           ox[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, v.w, ox[3], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (wave == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -564,7 +573,8 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * lg + r;
       if (i < P)
-        RRT_STORE_O((f32x4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)), ((f32x4){oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]}));
+        RRT_STORE_O((f32x4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)),
+                    ((f32x4){oacc[0][r] * ir[r], oacc[1][r] * ir[r], oacc[2][r] * ir[r], oacc[3][r] * ir[r]}));
     }
     // partials of the shared-out tile: O [query 4 lg + r][d = 4 lr + c] unnormalised, the query's max and sum
     {
@@ -656,24 +666,21 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[jt][r]);
     cmax = max_xor32(max_xor16(cmax));
-    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
-    {
-      const f32x4 c4 = {cmax, cmax, cmax, cmax};
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int jt = 0; jt < MT; ++jt) {
-        f32x4 t = s[jt] - c4;
+    for (int jt = 0; jt < MT; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = __builtin_amdgcn_exp2f(t[r]);
-        s[jt] = t;
-        acc4 += t;
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[jt][r] - cmax);
+        s[jt][r] = e;
+        a4[r] += e;
       }
-    }
-    const float psum = sum_xor32(sum_xor16((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])));
+    const float psum = sum_xor32(sum_xor16((a4[0] + a4[1]) + (a4[2] + a4[3])));
+    float ir[4];                                     // 1 / sum of query 4 lg + r: permute issued here, consumed after P.V
     {
-      const float inv = 1.0f / psum;                // applied where a lane's probabilities all belong to its query
-      const f32x4 i4 = {inv, inv, inv, inv};
+      const float inv = 1.0f / psum;
 #pragma unroll
-      for (int jt = 0; jt < MT; ++jt) s[jt] *= i4;
+      for (int r = 0; r < 4; ++r) ir[r] = __shfl(inv, 4 * lg + r);
     }
     RRT_TRACE_MARK();                               // tile: softmax done
     f32x4 oacc[4];
@@ -696,7 +703,8 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * lg + r;
       if (i < P)
-        RRT_STORE_O((f32x4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)), ((f32x4){oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]}));
+        RRT_STORE_O((f32x4*)(O + (size_t)(row0 + i) * D + head * HD + (lr << 2)),
+                    ((f32x4){oacc[0][r] * ir[r], oacc[1][r] * ir[r], oacc[2][r] * ir[r], oacc[3][r] * ir[r]}));
     }
     RRT_TRACE_MARK();                               // tile: O stored
   }

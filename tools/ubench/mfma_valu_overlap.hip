@@ -9,7 +9,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int MODE, bool BF = false>
+template <int MODE, bool BF = false, bool PRIO = false>
 __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* cyc, int iters) {
   const int wave = threadIdx.x >> 6;
   f32x4 acc[8];
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* cyc,
       }
     }
   } else if (do_valu) {
+    if (PRIO) __builtin_amdgcn_s_setprio(3);
     if (MODE == 5 || MODE == 7) {
       for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -68,12 +69,12 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* cyc,
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <int MODE, bool BF = false>
+template <int MODE, bool BF = false, bool PRIO = false>
 void run(const char* what, float* out, unsigned long long* cyc, int iters) {
   const int nb = 256;
   std::vector<unsigned long long> h(nb * 8);
-  k<MODE, BF><<<nb, 512>>>(out, cyc, iters);
-  k<MODE, BF><<<nb, 512>>>(out, cyc, iters);
+  k<MODE, BF, PRIO><<<nb, 512>>>(out, cyc, iters);
+  k<MODE, BF, PRIO><<<nb, 512>>>(out, cyc, iters);
   hipDeviceSynchronize();
   hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
   std::vector<double> lo, hi;
@@ -103,6 +104,8 @@ int main() {
   run<5>("5: waves 0-3 MFMA, waves 4-7 v_exp", out, cyc, iters);
   run<4>("4: all waves MFMA + 6 independent fma per MFMA in the same wave", out, cyc, iters);
   run<6>("6: all waves MFMA + 2 v_exp per MFMA in the same wave", out, cyc, iters);
+  run<2, false, true>("2p: waves 0-3 MFMA, waves 4-7 VALU fma at s_setprio 3", out, cyc, iters);
+  run<5, false, true>("5p: waves 0-3 MFMA, waves 4-7 v_exp at s_setprio 3", out, cyc, iters);
   printf("---- the same with v_mfma_f32_16x16x32_bf16\n");
   run<1, true>("1: waves 0-3 MFMA bf16 (16 K each), waves 4-7 idle", out, cyc, iters);
   run<0, true>("0: all 8 waves MFMA bf16 (2 per SIMD)", out, cyc, iters);
@@ -110,5 +113,6 @@ int main() {
   run<5, true>("5: waves 0-3 MFMA bf16, waves 4-7 v_exp", out, cyc, iters);
   run<4, true>("4: all waves MFMA bf16 + 6 independent fma per MFMA in the same wave", out, cyc, iters);
   run<6, true>("6: all waves MFMA bf16 + 2 v_exp per MFMA in the same wave", out, cyc, iters);
+  run<2, true, true>("2p: waves 0-3 MFMA bf16, waves 4-7 VALU fma at s_setprio 3", out, cyc, iters);
   return 0;
 }
