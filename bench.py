@@ -291,6 +291,7 @@ class EncoderWorkload:
         if want_gate and self.mil is None:
             _lib.check(self.lib.rrt_phase_gate_create(C.byref(self.gate)), "phase gate")
         self.extra = {}
+        self._w16_mode = [None] * S      # compute mode of the 16-bit weight images in each stream's workspace
 
     def _mark(self, a, b):
         for j in range(self._lib.EV_COUNT):
@@ -310,10 +311,16 @@ class EncoderWorkload:
                 continue
             # mark the dominant kernel: [after LN+partition, after the fused R-MSA core]
             evs = self._mark(*self.ev_pairs[i * self.S + s_]) if timed else None
+            # reduced-precision modes: this stream's workspace keeps the 16-bit weight images of the (unchanged)
+            # weights from its first call on, as rrt_mil_amd.RRTEncoder does between forwards (weights16_valid)
+            mode = self.enc._desc.compute
+            self.enc._desc.weights16_valid = int(mode != _lib.COMPUTE_F32 and self._w16_mode[s_] == mode)
+            self._w16_mode[s_] = mode
             rc = lib.rrt_encoder_forward_gated_f32(C.byref(self.enc._desc), C.byref(self.w), x.data_ptr(),
                                                    self.outs[s_].data_ptr(), self.n, self.wss[s_].data_ptr(),
                                                    self.wss[s_].numel(), self.streams[s_], self.gate, evs)
             _lib.check(rc, "forward")
+        self.enc._desc.weights16_valid = 0
 
     def sync(self):
         self.torch.cuda.synchronize()

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 17
+#define RRT_ABI_VERSION 18
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -94,6 +94,11 @@ typedef struct rrt_encoder_desc {
   /* EPEG ablations (rmsa.py:76-85,106-129; inference only, unfused path): */
   int32_t epeg_2d;         /* 1: k x k kernel -- over the score map ('attn') or over v's sqrt(P) x sqrt(P) image ('value_*') */
   int32_t epeg_type;       /* RRT_EPEG_ATTN (default) / RRT_EPEG_VALUE_BF / RRT_EPEG_VALUE_AF */
+  /* Reduced-precision modes (BF16 / F16 / F32X3) keep 16-bit images of the R-MSA weights at the START of the workspace
+   * (4 dim^2 floats per layer, whatever n_tokens is).  1: the images in THIS workspace were written by an earlier
+   * call with the same weights, dim, n_rmsa_layers and compute -- skip the conversion (one launch, ~5 us).  The
+   * library keeps no state: 0 is always right, 1 is the caller's promise (rrt_mil_amd tracks parameter versions). */
+  int32_t weights16_valid;
 } rrt_encoder_desc;
 
 /* One TransLayer's parameters: InnerAttention, modules/rmsa.py:57-89 (+ the optional FFN).  Row-major, fp32.
@@ -122,6 +127,10 @@ typedef struct rrt_encoder_weights {
   /* pos_embedding.proj / proj1 / proj2 (depth-wise [dim, 1, k, k] or [dim, 1, k, 1]; PEG: only [0]); biases may be
    * NULL (peg_bias = False) */
   const float *pos_w[3], *pos_b[3];
+  /* 0 = unknown.  Otherwise a number the caller changes whenever any weight VALUE changes (the pointers alone do not
+   * tell): the executor, which owns its workspaces, skips the 16-bit weight conversion of the reduced-precision modes
+   * while it stays the same.  Stateless entry points ignore it (see rrt_encoder_desc.weights16_valid). */
+  uint64_t version;
 } rrt_encoder_weights;
 
 int         rrt_abi_version(void);

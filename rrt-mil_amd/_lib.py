@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _f32p = C.POINTER(C.c_float)
 
@@ -29,7 +29,7 @@ class EncoderDesc(C.Structure):
                 ("crmsa_mlp", C.c_int32), ("all_shortcut", C.c_int32), ("compute", C.c_int32),
                 ("ffn", C.c_int32), ("ffn_act", C.c_int32), ("ffn_hidden", C.c_int32),
                 ("pos", C.c_int32), ("pos_pos", C.c_int32), ("peg_k", C.c_int32), ("peg_1d", C.c_int32),
-                ("epeg_2d", C.c_int32), ("epeg_type", C.c_int32)]
+                ("epeg_2d", C.c_int32), ("epeg_type", C.c_int32), ("weights16_valid", C.c_int32)]
 
 
 class AttnWeights(C.Structure):
@@ -42,7 +42,7 @@ class EncoderWeights(C.Structure):
     _fields_ = [("rmsa", AttnWeights * RRT_MAX_RMSA_LAYERS), ("crmsa", AttnWeights),
                 ("phi", C.c_void_p), ("phi0_w", C.c_void_p), ("phi2_w", C.c_void_p),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
-                ("pos_w", C.c_void_p * 3), ("pos_b", C.c_void_p * 3)]
+                ("pos_w", C.c_void_p * 3), ("pos_b", C.c_void_p * 3), ("version", C.c_uint64)]
 
 
 class AttnGrads(C.Structure):

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(Cast16Jobs jobs) {
   }
 }
 
-template <int NV, int PREC>   // float4 per lane: supports dim <= NV*256
+template <int NV, int PREC, bool FULL>   // float4 per lane: dim <= NV*256; FULL: dim == NV*256, no lane predication (ln_partition.hip)
 __global__ __launch_bounds__(256) void ln_partition16_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void ln_partition16_kernel(const float* __rest
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      if (c < dim) *(uint2*)(dst + c) = make_uint2(0u, 0u);
+      if (FULL || c < dim) *(uint2*)(dst + c) = make_uint2(0u, 0u);
     }
     return;
   }
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_partition16_kernel(const float* __rest
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    r[v] = (c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[v] = (FULL || c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     sum += (r[v].x + r[v].y) + (r[v].z + r[v].w);
   }
   const float inv_d = 1.0f / (float)dim;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void ln_partition16_kernel(const float* __rest
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    if (c < dim) {
+    if (FULL || c < dim) {
       float a = r[v].x - mean, b = r[v].y - mean, cc = r[v].z - mean, d = r[v].w - mean;
       sq += (a * a + b * b) + (cc * cc + d * d);
     }
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_partition16_kernel(const float* __rest
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    if (c < dim) {
+    if (FULL || c < dim) {
       float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
       *(uint2*)(dst + c) = pack4<PREC>((r[v].x - mean) * rstd * gm.x + bt.x, (r[v].y - mean) * rstd * gm.y + bt.y,
                                        (r[v].z - mean) * rstd * gm.z + bt.z, (r[v].w - mean) * rstd * gm.w + bt.w);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void cast_split_kernel(Cast16Jobs jobs) {
   }
 }
 
-template <int NV>
+template <int NV, bool FULL>
 __global__ __launch_bounds__(256) void ln_partition_split_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta,
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void ln_partition_split_kernel(const float* __
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      if (c < dim) *(float4*)(dst + (size_t)c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (FULL || c < dim) *(float4*)(dst + (size_t)c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
   }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void ln_partition_split_kernel(const float* __
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    r[v] = (c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[v] = (FULL || c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     sum += (r[v].x + r[v].y) + (r[v].z + r[v].w);
   }
   const float inv_d = 1.0f / (float)dim;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void ln_partition_split_kernel(const float* __
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    if (c < dim) {
+    if (FULL || c < dim) {
       float a = r[v].x - mean, b = r[v].y - mean, cc = r[v].z - mean, d = r[v].w - mean;
       sq += (a * a + b * b) + (cc * cc + d * d);
     }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void ln_partition_split_kernel(const float* __
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    if (c < dim) {
+    if (FULL || c < dim) {
       float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
       uint2 hi, lo;
       split4((r[v].x - mean) * rstd * gm.x + bt.x, (r[v].y - mean) * rstd * gm.y + bt.y,
@@ -190,10 +190,16 @@ hipError_t launch_ln_partition_split(const float* x, const float* gamma, const f
                                      const GridDev& g, hipStream_t st) {
   if (dim % 32) return hipErrorInvalidValue;
   dim3 grid((g.Np + 3) / 4), block(256);
-  if (dim <= 256) ln_partition_split_kernel<1><<<grid, block, 0, st>>>(x, gamma, beta, (char*)u, dim, g);
-  else if (dim <= 512) ln_partition_split_kernel<2><<<grid, block, 0, st>>>(x, gamma, beta, (char*)u, dim, g);
-  else if (dim <= 1024) ln_partition_split_kernel<4><<<grid, block, 0, st>>>(x, gamma, beta, (char*)u, dim, g);
-  else ln_partition_split_kernel<8><<<grid, block, 0, st>>>(x, gamma, beta, (char*)u, dim, g);
+#define RRT_LNPS(NV)                                                                                          \
+  do {                                                                                                      \
+    if (dim == NV * 256) ln_partition_split_kernel<NV, true><<<grid, block, 0, st>>>(x, gamma, beta, (char*)u, dim, g);  \
+    else ln_partition_split_kernel<NV, false><<<grid, block, 0, st>>>(x, gamma, beta, (char*)u, dim, g);                 \
+  } while (0)
+  if (dim <= 256) RRT_LNPS(1);
+  else if (dim <= 512) RRT_LNPS(2);
+  else if (dim <= 1024) RRT_LNPS(4);
+  else RRT_LNPS(8);
+#undef RRT_LNPS
   return hipGetLastError();
 }
 
@@ -217,8 +223,13 @@ hipError_t launch_ln_partition16(const float* x, const float* gamma, const float
   dim3 grid((g.Np + 3) / 4), block(256);
 #define RRT_LNP16(NV)                                                                               \
   do {                                                                                              \
-    if (prec == 1) ln_partition16_kernel<NV, 1><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);  \
-    else ln_partition16_kernel<NV, 2><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);           \
+    if (dim == NV * 256) {                                                                          \
+      if (prec == 1) ln_partition16_kernel<NV, 1, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);  \
+      else ln_partition16_kernel<NV, 2, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);           \
+    } else {                                                                                        \
+      if (prec == 1) ln_partition16_kernel<NV, 1, false><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g); \
+      else ln_partition16_kernel<NV, 2, false><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);          \
+    }                                                                                               \
   } while (0)
   if (dim <= 256) RRT_LNP16(1);
   else if (dim <= 512) RRT_LNP16(2);

@@ -57,6 +57,31 @@ __device__ __forceinline__ bool rrt_drop_keep(unsigned seed, unsigned long long 
   return h >= thresh;
 }
 
+// ---- lane ^ 16 / lane ^ 32 reductions on the VALU ------------------------------------------------
+// gfx950 v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two registers.  __shfl_xor lowers to
+// ds_bpermute_b32, which queues in the LDS pipe behind every wave's fragment reads (traced in the attention phases: a
+// softmax with six dependent bpermutes took 3.5 K cycles next to ~1.5 K of VALU work).
+static __device__ __forceinline__ float max_xor16(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static __device__ __forceinline__ float max_xor32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static __device__ __forceinline__ float sum_xor16(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+static __device__ __forceinline__ float sum_xor32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Wave-wide reductions without LDS traffic: __shfl_xor lowers to ds_bpermute_b32 (an LDS-pipe round
 // trip per step, 6 dependent steps per reduction); here 4 DPP row rotations reduce each 16-lane row
 // in the VALU and 4 v_readlane + scalar-operand adds combine the rows.  Result is wave-uniform.
@@ -70,7 +95,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += RRT_DPP_ROR(v, 4);
   v += RRT_DPP_ROR(v, 2);
   v += RRT_DPP_ROR(v, 1);
+#ifdef RRT_WAVE_SUM_READLANE
   return (rrt_readlane(v, 0) + rrt_readlane(v, 16)) + (rrt_readlane(v, 32) + rrt_readlane(v, 48));
+#else
+  return sum_xor32(sum_xor16(v));     // rows combined by lane swaps, the result in every lane (no SGPR round trip)
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, RRT_DPP_ROR(v, 8));
@@ -124,31 +153,6 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 }
 
 #define LN_EPS 1e-5f
-
-// ---- lane ^ 16 / lane ^ 32 reductions on the VALU ------------------------------------------------
-// gfx950 v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two registers.  __shfl_xor lowers to
-// ds_bpermute_b32, which queues in the LDS pipe behind every wave's fragment reads (traced in the attention phases: a
-// softmax with six dependent bpermutes took 3.5 K cycles next to ~1.5 K of VALU work).
-static __device__ __forceinline__ float max_xor16(float v) {
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-static __device__ __forceinline__ float max_xor32(float v) {
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-static __device__ __forceinline__ float sum_xor16(float v) {
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-static __device__ __forceinline__ float sum_xor32(float v) {
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 // ---- optional in-kernel timeline tracing (tools/build_ablation.sh trace -DRRT_TRACE) ------------
 // Per wave: up to RRT_TRACE_EV 64-bit shader-clock stamps + HW_ID/XCC_ID, written to a device

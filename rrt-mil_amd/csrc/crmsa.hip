@@ -19,6 +19,16 @@
 //   crmsa_dispatch_ln_kernel: 2 tokens / wave.  k-term axpy + residual (+shortcut) + LayerNorm.
 #include "internal.h"
 
+#ifdef RRT_DBG_LOGITS
+__device__ float g_dbg_sq[4096 * 64];
+__device__ float g_dbg_tot[4096 * 64];
+extern "C" int rrt_dbg_logits_read(float* sq, float* tot) {
+  hipError_t e = hipMemcpyFromSymbol(sq, HIP_SYMBOL(g_dbg_sq), sizeof(float) * 4096 * 64);
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(tot, HIP_SYMBOL(g_dbg_tot), sizeof(float) * 4096 * 64);
+  return (int)e;
+}
+#endif
+
 namespace {
 
 constexpr int KMAX = RRT_MAX_CRMSA_K;
@@ -27,7 +37,8 @@ constexpr int KMAX = RRT_MAX_CRMSA_K;
 constexpr int RW = 4;
 constexpr int RW_DISPATCH = 2;
 
-template <int NV>
+// FULL: dim == NV * 256 exactly (every lane's columns exist): no column guards in the row loops
+template <int NV, bool FULL>
 __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restrict__ x1,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
@@ -56,7 +67,7 @@ __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restri
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      r[i][v] = (t < g.L && c < dim) ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r[i][v] = (t < g.L && (FULL || c < dim)) ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       sum[i] += (r[i][v].x + r[i][v].y) + (r[i][v].z + r[i][v].w);
     }
   }
@@ -70,19 +81,28 @@ __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restri
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      if (c < dim) {
+      if (FULL || c < dim) {
         float a = r[i][v].x - mean[i], b = r[i][v].y - mean[i], cc = r[i][v].z - mean[i], d = r[i][v].w - mean[i];
         sq[i] += (a * a + b * b) + (cc * cc + d * d);
       }
     }
   }
+#ifdef RRT_DBG_LOGITS
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const float tot = wave_sum(sq[i]);
+    if (t0 + i < 4096) { g_dbg_sq[(t0 + i) * 64 + lane] = sq[i]; g_dbg_tot[(t0 + i) * 64 + lane] = tot; }
+    rstd[i] = 1.0f / sqrtf(tot * inv_d + LN_EPS);
+  }
+#else
 #pragma unroll
   for (int i = 0; i < RW; ++i) rstd[i] = 1.0f / sqrtf(wave_sum(sq[i]) * inv_d + LN_EPS);
+#endif
   // normalise in place: r <- LN(x1) rows
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    if (c < dim) {
+    if (FULL || c < dim) {
       const float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
@@ -100,7 +120,7 @@ __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restri
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      if (c < dim) {
+      if (FULL || c < dim) {
         const float4 ph = *(const float4*)(phi_t + n * dim + c);
 #pragma unroll
         for (int i = 0; i < RW; ++i)
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
   }
 }
 
-template <int NV, bool CRMSA>
+template <int NV, bool CRMSA, bool FULL>   // FULL: dim == NV * 256, no lane predication (see ln_partition.hip)
 __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
     const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ wdisp,
     const float* __restrict__ rep2, const float* __restrict__ gamma,
@@ -296,8 +316,8 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      r[i][v] = c < dim ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (x0 && c < dim) {
+      r[i][v] = (FULL || c < dim) ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x0 && (FULL || c < dim)) {
         float4 s = *(const float4*)(x0 + (size_t)t * dim + c);
         r[i][v].x += s.x; r[i][v].y += s.y; r[i][v].z += s.z; r[i][v].w += s.w;
       }
@@ -318,7 +338,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
 #pragma unroll
           for (int v = 0; v < NV; ++v) {
             int c = (v * 64 + lane) * 4;
-            if (c < dim) {
+            if (FULL || c < dim) {
               const float4 q = *(const float4*)(rp + c);
               r[i][v].x += w * q.x; r[i][v].y += w * q.y; r[i][v].z += w * q.z; r[i][v].w += w * q.w;
             }
@@ -333,7 +353,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         int c = (v * 64 + lane) * 4;
-        if (c < dim) *(float4*)(y + (size_t)(t0 + i) * dim + c) = r[i][v];
+        if (FULL || c < dim) *(float4*)(y + (size_t)(t0 + i) * dim + c) = r[i][v];
       }
     }
     return;
@@ -353,7 +373,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      if (c < dim) {
+      if (FULL || c < dim) {
         float a = r[i][v].x - mean[i], b = r[i][v].y - mean[i], cc = r[i][v].z - mean[i], d = r[i][v].w - mean[i];
         sq += (a * a + b * b) + (cc * cc + d * d);
       }
@@ -363,7 +383,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    if (c < dim) {
+    if (FULL || c < dim) {
       const float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
 #pragma unroll
       for (int i = 0; i < RW; ++i)
@@ -410,9 +430,13 @@ hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
                            const float* rep2, const float* gamma, const float* beta, float* y, int L,
                            int dim, int k, const GridDev& g, hipStream_t st) {
   dim3 grid((L + 4 * RW_DISPATCH - 1) / (4 * RW_DISPATCH)), block(256);
-#define RRT_DISPATCH(NV)                                                                    \
-  crmsa_dispatch_ln_kernel<NV, CRMSA><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, \
-                                                              beta, y, L, dim, k, g)
+#define RRT_DISPATCH(NV)                                                                                         \
+  do {                                                                                                           \
+    if (dim == NV * 256)                                                                                         \
+      crmsa_dispatch_ln_kernel<NV, CRMSA, true><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g);  \
+    else                                                                                                         \
+      crmsa_dispatch_ln_kernel<NV, CRMSA, false><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
+  } while (0)
   if (dim <= 256) RRT_DISPATCH(1);
   else if (dim <= 512) RRT_DISPATCH(2);
   else if (dim <= 1024) RRT_DISPATCH(4);
@@ -430,7 +454,10 @@ hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float*
   dim3 grid(ngroups < 1024 ? ngroups : 1024), block(256);     // <= 4 resident blocks per CU, grid-stride
   const size_t lds = (size_t)dim * k * sizeof(float);
 #define RRT_LOGITS(NV) \
-  crmsa_logits_kernel<NV><<<grid, block, lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, dim, k, g8)
+  do {                                                                                                      \
+    if (dim == NV * 256) crmsa_logits_kernel<NV, true><<<grid, block, lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, dim, k, g8);  \
+    else crmsa_logits_kernel<NV, false><<<grid, block, lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, dim, k, g8);               \
+  } while (0)
   if (dim <= 256) RRT_LOGITS(1);
   else if (dim <= 512) RRT_LOGITS(2);
   else if (dim <= 1024) RRT_LOGITS(4);

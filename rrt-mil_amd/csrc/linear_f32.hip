@@ -656,12 +656,14 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
     if (have_prev) store_all_slices<MT, NT, MODE>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
 }
 
-template <typename KernT>
-void allow_lds(KernT kern, int lds_bytes) {          // > 64 KiB of dynamic LDS needs the attribute (once per kernel per device)
-  static OncePerDevice once;
-  if (lds_bytes > 64 * 1024 && once.first())
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-}
+// > 64 KiB of dynamic LDS needs the attribute, once per kernel per device: the static lives at the call site (inside
+// the launcher's template instantiation), one per kernel
+#define RRT_ALLOW_LDS(kern, lds_bytes)                                                                          \
+  do {                                                                                                          \
+    static OncePerDevice once_;                                                                                 \
+    if ((lds_bytes) > 64 * 1024 && once_.first())                                                               \
+      (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (lds_bytes));  \
+  } while (0)
 
 template <int MT, int NT, int MODE, int PREC>
 hipError_t launch_cfg16(const void* A, const void* B, float* C, int M, int N, int K, int grid_cap,
@@ -673,11 +675,11 @@ hipError_t launch_cfg16(const void* A, const void* B, float* C, int M, int N, in
   const int grid = ntiles < grid_cap ? ntiles : grid_cap;
   if (ntiles <= grid) {                                // no block gets a second tile: nothing to defer
     auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true, false>;
-    allow_lds(kws, LDS_BYTES);
+    RRT_ALLOW_LDS(kws, LDS_BYTES);
     kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
   } else {
     auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true, true>;
-    allow_lds(kws, LDS_BYTES);
+    RRT_ALLOW_LDS(kws, LDS_BYTES);
     kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
   }
   return hipGetLastError();
@@ -698,11 +700,11 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
       static const bool force_defer = getenv("RRT_LINEAR_DEFER") != nullptr;   // tuning hook
       if (ntiles <= grid && !force_defer) {            // no block gets a second tile: nothing to defer
         auto kws = linear_ws_kernel<MT, NT, MODE, PREC, false, false>;
-        allow_lds(kws, LDS_BYTES);
+        RRT_ALLOW_LDS(kws, LDS_BYTES);
         kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
       } else {
         auto kws = linear_ws_kernel<MT, NT, MODE, PREC, false, true>;
-        allow_lds(kws, LDS_BYTES);
+        RRT_ALLOW_LDS(kws, LDS_BYTES);
         kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
       }
       return hipGetLastError();

@@ -6,7 +6,11 @@
 // token row, float4 (16 B/lane) accesses, two-pass mean/variance held in registers.
 #include "internal.h"
 
-template <int NV>   // float4 per lane: supports dim <= NV*256
+// FULL: dim == NV * 256 (every lane's columns exist) -> no lane predication in the row loops.  Not only a few
+// instructions: the predicated form (v_cmp -> SGPR mask -> v_cndmask / s_and_saveexec around packed fp32 ops) gave
+// wrong values in lanes 48..63 of a row now and then when the wave shared its SIMD with bf16-MFMA waves of another
+// kernel (found as run-to-run differences of crmsa_logits_kernel next to rmsa_fused_x3_kernel)
+template <int NV, bool FULL>   // float4 per lane: supports dim <= NV*256
 __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
@@ -19,7 +23,7 @@ __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restri
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      if (c < dim) *(float4*)(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (FULL || c < dim) *(float4*)(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
   }
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restri
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    r[v] = (c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[v] = (FULL || c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     sum += (r[v].x + r[v].y) + (r[v].z + r[v].w);
   }
   const float inv_d = 1.0f / (float)dim;
@@ -38,7 +42,7 @@ __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restri
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    if (c < dim) {
+    if (FULL || c < dim) {
       float a = r[v].x - mean, b = r[v].y - mean, cc = r[v].z - mean, d = r[v].w - mean;
       sq += (a * a + b * b) + (cc * cc + d * d);
     }
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restri
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    if (c < dim) {
+    if (FULL || c < dim) {
       float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
       float4 o;
       o.x = (r[v].x - mean) * rstd * gm.x + bt.x;
@@ -62,9 +66,15 @@ __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restri
 hipError_t launch_ln_partition(const float* x, const float* gamma, const float* beta, float* u,
                                int dim, const GridDev& g, hipStream_t st) {
   dim3 grid((g.Np + 3) / 4), block(256);
-  if (dim <= 256) ln_partition_kernel<1><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);
-  else if (dim <= 512) ln_partition_kernel<2><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);
-  else if (dim <= 1024) ln_partition_kernel<4><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);
-  else ln_partition_kernel<8><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);
+#define RRT_LNP(NV)                                                                              \
+  do {                                                                                         \
+    if (dim == NV * 256) ln_partition_kernel<NV, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);  \
+    else ln_partition_kernel<NV, false><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);                 \
+  } while (0)
+  if (dim <= 256) RRT_LNP(1);
+  else if (dim <= 512) RRT_LNP(2);
+  else if (dim <= 1024) RRT_LNP(4);
+  else RRT_LNP(8);
+#undef RRT_LNP
   return hipGetLastError();
 }

@@ -311,8 +311,24 @@ class RRTEncoder(nn.Module):
             w.fc2_w, w.fc2_b = self._ptr(layer.mlp.fc2.weight), self._ptr(layer.mlp.fc2.bias)
         return w
 
+    def _weights_version(self):
+        """A number that changes whenever an R-MSA qkv / proj weight does (storage pointer or autograd version counter:
+        optimizer steps, load_state_dict, .to(), in-place ops all bump one of them; writes through ``p.data`` do not --
+        call invalidate_weight_cache() after those).  Lets the library keep the 16-bit weight images of the
+        reduced-precision modes across calls (rrt_encoder_desc.weights16_valid, rrt_encoder_weights.version)."""
+        fp = tuple((p.data_ptr(), p._version) for layer in self.layers.children()
+                   for p in (layer.attn.attn.qkv.weight, layer.attn.attn.proj.weight))
+        if fp != getattr(self, "_w_fp", None):
+            self._w_fp, self._w_ver = fp, getattr(self, "_w_ver", 0) + 1
+        return self._w_ver
+
+    def invalidate_weight_cache(self):
+        """Forget the cached 16-bit weight images (needed only after writing weights through ``.data``)."""
+        self._w_fp, self._w16_key = None, None
+
     def _weights(self):
         w = _lib.EncoderWeights()
+        w.version = self._weights_version()
         for i, layer in enumerate(self.layers.children()):
             w.rmsa[i] = self._attn_weights(layer)
         if self._desc.cr_msa:
@@ -447,8 +463,13 @@ class RRTEncoder(nn.Module):
         self._desc.compute = self._compute_mode()
         with torch.cuda.device(x2d.device):      # kernels launch on the bag's device, whatever the current one is
             stream = torch.cuda.current_stream(x2d.device).cuda_stream
+            # the 16-bit weight images at the head of this workspace are still those of these weights?
+            key = (ws.data_ptr(), self._desc.compute, w.version, stream)
+            self._desc.weights16_valid = int(self._desc.compute != _lib.COMPUTE_F32 and key == getattr(self, "_w16_key", None))
             rc = lib.rrt_encoder_forward_f32(C.byref(self._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
                                              ws.data_ptr(), ws.numel(), stream)
+            self._desc.weights16_valid = 0
+            self._w16_key = key if rc == 0 and self._desc.compute != _lib.COMPUTE_F32 else None
         _lib.check(rc, "rrt_encoder_forward_f32")
         return y
 

@@ -1028,6 +1028,77 @@ def test_encoder_amp_against_restatement_and_reference_autocast(name, dt):
     assert to_fp32.max() > 1e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [torch.bfloat16, "f32x3"])
+def test_weight_image_cache_follows_the_parameters(mode):
+    """The 16-bit weight images of the reduced-precision modes are kept in the workspace between forwards
+    (rrt_encoder_desc.weights16_valid; rrt_mil_amd tracks parameter versions): a cached call is bit-identical to an
+    uncached one, and a weight update -- an optimizer-style in-place op -- is picked up by the next forward."""
+    from hip_util import encoder_from_state, dev
+    g = load_golden("G3_d512_n9000")
+    x, st, cfg = synth_case(g)
+    xb = dev(x[:3000]).unsqueeze(0)
+    enc = encoder_from_state(st, cfg)
+    enc.compute_dtype = mode
+    y1 = enc(xb).clone()
+    assert enc._w16_key is not None
+    y2 = enc(xb).clone()                                  # second call: conversion skipped
+    assert torch.equal(y1, y2)
+    with torch.no_grad():
+        list(enc.layers.children())[0].attn.attn.qkv.weight.mul_(1.25)
+    y3 = enc(xb).clone()
+    fresh = encoder_from_state({k: (v * 1.25 if k == "layers.0.attn.attn.qkv.weight" else v) for k, v in st.items()}, cfg)
+    fresh.compute_dtype = mode
+    y4 = fresh(xb)
+    torch.cuda.synchronize()
+    assert torch.equal(y3, y4) and not torch.equal(y3, y1)
+    # executor path (forward_bags): versions ride in rrt_encoder_weights.version
+    a = enc.forward_bags([xb, xb], streams=2)
+    b = enc.forward_bags([xb, xb], streams=2)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], y3) and torch.equal(b[1], y3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f32x3"])
+def test_concurrent_forwards_are_bit_reproducible(mode):
+    """Two forwards in flight on two streams (own workspaces) give, run after run, exactly the bits of a forward that
+    had the chip to itself.  Round 2 found the LayerNorm-type kernels of the CR-MSA tail returning slightly different
+    statistics (lanes 48..63 of a row, ~1e-4 relative) now and then when their waves shared a SIMD with the bf16-MFMA
+    waves of the other bag's R-MSA kernel: lane-predicated code (column guards) around packed fp32 ops; the kernels
+    now run guard-free when dim is a multiple of 256."""
+    import ctypes as C
+    from hip_util import encoder_from_state, dev
+    g = load_golden("G3_d512_n9000")
+    x, st, cfg = synth_case(g)
+    n = 3000
+    xb = dev(x[:n]).contiguous()
+    lib = _lib.load()
+    enc = encoder_from_state(st, cfg)
+    enc._desc.compute = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f32x3": _lib.COMPUTE_F32X3}[mode]
+    w = enc._weights()
+    need = C.c_size_t()
+    _lib.check(lib.rrt_encoder_workspace_size(C.byref(enc._desc), n, C.byref(need)), "workspace size")
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    ws = [torch.zeros(need.value, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    ys = [torch.zeros_like(xb) for _ in range(2)]
+
+    def run(i):
+        _lib.check(lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), xb.data_ptr(), ys[i].data_ptr(), n,
+                                               ws[i].data_ptr(), ws[i].numel(), streams[i].cuda_stream), "forward")
+    torch.cuda.synchronize()
+    run(0)
+    torch.cuda.synchronize()
+    ref = ys[0].clone()
+    bad = 0
+    for _ in range(40):
+        run(0)
+        run(1)
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(ys[0], ref)) + int(not torch.equal(ys[1], ref))
+    assert bad == 0, f"{bad} of 80 concurrent forwards differ from the solo run"
+
+
 # ------------------------------------------------------------------ RRT_COMPUTE_F32X3: fp32 emulated on the bf16 matrix cores
 def _split_image(a):
     """numpy restatement of cast16.hip's split image: per 32 elements [32 bf16 hi | 32 bf16 lo] as uint16 bits"""
