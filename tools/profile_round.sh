@@ -33,5 +33,12 @@ for dt in f32 bf16; do
     fi
   done
 done
+timeout 300 python $R/bench.py --dtype f32x3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_config1_f32x3.bench.json 2>/dev/null
+timeout 300 python $R/bench.py --streams 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_1stream.bench.json 2>/dev/null
+timeout 300 python $R/bench.py --streams 4 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_4streams.bench.json 2>/dev/null
+if [ -f $R/tools/_abl/librrt_trace.so ]; then
+  RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_fused.py > $OUT/${TAG}_trace_fused_f32_wave_timeline.txt 2>/dev/null
+fi
+[ -x $R/tools/_abl/mfma_valu_overlap ] && timeout 120 $R/tools/_abl/mfma_valu_overlap > $OUT/${TAG}_ubench_mfma_valu_overlap.txt 2>&1
 tail -1 $OUT/${TAG}_bench_default.bench.json | cut -c1-200
 head -14 $OUT/${TAG}_bench_1stream.kernel_stats.txt
