@@ -19,16 +19,6 @@
 //   crmsa_dispatch_ln_kernel: 2 tokens / wave.  k-term axpy + residual (+shortcut) + LayerNorm.
 #include "internal.h"
 
-#ifdef RRT_DBG_LOGITS
-__device__ float g_dbg_sq[4096 * 64];
-__device__ float g_dbg_tot[4096 * 64];
-extern "C" int rrt_dbg_logits_read(float* sq, float* tot) {
-  hipError_t e = hipMemcpyFromSymbol(sq, HIP_SYMBOL(g_dbg_sq), sizeof(float) * 4096 * 64);
-  if (e == hipSuccess) e = hipMemcpyFromSymbol(tot, HIP_SYMBOL(g_dbg_tot), sizeof(float) * 4096 * 64);
-  return (int)e;
-}
-#endif
-
 namespace {
 
 constexpr int KMAX = RRT_MAX_CRMSA_K;
@@ -87,17 +77,8 @@ __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restri
       }
     }
   }
-#ifdef RRT_DBG_LOGITS
-#pragma unroll
-  for (int i = 0; i < RW; ++i) {
-    const float tot = wave_sum(sq[i]);
-    if (t0 + i < 4096) { g_dbg_sq[(t0 + i) * 64 + lane] = sq[i]; g_dbg_tot[(t0 + i) * 64 + lane] = tot; }
-    rstd[i] = 1.0f / sqrtf(tot * inv_d + LN_EPS);
-  }
-#else
 #pragma unroll
   for (int i = 0; i < RW; ++i) rstd[i] = 1.0f / sqrtf(wave_sum(sq[i]) * inv_d + LN_EPS);
-#endif
   // normalise in place: r <- LN(x1) rows
 #pragma unroll
   for (int v = 0; v < NV; ++v) {

@@ -28,11 +28,7 @@
 
 namespace {
 
-#ifdef RRT_NT_STORE
-#define RRT_STORE_O(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
-#define RRT_STORE_O(ptr, val) (*(ptr) = (val))
-#endif
+#define RRT_STORE_O(ptr, val) (*(ptr) = (val))   // (non-temporal stores measured: no gain)
 
 constexpr int BK = 32;
 constexpr int HD = 64;
@@ -88,11 +84,7 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
   constexpr int LA = (NA + 3) / 4, LB = NB / 4;    // per loader wave (four of them)
   constexpr int NT = 3;                            // 16-column tiles per compute wave (4 x 48 = 192)
   constexpr int LDS_MAIN = (2 * STAGE > 3 * TILE ? 2 * STAGE : 3 * TILE) * 4;   // bytes: staging ring / Q, K, V tiles
-#ifdef RRT_NOPIPE
-  constexpr bool PIPE = false;
-#else
   constexpr bool PIPE = PREC == PREC_F32 && MT <= 11;   // software-pipelined projection loop (phase 1)
-#endif
   constexpr bool SPLIT_LAST = MT == 9;             // nine tiles on eight waves: the ninth is shared out (phase 4)
   constexpr int RUN = (BM * 16 + 511) / 512;       // query rows per stencil thread: 5 for BM = 144
   constexpr int TAP_OFF = 12 + RUN - 1;            // tap t lives at taps[t + TAP_OFF]; taps[12..] is 16-byte aligned
