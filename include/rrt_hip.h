@@ -44,7 +44,7 @@ enum { RRT_COMPUTE_F32 = 0, RRT_COMPUTE_BF16 = 1, RRT_COMPUTE_F16 = 2, RRT_COMPU
  * three bf16 MFMAs with fp32 accumulation, hi.hi + hi.lo + lo.hi.  Attention, LayerNorm, CR-MSA and every other GEMM
  * are the F32 path's.  Measured distance to the F32 path on the encoder output: ~1e-6; regions of 49..144
  * tokens with head dim 64, anything else silently takes the exact F32 kernels. */
-/* In BF16 / F16 on regions of 17..208 tokens with head dim 64 the R-MSA layers run on 16-bit data end to end
+/* In BF16 / F16 on regions of 17..256 tokens with head dim 64 the R-MSA layers run on 16-bit data end to end
  * (rrt_ln_partition16 -> rrt_rmsa_fused16 -> rrt_linear16_f32 below): the LayerNorm output, the weights and the
  * attention output live in HBM in 16 bits, and Q~, K, V and the softmax probabilities go to the matrix cores in 16
  * bits too (fp32 accumulation, fp32 softmax statistics) -- what autocast does to nn.Linear, q k^T and attn v.
@@ -223,7 +223,7 @@ int rrt_rmsa_fused_f32(const float *u, const float *qkv_w, const float *qkv_b, c
  *  linear16      : C fp32 [M, N] = A16 [M, K] . B16 [N, K]^T + bias; with resid != NULL the un-partition + residual
  *                  epilogue of rrt_linear_unpartition_residual_f32 (M = H*H of g); K % 64 == 0, M >= 128;
  *  rmsa_fused16  : rrt_rmsa_fused_f32 on 16-bit u / qkv_w, attention operands in 16 bits, o in 16 bits
- *                  (rmsa.py:100-122 under autocast); head dim 64, 16 < P <= 208. */
+ *                  (rmsa.py:100-122 under autocast); head dim 64, 16 < P <= 256. */
 int rrt_cast16(const float *src, uint16_t *dst, int64_t n, int32_t compute, void *stream);
 int rrt_ln_partition16(const float *x, const float *gamma, const float *beta, uint16_t *u, int64_t L,
                        int32_t dim, const rrt_grid *g, int32_t compute, void *stream);

@@ -684,7 +684,7 @@ int rrt_rmsa_fused16(const uint16_t* u, const uint16_t* qkv_w, const float* qkv_
   if (compute != RRT_COMPUTE_BF16 && compute != RRT_COMPUTE_F16) return unsupported("compute must be BF16 or F16");
   const int ek = pe_w ? epeg_k : 0;
   if (!rmsa_fused16_supported(P, dim, heads, ek) || !rmsa_fused_supported_rows((long)n_regions * P, dim))
-    return unsupported("rmsa_fused16: needs head dim 64, 16 < P <= 208, epeg_k <= 63");
+    return unsupported("rmsa_fused16: needs head dim 64, 16 < P <= 256, epeg_k <= 63");
   return (int)launch_rmsa_fused16(u, qkv_w, qkv_b, pe_w, o, n_regions, P, dim, heads, ek, compute, (hipStream_t)stream);
 }
 

@@ -111,7 +111,10 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
   constexpr int NT = 3;                              // 16-column tiles per compute wave (4 x 48 = 192)
   constexpr int QF_B = BM * 256, KS_B = BM * ROWB;   // fp32 Q tile, 16-bit K tile
   static_assert(16 * MTP * 2 <= VT_PITCH, "V^T row");
-  constexpr int RING_B = 3 * STAGE_B, TILES_B = QF_B + KS_B + 64 * VT_PITCH;
+  // three ring stages while they fit (MT <= 13); regions of 209..256 tokens (MT = 15, 16) get two: their tiles alone
+  // are 125 / 131 KiB, and a K tile there carries enough MFMAs (15-16 row tiles) to cover one DMA round trip
+  constexpr int NSTG = MT <= 13 ? 3 : 2;
+  constexpr int RING_B = NSTG * STAGE_B, TILES_B = QF_B + KS_B + 64 * VT_PITCH;
   constexpr int LDS_MAIN = RING_B > TILES_B ? RING_B : TILES_B;
   constexpr int RUN = (BM + 31) / 32;                // query rows per stencil thread (512 threads = 32 runs x 16 slots)
   constexpr int TAP_OFF = 12 + RUN - 1;              // tap t lives at taps[t + TAP_OFF]; taps[12..] is 16-byte aligned
@@ -188,20 +191,30 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
     };
     const bool full = (LA - 1) * 4 + lw < NA;       // this loader issues LA (else LA - 1) A pieces per stage
     stage(0, lds_b);
-    if (nk > 1) stage(1, lds_b + STAGE_B);
+    if (NSTG == 3 && nk > 1) stage(1, lds_b + STAGE_B);
     RRT_TRACE_MARK();                               // loader [2] first stages issued
-    int slot = 2;                                   // ring slot of stage kt + 2
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) {                            // stage kt landed; stage kt + 1 may still be in flight
-        if (full) wait_vmcnt<LA + LB>(); else wait_vmcnt<LA - 1 + LB>();
-      } else {
-        wait_vm0();
+    if constexpr (NSTG == 3) {
+      int slot = 2;                                 // ring slot of stage kt + 2
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {                          // stage kt landed; stage kt + 1 may still be in flight
+          if (full) wait_vmcnt<LA + LB>(); else wait_vmcnt<LA - 1 + LB>();
+        } else {
+          wait_vm0();
+        }
+        if (kt == 0 || kt == 4) RRT_TRACE_MARK();   // loader [3,5] K tile 0 / 4 landed
+        __syncthreads();                            // publishes K tile kt; everyone is done with tile kt - 1
+        if (kt + 2 < nk) stage(kt + 2, lds_b + slot * STAGE_B);
+        slot = slot == 2 ? 0 : slot + 1;
+        if (kt == 0 || kt == 4) RRT_TRACE_MARK();   // loader [4,6] next stage issued
       }
-      if (kt == 0 || kt == 4) RRT_TRACE_MARK();     // loader [3,5] K tile 0 / 4 landed
-      __syncthreads();                              // publishes K tile kt; everyone is done with tile kt - 1
-      if (kt + 2 < nk) stage(kt + 2, lds_b + slot * STAGE_B);
-      slot = slot == 2 ? 0 : slot + 1;
-      if (kt == 0 || kt == 4) RRT_TRACE_MARK();     // loader [4,6] next stage issued
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        wait_vm0();                                 // stage kt landed
+        if (kt == 0 || kt == 4) RRT_TRACE_MARK();
+        __syncthreads();                            // publishes K tile kt; everyone is done with tile kt - 1
+        if (kt + 1 < nk) stage(kt + 1, lds_b + ((kt + 1) & 1) * STAGE_B);
+        if (kt == 0 || kt == 4) RRT_TRACE_MARK();
+      }
     }
     __syncthreads();                                // "the staging ring is dead"
     RRT_TRACE_MARK();                               // loader [7]
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void rmsa_fused16_kernel(const uint16_t* __
       if (kt == 0 || kt == 1 || kt == 4) RRT_TRACE_MARK();   // compute [2,3,4] barrier kt passed
       const char* As = smem + slot * STAGE_B;
       const char* Bs = As + BM * ROWB;
-      slot = slot == 2 ? 0 : slot + 1;
+      slot = slot == NSTG - 1 ? 0 : slot + 1;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         Frag a8[MT], b8[NT];
@@ -432,7 +445,7 @@ template <int MT, int PREC>
 hipError_t launch_mt(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
                      int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
   constexpr int BM = 16 * MT;
-  constexpr size_t RING = (size_t)3 * (BM + BN) * ROWB, TILES = (size_t)BM * (256 + ROWB) + 64 * VT_PITCH;
+  constexpr size_t RING = (size_t)(MT <= 13 ? 3 : 2) * (BM + BN) * ROWB, TILES = (size_t)BM * (256 + ROWB) + 64 * VT_PITCH;
   constexpr size_t LDS = (RING > TILES ? RING : TILES) + 512;          // + the EPEG tap table
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = rmsa_fused16_kernel<MT, PREC>;
@@ -454,8 +467,8 @@ RRT_TRACE_DEFINE_READER(rrt_debug_trace_fused16)
 bool rmsa_fused16_supported(int P, int D, int heads, int epeg_k) {
   static const bool off = getenv("RRT_NO_FUSED16") != nullptr;
   if (off) return false;
-  // one block holds a whole region (P <= 208 -> MT <= 13); 64-element K tiles; 32-bit DMA byte offsets
-  return heads > 0 && D == heads * HD && D % 64 == 0 && P > 16 && P <= 208 && epeg_k >= 0 && epeg_k <= 63;
+  // one block holds a whole region (P <= 256 -> MT <= 16); 64-element K tiles; 32-bit DMA byte offsets
+  return heads > 0 && D == heads * HD && D % 64 == 0 && P > 16 && P <= 256 && epeg_k >= 0 && epeg_k <= 63;
 }
 
 hipError_t launch_rmsa_fused16(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w,
@@ -465,6 +478,8 @@ hipError_t launch_rmsa_fused16(const uint16_t* U, const uint16_t* W, const float
 #define RRT_FUSED16(MT_)                                                                                \
   return prec == 1 ? launch_mt<MT_, 1>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st)          \
                    : launch_mt<MT_, 2>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st);
+  if (P > 240) { RRT_FUSED16(16) }
+  if (P > 208) { RRT_FUSED16(15) }
   if (P > 176) { RRT_FUSED16(13) }
   if (P > 144) { RRT_FUSED16(11) }
   if (P > 128) { RRT_FUSED16(9) }
