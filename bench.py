@@ -304,6 +304,9 @@ class EncoderWorkload:
         for s_ in range(self.S):
             x = self.bags[(i * self.S + s_) % len(self.bags)]
             if self.mil is not None:
+                mode = self.mdesc.enc.compute     # (as RRTMIL.forward_bag: the 16-bit weight images stay in the workspace)
+                self.mdesc.enc.weights16_valid = int(mode != _lib.COMPUTE_F32 and self._w16_mode[s_] == mode)
+                self._w16_mode[s_] = mode
                 rc = lib.rrt_mil_forward_f32(C.byref(self.mdesc), C.byref(self.mw), x.data_ptr(), self.outs[s_].data_ptr(),
                                              None, 0, None, self.n, self.wss[s_].data_ptr(), self.wss[s_].numel(),
                                              self.streams[s_])

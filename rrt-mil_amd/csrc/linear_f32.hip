@@ -730,11 +730,15 @@ struct Cfg { int mt, nt, cap; };
 //   grid = min(tiles, cap), rounds = ceil(tiles / grid), blocks per CU = ceil(grid / 256)
 //   cost = rounds * blocks_per_cu * MT * NT      [co-resident blocks share the CU's matrix pipes]
 // Candidates are ordered by preference; a later one must be strictly cheaper to win.
-Cfg choose(int M, int N) {
+Cfg choose(int M, int N, int prec = PREC_F32) {
   if (const char* e = getenv("RRT_LINEAR_CFG")) {   // tuning hook: "mt,nt,cap"
     Cfg c{};
     if (sscanf(e, "%d,%d,%d", &c.mt, &c.nt, &c.cap) == 3) return c;
   }
+  // operands rounded to 16 bits after LDS (fp32 bytes through the DMA path, 1/16 of the MFMA time): the K loop is bound
+  // by DMA issue, and three 96-row blocks per CU keep more of it in flight than two 144-row ones (patch_to_emb at
+  // N = 9000 x 1024 -> 512: 36.3 -> ~31 us)
+  if (prec != PREC_F32 && (M + 95) / 96 * ((N + 63) / 64) >= 512) return Cfg{6, 1, 768};
   static const Cfg cands[] = {{9, 1, 512}, {8, 1, 512}, {9, 2, 512}, {8, 2, 512}, {9, 2, 256},
                               {8, 2, 256}, {4, 1, 512}, {2, 1, 512}};
   Cfg best = cands[0];
@@ -821,7 +825,7 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
                          const LinearEpilogue& ep, hipStream_t st) {
   const bool u = ep.resid != nullptr;
   if (ep.drop_on && (ep.prec != PREC_F32 || ep.act)) return hipErrorInvalidValue;   // dropout: fp32 training only
-  const Cfg c = choose(M, N);
+  const Cfg c = choose(M, N, ep.prec);
 #define RRT_CASE(MT_, NT_)                                                                          \
   if (c.mt == MT_ && c.nt == NT_) {                                                                 \
     if (ep.prec == PREC_BF16) return RRT_MODES(MT_, NT_, PREC_BF16);                                \

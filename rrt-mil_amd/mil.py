@@ -178,10 +178,16 @@ class RRTMIL(nn.Module):
         logits = torch.empty(d.n_classes, dtype=torch.float32, device=x2d.device)
         attn = torch.empty(n, dtype=torch.float32, device=x2d.device) if return_attn else None
         with torch.cuda.device(x2d.device):      # kernels launch on the bag's device, whatever the current one is
+            stream = torch.cuda.current_stream(x2d.device).cuda_stream
+            # reduced-precision modes: the encoder's 16-bit weight images inside this workspace (their place depends on
+            # n) are still those of these weights?  (rrt_encoder_desc.weights16_valid, see RRTEncoder.forward_bag)
+            key = (self._ws.data_ptr(), d.enc.compute, w.enc.version, stream, n)
+            lowp = d.enc.compute != _lib.COMPUTE_F32
+            d.enc.weights16_valid = int(lowp and key == getattr(self, "_w16_key", None))
             rc = lib.rrt_mil_forward_f32(C.byref(d), C.byref(w), x2d.data_ptr(), logits.data_ptr(),
                                          attn.data_ptr() if return_attn else None, int(bool(no_norm)), None, n,
-                                         self._ws.data_ptr(), self._ws.numel(),
-                                         torch.cuda.current_stream(x2d.device).cuda_stream)
+                                         self._ws.data_ptr(), self._ws.numel(), stream)
+            self._w16_key = key if rc == 0 and lowp else None
         _lib.check(rc, "rrt_mil_forward_f32")
         return (logits, attn) if return_attn else logits
 
