@@ -24,8 +24,8 @@ namespace {
 constexpr int KMAX = RRT_MAX_CRMSA_K;
 
 // rows handled by one wave (independent loads in flight per wave = RW * NV float4)
-constexpr int RW = 4;
-constexpr int RW_DISPATCH = 2;
+constexpr int RW = 2;             // (4 until the column guards went: 9.1 -> 7.6 us at N = 9000)
+constexpr int RW_DISPATCH = 1;    // (2 until the column guards went: 10.0 -> 9.0 us)
 
 // FULL: dim == NV * 256 exactly (every lane's columns exist): no column guards in the row loops
 template <int NV, bool FULL>
