@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 18
+#define RRT_ABI_VERSION 19
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -262,6 +262,13 @@ int rrt_crmsa_logits_f32(const float *x1, const float *gamma, const float *beta,
 int rrt_crmsa_combine_f32(const float *x1, const float *gamma, const float *beta,
                           const float *mean_rstd, const float *logits, float *wdisp, float *rep,
                           int64_t L, int32_t dim, int32_t k, const rrt_grid *g8, void *stream);
+/* logits + combine in one pass over x1 (dim = 512, k <= 3, CR-MSA regions of <= 144 tokens: one block per region, the rows
+ * are read once and stay in registers; rrt_encoder_forward_f32 uses it under RRT_CRMSA_REGION=1 -- better with several
+ * bags in flight, worse with one); same outputs as the two calls above
+ * (mean_rstd and logits may be NULL); RRT_E_UNSUPPORTED outside that range. */
+int rrt_crmsa_region_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
+                         float *mean_rstd, float *logits, float *wdisp, float *rep,
+                         int64_t L, int32_t dim, int32_t k, const rrt_grid *g8, void *stream);
 int rrt_crmsa_dispatch_ln_f32(const float *x1, const float *x0, const float *wdisp,
                               const float *rep2, const float *gamma,
                               const float *beta, float *y, int64_t L, int32_t dim, int32_t k,

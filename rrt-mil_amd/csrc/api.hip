@@ -519,6 +519,9 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     RRT_TRY(launch_linear(ws.v8, w->phi0_w, ws.hid, gd8.Np, D / 4, D, ep, st));
     RRT_TRY(launch_crmsa_mlp_logits(ws.hid, w->phi2_w, ws.logits, gd8.Np, D / 4, k, st));
     RRT_TRY(launch_crmsa_combine(ws.v8, nullptr, nullptr, nullptr, ws.logits, ws.wdisp, ws.rep, D, k, gd8, st));
+  } else if (crmsa_region_enabled() && crmsa_region_supported(D, k, gd8)) {
+    // logits + combine in one pass over x1 (one block of 16 waves per region, the rows stay in registers)
+    RRT_TRY(launch_crmsa_region(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, nullptr, ws.wdisp, ws.rep, k, gd8, st));
   } else {
     RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, ws.mean_rstd, ws.logits, D, k, gd8, st));
     RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, ws.mean_rstd, ws.logits, ws.wdisp, ws.rep, D, k,
@@ -743,6 +746,15 @@ int rrt_crmsa_combine_f32(const float* x1, const float* gamma, const float* beta
   if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4) return unsupported("crmsa: k in [1,8], dim%4==0");
   return (int)launch_crmsa_combine(x1, gamma, beta, mean_rstd, logits, wdisp, rep, dim, k, to_dev(*g8),
                                    (hipStream_t)stream);
+}
+
+int rrt_crmsa_region_f32(const float* x1, const float* gamma, const float* beta, const float* phi, float* mean_rstd,
+                         float* logits, float* wdisp, float* rep, int64_t L, int32_t dim, int32_t k, const rrt_grid* g8,
+                         void* stream) {
+  if (!x1 || !gamma || !beta || !phi || !wdisp || !rep || !g8 || L != g8->L) return RRT_E_INVALID;
+  const GridDev gd = to_dev(*g8);
+  if (!crmsa_region_supported(dim, k, gd)) return unsupported("crmsa_region: dim = 512, k <= 3, regions of <= 144 tokens");
+  return (int)launch_crmsa_region(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, k, gd, (hipStream_t)stream);
 }
 
 int rrt_crmsa_dispatch_ln_f32(const float* x1, const float* x0, const float* wdisp,

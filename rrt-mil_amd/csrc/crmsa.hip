@@ -279,6 +279,218 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
   }
 }
 
+// ---- logits + combine in ONE pass over x1 (dim = 512, P <= 16 * NR_MAX, k <= 3) -------------------------------------
+// One block of 16 waves per region.  Wave w owns the region's rows w, w + 16, ... (<= NR_MAX = 9 of them, two float4
+// per lane each: 72 registers) and issues every load at once -- one memory round trip for the whole region, and the
+// rows are read from HBM exactly once per bag (the two-kernel form read them twice and paid two launches, two ramps
+// and two drains: 7.6 + 8.8 us).  Then, per row and exactly as crmsa_logits_kernel does it: two-pass LayerNorm
+// statistics, normalised row, k dot products -> (mean, rstd, logits) in LDS.  After a barrier the region statistics
+// and the combine coefficients are built as in crmsa_combine_kernel, and each wave contracts ITS rows, still in
+// registers, into a partial rep [k x 512]; the 16 partials are summed through LDS in a fixed order (waves w + 8 into
+// w, then eight per column) and LayerNorm's affine is applied once:  rep = gamma * (W.X1 - c0) + beta * c1.
+constexpr int REGION_NR_MAX = 9;
+constexpr int REGION_KMAX = 3;
+__global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restrict__ x1,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ phi,
+                                                            float* __restrict__ mean_rstd,
+                                                            float* __restrict__ logits,
+                                                            float* __restrict__ wdisp,
+                                                            float* __restrict__ rep, int k, GridDev g) {
+  constexpr int DIM = 512, NR = REGION_NR_MAX, KM = REGION_KMAX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* phi_t = (float*)smem;                      // [KM][DIM]
+  float* s_lg = phi_t + KM * DIM;                   // [P][KM] logits
+  float* s_mr = s_lg + NR * 16 * KM;                // [P][2] mean, rstd (rstd = 0: pad token)
+  float* s_w = s_mr + NR * 16 * 2;                  // [P][KM] combine coefficient x rstd
+  float4* s_part = (float4*)(s_w + NR * 16 * KM);   // [8][KM][128] float4: partial rep of waves w (+ w + 8)
+  __shared__ float s_stat[KM][3];
+  __shared__ float s_c0[KM][16], s_c1[KM][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int reg = blockIdx.x, R = g.rs * g.rs;
+  const int ri = reg / g.rs, rj = reg - ri * g.rs;
+  for (int idx = tid; idx < DIM * k; idx += 1024) {
+    const int d = idx / k, n = idx - d * k;
+    phi_t[n * DIM + d] = phi[idx];
+  }
+  // ---- this wave's rows: every load in flight at once
+  float4 r[NR][2];
+  int tokv[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int p = wave + 16 * j;
+    int t = -1;
+    if (p < g.P) {
+      const int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
+      t = (ri * g.s + pi) * g.H + rj * g.s + pj;
+      if (t >= g.L) t = -1;
+    }
+    tokv[j] = t;
+    const float* src = x1 + (size_t)(t < 0 ? 0 : t) * DIM;
+    r[j][0] = *(const float4*)(src + lane * 4);
+    r[j][1] = *(const float4*)(src + 256 + lane * 4);
+  }
+  const float4 gm0 = *(const float4*)(gamma + lane * 4), gm1 = *(const float4*)(gamma + 256 + lane * 4);
+  const float4 bt0 = *(const float4*)(beta + lane * 4), bt1 = *(const float4*)(beta + 256 + lane * 4);
+  __syncthreads();                                  // phi_t staged
+  // ---- LayerNorm statistics + logits per row (the arithmetic of crmsa_logits_kernel)
+  const float inv_d = 1.0f / (float)DIM;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int p = wave + 16 * j;
+    if (p >= g.P) continue;                         // wave-uniform
+    const float4 a = r[j][0], b = r[j][1];
+    const float mean = wave_sum(((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) * inv_d;
+    float sq;
+    {
+      const float a0 = a.x - mean, a1 = a.y - mean, a2 = a.z - mean, a3 = a.w - mean;
+      const float b0 = b.x - mean, b1 = b.y - mean, b2 = b.z - mean, b3 = b.w - mean;
+      sq = ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3));
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
+    float4 v0, v1;
+    v0.x = (a.x - mean) * rstd * gm0.x + bt0.x; v0.y = (a.y - mean) * rstd * gm0.y + bt0.y;
+    v0.z = (a.z - mean) * rstd * gm0.z + bt0.z; v0.w = (a.w - mean) * rstd * gm0.w + bt0.w;
+    v1.x = (b.x - mean) * rstd * gm1.x + bt1.x; v1.y = (b.y - mean) * rstd * gm1.y + bt1.y;
+    v1.z = (b.z - mean) * rstd * gm1.z + bt1.z; v1.w = (b.w - mean) * rstd * gm1.w + bt1.w;
+    const bool real = tokv[j] >= 0;
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        const float4 p0 = *(const float4*)(phi_t + n * DIM + lane * 4), p1 = *(const float4*)(phi_t + n * DIM + 256 + lane * 4);
+        const float acc = wave_sum(((v0.x * p0.x + v0.y * p0.y) + (v0.z * p0.z + v0.w * p0.w)) +
+                                   ((v1.x * p1.x + v1.y * p1.y) + (v1.z * p1.z + v1.w * p1.w)));
+        if (lane == 0) s_lg[p * KM + n] = real ? acc : 0.f;      // pad tokens carry zero rows -> zero logits
+      }
+    if (lane == 0) {
+      s_mr[2 * p] = real ? mean : 0.f;
+      s_mr[2 * p + 1] = real ? rstd : 0.f;
+      if (real && mean_rstd) { mean_rstd[2 * (size_t)tokv[j]] = mean; mean_rstd[2 * (size_t)tokv[j] + 1] = rstd; }
+    }
+  }
+  __syncthreads();
+  // ---- region statistics: wave n handles representative n
+  if (wave < k) {
+    const int n = wave;
+    float mx = -3.0e38f, mn = 3.0e38f;
+    for (int p = lane; p < g.P; p += 64) {
+      const float v = s_lg[p * KM + n];
+      mx = fmaxf(mx, v);
+      mn = fminf(mn, v);
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    float se = 0.f;
+    for (int p = lane; p < g.P; p += 64) se += __expf(s_lg[p * KM + n] - mx);
+    se = wave_sum(se);
+    if (lane == 0) { s_stat[n][0] = mx; s_stat[n][1] = mn; s_stat[n][2] = 1.0f / se; }
+  }
+  __syncthreads();
+  // ---- logits (region-major, for the training stash / debugging), dispatch weights, combine coefficients
+  {
+    float c0[KM], c1[KM];
+#pragma unroll
+    for (int n = 0; n < KM; ++n) c0[n] = c1[n] = 0.f;
+    for (int p = tid; p < g.P; p += 1024) {
+      float v[KM], e[KM];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int n = 0; n < KM; ++n)
+        if (n < k) { v[n] = s_lg[p * KM + n]; mx = fmaxf(mx, v[n]); }
+      float se = 0.f;
+#pragma unroll
+      for (int n = 0; n < KM; ++n)
+        if (n < k) { e[n] = __expf(v[n] - mx); se += e[n]; }
+      const float inv = 1.0f / se;
+      const float mean = s_mr[2 * p], rstd = s_mr[2 * p + 1];
+      const bool real = rstd != 0.f;
+#pragma unroll
+      for (int n = 0; n < KM; ++n)
+        if (n < k) {
+          const size_t o = ((size_t)reg * g.P + p) * k + n;
+          if (logits) logits[o] = v[n];
+          wdisp[o] = (v[n] - s_stat[n][1]) / (s_stat[n][0] - s_stat[n][1] + 1e-8f) * (e[n] * inv);
+          const float c = real ? __expf(v[n] - s_stat[n][0]) * s_stat[n][2] : 0.f;
+          s_w[p * KM + n] = c * rstd;
+          c0[n] += c * rstd * mean;
+          c1[n] += c;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        const float a = wave_sum(c0[n]), b = wave_sum(c1[n]);
+        if (lane == 0) { s_c0[n][wave] = a; s_c1[n][wave] = b; }
+      }
+  }
+  __syncthreads();
+  // ---- contraction over this wave's rows (registers), then the 16 partials through LDS
+  float4 acc[KM][2];
+#pragma unroll
+  for (int n = 0; n < KM; ++n) acc[n][0] = acc[n][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int p = wave + 16 * j;
+    if (p >= g.P) continue;
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        const float w = s_w[p * KM + n];            // 0 for pad tokens
+        acc[n][0].x += w * r[j][0].x; acc[n][0].y += w * r[j][0].y; acc[n][0].z += w * r[j][0].z; acc[n][0].w += w * r[j][0].w;
+        acc[n][1].x += w * r[j][1].x; acc[n][1].y += w * r[j][1].y; acc[n][1].z += w * r[j][1].z; acc[n][1].w += w * r[j][1].w;
+      }
+  }
+  if (wave >= 8) {
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        s_part[((wave - 8) * KM + n) * 128 + lane] = acc[n][0];
+        s_part[((wave - 8) * KM + n) * 128 + 64 + lane] = acc[n][1];
+      }
+  }
+  __syncthreads();
+  if (wave < 8) {
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        float4 a = s_part[(wave * KM + n) * 128 + lane], b = s_part[(wave * KM + n) * 128 + 64 + lane];
+        a.x += acc[n][0].x; a.y += acc[n][0].y; a.z += acc[n][0].z; a.w += acc[n][0].w;
+        b.x += acc[n][1].x; b.y += acc[n][1].y; b.z += acc[n][1].z; b.w += acc[n][1].w;
+        acc[n][0] = a; acc[n][1] = b;
+      }
+  }
+  __syncthreads();
+  if (wave < 8) {
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        s_part[(wave * KM + n) * 128 + lane] = acc[n][0];
+        s_part[(wave * KM + n) * 128 + 64 + lane] = acc[n][1];
+      }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < k * 128; idx += 1024) {
+    const int n = idx >> 7, c = idx & 127;
+    float4 a = s_part[n * 128 + c];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      const float4 b = s_part[(q * KM + n) * 128 + c];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { c0 += s_c0[n][w]; c1 += s_c1[n][w]; }
+    const float4 gm = *(const float4*)(gamma + c * 4), bt = *(const float4*)(beta + c * 4);
+    float4 out;
+    out.x = gm.x * (a.x - c0) + bt.x * c1;
+    out.y = gm.y * (a.y - c0) + bt.y * c1;
+    out.z = gm.z * (a.z - c0) + bt.z * c1;
+    out.w = gm.w * (a.w - c0) + bt.w * c1;
+    *(float4*)(rep + ((size_t)n * R + reg) * DIM + c * 4) = out;   // rep [k, R, D]
+  }
+}
+
 template <int NV, bool CRMSA, bool FULL>   // FULL: dim == NV * 256, no lane predication (see ln_partition.hip)
 __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
     const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ wdisp,
@@ -444,6 +656,30 @@ hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float*
   else if (dim <= 1024) RRT_LOGITS(4);
   else RRT_LOGITS(8);
 #undef RRT_LOGITS
+  return hipGetLastError();
+}
+
+// logits + combine as one kernel where it applies (dim 512, regions of <= 144 tokens, k <= 3); false -> the two kernels
+bool crmsa_region_supported(int dim, int k, const GridDev& g8) {
+  return dim == 512 && k >= 1 && k <= REGION_KMAX && g8.P <= 16 * REGION_NR_MAX;
+}
+// Whether the encoder forward uses it: opt-in (RRT_CRMSA_REGION=1).  Measured at N = 9000:
+// the 64-block kernel takes 20.2 us against 7.6 + 8.8 for the two chip-wide ones (its LayerNorm / dot-product VALU work
+// sits on a quarter of the CUs), so one bag in flight loses 1.7 %; two bags in flight gain 4 % (it leaves 192 CUs to
+// the other bag's R-MSA kernel), at the price of that kernel's in-flight duration (0.74 -> 0.65-0.70 of peak).
+bool crmsa_region_enabled() {
+  static const bool on = getenv("RRT_CRMSA_REGION") != nullptr;
+  return on;
+}
+hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float* beta, const float* phi,
+                               float* mean_rstd, float* logits, float* wdisp, float* rep, int k, const GridDev& g8,
+                               hipStream_t st) {
+  const size_t lds = (size_t)(REGION_KMAX * 512 + REGION_NR_MAX * 16 * (2 * REGION_KMAX + 2)) * 4 +
+                     (size_t)8 * REGION_KMAX * 128 * 16;
+  auto kern = crmsa_region_kernel;
+  static OncePerDevice once;
+  if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<dim3(g8.rs * g8.rs), dim3(1024), lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, k, g8);
   return hipGetLastError();
 }
 

@@ -91,6 +91,11 @@ hipError_t launch_add_cols(float* dst, const float* src, size_t rows, int dim, i
 hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float* beta,
                                const float* phi, float* mean_rstd, float* logits, int dim, int k,
                                const GridDev& g8, hipStream_t st);
+bool crmsa_region_supported(int dim, int k, const GridDev& g8);
+bool crmsa_region_enabled();
+hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float* beta, const float* phi,
+                               float* mean_rstd, float* logits, float* wdisp, float* rep, int k, const GridDev& g8,
+                               hipStream_t st);
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
                                 const float* mean_rstd, const float* logits, float* wdisp,
                                 float* rep, int dim, int k, const GridDev& g8, hipStream_t st);

@@ -222,6 +222,41 @@ def test_crmsa_stages(L, D, k):
     _cmp(y.cpu().numpy(), ref, 2e-5, "crmsa dispatch + LN")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,k", [(9000, 3), (9000, 1), (7000, 2), (3000, 3), (50, 3), (8100, 3)])
+def test_crmsa_region_kernel_matches_logits_plus_combine(L, k):
+    """logits + combine in one pass (crmsa_region_kernel) against the two-kernel form on the same inputs: the LayerNorm
+    statistics and logits are the same arithmetic (bit-identical), the representatives differ by summation order only."""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    D = 512
+    g8 = _lib.region_grid(L, 8)
+    Np8, R8 = g8.H * g8.H, 64
+    x1 = synth.normal("crr/x1", (L, D)) * 1.3 + 0.2
+    gm = 1.0 + synth.uniform("crr/g", (D,), -0.3, 0.3)
+    bt = synth.uniform("crr/b", (D,), -0.2, 0.2)
+    phi = synth.uniform("crr/phi", (D, k), -1, 1) * (3.0 / np.sqrt(D))
+    d_x1, d_gm, d_bt, d_phi = dev(x1), dev(gm), dev(bt), dev(phi)
+    out = {}
+    for tag in ("two", "one"):
+        mr = torch.full((L, 2), float("nan"), device=DEV)
+        lg = torch.full((Np8, k), float("nan"), device=DEV)
+        wd = torch.full((Np8, k), float("nan"), device=DEV)
+        rep = torch.full((k, R8, D), float("nan"), device=DEV)
+        if tag == "two":
+            _lib.check(lib.rrt_crmsa_logits_f32(p(d_x1), p(d_gm), p(d_bt), p(d_phi), p(mr), p(lg), L, D, k, C.byref(g8), stream()), "logits")
+            _lib.check(lib.rrt_crmsa_combine_f32(p(d_x1), p(d_gm), p(d_bt), p(mr), p(lg), p(wd), p(rep), L, D, k, C.byref(g8), stream()), "combine")
+        else:
+            _lib.check(lib.rrt_crmsa_region_f32(p(d_x1), p(d_gm), p(d_bt), p(d_phi), p(mr), p(lg), p(wd), p(rep), L, D, k, C.byref(g8), stream()), "region")
+        torch.cuda.synchronize()
+        out[tag] = [t.cpu().numpy() for t in (mr, lg, wd, rep)]
+    assert np.array_equal(out["one"][0], out["two"][0]), "mean / rstd"
+    assert np.array_equal(out["one"][1], out["two"][1], equal_nan=True), "logits"
+    assert np.array_equal(out["one"][2], out["two"][2], equal_nan=True), "dispatch weights"
+    d = np.abs(out["one"][3].astype(np.float64) - out["two"][3])
+    assert np.isfinite(out["one"][3]).all() and d.max() <= 2e-6 * max(1.0, np.abs(out["two"][3]).max()), d.max()
+
+
 # ------------------------------------------------------------------ whole path
 SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G7", "G8", "G11", "G13", "G15", "G16")) and "mlp" not in n]
 # crmsa_mlp needs dim % 128 == 0 on the HIP path (hidden = dim/4 is a GEMM K): D=64 golden is out of range
