@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 19
+#define RRT_ABI_VERSION 20
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -269,6 +269,14 @@ int rrt_crmsa_combine_f32(const float *x1, const float *gamma, const float *beta
 int rrt_crmsa_region_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
                          float *mean_rstd, float *logits, float *wdisp, float *rep,
                          int64_t L, int32_t dim, int32_t k, const rrt_grid *g8, void *stream);
+/* The same at full chip width, what rrt_encoder_forward_f32 uses (dim = 512, k <= 3, regions of 4..144 tokens, at least one
+ * R-MSA layer): four blocks per region, each with a quarter of the rows; the quarter that arrives last merges the four
+ * partial records like an online softmax (nobody waits for anybody).  scratch: 256 + 64 * 4 * 3 * 520 * 4 bytes; logits
+ * must be given (the merging block reads them); mean_rstd may be NULL. */
+int rrt_crmsa_region4_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
+                          float *mean_rstd, float *logits, float *wdisp, float *rep,
+                          int64_t L, int32_t dim, int32_t k, const rrt_grid *g8,
+                          void *scratch, size_t scratch_bytes, void *stream);
 int rrt_crmsa_dispatch_ln_f32(const float *x1, const float *x0, const float *wdisp,
                               const float *rep2, const float *gamma,
                               const float *beta, float *y, int64_t L, int32_t dim, int32_t k,

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _f32p = C.POINTER(C.c_float)
 
@@ -117,6 +117,8 @@ SIGNATURES = {
     "rrt_crmsa_combine_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32,
                                                           C.POINTER(Grid), C.c_void_p]),
     "rrt_crmsa_region_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_void_p]),
+    "rrt_crmsa_region4_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_void_p,
+                                                         C.c_size_t, C.c_void_p]),
     "rrt_crmsa_dispatch_ln_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32,
                                                               C.POINTER(Grid), C.c_void_p]),
     "rrt_crmsa_mlp_logits_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

@@ -29,6 +29,8 @@ struct Workspace {
   float *ffn_ln, *ffn_hid, *xp;
   float* pe_out;     // value-EPEG ablation: the conv's output [Np, D]
   uint16_t* w16;     // reduced-precision modes: 16-bit copies of the R-MSA layers' qkv / proj weights (4 D^2 per layer)
+  float* cr_part;    // crmsa_region4_kernel: partial records of the region quarters
+  int* cr_cnt;       // ... and the 64 arrival counters (zeroed by an R-MSA GEMM of the same forward)
   size_t bytes;
 };
 
@@ -69,6 +71,10 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     w.rep_qkv = take(k * R8 * 3 * D);
     w.rep_o = take(k * R8 * D);
     w.rep2 = take(k * R8 * D);
+    if (d.n_rmsa_layers > 0) {
+      w.cr_part = take(crmsa_region4_scratch_floats(to_dev(g8)));
+      w.cr_cnt = (int*)take(64);
+    }
     if (d.crmsa_mlp) {
       w.v8 = take(Np8 * D);
       w.hid = take(Np8 * (D / 4));
@@ -367,6 +373,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       ep.bias = lw.proj_b;
       ep.resid = xin;
       ep.g = gd;
+      ep.zero64 = ws.cr_cnt;
       RRT_TRY(launch_linear16(o16, wq16 + (size_t)3 * D * D, xout, gd.Np, D, D, ep, st));
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;
@@ -392,6 +399,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       ep.bias = lw.proj_b;
       ep.resid = xin;
       ep.g = gd;
+      ep.zero64 = ws.cr_cnt;
       RRT_TRY(launch_linear_split(ws.qkv, wq + (size_t)6 * D * D, xout, gd.Np, D, D, ep, st));
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;
@@ -432,6 +440,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       ep.bias = lw.proj_b;
       ep.resid = xin;
       ep.g = gd;
+      ep.zero64 = ws.cr_cnt;
       RRT_TRY(launch_linear(ws.uo, lw.proj_w, xout, gd.Np, D, D, ep, st));
       xin = xout;
       if (desc->ffn) {
@@ -460,6 +469,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       ep.bias = lw.proj_b;
       ep.resid = xin;
       ep.g = gd;
+      ep.zero64 = ws.cr_cnt;
       RRT_TRY(launch_linear(ws.qkv, lw.proj_w, xout, gd.Np, D, D, ep, st));
       if (gt && gate_proj) { RRT_TRY(hipEventRecord(gt->done, st)); gt->armed = true; }
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
@@ -488,6 +498,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     ep.bias = lw.proj_b;
     ep.resid = xin;
     ep.g = gd;
+    ep.zero64 = ws.cr_cnt;
     RRT_TRY(launch_linear(ws.uo, lw.proj_w, xout, gd.Np, D, D, ep, st));
     if (li == 0) RRT_MARK(RRT_EV_PROJ);
     xin = xout;
@@ -519,6 +530,11 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     RRT_TRY(launch_linear(ws.v8, w->phi0_w, ws.hid, gd8.Np, D / 4, D, ep, st));
     RRT_TRY(launch_crmsa_mlp_logits(ws.hid, w->phi2_w, ws.logits, gd8.Np, D / 4, k, st));
     RRT_TRY(launch_crmsa_combine(ws.v8, nullptr, nullptr, nullptr, ws.logits, ws.wdisp, ws.rep, D, k, gd8, st));
+  } else if (ws.cr_cnt && desc->n_rmsa_layers > 0 && crmsa_region4_supported(D, k, gd8)) {
+    // logits + combine in one pass over x1: four blocks per region, the last to arrive merges (crmsa_region4_kernel).
+    // Its counters were zeroed by this forward's last R-MSA out-projection.
+    RRT_TRY(launch_crmsa_region4(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, ws.logits, ws.wdisp, ws.rep, ws.cr_part,
+                                 ws.cr_cnt, k, gd8, st));
   } else if (crmsa_region_enabled() && crmsa_region_supported(D, k, gd8)) {
     // logits + combine in one pass over x1 (one block of 16 waves per region, the rows stay in registers)
     RRT_TRY(launch_crmsa_region(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, nullptr, ws.wdisp, ws.rep, k, gd8, st));
@@ -755,6 +771,19 @@ int rrt_crmsa_region_f32(const float* x1, const float* gamma, const float* beta,
   const GridDev gd = to_dev(*g8);
   if (!crmsa_region_supported(dim, k, gd)) return unsupported("crmsa_region: dim = 512, k <= 3, regions of <= 144 tokens");
   return (int)launch_crmsa_region(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, k, gd, (hipStream_t)stream);
+}
+
+int rrt_crmsa_region4_f32(const float* x1, const float* gamma, const float* beta, const float* phi, float* mean_rstd,
+                          float* logits, float* wdisp, float* rep, int64_t L, int32_t dim, int32_t k, const rrt_grid* g8,
+                          void* scratch, size_t scratch_bytes, void* stream) {
+  if (!x1 || !gamma || !beta || !phi || !logits || !wdisp || !rep || !g8 || !scratch || L != g8->L) return RRT_E_INVALID;
+  const GridDev gd = to_dev(*g8);
+  if (!crmsa_region4_supported(dim, k, gd)) return unsupported("crmsa_region4: dim = 512, k <= 3, regions of 4..144 tokens");
+  if (scratch_bytes < 256 + crmsa_region4_scratch_floats(gd) * sizeof(float)) return RRT_E_WORKSPACE;
+  hipError_t e = hipMemsetAsync(scratch, 0, 256, (hipStream_t)stream);      // the arrival counters
+  if (e != hipSuccess) return (int)e;
+  return (int)launch_crmsa_region4(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, (float*)((char*)scratch + 256),
+                                   (int*)scratch, k, gd, (hipStream_t)stream);
 }
 
 int rrt_crmsa_dispatch_ln_f32(const float* x1, const float* x0, const float* wdisp,

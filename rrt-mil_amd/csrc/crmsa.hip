@@ -491,6 +491,285 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
   }
 }
 
+// ---- the same at full chip width: FOUR blocks per region -------------------------------------------------------------
+// Block (region, q) owns a quarter of the region's rows (<= 36: 12 waves x 3 rows, every load in flight at once) and does
+// for them what crmsa_region_kernel does for all of them -- LayerNorm statistics and logits (global: the region's last
+// block needs every row's), LOCAL softmax statistics, the contraction of its rows with exp(Lg - local max) * rstd -- and
+// leaves a partial record (rep_b [k][512], local max, sum, c0, c1, min) in the workspace.  The quarter that arrives
+// last (an atomic counter per region; nobody waits for anybody) merges the four records like an online softmax,
+// applies LayerNorm's affine, and writes the region's dispatch weights.  256 blocks: the VALU work that made the
+// one-block form slow sits on every CU again.  The counters must be zero at the start: an earlier GEMM of the same
+// forward zeroes them (LinearEpilogue.zero64), the merging block leaves them zero.
+constexpr int R4_ROWS = 3;                          // rows per wave
+constexpr int R4_WAVES = 12;
+constexpr int R4_REC = REGION_KMAX * (512 + 8);     // floats per partial record
+// Device-coherent accesses for the hand-over between the quarters of a region.  The eight XCDs have private L2s, so an
+// ordinary store may sit dirty in the writer's L2 and an ordinary load may hit a stale line in the reader's; a
+// __threadfence() repairs that by writing the whole L2 back (measured: 100 us for the 3072 waves of this kernel).  Relaxed
+// agent-scope atomics are single write-through stores / L2-bypassing loads (sc1) instead, and a wave that waited for its
+// stores (vmcnt 0) before the block barrier has them in memory before the arrival counter moves.
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const float* __restrict__ x1,
+                                                                      const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta,
+                                                                      const float* __restrict__ phi,
+                                                                      float* __restrict__ mean_rstd,
+                                                                      float* __restrict__ logits,
+                                                                      float* __restrict__ wdisp,
+                                                                      float* __restrict__ rep,
+                                                                      float* __restrict__ part_g, int* __restrict__ counters,
+                                                                      int k, GridDev g) {
+  constexpr int DIM = 512, NR = R4_ROWS, NW = R4_WAVES, KM = REGION_KMAX, PQM = NR * NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* phi_t = (float*)smem;                      // [KM][DIM]
+  float* s_lg = phi_t + KM * DIM;                   // [PQM][KM]
+  float* s_mr = s_lg + PQM * KM;                    // [PQM][2]
+  float* s_w = s_mr + PQM * 2;                      // [PQM][KM]
+  float4* s_part = (float4*)(s_w + PQM * KM);       // [NW / 2][KM][128] float4
+  __shared__ float s_stat[KM][3];                   // local max, min, sum of exp (all rows of the quarter)
+  __shared__ float s_c0[KM][NW], s_c1[KM][NW];
+  __shared__ float s_mrg[KM][4];                    // merge: M, 1 / L, c0 / L, c1 / L ... of the region
+  __shared__ float s_mm[KM][2];                     // region min, max
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int reg = blockIdx.x >> 2, q = blockIdx.x & 3, R = g.rs * g.rs;
+  const int ri = reg / g.rs, rj = reg - ri * g.rs;
+  const int PQ = (g.P + 3) >> 2;                    // rows per quarter
+  for (int idx = tid; idx < DIM * k; idx += 64 * NW) {
+    const int d = idx / k, n = idx - d * k;
+    phi_t[n * DIM + d] = phi[idx];
+  }
+  float4 r[NR][2];
+  int tokv[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int rq = wave + NW * j, p = q * PQ + rq;
+    int t = -1;
+    if (rq < PQ && p < g.P) {
+      const int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
+      t = (ri * g.s + pi) * g.H + rj * g.s + pj;
+      if (t >= g.L) t = -1;
+    }
+    tokv[j] = t;
+    const float* src = x1 + (size_t)(t < 0 ? 0 : t) * DIM;
+    r[j][0] = *(const float4*)(src + lane * 4);
+    r[j][1] = *(const float4*)(src + 256 + lane * 4);
+  }
+  const float4 gm0 = *(const float4*)(gamma + lane * 4), gm1 = *(const float4*)(gamma + 256 + lane * 4);
+  const float4 bt0 = *(const float4*)(beta + lane * 4), bt1 = *(const float4*)(beta + 256 + lane * 4);
+  __syncthreads();
+  const float inv_d = 1.0f / (float)DIM;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int rq = wave + NW * j, p = q * PQ + rq;
+    if (rq >= PQ || p >= g.P) continue;             // wave-uniform
+    const float4 a = r[j][0], b = r[j][1];
+    const float mean = wave_sum(((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) * inv_d;
+    float sq;
+    {
+      const float a0 = a.x - mean, a1 = a.y - mean, a2 = a.z - mean, a3 = a.w - mean;
+      const float b0 = b.x - mean, b1 = b.y - mean, b2 = b.z - mean, b3 = b.w - mean;
+      sq = ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3));
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
+    float4 v0, v1;
+    v0.x = (a.x - mean) * rstd * gm0.x + bt0.x; v0.y = (a.y - mean) * rstd * gm0.y + bt0.y;
+    v0.z = (a.z - mean) * rstd * gm0.z + bt0.z; v0.w = (a.w - mean) * rstd * gm0.w + bt0.w;
+    v1.x = (b.x - mean) * rstd * gm1.x + bt1.x; v1.y = (b.y - mean) * rstd * gm1.y + bt1.y;
+    v1.z = (b.z - mean) * rstd * gm1.z + bt1.z; v1.w = (b.w - mean) * rstd * gm1.w + bt1.w;
+    const bool real = tokv[j] >= 0;
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        const float4 p0 = *(const float4*)(phi_t + n * DIM + lane * 4), p1 = *(const float4*)(phi_t + n * DIM + 256 + lane * 4);
+        const float acc = wave_sum(((v0.x * p0.x + v0.y * p0.y) + (v0.z * p0.z + v0.w * p0.w)) +
+                                   ((v1.x * p1.x + v1.y * p1.y) + (v1.z * p1.z + v1.w * p1.w)));
+        if (lane == 0) {
+          const float lgv = real ? acc : 0.f;       // pad tokens carry zero rows -> zero logits
+          s_lg[rq * KM + n] = lgv;
+          st_agent(logits + ((size_t)reg * g.P + p) * k + n, lgv);
+        }
+      }
+    if (lane == 0) {
+      s_mr[2 * rq] = real ? mean : 0.f;
+      s_mr[2 * rq + 1] = real ? rstd : 0.f;
+      if (real && mean_rstd) { mean_rstd[2 * (size_t)tokv[j]] = mean; mean_rstd[2 * (size_t)tokv[j] + 1] = rstd; }
+    }
+  }
+  __syncthreads();
+  const int nrow = min(PQ, g.P - q * PQ);           // rows of this quarter (>= 1: P >= 4 is checked by the launcher)
+  if (wave < k) {
+    const int n = wave;
+    float mx = -3.0e38f, mn = 3.0e38f;
+    for (int p = lane; p < nrow; p += 64) {
+      const float v = s_lg[p * KM + n];
+      mx = fmaxf(mx, v);
+      mn = fminf(mn, v);
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    float se = 0.f;
+    for (int p = lane; p < nrow; p += 64) se += __expf(s_lg[p * KM + n] - mx);
+    se = wave_sum(se);
+    if (lane == 0) { s_stat[n][0] = mx; s_stat[n][1] = mn; s_stat[n][2] = se; }
+  }
+  __syncthreads();
+  {
+    float c0[KM], c1[KM];
+#pragma unroll
+    for (int n = 0; n < KM; ++n) c0[n] = c1[n] = 0.f;
+    for (int p = tid; p < nrow; p += 64 * NW) {
+      const float mean = s_mr[2 * p], rstd = s_mr[2 * p + 1];
+      const bool real = rstd != 0.f;
+#pragma unroll
+      for (int n = 0; n < KM; ++n)
+        if (n < k) {
+          const float c = real ? __expf(s_lg[p * KM + n] - s_stat[n][0]) : 0.f;   // unnormalised, local max
+          s_w[p * KM + n] = c * rstd;
+          c0[n] += c * rstd * mean;
+          c1[n] += c;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        const float a = wave_sum(c0[n]), b = wave_sum(c1[n]);
+        if (lane == 0) { s_c0[n][wave] = a; s_c1[n][wave] = b; }
+      }
+  }
+  __syncthreads();
+  float4 acc[KM][2];
+#pragma unroll
+  for (int n = 0; n < KM; ++n) acc[n][0] = acc[n][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int rq = wave + NW * j;
+    if (rq >= nrow) continue;
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        const float w = s_w[rq * KM + n];
+        acc[n][0].x += w * r[j][0].x; acc[n][0].y += w * r[j][0].y; acc[n][0].z += w * r[j][0].z; acc[n][0].w += w * r[j][0].w;
+        acc[n][1].x += w * r[j][1].x; acc[n][1].y += w * r[j][1].y; acc[n][1].z += w * r[j][1].z; acc[n][1].w += w * r[j][1].w;
+      }
+  }
+  constexpr int HW = NW / 2;
+  if (wave >= HW) {
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        s_part[((wave - HW) * KM + n) * 128 + lane] = acc[n][0];
+        s_part[((wave - HW) * KM + n) * 128 + 64 + lane] = acc[n][1];
+      }
+  }
+  __syncthreads();
+  if (wave < HW) {
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        float4 a = s_part[(wave * KM + n) * 128 + lane], b = s_part[(wave * KM + n) * 128 + 64 + lane];
+        a.x += acc[n][0].x; a.y += acc[n][0].y; a.z += acc[n][0].z; a.w += acc[n][0].w;
+        b.x += acc[n][1].x; b.y += acc[n][1].y; b.z += acc[n][1].z; b.w += acc[n][1].w;
+        acc[n][0] = a; acc[n][1] = b;
+      }
+  }
+  __syncthreads();
+  if (wave < HW) {
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) {
+        s_part[(wave * KM + n) * 128 + lane] = acc[n][0];
+        s_part[(wave * KM + n) * 128 + 64 + lane] = acc[n][1];
+      }
+  }
+  __syncthreads();
+  // ---- this quarter's record -> workspace
+  float* rec = part_g + (size_t)(reg * 4 + q) * R4_REC;
+  for (int idx = tid; idx < k * 128; idx += 64 * NW) {
+    const int n = idx >> 7, c = idx & 127;
+    float4 a = s_part[n * 128 + c];
+#pragma unroll
+    for (int w = 1; w < HW; ++w) {
+      const float4 b = s_part[(w * KM + n) * 128 + c];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float* dst = rec + n * (DIM + 8) + c * 4;
+    st_agent(dst, a.x); st_agent(dst + 1, a.y); st_agent(dst + 2, a.z); st_agent(dst + 3, a.w);
+  }
+  if (tid < k) {
+    const int n = tid;
+    float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { c0 += s_c0[n][w]; c1 += s_c1[n][w]; }
+    float* st = rec + n * (DIM + 8) + DIM;
+    st_agent(st, s_stat[n][0]); st_agent(st + 1, s_stat[n][1]); st_agent(st + 2, s_stat[n][2]);
+    st_agent(st + 3, c0); st_agent(st + 4, c1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record (and the logits) are in memory ...
+  __syncthreads();
+  if (tid == 0)                                     // ... before this quarter counts as arrived
+    s_last = __hip_atomic_fetch_add(counters + reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3;
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) __hip_atomic_store(counters + reg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next forward
+  const float* rec0 = part_g + (size_t)(reg * 4) * R4_REC;
+  if (tid < k) {
+    const int n = tid;
+    float M = -3.0e38f, mn = 3.0e38f;
+    for (int b = 0; b < 4; ++b) {
+      const float* st = rec0 + b * R4_REC + n * (DIM + 8) + DIM;
+      M = fmaxf(M, ld_agent(st));
+      mn = fminf(mn, ld_agent(st + 1));
+    }
+    float L = 0.f, c0 = 0.f, c1 = 0.f;
+    for (int b = 0; b < 4; ++b) {
+      const float* st = rec0 + b * R4_REC + n * (DIM + 8) + DIM;
+      const float sc = __expf(ld_agent(st) - M);
+      L += sc * ld_agent(st + 2); c0 += sc * ld_agent(st + 3); c1 += sc * ld_agent(st + 4);
+    }
+    s_mrg[n][0] = M; s_mrg[n][1] = 1.0f / L; s_mrg[n][2] = c0 / L; s_mrg[n][3] = c1 / L;
+    s_mm[n][0] = mn; s_mm[n][1] = M;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < k * 128; idx += 64 * NW) {
+    const int n = idx >> 7, c = idx & 127;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < 4; ++b) {
+      const float* rb = rec0 + b * R4_REC + n * (DIM + 8);
+      const float sc = __expf(ld_agent(rb + DIM) - s_mrg[n][0]) * s_mrg[n][1];
+      const float* vp = rb + c * 4;
+      a.x += sc * ld_agent(vp); a.y += sc * ld_agent(vp + 1); a.z += sc * ld_agent(vp + 2); a.w += sc * ld_agent(vp + 3);
+    }
+    const float c0 = s_mrg[n][2], c1 = s_mrg[n][3];
+    const float4 gm = *(const float4*)(gamma + c * 4), bt = *(const float4*)(beta + c * 4);
+    float4 out;
+    out.x = gm.x * (a.x - c0) + bt.x * c1;
+    out.y = gm.y * (a.y - c0) + bt.y * c1;
+    out.z = gm.z * (a.z - c0) + bt.z * c1;
+    out.w = gm.w * (a.w - c0) + bt.w * c1;
+    *(float4*)(rep + ((size_t)n * R + reg) * DIM + c * 4) = out;
+  }
+  // dispatch weights of the whole region (rmsa.py:310-314, :324-325) from the four quarters' logits
+  for (int p = tid; p < g.P; p += 64 * NW) {
+    float v[KM], e[KM];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) { v[n] = ld_agent(logits + ((size_t)reg * g.P + p) * k + n); mx = fmaxf(mx, v[n]); }
+    float se = 0.f;
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) { e[n] = __expf(v[n] - mx); se += e[n]; }
+    const float inv = 1.0f / se;
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k)
+        wdisp[((size_t)reg * g.P + p) * k + n] = (v[n] - s_mm[n][0]) / (s_mm[n][1] - s_mm[n][0] + 1e-8f) * (e[n] * inv);
+  }
+}
+
 template <int NV, bool CRMSA, bool FULL>   // FULL: dim == NV * 256, no lane predication (see ln_partition.hip)
 __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
     const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ wdisp,
@@ -680,6 +959,22 @@ hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float*
   static OncePerDevice once;
   if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   kern<<<dim3(g8.rs * g8.rs), dim3(1024), lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, k, g8);
+  return hipGetLastError();
+}
+
+bool crmsa_region4_supported(int dim, int k, const GridDev& g8) {
+  static const bool off = getenv("RRT_NO_CRMSA_REGION4") != nullptr;
+  return !off && dim == 512 && k >= 1 && k <= REGION_KMAX && g8.P >= 4 && g8.P <= 4 * R4_ROWS * R4_WAVES;
+}
+size_t crmsa_region4_scratch_floats(const GridDev& g8) { return (size_t)g8.rs * g8.rs * 4 * R4_REC; }
+hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float* beta, const float* phi,
+                                float* mean_rstd, float* logits, float* wdisp, float* rep, float* part_g, int* counters,
+                                int k, const GridDev& g8, hipStream_t st) {
+  constexpr int PQM = R4_ROWS * R4_WAVES;
+  const size_t lds = (size_t)(REGION_KMAX * 512 + PQM * (2 * REGION_KMAX + 2)) * 4 +
+                     (size_t)(R4_WAVES / 2) * REGION_KMAX * 128 * 16;
+  crmsa_region4_kernel<<<dim3(g8.rs * g8.rs * 4), dim3(64 * R4_WAVES), lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits,
+                                                                                  wdisp, rep, part_g, counters, k, g8);
   return hipGetLastError();
 }
 

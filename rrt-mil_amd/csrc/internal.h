@@ -37,6 +37,9 @@ struct LinearEpilogue {
   // un-partition + residual (used when resid != null): C row = token, A row = slot
   const float* resid;
   GridDev g;
+  // side job: block 0 zeroes 64 ints (the CR-MSA region kernel's arrival counters: they must be 0 when it starts,
+  // and some kernel earlier in the same forward has to do it -- the workspace is the caller's, uninitialised)
+  int* zero64;
 };
 hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
                          const LinearEpilogue& ep, hipStream_t st);
@@ -93,6 +96,11 @@ hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float*
                                const GridDev& g8, hipStream_t st);
 bool crmsa_region_supported(int dim, int k, const GridDev& g8);
 bool crmsa_region_enabled();
+bool crmsa_region4_supported(int dim, int k, const GridDev& g8);
+size_t crmsa_region4_scratch_floats(const GridDev& g8);
+hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float* beta, const float* phi,
+                                float* mean_rstd, float* logits, float* wdisp, float* rep, float* part_g, int* counters,
+                                int k, const GridDev& g8, hipStream_t st);
 hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float* beta, const float* phi,
                                float* mean_rstd, float* logits, float* wdisp, float* rep, int k, const GridDev& g8,
                                hipStream_t st);

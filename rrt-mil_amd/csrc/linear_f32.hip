@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
   float* lds = (float*)smem;              // [2][A: BM*BK | B: BN*BK]
 
   RRT_TRACE_INIT(1 << 30);   // (untraced kernel: null tracer so the shared epilogue compiles)
+  if (ep.zero64 != nullptr && blockIdx.x == 0 && threadIdx.x < 64) ep.zero64[threadIdx.x] = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lr = lane & 15, lg = lane >> 4;
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
     const int b = blockIdx.x, q = G >> 3, r = G & 7, xcd = b & 7, idx = b >> 3;
     first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  if (ep.zero64 != nullptr && blockIdx.x == 0 && threadIdx.x < 64) ep.zero64[threadIdx.x] = 0;
   if (first >= ntiles) return;
   const int nk = K / BKE;
   RRT_TRACE_INIT(blockIdx.x * 6 + wave);

@@ -238,7 +238,9 @@ def test_crmsa_region_kernel_matches_logits_plus_combine(L, k):
     phi = synth.uniform("crr/phi", (D, k), -1, 1) * (3.0 / np.sqrt(D))
     d_x1, d_gm, d_bt, d_phi = dev(x1), dev(gm), dev(bt), dev(phi)
     out = {}
-    for tag in ("two", "one"):
+    scratch = torch.full((256 + 64 * 4 * 3 * 520 * 4,), 0x5A, dtype=torch.uint8, device=DEV)
+    tags = ("two", "one", "four", "four again") if 4 <= g8.s * g8.s <= 144 else ("two", "one")
+    for tag in tags:
         mr = torch.full((L, 2), float("nan"), device=DEV)
         lg = torch.full((Np8, k), float("nan"), device=DEV)
         wd = torch.full((Np8, k), float("nan"), device=DEV)
@@ -246,15 +248,25 @@ def test_crmsa_region_kernel_matches_logits_plus_combine(L, k):
         if tag == "two":
             _lib.check(lib.rrt_crmsa_logits_f32(p(d_x1), p(d_gm), p(d_bt), p(d_phi), p(mr), p(lg), L, D, k, C.byref(g8), stream()), "logits")
             _lib.check(lib.rrt_crmsa_combine_f32(p(d_x1), p(d_gm), p(d_bt), p(mr), p(lg), p(wd), p(rep), L, D, k, C.byref(g8), stream()), "combine")
-        else:
+        elif tag == "one":
             _lib.check(lib.rrt_crmsa_region_f32(p(d_x1), p(d_gm), p(d_bt), p(d_phi), p(mr), p(lg), p(wd), p(rep), L, D, k, C.byref(g8), stream()), "region")
+        else:                                   # four blocks per region, the last arrival merges (twice: counters left at 0)
+            _lib.check(lib.rrt_crmsa_region4_f32(p(d_x1), p(d_gm), p(d_bt), p(d_phi), p(mr), p(lg), p(wd), p(rep), L, D, k, C.byref(g8),
+                                                 p(scratch), scratch.numel(), stream()), "region4")
         torch.cuda.synchronize()
         out[tag] = [t.cpu().numpy() for t in (mr, lg, wd, rep)]
-    assert np.array_equal(out["one"][0], out["two"][0]), "mean / rstd"
-    assert np.array_equal(out["one"][1], out["two"][1], equal_nan=True), "logits"
-    assert np.array_equal(out["one"][2], out["two"][2], equal_nan=True), "dispatch weights"
-    d = np.abs(out["one"][3].astype(np.float64) - out["two"][3])
-    assert np.isfinite(out["one"][3]).all() and d.max() <= 2e-6 * max(1.0, np.abs(out["two"][3]).max()), d.max()
+    for tag in tags[1:]:
+        assert np.array_equal(out[tag][0], out["two"][0]), f"{tag}: mean / rstd"
+        assert np.array_equal(out[tag][1], out["two"][1], equal_nan=True), f"{tag}: logits"
+        if tag == "one":
+            assert np.array_equal(out[tag][2], out["two"][2], equal_nan=True), "dispatch weights"
+        else:                                   # the region max / min are the same numbers; the same formula
+            dw = np.abs(np.nan_to_num(out[tag][2]) - np.nan_to_num(out["two"][2]))
+            assert np.array_equal(np.isnan(out[tag][2]), np.isnan(out["two"][2])) and dw.max() <= 1e-6, dw.max()
+        d = np.abs(out[tag][3].astype(np.float64) - out["two"][3])
+        assert np.isfinite(out[tag][3]).all() and d.max() <= 3e-6 * max(1.0, np.abs(out["two"][3]).max()), (tag, d.max())
+    if "four" in out:
+        assert np.array_equal(out["four"][3], out["four again"][3])
 
 
 # ------------------------------------------------------------------ whole path
