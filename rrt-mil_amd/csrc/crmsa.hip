@@ -537,10 +537,6 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   const int reg = blockIdx.x >> 2, q = blockIdx.x & 3, R = g.rs * g.rs;
   const int ri = reg / g.rs, rj = reg - ri * g.rs;
   const int PQ = (g.P + 3) >> 2;                    // rows per quarter
-  for (int idx = tid; idx < DIM * k; idx += 64 * NW) {
-    const int d = idx / k, n = idx - d * k;
-    phi_t[n * DIM + d] = phi[idx];
-  }
   float4 r[NR][2];
   int tokv[NR];
 #pragma unroll
@@ -559,6 +555,10 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   }
   const float4 gm0 = *(const float4*)(gamma + lane * 4), gm1 = *(const float4*)(gamma + 256 + lane * 4);
   const float4 bt0 = *(const float4*)(beta + lane * 4), bt1 = *(const float4*)(beta + 256 + lane * 4);
+  for (int idx = tid; idx < DIM * k; idx += 64 * NW) {      // after the row loads: one memory round trip, not two
+    const int d = idx / k, n = idx - d * k;
+    phi_t[n * DIM + d] = phi[idx];
+  }
   __syncthreads();
   const float inv_d = 1.0f / (float)DIM;
 #pragma unroll

@@ -377,6 +377,77 @@ __global__ __launch_bounds__(256) void region_attn_generic_kernel(const float* _
   }
 }
 
+// P = 64 without EPEG (the MSA over CR-MSA's 64 region representatives, modules/rmsa.py:322): nothing goes through LDS and
+// there is no barrier -- a wave owns 16 queries and issues every load of its Q, K and V fragments up front, straight into
+// the MFMA operand layouts (K: a float4 of head dim per lane and 16-dim chunk, its four elements feed four consecutive
+// MFMAs, which permutes the reduction identically on both sides; V: one key row element per lane), so the kernel is one
+// memory round trip + 128 MFMAs: 6.4 us against 7.2 for the K/V-ring kernel on these 24 small problems.
+// grid (heads, regions), 4 waves; q already scaled by the projection's epilogue.
+__global__ __launch_bounds__(256) void region_attn64_kernel(const float* __restrict__ qkv, float* __restrict__ o, int dim) {
+  const int LDQ = 3 * dim;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int head = blockIdx.x, reg = blockIdx.y;
+  const float* base = qkv + (size_t)reg * 64 * LDQ + head * HD;
+  float4 qf[4], kf[4][4];
+  float vf[4][4][4];                                       // [kt][j][dt]: V[key 16 kt + 4 g + j][d 16 dt + r]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qf[i] = *(const float4*)(base + (size_t)(16 * wave + r) * LDQ + 16 * i + 4 * g);
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kf[kt][i] = *(const float4*)(base + (size_t)(16 * kt + r) * LDQ + dim + 16 * i + 4 * g);
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vf[kt][j][dt] = base[(size_t)(16 * kt + 4 * g + j) * LDQ + 2 * dim + 16 * dt + r];
+  __builtin_amdgcn_sched_barrier(0);                      // every load is issued before the first MFMA waits
+  // S^T = K q^T: st[kt][j] = score(query 16 wave + r, key 16 kt + 4 g + j)
+  f32x4 st[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][i].x, qf[i].x, st[kt], 0, 0, 0);
+      st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][i].y, qf[i].y, st[kt], 0, 0, 0);
+      st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][i].z, qf[i].z, st[kt], 0, 0, 0);
+      st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][i].w, qf[i].w, st[kt], 0, 0, 0);
+    }
+  }
+  float mx = NEG_BIG;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mx = fmaxf(mx, st[kt][j]);
+  mx = max_xor32(max_xor16(mx));
+  float se = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st[kt][j] = __expf(st[kt][j] - mx);
+      se += st[kt][j];
+    }
+  se = sum_xor32(sum_xor16(se));
+  const float inv = 1.0f / se;
+  // O^T = V^T P^T: a = V[key][d 16 dt + r], b = this lane's probability for that key (query r)
+  f32x4 ot[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][j][dt], st[kt][j], ot[dt], 0, 0, 0);
+  float* orow = o + (size_t)(reg * 64 + 16 * wave + r) * dim + head * HD;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+    *(float4*)(orow + 16 * dt + 4 * g) = make_float4(ot[dt][0] * inv, ot[dt][1] * inv, ot[dt][2] * inv, ot[dt][3] * inv);
+}
+
 }  // namespace
 
 #ifdef RRT_TRACE
@@ -396,6 +467,11 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     region_attn_generic_kernel<<<dim3((P + 3) / 4, heads, n_regions), 256, lds, st>>>(
         qkv, pe_w, o, P, dim, hd, epeg_k);
+    return hipGetLastError();
+  }
+  static const bool no64 = getenv("RRT_NO_ATTN64") != nullptr;
+  if (P == 64 && epeg_k == 0 && !no64) {
+    region_attn64_kernel<<<dim3(heads, n_regions), 256, 0, st>>>(qkv, o, dim);
     return hipGetLastError();
   }
   const int ntiles = (P + 15) / 16;

@@ -197,62 +197,99 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
       // fragments of the next half are always in flight under the 108 MFMAs of the current one.  With one compute
       // wave per SIMD nothing else covers an LDS round trip: fetching a stage's first fragments right after its
       // barrier left the matrix pipe idle ~580 of every 7.5 K cycles (traced).
-      float4 af0[MT], bf0[NT], af1[MT], bf1[NT];
-      auto fetch = [&](const float* As, int kk, float4 (&af)[MT], float4 (&bf)[NT]) {
-        const float* Bs = As + BM * BK;
-        const int cslot = 4 * kk + lg;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          int row = wave * (16 * NT) + j * 16 + lr;
-          bf[j] = *(const float4*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          int row = i * 16 + lr;
-          af[i] = *(const float4*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
-        }
+      // Register budget: the A fragments are single-buffered and refilled IN PLACE -- row tile i's fragment of the next
+      // half is read right behind the 12 MFMAs that were the last users of the current one (a full half, ~3 K cycles,
+      // before it is needed), the three B fragments alternate between two sets.  36 VGPRs less than two full fragment
+      // sets: the kernel allocates 208 instead of 240, which leaves a SIMD room for a wave of ANOTHER kernel next to
+      // its two (the other bag's LayerNorm / CR-MSA kernels no longer wait for a block to retire).
+      float4 af[MT], bfr[2][NT];
+      auto a_frag = [&](const float* As, int kk, int i) {
+        const int row = i * 16 + lr;
+        return *(const float4*)(As + row * BK + (((4 * kk + lg) ^ ((row >> 1) & 7)) << 2));
       };
-      auto mma = [&](const float4 (&af)[MT], const float4 (&bf)[NT]) {
+      auto b_frag = [&](const float* As, int kk, int j) {
+        const int row = wave * (16 * NT) + j * 16 + lr;
+        return *(const float4*)(As + BM * BK + row * BK + (((4 * kk + lg) ^ ((row >> 1) & 7)) << 2));
+      };
+      // A step = one row tile of one half k tile = 12 MFMAs (k step outer, column tile inner: an accumulator comes round
+      // every third MFMA) + one refill read, issued in the shadow of the step's last MFMA (a wave issues in order).
+      // The refill lags ONE step: behind step i goes the next-half fragment of row tile i - 1, whose registers the
+      // matrix pipe finished reading a step ago (refilling row tile i itself made the compiler rotate accumulator and
+      // fragment registers and pay the MFMA-source hazard in s_nops: ~120 cycles per k tile).
+      auto mm = [&](const int i, const float4 (&bc)[NT]) {
 #pragma unroll
         for (int comp = 0; comp < 4; ++comp)
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              const float a = comp == 0 ? af[i].x : comp == 1 ? af[i].y : comp == 2 ? af[i].z : af[i].w;
-              const float b = comp == 0 ? bf[j].x : comp == 1 ? bf[j].y : comp == 2 ? bf[j].z : bf[j].w;
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
-            }
+          for (int j = 0; j < NT; ++j) {
+            const float a = comp == 0 ? af[i].x : comp == 1 ? af[i].y : comp == 2 ? af[i].z : af[i].w;
+            const float b = comp == 0 ? bc[j].x : comp == 1 ? bc[j].y : comp == 2 ? bc[j].z : bc[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       };
+      // first half of a k tile (stage As; B set 0), refilling towards its second half (B set 1); owe = row tile MT - 1's
+      // first-half fragment has not been read yet (it is owed by the previous second half)
+      auto first_half = [&](const float* As, const bool owe) {
+        mm(0, bfr[0]);
+        if (owe) af[MT - 1] = a_frag(As, 0, MT - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 1; i < MT; ++i) {
+          mm(i, bfr[0]);
+          af[i - 1] = a_frag(As, 1, i - 1);
+          if (i <= NT) bfr[1][i - 1] = b_frag(As, 1, i - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      // second half up to the barrier: two steps; the first one carries the last read of the stage
+      auto second_head = [&](const float* As) {
+        mm(0, bfr[1]);
+        af[MT - 1] = a_frag(As, 1, MT - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1, bfr[1]);
+      };
+      // ... and behind it, refilling towards the next k tile's first half (stage nAs)
+      auto second_tail = [&](const float* nAs, const bool refill) {
+        if (refill) {
+          af[0] = a_frag(nAs, 0, 0);
+          bfr[0][0] = b_frag(nAs, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 2; i < MT; ++i) {
+          mm(i, bfr[1]);
+          if (refill) {
+            af[i - 1] = a_frag(nAs, 0, i - 1);
+            if (i <= NT) bfr[0][i - 1] = b_frag(nAs, 0, i - 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
+      static_assert(MT > NT, "the refill schedule needs more row tiles than column tiles");
       __syncthreads();                              // K tile 0 published
       RRT_TRACE_MARK();                             // [2]
-      fetch(lds, 0, af0, bf0);
-      // one LDS read behind each of the first MT + NT MFMAs of a half, the rest of the MFMAs after them: a wave
-      // issues in order, so a bunch of 12 reads between two MFMA runs drains the matrix pipe while the four waves'
-      // reads queue up at the LDS (traced: ~770 cycles per bunch); issued in the shadow of an MFMA they are free
-      auto interleave = [&]() {
 #pragma unroll
-        for (int q = 0; q < MT + NT; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT - (MT + NT), 0);
-      };
-      for (int kt = 0; kt < nk; ++kt) {
+      for (int i = 0; i < MT; ++i) af[i] = a_frag(lds, 0, i);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bfr[0][j] = b_frag(lds, 0, j);
+      // Barrier B_kt (stage kt is in registers everywhere, stage kt + 1 published) sits two steps into the second half
+      // of k tile kt: the last read of stage kt went out 12 MFMAs earlier, so its lgkmcnt(0) does not wait (directly
+      // behind the first half it idled ~150 cycles per k tile) -- and the loop is rotated so that its back edge is right
+      // behind the barrier, where the conservative lgkmcnt(0) the compiler puts at a loop header is free too.
+      first_half(lds, false);
+      second_head(lds);
+      __syncthreads();                                            // B_0
+      RRT_TRACE_MARK();                                           // [3] B_0
+      for (int kt = 1; kt < nk; ++kt) {
         const float* As = lds + (kt & 1) * STAGE;
         __builtin_amdgcn_sched_barrier(0);
-        fetch(As, 1, af1, bf1);
-        mma(af0, bf0);
-        interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                            // B_kt: stage kt is in registers everywhere, stage kt + 1 published
-        if (kt == 0 || kt == 7) RRT_TRACE_MARK();   // [3,4] B_0, B_7
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(lds + ((kt + 1) & 1) * STAGE, 0, af0, bf0);   // (after the last tile: a stale stage, never used)
-        mma(af1, bf1);
-        interleave();
-        __builtin_amdgcn_sched_barrier(0);
+        second_tail(As, true);                                    // rest of k tile kt - 1
+        first_half(As, true);
+        second_head(As);
+        __syncthreads();                                          // B_kt
+        if (kt == 7) RRT_TRACE_MARK();                            // [4] B_7
       }
+      second_tail(nullptr, false);                                // rest of the last k tile
     } else {
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();

@@ -143,7 +143,7 @@ def _attn_ref(qkv, pe_w, R, P, D, heads, epeg_k):
 @pytest.mark.parametrize("R,P,D,heads,ek", [(64, 144, 512, 8, 15), (8, 121, 512, 8, 15), (4, 256, 512, 8, 21),
                                             (3, 64, 512, 8, 0), (64, 9, 512, 8, 15), (64, 1, 512, 8, 15),
                                             (2, 49, 512, 8, 9), (2, 484, 512, 8, 15), (5, 100, 128, 2, 15),
-                                            (3, 64, 512, 1, 0), (64, 9, 64, 8, 15), (2, 37, 96, 3, 5)])
+                                            (3, 64, 512, 1, 0), (64, 9, 64, 8, 15), (2, 37, 96, 3, 5), (5, 64, 128, 2, 0)])
 def test_region_attention(R, P, D, heads, ek):
     from hip_util import dev, region_attention
     qkv = synth.normal(f"att/{R}x{P}x{D}", (R * P, 3 * D)) * 0.7
