@@ -10,12 +10,13 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_*
 timeout 600 python $R/bench.py > $OUT/${TAG}_bench_default.bench.json 2> /tmp/bench.err || tail -5 /tmp/bench.err
-timeout 300 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_steps20.bench.json 2>/dev/null
+timeout 600 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_cmd.bench.json 2>/dev/null
 for c in 2 3 4; do timeout 300 python $R/bench.py --config $c --no-cpu-baseline --steps 100 > $OUT/${TAG}_bench_config$c.bench.json 2>/dev/null; done
 timeout 300 python $R/bench.py --dtype bf16 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_config1_bf16.bench.json 2>/dev/null
 X="--no-cpu-baseline --no-extras"
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o a -- python $R/bench.py $X > /tmp/a.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_a/a_results.db > $OUT/${TAG}_bench_default_2streams.kernel_stats.txt
+python $R/tools/rocprof_timeline.py /tmp/prof_a/a_results.db 48 < /dev/null | cut -c1-130 > $OUT/${TAG}_timeline_2streams.txt
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b -- python $R/bench.py --streams 1 $X > /tmp/b.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_b/b_results.db > $OUT/${TAG}_bench_1stream.kernel_stats.txt
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_c -o c -- python $R/bench.py --dtype bf16 --streams 1 $X > /tmp/c.log 2>&1
