@@ -388,14 +388,15 @@ class EncoderWorkload:
                                "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((self.dtype, self.n)),
                                "note": f"mean over {len(self.ev_pairs)} launches of the timed region (every "
                                        f"{self.ev_every}. step, all streams; {self.S} bag(s) "
-                                       "in flight per GPU: a launch shares the chip with the other bag's kernels -- "
-                                       "see roofline_isolated)"}
+                                       "in flight per GPU: the other bag's kernels are co-resident on this launch's "
+                                       "CUs for its whole duration and take issue slots from it -- the kernel's own "
+                                       "number is roofline_isolated)"}
         ach = flops / (iso_ms * 1e-3) / 1e12
         iso = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                "frac": round(ach / peak, 4), "flops_per_launch": flops, "avg_launch_ms": round(iso_ms, 5),
                "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((self.dtype, self.n)),
-               "note": "same kernel, untimed pass with one bag in flight (forwards back to back on one stream, median "
-                       "of 10 launches)"}
+               "note": "same kernel, untimed pass with one bag in flight (forwards back to back on one stream after 150 "
+                       "forwards of lead, every fourth one instrumented, median of 10 launches)"}
         if self.mil is None:
             rec["roofline_isolated"] = iso
         else:
