@@ -271,7 +271,7 @@ int rrt_crmsa_region_f32(const float *x1, const float *gamma, const float *beta,
                          int64_t L, int32_t dim, int32_t k, const rrt_grid *g8, void *stream);
 /* The same at full chip width, what rrt_encoder_forward_f32 uses (dim = 512, k <= 3, regions of 4..144 tokens, at least one
  * R-MSA layer): four blocks per region, each with a quarter of the rows; the quarter that arrives last merges the four
- * partial records like an online softmax (nobody waits for anybody).  scratch: 256 + 64 * 4 * 3 * 520 * 4 bytes; logits
+ * partial records like an online softmax (nobody waits for anybody).  scratch: 256 + 64 * 8 * 3 * 520 * 4 bytes; logits
  * must be given (the merging block reads them); mean_rstd may be NULL. */
 int rrt_crmsa_region4_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
                           float *mean_rstd, float *logits, float *wdisp, float *rep,

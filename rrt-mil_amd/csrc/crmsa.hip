@@ -500,9 +500,8 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
 // applies LayerNorm's affine, and writes the region's dispatch weights.  256 blocks: the VALU work that made the
 // one-block form slow sits on every CU again.  The counters must be zero at the start: an earlier GEMM of the same
 // forward zeroes them (LinearEpilogue.zero64), the merging block leaves them zero.
-constexpr int R4_ROWS = 3;                          // rows per wave
-constexpr int R4_WAVES = 12;
 constexpr int R4_REC = REGION_KMAX * (512 + 8);     // floats per partial record
+constexpr int R4_NB_MAX = 8;                        // blocks per region, at most
 // Device-coherent accesses for the hand-over between the quarters of a region.  The eight XCDs have private L2s, so an
 // ordinary store may sit dirty in the writer's L2 and an ordinary load may hit a stale line in the reader's; a
 // __threadfence() repairs that by writing the whole L2 back (measured: 100 us for the 3072 waves of this kernel).  Relaxed
@@ -511,6 +510,7 @@ constexpr int R4_REC = REGION_KMAX * (512 + 8);     // floats per partial record
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+template <int NB, int R4_WAVES, int R4_ROWS>     // blocks per region, waves per block, rows per wave
 __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const float* __restrict__ x1,
                                                                       const float* __restrict__ gamma,
                                                                       const float* __restrict__ beta,
@@ -534,9 +534,9 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   __shared__ float s_mm[KM][2];                     // region min, max
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int reg = blockIdx.x >> 2, q = blockIdx.x & 3, R = g.rs * g.rs;
+  const int reg = blockIdx.x / NB, q = blockIdx.x - reg * NB, R = g.rs * g.rs;
   const int ri = reg / g.rs, rj = reg - ri * g.rs;
-  const int PQ = (g.P + 3) >> 2;                    // rows per quarter
+  const int PQ = (g.P + NB - 1) / NB;               // rows per part ("quarter": NB = 4)
   float4 r[NR][2];
   int tokv[NR];
 #pragma unroll
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   }
   __syncthreads();
   // ---- this quarter's record -> workspace
-  float* rec = part_g + (size_t)(reg * 4 + q) * R4_REC;
+  float* rec = part_g + (size_t)(reg * NB + q) * R4_REC;
   for (int idx = tid; idx < k * 128; idx += 64 * NW) {
     const int n = idx >> 7, c = idx & 127;
     float4 a = s_part[n * 128 + c];
@@ -710,21 +710,21 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record (and the logits) are in memory ...
   __syncthreads();
   if (tid == 0)                                     // ... before this quarter counts as arrived
-    s_last = __hip_atomic_fetch_add(counters + reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3;
+    s_last = __hip_atomic_fetch_add(counters + reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NB - 1;
   __syncthreads();
   if (!s_last) return;
   if (tid == 0) __hip_atomic_store(counters + reg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next forward
-  const float* rec0 = part_g + (size_t)(reg * 4) * R4_REC;
+  const float* rec0 = part_g + (size_t)(reg * NB) * R4_REC;
   if (tid < k) {
     const int n = tid;
     float M = -3.0e38f, mn = 3.0e38f;
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < NB; ++b) {
       const float* st = rec0 + b * R4_REC + n * (DIM + 8) + DIM;
       M = fmaxf(M, ld_agent(st));
       mn = fminf(mn, ld_agent(st + 1));
     }
     float L = 0.f, c0 = 0.f, c1 = 0.f;
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < NB; ++b) {
       const float* st = rec0 + b * R4_REC + n * (DIM + 8) + DIM;
       const float sc = __expf(ld_agent(st) - M);
       L += sc * ld_agent(st + 2); c0 += sc * ld_agent(st + 3); c1 += sc * ld_agent(st + 4);
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   for (int idx = tid; idx < k * 128; idx += 64 * NW) {
     const int n = idx >> 7, c = idx & 127;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < NB; ++b) {
       const float* rb = rec0 + b * R4_REC + n * (DIM + 8);
       const float sc = __expf(ld_agent(rb + DIM) - s_mrg[n][0]) * s_mrg[n][1];
       const float* vp = rb + c * 4;
@@ -962,20 +962,32 @@ hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float*
   return hipGetLastError();
 }
 
+// Two shapes: four blocks of 12 waves x 3 rows per region (fewest hand-overs: best with one bag in flight), or eight
+// blocks of 4 waves x 5 rows (RRT_REGION4_CFG=8): one wave per SIMD at ~100 VGPRs, which fits next to two waves of the
+// other bag's fused R-MSA kernel (184 VGPRs each) -- the 12-wave block has to wait for one of its blocks to retire.
 bool crmsa_region4_supported(int dim, int k, const GridDev& g8) {
   static const bool off = getenv("RRT_NO_CRMSA_REGION4") != nullptr;
-  return !off && dim == 512 && k >= 1 && k <= REGION_KMAX && g8.P >= 4 && g8.P <= 4 * R4_ROWS * R4_WAVES;
+  return !off && dim == 512 && k >= 1 && k <= REGION_KMAX && g8.P >= 4 && g8.P <= 144;
 }
-size_t crmsa_region4_scratch_floats(const GridDev& g8) { return (size_t)g8.rs * g8.rs * 4 * R4_REC; }
+size_t crmsa_region4_scratch_floats(const GridDev& g8) { return (size_t)g8.rs * g8.rs * R4_NB_MAX * R4_REC; }
+template <int NB, int NW, int NR>
+static hipError_t launch_region4_cfg(const float* x1, const float* gamma, const float* beta, const float* phi,
+                                     float* mean_rstd, float* logits, float* wdisp, float* rep, float* part_g,
+                                     int* counters, int k, const GridDev& g8, hipStream_t st) {
+  static_assert(NB <= R4_NB_MAX && NB * NW * NR >= 144 && NW >= REGION_KMAX && NW % 2 == 0, "region4 shape");
+  constexpr int PQM = NR * NW;
+  const size_t lds = (size_t)(REGION_KMAX * 512 + PQM * (2 * REGION_KMAX + 2)) * 4 + (size_t)(NW / 2) * REGION_KMAX * 128 * 16;
+  crmsa_region4_kernel<NB, NW, NR><<<dim3(g8.rs * g8.rs * NB), dim3(64 * NW), lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits,
+                                                                                         wdisp, rep, part_g, counters, k, g8);
+  return hipGetLastError();
+}
 hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float* beta, const float* phi,
                                 float* mean_rstd, float* logits, float* wdisp, float* rep, float* part_g, int* counters,
                                 int k, const GridDev& g8, hipStream_t st) {
-  constexpr int PQM = R4_ROWS * R4_WAVES;
-  const size_t lds = (size_t)(REGION_KMAX * 512 + PQM * (2 * REGION_KMAX + 2)) * 4 +
-                     (size_t)(R4_WAVES / 2) * REGION_KMAX * 128 * 16;
-  crmsa_region4_kernel<<<dim3(g8.rs * g8.rs * 4), dim3(64 * R4_WAVES), lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits,
-                                                                                  wdisp, rep, part_g, counters, k, g8);
-  return hipGetLastError();
+  static const int cfg = getenv("RRT_REGION4_CFG") ? atoi(getenv("RRT_REGION4_CFG")) : 4;
+  if (cfg == 8 && g8.P > 96)
+    return launch_region4_cfg<8, 4, 5>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, part_g, counters, k, g8, st);
+  return launch_region4_cfg<4, 12, 3>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, part_g, counters, k, g8, st);
 }
 
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,

@@ -238,7 +238,7 @@ def test_crmsa_region_kernel_matches_logits_plus_combine(L, k):
     phi = synth.uniform("crr/phi", (D, k), -1, 1) * (3.0 / np.sqrt(D))
     d_x1, d_gm, d_bt, d_phi = dev(x1), dev(gm), dev(bt), dev(phi)
     out = {}
-    scratch = torch.full((256 + 64 * 4 * 3 * 520 * 4,), 0x5A, dtype=torch.uint8, device=DEV)
+    scratch = torch.full((256 + 64 * 8 * 3 * 520 * 4,), 0x5A, dtype=torch.uint8, device=DEV)
     tags = ("two", "one", "four", "four again") if 4 <= g8.s * g8.s <= 144 else ("two", "one")
     for tag in tags:
         mr = torch.full((L, 2), float("nan"), device=DEV)
