@@ -733,6 +733,18 @@ struct Cfg { int mt, nt, cap; };
 //   cost = rounds * blocks_per_cu * MT * NT      [co-resident blocks share the CU's matrix pipes]
 // Candidates are ordered by preference; a later one must be strictly cheaper to win.
 Cfg choose(int M, int N, int prec = PREC_F32) {
+  if (const char* e = getenv("RRT_LINEAR_CFG_BIG")) {   // tuning hook for the bag-sized GEMMs only: "mt,nt,cap"
+    Cfg c{};
+    if (M > 1024 && sscanf(e, "%d,%d,%d", &c.mt, &c.nt, &c.cap) == 3) return c;
+  }
+  // The R-MSA out-projection of a bag of ~7.6-9.2 k tokens (N = 512, 640..768 tiles of 96 rows): a 96 x 64 block needs 40 KiB
+  // of LDS, which fits NEXT TO a block of the other bag's fused R-MSA kernel (114 KiB of the CU's 160) -- the 144-row
+  // block's 52 KiB does not, so with two bags in flight that GEMM could not start on a CU until the fused block
+  // retired.  Alone the two shapes take the same time (46.5 us at N = 9000); two bags in flight: 4.79 -> 4.84 k slides/s.
+  if (prec == PREC_F32 && N == 512) {
+    const long t96 = (long)((M + 95) / 96) * 8;
+    if (t96 >= 640 && t96 <= 768) return Cfg{6, 1, 768};
+  }
   if (const char* e = getenv("RRT_LINEAR_CFG")) {   // tuning hook: "mt,nt,cap"
     Cfg c{};
     if (sscanf(e, "%d,%d,%d", &c.mt, &c.nt, &c.cap) == 3) return c;
