@@ -3,7 +3,7 @@
 Restates ``RegionAttntion.padding`` / ``CrossRegionAttntion.padding``
 (reference modules/rmsa.py:175-202 and :261-288, identical bodies) and the
 index map of ``region_partition`` / ``region_reverse`` (modules/rmsa.py:28-54).
-The C library computes the same numbers (csrc/geometry.h); tests pin both
+The C library computes the same numbers (`rrt_region_grid`, csrc/api.hip); tests pin both
 against golden values taken from the reference's own ``padding()``.
 """
 from dataclasses import dataclass
