@@ -95,9 +95,11 @@ typedef struct rrt_encoder_desc {
   int32_t epeg_2d;         /* 1: k x k kernel -- over the score map ('attn') or over v's sqrt(P) x sqrt(P) image ('value_*') */
   int32_t epeg_type;       /* RRT_EPEG_ATTN (default) / RRT_EPEG_VALUE_BF / RRT_EPEG_VALUE_AF */
   /* Reduced-precision modes (BF16 / F16 / F32X3) keep 16-bit images of the R-MSA weights at the START of the workspace
-   * (4 dim^2 floats per layer, whatever n_tokens is).  1: the images in THIS workspace were written by an earlier
-   * call with the same weights, dim, n_rmsa_layers and compute -- skip the conversion (one launch, ~5 us).  The
-   * library keeps no state: 0 is always right, 1 is the caller's promise (rrt_mil_amd tracks parameter versions). */
+   * (4 dim^2 floats per layer, whatever n_tokens is).  With 0 EVERY call in such a mode writes them (one launch,
+   * ~5 us), whether or not this bag's region size takes the 16-bit kernels -- so "an earlier successful call on this
+   * workspace with the same weights, dim, n_rmsa_layers and compute" is all that 1 has to promise; the bag sizes of
+   * the two calls need not match.  The library keeps no state: 0 is always right, 1 is the caller's promise
+   * (rrt_mil_amd tracks parameter versions). */
   int32_t weights16_valid;
 } rrt_encoder_desc;
 
@@ -221,7 +223,8 @@ int rrt_rmsa_fused_f32(const float *u, const float *qkv_w, const float *qkv_b, c
  *  cast16        : dst[i] = (16-bit) src[i], n % 4 == 0 (the nn.Linear weights, once per forward);
  *  ln_partition16: rrt_ln_partition_f32 with the normalised rows rounded to 16 bits (what autocast feeds nn.Linear);
  *  linear16      : C fp32 [M, N] = A16 [M, K] . B16 [N, K]^T + bias; with resid != NULL the un-partition + residual
- *                  epilogue of rrt_linear_unpartition_residual_f32 (M = H*H of g); K % 64 == 0, M >= 128;
+ *                  epilogue of rrt_linear_unpartition_residual_f32 (M = H*H of g); K % 64 == 0 (any M: ragged
+ *                  row tiles are masked);
  *  rmsa_fused16  : rrt_rmsa_fused_f32 on 16-bit u / qkv_w, attention operands in 16 bits, o in 16 bits
  *                  (rmsa.py:100-122 under autocast); head dim 64, 16 < P <= 256. */
 int rrt_cast16(const float *src, uint16_t *dst, int64_t n, int32_t compute, void *stream);

@@ -47,8 +47,9 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
   const size_t Np = (size_t)g.H * g.H, Np8 = (size_t)g8.H * g8.H;
   const size_t R8 = (size_t)g8.regions_side * g8.regions_side;
   if (d.n_rmsa_layers > 0) {
-    // first, so that its place does not depend on n_tokens (desc.weights16_valid); carved in every mode (2 MB per
-    // layer at D = 512): the size must not depend on desc.compute, which callers flip between calls on one workspace
+    // first, so that its place does not depend on n_tokens (desc.weights16_valid); carved in every mode (4 D^2 floats
+    // = 4 MiB per layer at D = 512): the size must not depend on desc.compute, which callers flip between calls on one
+    // workspace
     w.w16 = (uint16_t*)take((size_t)d.n_rmsa_layers * 4 * D * D);     // (F32X3: (hi, lo) pairs = 4 bytes per weight)
     w.uo = take(Np * D);
     w.qkv = take(Np * 3 * D);
@@ -307,22 +308,23 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
   // workspace (desc.weights16_valid; the ABI itself keeps no state).
   // EPEG ablations (epeg_2d, epeg_type = value_*): unfused path with their own kernels (epeg_variants.hip)
   const bool epeg_variant = desc->epeg && (desc->epeg_2d || desc->epeg_type != RRT_EPEG_ATTN);
+  // The images are written whenever a reduced / emulated mode is asked for and the caller does not vouch for them --
+  // whether or not THIS bag's regions take the 16-bit kernels: the workspace (and the caller's validity key) outlives
+  // the bag, and the next, smaller bag on it may take them (a 20 k-token bag followed by a 9 k-token one).
   bool lowp16 = false;
-  if (desc->n_rmsa_layers > 0 && desc->compute != RRT_COMPUTE_F32 && !epeg_variant) {
+  if (desc->n_rmsa_layers > 0 && desc->compute != RRT_COMPUTE_F32 && !epeg_variant && D % 64 == 0) {
     const GridDev gd = to_dev(g);
     lowp16 = rmsa_fused16_supported(gd.P, D, desc->n_heads, desc->epeg ? desc->epeg_k : 0) &&
-             rmsa_fused_supported_rows(gd.Np, D) && D % 64 == 0;
-    if (lowp16) {
-      Cast16Jobs jobs{};
-      for (int li = 0; li < desc->n_rmsa_layers; ++li) {
-        const rrt_attn_weights& lw = w->rmsa[li];
-        if (!lw.qkv_w || !lw.proj_w) return RRT_E_INVALID;
-        uint16_t* base = ws.w16 + (size_t)li * 4 * D * D;
-        jobs.src[jobs.count] = lw.qkv_w; jobs.dst[jobs.count] = base; jobs.n4[jobs.count++] = (size_t)3 * D * D / 4;
-        jobs.src[jobs.count] = lw.proj_w; jobs.dst[jobs.count] = base + (size_t)3 * D * D; jobs.n4[jobs.count++] = (size_t)D * D / 4;
-      }
-      if (!desc->weights16_valid) RRT_TRY(launch_cast16(jobs, desc->compute, st));
+             rmsa_fused_supported_rows(gd.Np, D);
+    Cast16Jobs jobs{};
+    for (int li = 0; li < desc->n_rmsa_layers; ++li) {
+      const rrt_attn_weights& lw = w->rmsa[li];
+      if (!lw.qkv_w || !lw.proj_w) return RRT_E_INVALID;
+      uint16_t* base = ws.w16 + (size_t)li * 4 * D * D;
+      jobs.src[jobs.count] = lw.qkv_w; jobs.dst[jobs.count] = base; jobs.n4[jobs.count++] = (size_t)3 * D * D / 4;
+      jobs.src[jobs.count] = lw.proj_w; jobs.dst[jobs.count] = base + (size_t)3 * D * D; jobs.n4[jobs.count++] = (size_t)D * D / 4;
     }
+    if (!desc->weights16_valid) RRT_TRY(launch_cast16(jobs, desc->compute, st));
   }
   // RRT_COMPUTE_F32X3: the qkv and proj GEMMs of the R-MSA layers emulated in fp32 on the bf16 matrix cores (operands
   // as (hi, lo) bf16 pairs, three MFMAs per product; rmsa_fused_x3.hip, cast16.hip); attention and everything else as F32
@@ -330,17 +332,15 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
   if (want_x3 && desc->n_rmsa_layers > 0 && !epeg_variant) {
     const GridDev gd = to_dev(g);
     x3 = rmsa_fused_x3_supported(gd.P, D, desc->n_heads, desc->epeg ? desc->epeg_k : 0) && rmsa_fused_supported_rows(gd.Np, D);
-    if (x3) {
-      Cast16Jobs jobs{};
-      for (int li = 0; li < desc->n_rmsa_layers; ++li) {
-        const rrt_attn_weights& lw = w->rmsa[li];
-        if (!lw.qkv_w || !lw.proj_w) return RRT_E_INVALID;
-        uint16_t* base = ws.w16 + (size_t)li * 8 * D * D;          // 4 D^2 weights x 2 bf16
-        jobs.src[jobs.count] = lw.qkv_w; jobs.dst[jobs.count] = base; jobs.n4[jobs.count++] = (size_t)3 * D * D / 4;
-        jobs.src[jobs.count] = lw.proj_w; jobs.dst[jobs.count] = base + (size_t)6 * D * D; jobs.n4[jobs.count++] = (size_t)D * D / 4;
-      }
-      if (!desc->weights16_valid) RRT_TRY(launch_cast_split(jobs, st));
+    Cast16Jobs jobs{};
+    for (int li = 0; li < desc->n_rmsa_layers; ++li) {
+      const rrt_attn_weights& lw = w->rmsa[li];
+      if (!lw.qkv_w || !lw.proj_w) return RRT_E_INVALID;
+      uint16_t* base = ws.w16 + (size_t)li * 8 * D * D;          // 4 D^2 weights x 2 bf16
+      jobs.src[jobs.count] = lw.qkv_w; jobs.dst[jobs.count] = base; jobs.n4[jobs.count++] = (size_t)3 * D * D / 4;
+      jobs.src[jobs.count] = lw.proj_w; jobs.dst[jobs.count] = base + (size_t)6 * D * D; jobs.n4[jobs.count++] = (size_t)D * D / 4;
     }
+    if (!desc->weights16_valid) RRT_TRY(launch_cast_split(jobs, st));
   }
   // ---- R-MSA TransLayers: x = x + unpart(InnerAttention(part(pad(LN(x)))))  (rrt.py:117-125)
   for (int li = 0; li < desc->n_rmsa_layers; ++li) {
@@ -461,7 +461,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       // O goes to the qkv workspace (first Np*D floats), u stays in uo.
       RRT_TRY(launch_rmsa_fused(ws.uo, lw.qkv_w, lw.qkv_b, desc->epeg ? lw.pe_w : nullptr, ws.qkv,
                                 gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, desc->compute, st));
-      static const bool gate_proj = getenv("RRT_GATE_PROJ") != nullptr;
+      static const bool gate_proj = rrt_tune_env("RRT_GATE_PROJ") != nullptr;
       if (gt && !gate_proj) { RRT_TRY(hipEventRecord(gt->done, st)); gt->armed = true; }
       if (li == 0) { RRT_MARK(RRT_EV_QKV); RRT_MARK(RRT_EV_ATTN); }
       LinearEpilogue ep{};
@@ -956,8 +956,10 @@ int rrt_mil_forward_f32(const rrt_mil_desc* desc, const rrt_mil_weights* w, cons
   PoolWs pws = carve_pool(n_tokens, D, desc->pool_hidden, desc->pool_gated, enc_ws + align_up(enc_bytes, 256));
   hipStream_t st = (hipStream_t)stream;
 
+  // F32X3 concerns the R-MSA layers' big products only (encoder_forward): the GEMMs around the encoder are exact fp32
+  const int gemm_prec = desc->enc.compute == RRT_COMPUTE_F32X3 ? RRT_COMPUTE_F32 : desc->enc.compute;
   LinearEpilogue ep{};
-  ep.prec = desc->enc.compute;
+  ep.prec = gemm_prec;
   ep.bias = w->emb_b;
   ep.act = desc->emb_act;
   hipError_t e = launch_linear(x, w->emb_w, emb, (int)n_tokens, D, desc->input_dim, ep, st);
@@ -966,7 +968,7 @@ int rrt_mil_forward_f32(const rrt_mil_desc* desc, const rrt_mil_weights* w, cons
   if (rc) return rc;
   return pool_predict(y, w->pool_a_w, w->pool_a_b, desc->pool_gated ? w->pool_b_w : nullptr, w->pool_b_b,
                       w->pool_c_w, w->pool_c_b, w->pred_w, w->pred_b, nullptr, logits, attn, no_norm, n_tokens,
-                      D, desc->pool_hidden, desc->pool_act, desc->n_classes, desc->enc.compute, pws, st);
+                      D, desc->pool_hidden, desc->pool_act, desc->n_classes, gemm_prec, pws, st);
 }
 
 }  // extern "C"
@@ -1060,7 +1062,7 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
   // phase gate (the R-MSA cores of the bags in flight take turns): opt-in, RRT_GATE=1.  It paid +1.5 % at two bags in
   // flight with the round-1 kernels; with the round-2 kernels free-running streams are faster at every S (configs[4]
   // mix, bf16: 7.72 k vs 7.49 k slides/s; fp32: 3.74 k vs 3.68 k)
-  static const bool gate_on = getenv("RRT_GATE") != nullptr;
+  static const bool gate_on = rrt_tune_env("RRT_GATE") != nullptr;
   const bool gated = S == 2 && gate_on;
   for (int k = 0; k < n_bags && rc == RRT_OK; ++k) {
     const rrt_bag& b = bags[order[k]];

@@ -378,7 +378,7 @@ hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, co
   constexpr size_t LDS = ((size_t)3 * 16 * MT * HD + 2 * 16 * MT + 6 * 64) * sizeof(float);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   const float q_scale = 1.0f / sqrtf((float)HD);
-  static const bool six = getenv("RRT_ATTN_BWD_NW6") != nullptr;     // tuning hook (A/B of the two schedules)
+  static const bool six = rrt_tune_env("RRT_ATTN_BWD_NW6") != nullptr;     // tuning hook (A/B of the two schedules)
   if (MT >= 11 && !six) {           // measured: 9 tiles 221 (6 waves) vs 241 us; 11: 350 vs 291; 13: 516 vs 400
     auto kern = attn_bwd_kernel<MT, 4>;
     static OncePerDevice once;
@@ -824,7 +824,7 @@ hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const 
                                                                       1.0f / sqrtf((float)(D / heads)));
     return hipGetLastError();
   }
-  static const bool force_stream = getenv("RRT_ATTN_BWD_STREAM") != nullptr;   // tuning hook
+  static const bool force_stream = rrt_tune_env("RRT_ATTN_BWD_STREAM") != nullptr;   // tuning hook
   if (P > 208 || (force_stream && P > 48)) {
     const size_t rows = (size_t)n_regions * P;
     char* base = (char*)dpe_part + ((size_t)n_regions * heads * (epeg_k > 0 ? epeg_k : 1) * sizeof(float) + 255) / 256 * 256;

@@ -947,7 +947,7 @@ bool crmsa_region_supported(int dim, int k, const GridDev& g8) {
 // sits on a quarter of the CUs), so one bag in flight loses 1.7 %; two bags in flight gain 4 % (it leaves 192 CUs to
 // the other bag's R-MSA kernel), at the price of that kernel's in-flight duration (0.74 -> 0.65-0.70 of peak).
 bool crmsa_region_enabled() {
-  static const bool on = getenv("RRT_CRMSA_REGION") != nullptr;
+  static const bool on = rrt_tune_env("RRT_CRMSA_REGION") != nullptr;
   return on;
 }
 hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float* beta, const float* phi,
@@ -966,7 +966,7 @@ hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float*
 // blocks of 4 waves x 5 rows (RRT_REGION4_CFG=8): one wave per SIMD at ~100 VGPRs, which fits next to two waves of the
 // other bag's fused R-MSA kernel (184 VGPRs each) -- the 12-wave block has to wait for one of its blocks to retire.
 bool crmsa_region4_supported(int dim, int k, const GridDev& g8) {
-  static const bool off = getenv("RRT_NO_CRMSA_REGION4") != nullptr;
+  static const bool off = rrt_tune_env("RRT_NO_CRMSA_REGION4") != nullptr;
   return !off && dim == 512 && k >= 1 && k <= REGION_KMAX && g8.P >= 4 && g8.P <= 144;
 }
 size_t crmsa_region4_scratch_floats(const GridDev& g8) { return (size_t)g8.rs * g8.rs * R4_NB_MAX * R4_REC; }
@@ -984,7 +984,7 @@ static hipError_t launch_region4_cfg(const float* x1, const float* gamma, const 
 hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float* beta, const float* phi,
                                 float* mean_rstd, float* logits, float* wdisp, float* rep, float* part_g, int* counters,
                                 int k, const GridDev& g8, hipStream_t st) {
-  static const int cfg = getenv("RRT_REGION4_CFG") ? atoi(getenv("RRT_REGION4_CFG")) : 4;
+  static const int cfg = rrt_tune_env("RRT_REGION4_CFG") ? atoi(rrt_tune_env("RRT_REGION4_CFG")) : 4;
   if (cfg == 8 && g8.P > 96)
     return launch_region4_cfg<8, 4, 5>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, part_g, counters, k, g8, st);
   return launch_region4_cfg<4, 12, 3>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, part_g, counters, k, g8, st);

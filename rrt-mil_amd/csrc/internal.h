@@ -6,6 +6,16 @@
 
 GridDev to_dev(const rrt_grid& g);
 
+// Tuning hooks (tile shapes, kernel A/B switches) are read from the environment ONLY in a -DRRT_TUNING build
+// (tools/build_ablation.sh tune -DRRT_TUNING; tools/sweep_n.py and the RRT_*_CFG sweeps use it).  The product library
+// never looks at the process environment: its results and kernel choices depend on its arguments alone.
+#ifdef RRT_TUNING
+#include <stdlib.h>
+inline const char* rrt_tune_env(const char* name) { return getenv(name); }
+#else
+inline const char* rrt_tune_env(const char*) { return nullptr; }
+#endif
+
 // "Raise the dynamic-LDS cap of this kernel" has to happen once per DEVICE (the attribute lives in the device's
 // context): a process that drives two GPUs would otherwise fail its first > 64 KiB launch on the second one.
 struct OncePerDevice {

@@ -184,7 +184,7 @@ inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 int linear_bwd_chunks(int M, int N, int K, int* rows_per_chunk) {
   const long tiles = (long)((N + TN_BN - 1) / TN_BN) * ((K + TN_BK - 1) / TN_BK);
-  static const int target = getenv("RRT_TN_BLOCKS") ? atoi(getenv("RRT_TN_BLOCKS")) : 768;   // ~3 blocks per CU
+  static const int target = rrt_tune_env("RRT_TN_BLOCKS") ? atoi(rrt_tune_env("RRT_TN_BLOCKS")) : 768;   // ~3 blocks per CU
   int S = (int)((target + tiles - 1) / tiles);
   const int max_s = (M + 4 * TN_BM - 1) / (4 * TN_BM);      // at least 128 rows per chunk
   if (S > max_s) S = max_s;

@@ -697,9 +697,9 @@ hipError_t launch_cfg(const float* A, const float* B, float* C, int M, int N, in
   const int ntiles = tiles_m * tiles_n;
   const int grid = ntiles < grid_cap ? ntiles : grid_cap;
   if constexpr (MT >= 6) {
-    static const bool use_ws = getenv("RRT_LINEAR_NO_WS") == nullptr;
+    static const bool use_ws = rrt_tune_env("RRT_LINEAR_NO_WS") == nullptr;
     if (use_ws) {
-      static const bool force_defer = getenv("RRT_LINEAR_DEFER") != nullptr;   // tuning hook
+      static const bool force_defer = rrt_tune_env("RRT_LINEAR_DEFER") != nullptr;   // tuning hook
       if (ntiles <= grid && !force_defer) {            // no block gets a second tile: nothing to defer
         auto kws = linear_ws_kernel<MT, NT, MODE, PREC, false, false>;
         RRT_ALLOW_LDS(kws, LDS_BYTES);
@@ -733,7 +733,7 @@ struct Cfg { int mt, nt, cap; };
 //   cost = rounds * blocks_per_cu * MT * NT      [co-resident blocks share the CU's matrix pipes]
 // Candidates are ordered by preference; a later one must be strictly cheaper to win.
 Cfg choose(int M, int N, int prec = PREC_F32) {
-  if (const char* e = getenv("RRT_LINEAR_CFG_BIG")) {   // tuning hook for the bag-sized GEMMs only: "mt,nt,cap"
+  if (const char* e = rrt_tune_env("RRT_LINEAR_CFG_BIG")) {   // tuning hook for the bag-sized GEMMs only: "mt,nt,cap"
     Cfg c{};
     if (M > 1024 && sscanf(e, "%d,%d,%d", &c.mt, &c.nt, &c.cap) == 3) return c;
   }
@@ -745,7 +745,7 @@ Cfg choose(int M, int N, int prec = PREC_F32) {
     const long t96 = (long)((M + 95) / 96) * 8;
     if (t96 >= 640 && t96 <= 768) return Cfg{6, 1, 768};
   }
-  if (const char* e = getenv("RRT_LINEAR_CFG")) {   // tuning hook: "mt,nt,cap"
+  if (const char* e = rrt_tune_env("RRT_LINEAR_CFG")) {   // tuning hook: "mt,nt,cap"
     Cfg c{};
     if (sscanf(e, "%d,%d,%d", &c.mt, &c.nt, &c.cap) == 3) return c;
   }
@@ -820,7 +820,7 @@ hipError_t launch_linear16(const void* A, const void* B, float* C, int M, int N,
       if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
     }
   }
-  if (const char* e = getenv("RRT_LINEAR16_CFG")) {   // tuning hook: "mt,nt,cap"
+  if (const char* e = rrt_tune_env("RRT_LINEAR16_CFG")) {   // tuning hook: "mt,nt,cap"
     Cfg q{};
     if (sscanf(e, "%d,%d,%d", &q.mt, &q.nt, &q.cap) == 3) best = q;
   }

@@ -469,7 +469,7 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
         qkv, pe_w, o, P, dim, hd, epeg_k);
     return hipGetLastError();
   }
-  static const bool no64 = getenv("RRT_NO_ATTN64") != nullptr;
+  static const bool no64 = rrt_tune_env("RRT_NO_ATTN64") != nullptr;
   if (P == 64 && epeg_k == 0 && !no64) {
     region_attn64_kernel<<<dim3(heads, n_regions), 256, 0, st>>>(qkv, o, dim);
     return hipGetLastError();
@@ -486,7 +486,7 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
     if ((P < 16 * nw + epeg_k - 1 ? P : 16 * nw + epeg_k - 1) > 2 * kc) return hipErrorInvalidValue;
   }
   int tc_force = 0;
-  if (const char* e = getenv("RRT_ATTN_CFG")) {   // tuning hook: "tc,nw" (rejected if the Q rows do not fit)
+  if (const char* e = rrt_tune_env("RRT_ATTN_CFG")) {   // tuning hook: "tc,nw" (rejected if the Q rows do not fit)
     int a = 0, b = 0;
     if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= 3 && b >= 1 && b <= 4) {
       const int need = P < 16 * b + epeg_k - 1 ? P : 16 * b + epeg_k - 1;
@@ -495,7 +495,7 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
   }
   const int nqb = (ntiles + nw - 1) / nw;
   dim3 grid(nqb, heads, n_regions), block(nw * 64);
-  static const int direct = getenv("RRT_ATTN_DIRECT") ? atoi(getenv("RRT_ATTN_DIRECT")) : 0;
+  static const int direct = rrt_tune_env("RRT_ATTN_DIRECT") ? atoi(rrt_tune_env("RRT_ATTN_DIRECT")) : 0;
   if (direct) {
     // LDS = the Q staging rows only (16*nw queries + halo), 4-row granularity
     const int qrows = epeg_k > 0 ? (((P < 16 * nw + epeg_k - 1 ? P : 16 * nw + epeg_k - 1) + 3) & ~3) : 4;

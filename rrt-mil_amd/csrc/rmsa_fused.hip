@@ -766,7 +766,7 @@ RRT_TRACE_DEFINE_READER(rrt_debug_trace_fused)
 #endif
 
 bool rmsa_fused_supported(int P, int D, int heads, int epeg_k) {
-  static const bool off = getenv("RRT_NO_FUSED") != nullptr;
+  static const bool off = rrt_tune_env("RRT_NO_FUSED") != nullptr;
   if (off) return false;
   // one block holds a whole region: Q, K and V tiles of 16*MT rows in LDS -> P <= 208; MT in
   // {4, 6, 7, 8, 9, 11, 13} covers the region sizes s*s, s = 7..14, of bags of ~2.3k..12.5k tokens at

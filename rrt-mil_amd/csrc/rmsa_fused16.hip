@@ -465,7 +465,7 @@ RRT_TRACE_DEFINE_READER(rrt_debug_trace_fused16)
 #endif
 
 bool rmsa_fused16_supported(int P, int D, int heads, int epeg_k) {
-  static const bool off = getenv("RRT_NO_FUSED16") != nullptr;
+  static const bool off = rrt_tune_env("RRT_NO_FUSED16") != nullptr;
   if (off) return false;
   // one block holds a whole region (P <= 256 -> MT <= 16); 64-element K tiles; 32-bit DMA byte offsets
   return heads > 0 && D == heads * HD && D % 64 == 0 && P > 16 && P <= 256 && epeg_k >= 0 && epeg_k <= 63;

@@ -397,7 +397,7 @@ hipError_t launch_mt(const char* U, const char* W, const float* bqkv, const floa
 }  // namespace
 
 bool rmsa_fused_x3_supported(int P, int D, int heads, int epeg_k) {
-  static const bool off = getenv("RRT_NO_FUSED_X3") != nullptr;
+  static const bool off = rrt_tune_env("RRT_NO_FUSED_X3") != nullptr;
   if (off) return false;
   return heads > 0 && D == heads * HD && D % 32 == 0 && P > 48 && P <= 144 && epeg_k >= 0 && epeg_k <= 63;
 }

@@ -610,6 +610,41 @@ def test_forward_bags_mixed_sizes(streams):
     assert enc.forward_bags([]) == []
 
 
+@pytest.mark.parametrize("dt", [None, torch.bfloat16])
+def test_forward_bags_config4_hyperparameters(dt):
+    """BASELINE configs[4] as bench.py runs it: epeg_k=21, crmsa_k=5, a mix of bag sizes through the executor (several
+    streams, generic CR-MSA kernels, cached 16-bit weight images under bf16), every bag against the REAL reference:
+    fp32 vs the G5 / G19 goldens; bf16 vs the reference's own autocast runs (G16) where they exist and the fp32
+    goldens at the autocast bounds elsewhere."""
+    from hip_util import dev, encoder_from_state
+    names = ["G5_d512_n15000_k21_c5", "G19_d512_n5600_k21_c5", "G5_d512_n3000_k21_c5", "G19_d512_n11000_k21_c5"]
+    gs = [load_golden(n) for n in names]
+    x0, st, cfg = synth_case(gs[0])
+    assert cfg["epeg_k"] == 21 and cfg["crmsa_k"] == 5
+    enc = encoder_from_state(st, cfg)
+    enc.compute_dtype = dt
+    bags = [dev(synth_case(g)[0]) for g in gs]
+    for rep in range(2):                       # second pass: the weight images are cached, bags land on other streams
+        outs = enc.forward_bags(bags if rep == 0 else bags[::-1], streams=3)
+        torch.cuda.synchronize()
+        outs = outs if rep == 0 else outs[::-1]
+        for g, name, y in zip(gs, names, outs):
+            y = y.cpu().numpy()
+            if dt is None:
+                _cmp(y[g["rows"]], g["y_rows"], TOL_E2E, name)
+                s = np.array([y.astype(np.float64).sum(), np.abs(y.astype(np.float64)).sum()])
+                assert np.allclose(s, g["y_sums"][:2], rtol=1e-5, atol=N_ATOL(int(g["n"])))
+            else:
+                err = np.abs(y[g["rows"]] - g["y_rows"])
+                assert np.isfinite(y).all() and err.max() <= TOL_AMP_MAX and err.mean() <= TOL_AMP_MEAN, (name, err.max(), err.mean())
+                amp = "G16_amp_bf16_d512_n%d_k21_c5" % int(g["n"])
+                if amp in golden_names("G16"):
+                    ga = load_golden(amp)
+                    to_fp32 = np.abs(y[ga["rows"]] - ga["y32_rows"])
+                    amp_to_fp32 = np.abs(ga["y_rows"].astype(np.float64) - ga["y32_rows"])
+                    assert to_fp32.mean() <= amp_to_fp32.mean() and to_fp32.max() <= 1.1 * amp_to_fp32.max(), name
+
+
 def test_executor_rejects_bad_input():
     from hip_util import DEV, dev, encoder_from_state
     cfg = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)
@@ -1105,6 +1140,37 @@ def test_weight_image_cache_follows_the_parameters(mode):
     b = enc.forward_bags([xb, xb], streams=2)
     torch.cuda.synchronize()
     assert torch.equal(a[0], y3) and torch.equal(b[1], y3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,big", [(torch.bfloat16, 20000), ("f32x3", 10500), ("f32x3", 20000)])
+def test_weight_image_cache_survives_a_bag_that_skips_the_16bit_kernels(mode, big):
+    """Round-2 advisor finding: the validity key of the cached weight images did not say whether the call had written
+    them.  A bag whose regions the 16-bit / split kernels do not cover (N = 20000: P = 324; f32x3 also N = 10500:
+    P = 169) used to cast nothing, mark the cache valid, and let the next small bag on the SAME workspace read
+    uninitialised images.  Now every reduced-mode call writes them unless told they are valid."""
+    from hip_util import DEV, encoder_from_state, dev
+    g = load_golden("G3_d512_n9000")
+    x, st, cfg = synth_case(g)
+    fresh = encoder_from_state(st, cfg)
+    fresh.compute_dtype = mode
+    want = fresh(dev(x).unsqueeze(0)).clone()
+    enc = encoder_from_state(st, cfg)
+    enc.compute_dtype = mode
+    enc._desc.compute = enc._compute_mode()
+    enc._workspace(big, torch.device(DEV)).fill_(0xFF)                      # NaN-poisoned workspace: no image in it
+    yb = enc(dev(synth.bag(big, 512, tag="w16/big")).unsqueeze(0))          # first call on this encoder: the big bag
+    assert torch.isfinite(yb).all()
+    y = enc(dev(x).unsqueeze(0))                                             # same (larger) workspace, supported P
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
+    # executor: one stream, big bag first
+    ex = encoder_from_state(st, cfg)
+    ex.compute_dtype = mode
+    outs = ex.forward_bags([dev(synth.bag(big, 512, tag="w16/big")), dev(x)], streams=1)
+    outs2 = ex.forward_bags([dev(x)], streams=1)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], want[0]) and torch.equal(outs2[0], want[0])
 
 
 @pytest.mark.gpu

@@ -9,7 +9,7 @@ from oracle import rrt_oracle as O
 
 SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G8", "G11", "G13", "G15", "G16"))   # G8/G11/G13 = RRTMIL goldens; G15 / G16: below
          and int(load_golden(n)["n"]) <= 4096]
-LARGE = ["G3_d512_n9000", "G5_d512_n9000_c1_sc", "G17_epeg_attn2d_d512_n9000", "G17_epeg_valuebf_d512_n9000",
+LARGE = ["G3_d512_n9000", "G18_d512_n13000", "G19_d512_n5600_k21_c5", "G5_d512_n9000_c1_sc", "G17_epeg_attn2d_d512_n9000", "G17_epeg_valuebf_d512_n9000",
          "G17_epeg_valueaf_d512_n9000"]
 
 
