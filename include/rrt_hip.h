@@ -272,10 +272,11 @@ int rrt_crmsa_combine_f32(const float *x1, const float *gamma, const float *beta
 int rrt_crmsa_region_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
                          float *mean_rstd, float *logits, float *wdisp, float *rep,
                          int64_t L, int32_t dim, int32_t k, const rrt_grid *g8, void *stream);
-/* The same at full chip width, what rrt_encoder_forward_f32 uses (dim = 512, k <= 3, regions of 4..144 tokens, at least one
- * R-MSA layer): four blocks per region, each with a quarter of the rows; the quarter that arrives last merges the four
- * partial records like an online softmax (nobody waits for anybody).  scratch: 256 + 64 * 8 * 3 * 520 * 4 bytes; logits
- * must be given (the merging block reads them); mean_rstd may be NULL. */
+/* The same at full chip width, what rrt_encoder_forward_f32 uses (dim = 512, k <= 8, regions of 4..576 tokens -- bags up
+ * to ~36 k patches --, at least one R-MSA layer): 4 / 8 / 16 blocks per region (regions of <= 144 / 288 / 576 tokens), each
+ * with its share of the rows; the block that arrives last merges the partial records like an online softmax (nobody
+ * waits for anybody).  scratch: 256 + 64 * nb * km * 520 * 4 bytes with nb = 16 for regions of more than 288 tokens, else
+ * 8, and km = 3 for k <= 3, else 8; logits must be given (the merging block reads them); mean_rstd may be NULL. */
 int rrt_crmsa_region4_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
                           float *mean_rstd, float *logits, float *wdisp, float *rep,
                           int64_t L, int32_t dim, int32_t k, const rrt_grid *g8,

@@ -115,8 +115,9 @@ def round_lowp(a, dtype):
 class LowP:
     """Rounding points of the HIP path's reduced-precision modes (see the module docstring)."""
 
-    def __init__(self, dtype="bf16", attn=True):
-        self.dtype, self.attn = dtype, attn
+    def __init__(self, dtype="bf16", attn=True, stencil16=None):
+        # stencil16: None = as the library chooses (the pair kernel where it applies), True / False = force one form
+        self.dtype, self.attn, self.stencil16 = dtype, attn, stencil16
 
     def r(self, a):
         return round_lowp(a, self.dtype)
@@ -231,19 +232,40 @@ def _inner_attention64(x, st, pfx, heads, epeg_k, taps=None, lowp=None, attn_low
             taps[pfx + "proj_in"] = O
         return split_matmul_t(O.reshape(-1, D), Wp).reshape(B_, P, D) + st[pfx + "proj.bias"].astype(np.float64)
     if attn_lowp is not None:
-        # the kernels' form (DESIGN.md identities 1, 2): Q~ = Q + T Q built in fp32, then Q~, K, V and the
-        # unnormalised probabilities exp(S - max) go to the matrix cores in 16 bits; the row sum is taken over the
-        # unrounded probabilities (fp32 registers) and divides the fp32 accumulator at the end
-        qt = q
-        if pfx + "pe.weight" in st:
-            w = st[pfx + "pe.weight"].astype(np.float64).reshape(heads, epeg_k)
-            half = epeg_k // 2
-            qp = np.pad(q, ((0, 0), (0, 0), (half, half), (0, 0)))
-            qt = q.copy()
-            for t in range(epeg_k):
-                qt += w[None, :, t, None, None] * qp[:, :, t:t + P, :]
-        # (the kernels fold log2(e) into the stencil taps, round Q~ log2(e) and exponentiate with exp2)
-        S = attn_lowp.r(qt * 1.4426950408889634) @ attn_lowp.r(k).transpose(0, 1, 3, 2)
+        # the kernels' form (DESIGN.md identities 1, 2): Q~ = Q + T Q, then Q~, K, V and the unnormalised probabilities
+        # exp(S - max) go to the matrix cores in 16 bits; the row sum is taken over the unrounded probabilities (fp32
+        # registers) and divides the fp32 accumulator at the end.  Two forms of the stencil:
+        #   rmsa_fused16 (one region per block): built in fp32 from the unrounded Q, rounded once;
+        #   rmsa_pair16  (>= 8 regions of 17..176 tokens): on the matrix cores -- Q log2(e) is rounded to 16 bits FIRST, the
+        #   taps (identity included) enter as hi + lo 16-bit pairs, fp32 accumulation, then Q~ is rounded.
+        pair = attn_lowp.stencil16 if attn_lowp.stencil16 is not None else (B_ >= 8 and 16 < P <= 176)
+        L2E = 1.4426950408889634
+        if pair:
+            q16 = attn_lowp.r(q * L2E)
+            qt = q16
+            if pfx + "pe.weight" in st:
+                w = st[pfx + "pe.weight"].astype(np.float64).reshape(heads, epeg_k).copy()
+                half = epeg_k // 2
+                w[:, half] += 1.0                                           # the identity tap rides in the band
+                w = np.float32(w).astype(np.float64)                        # (the table holds fp32 values)
+                whi = attn_lowp.r(w)
+                w16 = whi + attn_lowp.r(w - whi)
+                qp = np.pad(q16, ((0, 0), (0, 0), (half, half), (0, 0)))
+                qt = np.zeros_like(q16)
+                for t in range(epeg_k):
+                    qt += w16[None, :, t, None, None] * qp[:, :, t:t + P, :]
+            S = attn_lowp.r(qt) @ attn_lowp.r(k).transpose(0, 1, 3, 2)
+        else:
+            qt = q
+            if pfx + "pe.weight" in st:
+                w = st[pfx + "pe.weight"].astype(np.float64).reshape(heads, epeg_k)
+                half = epeg_k // 2
+                qp = np.pad(q, ((0, 0), (0, 0), (half, half), (0, 0)))
+                qt = q.copy()
+                for t in range(epeg_k):
+                    qt += w[None, :, t, None, None] * qp[:, :, t:t + P, :]
+            # (the kernels fold log2(e) into the stencil taps, round Q~ log2(e) and exponentiate with exp2)
+            S = attn_lowp.r(qt * L2E) @ attn_lowp.r(k).transpose(0, 1, 3, 2)
         e = np.exp2(S - S.max(-1, keepdims=True))
         O = (attn_lowp.r(e) @ attn_lowp.r(v)) / e.sum(-1, keepdims=True)
         O = O.transpose(0, 2, 1, 3).reshape(B_, P, D)
@@ -361,8 +383,11 @@ def forward_f64(x, state, cfg=None, taps=None, lowp=None):
         mn, mx = Lg.min(-1, keepdims=True), Lg.max(-1, keepdims=True)
         Mm = (Lg - mn) / (mx - mn + 1e-8)
         rep = (Cw @ V).transpose(1, 0, 2)                                    # [k,R,D]
-        # (the representatives' 64-token attention stays in fp32 in every mode: only its GEMM operands round)
-        rep2 = _inner_attention64(rep, st, p + "attn.attn.", c["crmsa_heads"], 0, taps, lowp_small, None)
+        # bf16 / fp16 modes, head dim 64: the representatives go through the SAME fused 16-bit kernel as the R-MSA regions
+        # (k "regions" of 64 tokens, no EPEG) -- 16-bit operands of both projections and of the two attention products.
+        # Other head dims (crmsa_heads = 1): fp32 attention, only the GEMM operands round.
+        inner16 = lowp_small if (lowp_small is not None and D % 64 == 0 and D == 64 * c["crmsa_heads"]) else None
+        rep2 = _inner_attention64(rep, st, p + "attn.attn.", c["crmsa_heads"], 0, taps, lowp_small, inner16)
         out = np.einsum("rnp,nrd->rpd", Mm * Dw, rep2)                       # [R,P,D]
         z = np.empty((H * H, D))
         z[perm] = out.reshape(-1, D)

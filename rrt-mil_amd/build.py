@@ -11,9 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librrt_hip.so")
 STAMP = os.path.join(HERE, "csrc", ".build_stamp")
-SOURCES = ["ln_partition.hip", "cast16.hip", "linear_f32.hip", "region_attn.hip", "rmsa_fused.hip", "rmsa_fused16.hip", "rmsa_fused_x3.hip", "crmsa.hip", "epeg_variants.hip", "mil_pool.hip", "linear_bwd.hip", "ln_bwd.hip", "attn_bwd.hip", "crmsa_bwd.hip", "peg.hip",
+SOURCES = ["ln_partition.hip", "cast16.hip", "linear_f32.hip", "region_attn.hip", "rmsa_fused.hip", "rmsa_fused16.hip", "rmsa_pair16.hip", "rmsa_fused_x3.hip", "crmsa.hip", "epeg_variants.hip", "mil_pool.hip", "linear_bwd.hip", "ln_bwd.hip", "attn_bwd.hip", "crmsa_bwd.hip", "peg.hip",
            "api.hip"]
-HEADERS = ["common.h", "internal.h", os.path.join("..", "..", "include", "rrt_hip.h")]
+HEADERS = ["common.h", "internal.h", "fused16.h", os.path.join("..", "..", "include", "rrt_hip.h")]
 # -amdgpu-mfma-vgpr-form: gfx950 has one unified VGPR/AGPR file; keep MFMA accumulators in VGPRs so the
 # softmax / rescale VALU code does not shuttle them through v_accvgpr_read/write (hazard stalls).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",

@@ -29,6 +29,8 @@ struct Workspace {
   float *ffn_ln, *ffn_hid, *xp;
   float* pe_out;     // value-EPEG ablation: the conv's output [Np, D]
   uint16_t* w16;     // reduced-precision modes: 16-bit copies of the R-MSA layers' qkv / proj weights (4 D^2 per layer)
+  uint16_t* wcr16;   // ... and of CR-MSA's inner qkv / proj weights (4 D^2), bf16 / fp16 modes
+  uint16_t *rep16, *repo16;   // 16-bit representatives [k * 64, D] and their attention output (the fused 16-bit inner MSA)
   float* cr_part;    // crmsa_region4_kernel: partial records of the region quarters
   int* cr_cnt;       // ... and the 64 arrival counters (zeroed by an R-MSA GEMM of the same forward)
   size_t bytes;
@@ -46,11 +48,13 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
   const size_t D = d.dim;
   const size_t Np = (size_t)g.H * g.H, Np8 = (size_t)g8.H * g8.H;
   const size_t R8 = (size_t)g8.regions_side * g8.regions_side;
+  // the weight images first, so that their place does not depend on n_tokens (desc.weights16_valid)
+  if (d.n_rmsa_layers > 0) w.w16 = (uint16_t*)take((size_t)d.n_rmsa_layers * 4 * D * D);     // (F32X3: (hi, lo) pairs = 4 bytes per weight)
+  if (d.cr_msa) w.wcr16 = (uint16_t*)take(2 * D * D);                                         // 4 D^2 16-bit weights
   if (d.n_rmsa_layers > 0) {
-    // first, so that its place does not depend on n_tokens (desc.weights16_valid); carved in every mode (4 D^2 floats
+    // w16: its place does not depend on n_tokens (desc.weights16_valid); carved in every mode (4 D^2 floats
     // = 4 MiB per layer at D = 512): the size must not depend on desc.compute, which callers flip between calls on one
     // workspace
-    w.w16 = (uint16_t*)take((size_t)d.n_rmsa_layers * 4 * D * D);     // (F32X3: (hi, lo) pairs = 4 bytes per weight)
     w.uo = take(Np * D);
     w.qkv = take(Np * 3 * D);
     w.xa = take((size_t)N * D);
@@ -72,8 +76,10 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     w.rep_qkv = take(k * R8 * 3 * D);
     w.rep_o = take(k * R8 * D);
     w.rep2 = take(k * R8 * D);
+    w.rep16 = (uint16_t*)take(k * R8 * D / 2);
+    w.repo16 = (uint16_t*)take(k * R8 * D / 2);
     if (d.n_rmsa_layers > 0) {
-      w.cr_part = take(crmsa_region4_scratch_floats(to_dev(g8)));
+      w.cr_part = take(crmsa_region4_scratch_floats(to_dev(g8), d.crmsa_k));
       w.cr_cnt = (int*)take(64);
     }
     if (d.crmsa_mlp) {
@@ -312,19 +318,30 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
   // whether or not THIS bag's regions take the 16-bit kernels: the workspace (and the caller's validity key) outlives
   // the bag, and the next, smaller bag on it may take them (a 20 k-token bag followed by a 9 k-token one).
   bool lowp16 = false;
-  if (desc->n_rmsa_layers > 0 && desc->compute != RRT_COMPUTE_F32 && !epeg_variant && D % 64 == 0) {
-    const GridDev gd = to_dev(g);
-    lowp16 = rmsa_fused16_supported(gd.P, D, desc->n_heads, desc->epeg ? desc->epeg_k : 0) &&
-             rmsa_fused_supported_rows(gd.Np, D);
+  // CR-MSA's inner MSA over the 64 k representatives on the same 16-bit kernels (one fused launch + one GEMM instead
+  // of GEMM + attention + GEMM on fp32 data): head dim 64 only (crmsa_heads = dim / 64)
+  const bool inner16 = desc->cr_msa && desc->compute != RRT_COMPUTE_F32 && D % 64 == 0 &&
+                       rmsa_fused16_supported(64, D, desc->crmsa_heads, 0);
+  if (desc->compute != RRT_COMPUTE_F32 && D % 64 == 0) {
     Cast16Jobs jobs{};
-    for (int li = 0; li < desc->n_rmsa_layers; ++li) {
-      const rrt_attn_weights& lw = w->rmsa[li];
-      if (!lw.qkv_w || !lw.proj_w) return RRT_E_INVALID;
-      uint16_t* base = ws.w16 + (size_t)li * 4 * D * D;
-      jobs.src[jobs.count] = lw.qkv_w; jobs.dst[jobs.count] = base; jobs.n4[jobs.count++] = (size_t)3 * D * D / 4;
-      jobs.src[jobs.count] = lw.proj_w; jobs.dst[jobs.count] = base + (size_t)3 * D * D; jobs.n4[jobs.count++] = (size_t)D * D / 4;
+    if (desc->n_rmsa_layers > 0 && !epeg_variant) {
+      const GridDev gd = to_dev(g);
+      lowp16 = rmsa_fused16_supported(gd.P, D, desc->n_heads, desc->epeg ? desc->epeg_k : 0) &&
+               rmsa_fused_supported_rows(gd.Np, D);
+      for (int li = 0; li < desc->n_rmsa_layers; ++li) {
+        const rrt_attn_weights& lw = w->rmsa[li];
+        if (!lw.qkv_w || !lw.proj_w) return RRT_E_INVALID;
+        uint16_t* base = ws.w16 + (size_t)li * 4 * D * D;
+        jobs.src[jobs.count] = lw.qkv_w; jobs.dst[jobs.count] = base; jobs.n4[jobs.count++] = (size_t)3 * D * D / 4;
+        jobs.src[jobs.count] = lw.proj_w; jobs.dst[jobs.count] = base + (size_t)3 * D * D; jobs.n4[jobs.count++] = (size_t)D * D / 4;
+      }
     }
-    if (!desc->weights16_valid) RRT_TRY(launch_cast16(jobs, desc->compute, st));
+    if (inner16) {
+      if (!w->crmsa.qkv_w || !w->crmsa.proj_w) return RRT_E_INVALID;
+      jobs.src[jobs.count] = w->crmsa.qkv_w; jobs.dst[jobs.count] = ws.wcr16; jobs.n4[jobs.count++] = (size_t)3 * D * D / 4;
+      jobs.src[jobs.count] = w->crmsa.proj_w; jobs.dst[jobs.count] = ws.wcr16 + (size_t)3 * D * D; jobs.n4[jobs.count++] = (size_t)D * D / 4;
+    }
+    if (jobs.count && !desc->weights16_valid) RRT_TRY(launch_cast16(jobs, desc->compute, st));
   }
   // RRT_COMPUTE_F32X3: the qkv and proj GEMMs of the R-MSA layers emulated in fp32 on the bf16 matrix cores (operands
   // as (hi, lo) bf16 pairs, three MFMAs per product; rmsa_fused_x3.hip, cast16.hip); attention and everything else as F32
@@ -521,6 +538,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
   if (desc->crmsa_mlp ? (!w->phi0_w || !w->phi2_w) : !w->phi) return RRT_E_INVALID;
   const GridDev gd8 = to_dev(g8);
   const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
+  bool rep16_done = false;
   if (desc->crmsa_mlp) {
     // MLP phi (rmsa.py:248-252,305): v = LN(x1) materialised in region-major order, hidden = v W1^T on
     // the matrix cores, logits = tanh(hidden) W2^T; the combine then runs on the normalised rows
@@ -529,24 +547,45 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     ep.prec = desc->compute;
     RRT_TRY(launch_linear(ws.v8, w->phi0_w, ws.hid, gd8.Np, D / 4, D, ep, st));
     RRT_TRY(launch_crmsa_mlp_logits(ws.hid, w->phi2_w, ws.logits, gd8.Np, D / 4, k, st));
-    RRT_TRY(launch_crmsa_combine(ws.v8, nullptr, nullptr, nullptr, ws.logits, ws.wdisp, ws.rep, D, k, gd8, st));
-  } else if (ws.cr_cnt && desc->n_rmsa_layers > 0 && crmsa_region4_supported(D, k, gd8)) {
+    RRT_TRY(launch_crmsa_combine(ws.v8, nullptr, nullptr, nullptr, ws.logits, ws.wdisp, ws.rep, inner16 ? ws.rep16 : nullptr,
+                                 desc->compute, D, k, gd8, st));
+    rep16_done = inner16;
+  } else if (ws.cr_cnt && desc->n_rmsa_layers > 0 && crmsa_region4_supported(D, k, gd8) && gd8.P <= 144) {
     // logits + combine in one pass over x1: four blocks per region, the last to arrive merges (crmsa_region4_kernel).
-    // Its counters were zeroed by this forward's last R-MSA out-projection.
-    RRT_TRY(launch_crmsa_region4(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, ws.logits, ws.wdisp, ws.rep, ws.cr_part,
-                                 ws.cr_cnt, k, gd8, st));
+    // Its counters were zeroed by this forward's last R-MSA out-projection.  Regions of more than 144 tokens (8 / 16
+    // blocks per region: the kernel covers them, tests) stay with the two chip-wide kernels: measured on MI355X
+    // (tools/bench_crmsa.py) the merge of 8-16 partial records per region costs more than the second pass over x1
+    // -- N = 15000: 36 vs 24 us, N = 30000: 46-74 vs 39 us.
+    RRT_TRY(launch_crmsa_region4(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, ws.logits, ws.wdisp, ws.rep,
+                                 inner16 ? ws.rep16 : nullptr, desc->compute, ws.cr_part, ws.cr_cnt, k, gd8, st));
+    rep16_done = inner16;
   } else if (crmsa_region_enabled() && crmsa_region_supported(D, k, gd8)) {
     // logits + combine in one pass over x1 (one block of 16 waves per region, the rows stay in registers)
     RRT_TRY(launch_crmsa_region(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, nullptr, ws.wdisp, ws.rep, k, gd8, st));
   } else {
     RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, ws.mean_rstd, ws.logits, D, k, gd8, st));
-    RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, ws.mean_rstd, ws.logits, ws.wdisp, ws.rep, D, k,
-                                 gd8, st));
+    RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, ws.mean_rstd, ws.logits, ws.wdisp, ws.rep,
+                                 inner16 ? ws.rep16 : nullptr, desc->compute, D, k, gd8, st));
+    rep16_done = inner16;
   }
   RRT_MARK(RRT_EV_CR_COMBINE);
   // inner MSA over the representatives: batch = k, sequence = R8 regions, no EPEG (rmsa.py:322)
-  RRT_TRY(inner_attention(ws.rep, k, R8, cw, D, desc->crmsa_heads, 0, ws.rep_qkv, ws.rep_o, desc->compute, st));
-  {
+  if (inner16) {
+    // reduced-precision modes: qkv projection + attention of the (n, head) pairs as ONE launch of the 16-bit fused R-MSA
+    // kernel (k "regions" of 64 tokens, no EPEG), then the out-projection on 16-bit operands
+    if (!rep16_done) {
+      Cast16Jobs cj{};
+      cj.src[0] = ws.rep; cj.dst[0] = ws.rep16; cj.n4[0] = (size_t)k * R8 * D / 4; cj.count = 1;
+      RRT_TRY(launch_cast16(cj, desc->compute, st));
+    }
+    RRT_TRY(launch_rmsa_fused16(ws.rep16, ws.wcr16, cw.qkv_b, nullptr, ws.repo16, k, R8, D, desc->crmsa_heads, 0,
+                                desc->compute, st));
+    LinearEpilogue ep{};
+    ep.prec = desc->compute;
+    ep.bias = cw.proj_b;
+    RRT_TRY(launch_linear16(ws.repo16, ws.wcr16 + (size_t)3 * D * D, ws.rep2, k * R8, D, D, ep, st));
+  } else {
+    RRT_TRY(inner_attention(ws.rep, k, R8, cw, D, desc->crmsa_heads, 0, ws.rep_qkv, ws.rep_o, desc->compute, st));
     LinearEpilogue ep{};
     ep.prec = desc->compute;
     ep.bias = cw.proj_b;
@@ -760,7 +799,7 @@ int rrt_crmsa_combine_f32(const float* x1, const float* gamma, const float* beta
   if (!x1 || !logits || !wdisp || !rep || !g8 || L != g8->L) return RRT_E_INVALID;
   if (mean_rstd && (!gamma || !beta)) return RRT_E_INVALID;
   if (k <= 0 || k > RRT_MAX_CRMSA_K || dim % 4) return unsupported("crmsa: k in [1,8], dim%4==0");
-  return (int)launch_crmsa_combine(x1, gamma, beta, mean_rstd, logits, wdisp, rep, dim, k, to_dev(*g8),
+  return (int)launch_crmsa_combine(x1, gamma, beta, mean_rstd, logits, wdisp, rep, nullptr, 0, dim, k, to_dev(*g8),
                                    (hipStream_t)stream);
 }
 
@@ -778,12 +817,12 @@ int rrt_crmsa_region4_f32(const float* x1, const float* gamma, const float* beta
                           void* scratch, size_t scratch_bytes, void* stream) {
   if (!x1 || !gamma || !beta || !phi || !logits || !wdisp || !rep || !g8 || !scratch || L != g8->L) return RRT_E_INVALID;
   const GridDev gd = to_dev(*g8);
-  if (!crmsa_region4_supported(dim, k, gd)) return unsupported("crmsa_region4: dim = 512, k <= 3, regions of 4..144 tokens");
-  if (scratch_bytes < 256 + crmsa_region4_scratch_floats(gd) * sizeof(float)) return RRT_E_WORKSPACE;
+  if (!crmsa_region4_supported(dim, k, gd)) return unsupported("crmsa_region4: dim = 512, k <= 8, regions of 4..576 tokens");
+  if (scratch_bytes < 256 + crmsa_region4_scratch_floats(gd, k) * sizeof(float)) return RRT_E_WORKSPACE;
   hipError_t e = hipMemsetAsync(scratch, 0, 256, (hipStream_t)stream);      // the arrival counters
   if (e != hipSuccess) return (int)e;
-  return (int)launch_crmsa_region4(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, (float*)((char*)scratch + 256),
-                                   (int*)scratch, k, gd, (hipStream_t)stream);
+  return (int)launch_crmsa_region4(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, nullptr, 0,
+                                   (float*)((char*)scratch + 256), (int*)scratch, k, gd, (hipStream_t)stream);
 }
 
 int rrt_crmsa_dispatch_ln_f32(const float* x1, const float* x0, const float* wdisp,
@@ -1476,10 +1515,10 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
       e0.prec = desc->compute;
       RRT_TRY(launch_linear(s.v8, w->phi0_w, s.hid, gd8.Np, D / 4, D, e0, st));
       RRT_TRY(launch_crmsa_mlp_logits(s.hid, w->phi2_w, s.logits, gd8.Np, D / 4, k, st));
-      RRT_TRY(launch_crmsa_combine(s.v8, nullptr, nullptr, nullptr, s.logits, s.wdisp, s.rep, D, k, gd8, st));
+      RRT_TRY(launch_crmsa_combine(s.v8, nullptr, nullptr, nullptr, s.logits, s.wdisp, s.rep, nullptr, 0, D, k, gd8, st));
     } else {
       RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, s.mean_rstd, s.logits, D, k, gd8, st));
-      RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, s.mean_rstd, s.logits, s.wdisp, s.rep, D, k, gd8, st));
+      RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, s.mean_rstd, s.logits, s.wdisp, s.rep, nullptr, 0, D, k, gd8, st));
     }
     LinearEpilogue ep{};
     ep.prec = desc->compute;

@@ -23,6 +23,21 @@ namespace {
 
 constexpr int KMAX = RRT_MAX_CRMSA_K;
 
+// four fp32 values -> four 16-bit values (prec 1 bf16 / 2 fp16), the 16-bit copy of the representatives
+template <int PREC>
+__device__ __forceinline__ uint2 r4_pack4(float4 v) {
+  if constexpr (PREC == 2) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 r; r[0] = (_Float16)v.x; r[1] = (_Float16)v.y; r[2] = (_Float16)v.z; r[3] = (_Float16)v.w;
+    return __builtin_bit_cast(uint2, r);
+  } else {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    b4 r; r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+    return __builtin_bit_cast(uint2, r);
+  }
+}
+
+
 // rows handled by one wave (independent loads in flight per wave = RW * NV float4)
 constexpr int RW = 2;             // (4 until the column guards went: 9.1 -> 7.6 us at N = 9000)
 constexpr int RW_DISPATCH = 1;    // (2 until the column guards went: 10.0 -> 9.0 us)
@@ -142,8 +157,8 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
                                                             const float* __restrict__ mean_rstd,
                                                             const float* __restrict__ logits,
                                                             float* __restrict__ wdisp,
-                                                            float* __restrict__ rep, int dim, int k,
-                                                            GridDev g) {
+                                                            float* __restrict__ rep, uint16_t* __restrict__ rep16,
+                                                            int prec16, int dim, int k, GridDev g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Wc = (float*)smem;                         // [P][KMAX] combine coefficient x rstd
   int* tok = (int*)(Wc + (size_t)g.P * KMAX);       // [P] token index or -1 (pad)
@@ -276,6 +291,8 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
     out.z = gm.z * (a.z - c0) + bt.z * c1;
     out.w = gm.w * (a.w - c0) + bt.w * c1;
     *(float4*)(rep + ((size_t)n * R + reg) * dim + cc) = out;   // rep [k, R, D]
+    if (rep16)                                                  // reduced-precision modes: + the 16-bit A operand of the inner qkv GEMM
+      *(uint2*)(rep16 + ((size_t)n * R + reg) * dim + cc) = prec16 == 2 ? r4_pack4<2>(out) : r4_pack4<1>(out);
   }
 }
 
@@ -500,8 +517,8 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
 // applies LayerNorm's affine, and writes the region's dispatch weights.  256 blocks: the VALU work that made the
 // one-block form slow sits on every CU again.  The counters must be zero at the start: an earlier GEMM of the same
 // forward zeroes them (LinearEpilogue.zero64), the merging block leaves them zero.
-constexpr int R4_REC = REGION_KMAX * (512 + 8);     // floats per partial record
-constexpr int R4_NB_MAX = 8;                        // blocks per region, at most
+constexpr int R4_KMAX = RRT_MAX_CRMSA_K;            // k <= 8: the kernel is instantiated for KM = 3 and KM = 8 representatives
+constexpr int R4_NB_MAX = 16;                       // blocks per region, at most
 // Device-coherent accesses for the hand-over between the quarters of a region.  The eight XCDs have private L2s, so an
 // ordinary store may sit dirty in the writer's L2 and an ordinary load may hit a stale line in the reader's; a
 // __threadfence() repairs that by writing the whole L2 back (measured: 100 us for the 3072 waves of this kernel).  Relaxed
@@ -510,7 +527,9 @@ constexpr int R4_NB_MAX = 8;                        // blocks per region, at mos
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int NB, int R4_WAVES, int R4_ROWS>     // blocks per region, waves per block, rows per wave
+// KM: representatives the instantiation has registers for (k <= KM); KC: how many of them go through the block's
+// LDS reduction at a time (the [waves / 2][KC][512] buffer is 48 KiB at KC = 4)
+template <int NB, int R4_WAVES, int R4_ROWS, int KM_>     // blocks per region, waves per block, rows per wave
 __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const float* __restrict__ x1,
                                                                       const float* __restrict__ gamma,
                                                                       const float* __restrict__ beta,
@@ -519,15 +538,17 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
                                                                       float* __restrict__ logits,
                                                                       float* __restrict__ wdisp,
                                                                       float* __restrict__ rep,
+                                                                      uint16_t* __restrict__ rep16, int prec16,
                                                                       float* __restrict__ part_g, int* __restrict__ counters,
                                                                       int k, GridDev g) {
-  constexpr int DIM = 512, NR = R4_ROWS, NW = R4_WAVES, KM = REGION_KMAX, PQM = NR * NW;
+  constexpr int DIM = 512, NR = R4_ROWS, NW = R4_WAVES, KM = KM_, KC = KM_ < 4 ? KM_ : 4, PQM = NR * NW;
+  constexpr int R4_REC = KM * (DIM + 8);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* phi_t = (float*)smem;                      // [KM][DIM]
   float* s_lg = phi_t + KM * DIM;                   // [PQM][KM]
   float* s_mr = s_lg + PQM * KM;                    // [PQM][2]
   float* s_w = s_mr + PQM * 2;                      // [PQM][KM]
-  float4* s_part = (float4*)(s_w + PQM * KM);       // [NW / 2][KM][128] float4
+  float4* s_part = (float4*)(s_w + PQM * KM);       // [NW / 2][KC][128] float4
   __shared__ float s_stat[KM][3];                   // local max, min, sum of exp (all rows of the quarter)
   __shared__ float s_c0[KM][NW], s_c1[KM][NW];
   __shared__ float s_mrg[KM][4];                    // merge: M, 1 / L, c0 / L, c1 / L ... of the region
@@ -656,47 +677,46 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
       }
   }
   constexpr int HW = NW / 2;
-  if (wave >= HW) {
-#pragma unroll
-    for (int n = 0; n < KM; ++n)
-      if (n < k) {
-        s_part[((wave - HW) * KM + n) * 128 + lane] = acc[n][0];
-        s_part[((wave - HW) * KM + n) * 128 + 64 + lane] = acc[n][1];
-      }
-  }
-  __syncthreads();
-  if (wave < HW) {
-#pragma unroll
-    for (int n = 0; n < KM; ++n)
-      if (n < k) {
-        float4 a = s_part[(wave * KM + n) * 128 + lane], b = s_part[(wave * KM + n) * 128 + 64 + lane];
-        a.x += acc[n][0].x; a.y += acc[n][0].y; a.z += acc[n][0].z; a.w += acc[n][0].w;
-        b.x += acc[n][1].x; b.y += acc[n][1].y; b.z += acc[n][1].z; b.w += acc[n][1].w;
-        acc[n][0] = a; acc[n][1] = b;
-      }
-  }
-  __syncthreads();
-  if (wave < HW) {
-#pragma unroll
-    for (int n = 0; n < KM; ++n)
-      if (n < k) {
-        s_part[(wave * KM + n) * 128 + lane] = acc[n][0];
-        s_part[(wave * KM + n) * 128 + 64 + lane] = acc[n][1];
-      }
-  }
-  __syncthreads();
-  // ---- this quarter's record -> workspace
+  // ---- this quarter's record -> workspace: the NW per-wave partials summed through LDS in a fixed order, KC
+  // representatives at a time
   float* rec = part_g + (size_t)(reg * NB + q) * R4_REC;
-  for (int idx = tid; idx < k * 128; idx += 64 * NW) {
-    const int n = idx >> 7, c = idx & 127;
-    float4 a = s_part[n * 128 + c];
 #pragma unroll
-    for (int w = 1; w < HW; ++w) {
-      const float4 b = s_part[(w * KM + n) * 128 + c];
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  for (int n0 = 0; n0 < KM; n0 += KC) {
+    if (n0 >= k) break;
+    if (n0 > 0) __syncthreads();                    // the previous chunk's reads of s_part are done
+    if (wave >= HW) {
+#pragma unroll
+      for (int n = n0; n < n0 + KC && n < KM; ++n)
+        if (n < k) {
+          s_part[((wave - HW) * KC + n - n0) * 128 + lane] = acc[n][0];
+          s_part[((wave - HW) * KC + n - n0) * 128 + 64 + lane] = acc[n][1];
+        }
     }
-    float* dst = rec + n * (DIM + 8) + c * 4;
-    st_agent(dst, a.x); st_agent(dst + 1, a.y); st_agent(dst + 2, a.z); st_agent(dst + 3, a.w);
+    __syncthreads();
+    if (wave < HW) {
+#pragma unroll
+      for (int n = n0; n < n0 + KC && n < KM; ++n)
+        if (n < k) {
+          float4 a = s_part[(wave * KC + n - n0) * 128 + lane], b = s_part[(wave * KC + n - n0) * 128 + 64 + lane];
+          a.x += acc[n][0].x; a.y += acc[n][0].y; a.z += acc[n][0].z; a.w += acc[n][0].w;
+          b.x += acc[n][1].x; b.y += acc[n][1].y; b.z += acc[n][1].z; b.w += acc[n][1].w;
+          s_part[(wave * KC + n - n0) * 128 + lane] = a;
+          s_part[(wave * KC + n - n0) * 128 + 64 + lane] = b;
+        }
+    }
+    __syncthreads();
+    const int kc = min(KC, k - n0);
+    for (int idx = tid; idx < kc * 128; idx += 64 * NW) {
+      const int n = idx >> 7, c = idx & 127;
+      float4 a = s_part[n * 128 + c];
+#pragma unroll
+      for (int w = 1; w < HW; ++w) {
+        const float4 b = s_part[(w * KC + n) * 128 + c];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      float* dst = rec + (n0 + n) * (DIM + 8) + c * 4;
+      st_agent(dst, a.x); st_agent(dst + 1, a.y); st_agent(dst + 2, a.z); st_agent(dst + 3, a.w);
+    }
   }
   if (tid < k) {
     const int n = tid;
@@ -750,6 +770,11 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
     out.z = gm.z * (a.z - c0) + bt.z * c1;
     out.w = gm.w * (a.w - c0) + bt.w * c1;
     *(float4*)(rep + ((size_t)n * R + reg) * DIM + c * 4) = out;
+    // reduced-precision modes: the representatives also leave as the 16-bit A operand of their qkv projection
+    if (rep16) {
+      uint16_t* d16 = rep16 + ((size_t)n * R + reg) * DIM + c * 4;
+      *(uint2*)d16 = prec16 == 2 ? r4_pack4<2>(out) : r4_pack4<1>(out);
+    }
   }
   // dispatch weights of the whole region (rmsa.py:310-314, :324-325) from the four quarters' logits
   for (int p = tid; p < g.P; p += 64 * NW) {
@@ -962,37 +987,60 @@ hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float*
   return hipGetLastError();
 }
 
-// Two shapes: four blocks of 12 waves x 3 rows per region (fewest hand-overs: best with one bag in flight), or eight
-// blocks of 4 waves x 5 rows (RRT_REGION4_CFG=8): one wave per SIMD at ~100 VGPRs, which fits next to two waves of the
-// other bag's fused R-MSA kernel (184 VGPRs each) -- the 12-wave block has to wait for one of its blocks to retire.
+// Shapes.  Regions of <= 144 tokens (bags up to ~9.2 k patches): four blocks of 12 waves x 3 rows per region (fewest
+// hand-overs: best with one bag in flight; the tuning build also has eight blocks of 4 waves x 5 rows, RRT_REGION4_CFG=8:
+// one wave per SIMD at ~100 VGPRs, which fits next to two waves of the other bag's fused R-MSA kernel).  Round 3: regions
+// of <= 288 tokens take 8 blocks, <= 576 tokens 16 blocks of the same 12 x 3 shape (N = 30000: P8 = 484), and k <= 8
+// representatives (BASELINE configs[4]: crmsa_k = 5) the KM = 8 instantiation.
 bool crmsa_region4_supported(int dim, int k, const GridDev& g8) {
   static const bool off = rrt_tune_env("RRT_NO_CRMSA_REGION4") != nullptr;
-  return !off && dim == 512 && k >= 1 && k <= REGION_KMAX && g8.P >= 4 && g8.P <= 144;
+  return !off && dim == 512 && k >= 1 && k <= R4_KMAX && g8.P >= 4 && g8.P <= 36 * R4_NB_MAX;
 }
-size_t crmsa_region4_scratch_floats(const GridDev& g8) { return (size_t)g8.rs * g8.rs * R4_NB_MAX * R4_REC; }
-template <int NB, int NW, int NR>
+size_t crmsa_region4_scratch_floats(const GridDev& g8, int k) {
+  const int nb = g8.P > 288 ? 16 : 8;               // (8 also covers the tuning build's eight-block shape of small regions)
+  return (size_t)g8.rs * g8.rs * nb * (k <= 3 ? 3 : R4_KMAX) * (512 + 8);
+}
+template <int NB, int NW, int NR, int KM>
 static hipError_t launch_region4_cfg(const float* x1, const float* gamma, const float* beta, const float* phi,
-                                     float* mean_rstd, float* logits, float* wdisp, float* rep, float* part_g,
-                                     int* counters, int k, const GridDev& g8, hipStream_t st) {
-  static_assert(NB <= R4_NB_MAX && NB * NW * NR >= 144 && NW >= REGION_KMAX && NW % 2 == 0, "region4 shape");
-  constexpr int PQM = NR * NW;
-  const size_t lds = (size_t)(REGION_KMAX * 512 + PQM * (2 * REGION_KMAX + 2)) * 4 + (size_t)(NW / 2) * REGION_KMAX * 128 * 16;
-  crmsa_region4_kernel<NB, NW, NR><<<dim3(g8.rs * g8.rs * NB), dim3(64 * NW), lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits,
-                                                                                         wdisp, rep, part_g, counters, k, g8);
+                                     float* mean_rstd, float* logits, float* wdisp, float* rep, uint16_t* rep16, int prec16,
+                                     float* part_g, int* counters, int k, const GridDev& g8, hipStream_t st) {
+  static_assert(NB <= R4_NB_MAX && NW >= KM && NW % 2 == 0 && KM <= R4_KMAX, "region4 shape");
+  constexpr int PQM = NR * NW, KC = KM < 4 ? KM : 4;
+  const size_t lds = (size_t)(KM * 512 + PQM * (2 * KM + 2)) * 4 + (size_t)(NW / 2) * KC * 128 * 16;
+  auto kern = crmsa_region4_kernel<NB, NW, NR, KM>;
+  static OncePerDevice once;
+  if (lds > 64 * 1024 && once.first())
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<dim3(g8.rs * g8.rs * NB), dim3(64 * NW), lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16,
+                                                             part_g, counters, k, g8);
   return hipGetLastError();
 }
 hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float* beta, const float* phi,
-                                float* mean_rstd, float* logits, float* wdisp, float* rep, float* part_g, int* counters,
-                                int k, const GridDev& g8, hipStream_t st) {
+                                float* mean_rstd, float* logits, float* wdisp, float* rep, uint16_t* rep16, int prec16,
+                                float* part_g, int* counters, int k, const GridDev& g8, hipStream_t st) {
+#define RRT_R4(NB_, NW_, NR_)                                                                                          \
+  return k <= 3 ? launch_region4_cfg<NB_, NW_, NR_, 3>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, \
+                                                       part_g, counters, k, g8, st)                                   \
+                : launch_region4_cfg<NB_, NW_, NR_, 8>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, \
+                                                       part_g, counters, k, g8, st)
   static const int cfg = rrt_tune_env("RRT_REGION4_CFG") ? atoi(rrt_tune_env("RRT_REGION4_CFG")) : 4;
-  if (cfg == 8 && g8.P > 96)
-    return launch_region4_cfg<8, 4, 5>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, part_g, counters, k, g8, st);
-  return launch_region4_cfg<4, 12, 3>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, part_g, counters, k, g8, st);
+#ifdef RRT_TUNING
+  if (cfg == 86 && g8.P <= 576) { RRT_R4(8, 12, 6); }        // 8 blocks x 12 waves x 6 rows
+  if (cfg == 164 && g8.P <= 512) { RRT_R4(16, 8, 4); }       // 16 blocks x 8 waves x 4 rows
+  if (cfg == 166 && g8.P <= 576) { RRT_R4(16, 12, 3); }
+  if (cfg == 84 && g8.P <= 384) { RRT_R4(8, 12, 4); }
+#endif
+  if (g8.P > 288) { RRT_R4(16, 12, 3); }
+  if (g8.P > 144) { RRT_R4(8, 12, 3); }
+  if (cfg == 8 && g8.P > 96 && k <= 3)
+    return launch_region4_cfg<8, 4, 5, 3>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, part_g, counters, k, g8, st);
+  RRT_R4(4, 12, 3);
+#undef RRT_R4
 }
 
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
                                 const float* mean_rstd, const float* logits, float* wdisp,
-                                float* rep, int dim, int k, const GridDev& g8, hipStream_t st) {
+                                float* rep, uint16_t* rep16, int prec16, int dim, int k, const GridDev& g8, hipStream_t st) {
   dim3 grid(g8.rs * g8.rs, (dim + 63) / 64), block(256);
   const size_t lds = ((size_t)g8.P * KMAX + ((g8.P + 3) & ~3)) * 4 + (size_t)16 * KMAX * 16 * sizeof(float4);
   if (lds > 150 * 1024) return hipErrorInvalidValue;   // P8 > ~3500 tokens per region (N > 220k)
@@ -1000,7 +1048,7 @@ hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float
   auto kern = vnorm ? crmsa_combine_kernel<true> : crmsa_combine_kernel<false>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  kern<<<grid, block, lds, st>>>(x1, gamma, beta, mean_rstd, logits, wdisp, rep, dim, k, g8);
+  kern<<<grid, block, lds, st>>>(x1, gamma, beta, mean_rstd, logits, wdisp, rep, rep16, prec16, dim, k, g8);
   return hipGetLastError();
 }
 

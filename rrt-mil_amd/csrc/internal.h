@@ -55,7 +55,7 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
                          const LinearEpilogue& ep, hipStream_t st);
 
 // ---- 16-bit operand path of the reduced-precision modes (cast16.hip, linear_f32.hip IN16, rmsa_fused16.hip)
-constexpr int CAST16_MAX_JOBS = 2 * RRT_MAX_RMSA_LAYERS;
+constexpr int CAST16_MAX_JOBS = 2 * RRT_MAX_RMSA_LAYERS + 2;   // + CR-MSA's inner qkv / proj
 struct Cast16Jobs {
   const float* src[CAST16_MAX_JOBS];
   uint16_t* dst[CAST16_MAX_JOBS];
@@ -72,6 +72,11 @@ hipError_t launch_ln_partition_split(const float* x, const float* gamma, const f
 // C fp32 = A . B^T on split images of A [M, K] and B [N, K] (3 bf16 MFMAs per product: hi.hi + hi.lo + lo.hi)
 hipError_t launch_linear_split(const void* Asplit, const void* Bsplit, float* C, int M, int N, int K,
                                const LinearEpilogue& ep, hipStream_t st);
+// two regions x one head per block, EPEG stencil on the matrix cores (rmsa_pair16.hip); launch_rmsa_fused16 takes it
+// where it applies (>= 8 regions of <= 176 tokens)
+bool rmsa_pair16_supported(int n_regions, int P, int D, int heads, int epeg_k);
+hipError_t launch_rmsa_pair16(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
+                              int n_regions, int P, int D, int heads, int epeg_k, int prec, hipStream_t st);
 bool rmsa_fused_x3_supported(int P, int D, int heads, int epeg_k);
 hipError_t launch_rmsa_fused_x3(const void* Usplit, const void* Wsplit, const float* bqkv, const float* pe_w,
                                 void* Osplit, int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st);
@@ -107,16 +112,18 @@ hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float*
 bool crmsa_region_supported(int dim, int k, const GridDev& g8);
 bool crmsa_region_enabled();
 bool crmsa_region4_supported(int dim, int k, const GridDev& g8);
-size_t crmsa_region4_scratch_floats(const GridDev& g8);
+size_t crmsa_region4_scratch_floats(const GridDev& g8, int k);
+// rep16 (may be null): the representatives once more as 16-bit values (prec16 = 1 bf16 / 2 fp16), the A operand of the
+// inner MSA's qkv projection in the reduced-precision modes
 hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float* beta, const float* phi,
-                                float* mean_rstd, float* logits, float* wdisp, float* rep, float* part_g, int* counters,
-                                int k, const GridDev& g8, hipStream_t st);
+                                float* mean_rstd, float* logits, float* wdisp, float* rep, uint16_t* rep16, int prec16,
+                                float* part_g, int* counters, int k, const GridDev& g8, hipStream_t st);
 hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float* beta, const float* phi,
                                float* mean_rstd, float* logits, float* wdisp, float* rep, int k, const GridDev& g8,
                                hipStream_t st);
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
                                 const float* mean_rstd, const float* logits, float* wdisp,
-                                float* rep, int dim, int k, const GridDev& g8, hipStream_t st);
+                                float* rep, uint16_t* rep16, int prec16, int dim, int k, const GridDev& g8, hipStream_t st);
 // mean_rstd == nullptr: x1 is LN(x1) already, region-major [Np8, dim] (crmsa_mlp path)
 hipError_t launch_crmsa_mlp_logits(const float* hid, const float* w2, float* logits, int rows, int hdim,
                                    int k, hipStream_t st);

@@ -393,8 +393,10 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
 // 64 elements = the same 128-byte rows, so the staging ring, the XOR swizzle and the DMA schedule are byte for byte
 // those of the fp32 form; a 16-byte LDS slot is one 16x16x32 MFMA operand (k = 8 lg .. 8 lg + 7 of a 32-wide
 // sub-tile) and nothing is converted in the loop.
-template <int MT, int NT, int MODE, int PREC, bool IN16 = false, bool DEFER = true>
-__global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restrict__ Av,
+// NLW: loader waves (2 for the MFMA-bound fp32 forms; 4 for 16-bit operands, whose K loop is bound by how many LDS-DMA
+// pieces the CU keeps in flight -- tools/ubench/dma_rows.hip: 14 B/clk/CU with four issuing waves, 21 with eight)
+template <int MT, int NT, int MODE, int PREC, bool IN16 = false, bool DEFER = true, int NLW = 2>
+__global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void* __restrict__ Av,
                                                            const void* __restrict__ Bv,
                                                            float* __restrict__ C, int M, int N, int K,
                                                            int tiles_n, int ntiles, LinearEpilogue ep) {
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
   const char* const B = (const char*)Bv;
   constexpr int STAGE = (BM + BN) * BK;
   constexpr int NA = BM / 8, NB = BN / 8;                // DMA wave-instructions per A / B tile
-  constexpr int LA = (NA + 1) / 2, LB = NB / 2;          // per loader wave
+  constexpr int LA = (NA + NLW - 1) / NLW, LB = (NB + NLW - 1) / NLW;   // per loader wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = (float*)smem;
   const int lane = threadIdx.x & 63;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
   if (ep.zero64 != nullptr && blockIdx.x == 0 && threadIdx.x < 64) ep.zero64[threadIdx.x] = 0;
   if (first >= ntiles) return;
   const int nk = K / BKE;
-  RRT_TRACE_INIT(blockIdx.x * 6 + wave);
+  RRT_TRACE_INIT(blockIdx.x * (4 + NLW) + wave);
   RRT_TRACE_MARK();                                   // [1] entry
 
   if (wave >= 4) {
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
     auto tile_offsets = [&](int m0, int n0) {
 #pragma unroll
       for (int qi = 0; qi < LA; ++qi) {
-        int S = (qi * 2 + lw) * 64 + lane;
+        int S = (qi * NLW + lw) * 64 + lane;
         int row = S >> 3, p = S & 7;
         int gr = m0 + row;
         gr = gr < M ? gr : M - 1;
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
       }
 #pragma unroll
       for (int qi = 0; qi < LB; ++qi) {
-        int S = (qi * 2 + lw) * 64 + lane;
+        int S = (qi * NLW + lw) * 64 + lane;
         int row = S >> 3, p = S & 7;
         int gr = n0 + row;
         gr = gr < N ? gr : N - 1;
@@ -450,9 +452,10 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
     auto stage = [&](const char* abase, const char* bbase, unsigned buf) {
 #pragma unroll
       for (int qi = 0; qi < LA; ++qi)
-        if (qi * 2 + lw < NA) dma16s(abase, aoff[qi], buf + (qi * 2 + lw) * 1024);
+        if (qi * NLW + lw < NA) dma16s(abase, aoff[qi], buf + (qi * NLW + lw) * 1024);
 #pragma unroll
-      for (int qi = 0; qi < LB; ++qi) dma16s(bbase, boff[qi], buf + BM * BK * 4 + (qi * 2 + lw) * 1024);
+      for (int qi = 0; qi < LB; ++qi)
+        if (qi * NLW + lw < NB) dma16s(bbase, boff[qi], buf + BM * BK * 4 + (qi * NLW + lw) * 1024);
     };
     int tile = first;
     int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -667,6 +670,10 @@ __global__ __launch_bounds__(384, 2) void linear_ws_kernel(const void* __restric
       (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (lds_bytes));  \
   } while (0)
 
+#ifndef RRT_NLW16
+#define RRT_NLW16 4
+#endif
+constexpr int NLW16 = RRT_NLW16;      // loader waves of the 16-bit-operand GEMMs
 template <int MT, int NT, int MODE, int PREC>
 hipError_t launch_cfg16(const void* A, const void* B, float* C, int M, int N, int K, int grid_cap,
                         const LinearEpilogue& ep, hipStream_t st) {
@@ -676,13 +683,13 @@ hipError_t launch_cfg16(const void* A, const void* B, float* C, int M, int N, in
   const int ntiles = tiles_m * tiles_n;
   const int grid = ntiles < grid_cap ? ntiles : grid_cap;
   if (ntiles <= grid) {                                // no block gets a second tile: nothing to defer
-    auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true, false>;
+    auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true, false, NLW16>;
     RRT_ALLOW_LDS(kws, LDS_BYTES);
-    kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
+    kws<<<dim3(grid), dim3(64 * (4 + NLW16)), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
   } else {
-    auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true, true>;
+    auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true, true, NLW16>;
     RRT_ALLOW_LDS(kws, LDS_BYTES);
-    kws<<<dim3(grid), dim3(384), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
+    kws<<<dim3(grid), dim3(64 * (4 + NLW16)), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);
   }
   return hipGetLastError();
 }
@@ -811,7 +818,9 @@ hipError_t launch_linear16(const void* A, const void* B, float* C, int M, int N,
   {
     // (three 96-row blocks per CU first: at equal cost they keep more of the DMA-issue-bound loop in flight than two
     //  144-row ones -- 16.2 vs 17.3 us at N = 9000)
-    static const Cfg cands[] = {{6, 1, 768}, {9, 1, 512}, {8, 1, 512}, {9, 2, 512}, {8, 2, 512}, {9, 2, 256}, {8, 2, 256}};
+    // (the 64- and 32-row tiles: the 192-row out-projection of CR-MSA's representatives -- 24 / 48 blocks instead of 16)
+    static const Cfg cands[] = {{6, 1, 768}, {9, 1, 512}, {8, 1, 512}, {9, 2, 512}, {8, 2, 512}, {9, 2, 256}, {8, 2, 256},
+                                {4, 1, 512}, {2, 1, 512}};
     long best_cost = -1;
     for (const Cfg& c : cands) {
       long tiles = (long)((M + 16 * c.mt - 1) / (16 * c.mt)) * ((N + 64 * c.nt - 1) / (64 * c.nt));
@@ -837,6 +846,8 @@ hipError_t launch_linear16(const void* A, const void* B, float* C, int M, int N,
   RRT_CASE16(9, 2);
   RRT_CASE16(8, 2);
   RRT_CASE16(6, 1);
+  RRT_CASE16(4, 1);
+  RRT_CASE16(2, 1);
 #undef RRT_CASE16
 #undef RRT_MODES16
   return hipErrorInvalidValue;

@@ -1,0 +1,408 @@
+// rmsa_pair16.hip -- the fused 16-bit R-MSA core with TWO regions x one head per block (round 3).
+//
+// Same arithmetic interface as rmsa_fused16.hip (modules/rmsa.py:100-122 under the reference's --amp path): 16-bit U and
+// W in, 16-bit O out, qkv / scores / probabilities never leave the CU.  What changed is what bounds it.  Measured
+// (tools/ubench/dma_rows.hip = rmsa_fused16's projection loop with the MFMAs removed): streaming a block's operands --
+// the region's U panel and the head's W slice, 344 KB at P = 144 -- through the LDS-DMA path takes 20 of the kernel's
+// 28 us; a CU gets ~14 B/clk with four issuing waves, ~21 with eight, ~30 at best.  So:
+//   * one block owns a PAIR of regions and one head: the W slice (57 % of the bytes) is staged once for both regions'
+//     rows -- 245 KB per (region, head) instead of 344;
+//   * all eight waves issue DMA pieces AND multiply: waves 0-3 own region A's rows, waves 4-7 region B's, each wave one
+//     16-column tile of Q, of K and of V as before (no idle loader waves; the 2-stage ring of (2 BM + 192) x 128 B is as
+//     deep as a 160 KiB LDS allows);
+//   * the EPEG stencil runs on the matrix cores.  Along the query axis it is a banded Toeplitz product
+//     Q~[q, d] = sum_src T[q, src] Q[src, d],  T[q, src] = w_h[src - q + k/2] + [src == q]:  a 16-query tile meets its
+//     16 + 2 (k/2) source rows in one to three 32-wide MFMA steps.  Q leaves the projection TRANSPOSED (Q^T [d][token],
+//     16-bit, zero halo columns = the convolution's zero padding), so the A operand is one ds_read_b128; the B operand
+//     -- the band of T -- is the same for every tile and sits in registers as a (hi, lo) pair of 16-bit values (two
+//     MFMAs per step: the taps keep 16 significant bits); the result lands as four consecutive head-dim columns of a
+//     query = the row-major Q~ tile the score product reads.  5.6 K cycles of fp32 VALU work -> < 1 K.
+// Rounding points (oracle: forward_f64(lowp=LowP(.., attn=True, stencil16=True))): U, W; Q log2(e) hd^-0.5 (BEFORE the
+// stencil: one rounding more than rmsa_fused16, which ran the stencil in fp32), Q~, K, V, exp2(S - max), O.
+// Regions: any P <= 176 (MT <= 11 row tiles), head dim 64, at least 8 regions; others take rmsa_fused16.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "fused16.h"
+
+namespace {
+using namespace f16k;
+
+constexpr int VQ_B = 64 * VT_PITCH;     // per region: V^T [64][512 B]; before that, Q^T [64][512 B] for the stencil
+
+template <int MT, int PREC>
+__global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __restrict__ U,
+                                                             const uint16_t* __restrict__ W,
+                                                             const float* __restrict__ bqkv,
+                                                             const float* __restrict__ pe_w,
+                                                             uint16_t* __restrict__ O, int n_rows, int n_regions, int P,
+                                                             int D, int heads_rt, int epeg_k, float q_scale,
+                                                             int qs_pitch, int H8, int nstep) {
+  using H = H16<PREC>;
+  using Frag = typename H::frag;
+  using E = typename H::elem;
+  constexpr int BM = 16 * MT;
+  constexpr int MTP = (MT + 1) & ~1;                 // key tiles rounded up to whole 32-key MFMA blocks
+  constexpr int STAGE_B = (2 * BM + BN) * ROWB;      // bytes per pipeline stage: region A rows | region B rows | W rows
+  constexpr int NA = 2 * BM / 8, NB = BN / 8;        // 1-KiB DMA pieces (8 rows) per stage
+  constexpr int NP = NA + NB, LP = (NP + 7) / 8;     // pieces per stage / per wave
+  constexpr int QT_B = BM * ROWB, KS_B = BM * ROWB;
+  constexpr int REG_B = QT_B + KS_B + VQ_B;          // per region: Q~ | K | V^T (Q^T before the stencil)
+  constexpr int RING_B = 2 * STAGE_B, TILES_B = 2 * REG_B;
+  constexpr int LDS_MAIN = RING_B > TILES_B ? RING_B : TILES_B;
+  static_assert(16 * MTP * 2 <= VT_PITCH, "V^T row");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rsel = wave >> 2, cw = wave & 3;         // which region of the pair; which 16-column tile of Q / K / V
+  const int lr = lane & 15, lg = lane >> 4;
+  const unsigned lds_b = lds_addr_of(smem);
+  // XCD-aware block -> (pair, head) map: the head-blocks of a pair sit on ONE XCD (its U panels are fetched from HBM
+  // once and served to the other heads from that XCD's L2)
+  int head, pair;
+  {
+    const int b = blockIdx.x;
+    const int n_pairs = gridDim.x / heads_rt;
+    const int full = (n_pairs >> 3) * 8 * heads_rt;
+    if (b < full) {
+      const int xcd = b & 7, idx = b >> 3;
+      const int grp = idx / heads_rt;
+      pair = grp * 8 + xcd;
+      head = idx - grp * heads_rt;
+    } else {
+      const int rem = b - full;
+      pair = (n_pairs >> 3) * 8 + rem / heads_rt;
+      head = rem % heads_rt;
+    }
+  }
+  const int reg = 2 * pair + rsel;
+  const bool valid = reg < n_regions;                // (odd region count: the last pair's second half is a dummy)
+  const int row0 = (valid ? reg : 2 * pair) * P;
+  const int nk = D / 64;
+  const int half = epeg_k >> 1;
+  // the stencil's band, tap(i) = w_h[i] + [i == k/2] for i in [0, k), else 0, at index i + 32 of a 128-entry table
+  float* const taps = (float*)(smem + LDS_MAIN);
+  if (tid < 128) {
+    const int t = tid - 32;
+    float wt = (pe_w != nullptr && t >= 0 && t < epeg_k) ? pe_w[head * epeg_k + t] : 0.f;
+    if (t == half) wt += 1.0f;
+    taps[tid] = wt;
+  }
+  RRT_TRACE_INIT(blockIdx.x * 8 + wave);
+  RRT_TRACE_MARK();                                 // [1] entry
+
+  // ================================================================== phase 1: projection, both regions against one W tile
+  unsigned off[LP];
+#pragma unroll
+  for (int q = 0; q < LP; ++q) {
+    const int piece = q * 8 + wave;
+    const int p = lane & 7;
+    if (piece < NA) {
+      const int srow = piece * 8 + (lane >> 3);     // row of the stage's A part: [0, BM) region A, [BM, 2 BM) region B
+      const int rs = srow >= BM ? 1 : 0;
+      const int rr = (2 * pair + rs < n_regions) ? 2 * pair + rs : 2 * pair;
+      int gr = rr * P + (srow - rs * BM);
+      gr = gr < n_rows ? gr : n_rows - 1;           // rows past the last region: re-read (finite, never used)
+      off[q] = (unsigned)gr * (unsigned)D * 2u + (unsigned)((p ^ ((srow >> 1) & 7)) << 4);
+    } else {
+      const int wrow = (piece - NA) * 8 + (lane >> 3);    // [0, 192): wrow / 64 picks q / k / v
+      const int wr = (wrow >> 6) * D + head * HD + (wrow & 63);
+      off[q] = (unsigned)wr * (unsigned)D * 2u + (unsigned)((p ^ ((wrow >> 1) & 7)) << 4);
+    }
+  }
+  auto stage = [&](int kt, unsigned buf) {
+    const char* ub = (const char*)U + kt * ROWB;
+    const char* wb = (const char*)W + kt * ROWB;
+#pragma unroll
+    for (int q = 0; q < LP; ++q) {
+      const int piece = q * 8 + wave;
+      if (piece < NP) dma16s(piece < NA ? ub : wb, off[q], buf + piece * 1024);
+    }
+  };
+  f32x4 acc[MT][3];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  stage(0, lds_b);
+  // bias of this lane's columns: lands under the K loop
+  const int dk = 16 * cw + 4 * lg;                  // first of the lane's 4 K columns
+  const int dc = 16 * cw + lr;                      // the lane's Q / V column
+  float4 bk4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bq1 = 0.f, bv1 = 0.f;
+  if (bqkv) {
+    bq1 = bqkv[head * HD + dc];
+    bk4 = *(const float4*)(bqkv + D + head * HD + dk);
+    bv1 = bqkv[2 * D + head * HD + dc];
+  }
+  RRT_TRACE_MARK();                                 // [2] first stage issued
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vm0();                                     // this wave's pieces of stage kt landed
+    __syncthreads();                                // stage kt is complete; everyone is done with stage kt - 1
+    if (kt == 0 || kt == 1 || kt == 4) RRT_TRACE_MARK();   // [3,5,7]
+    if (kt + 1 < nk) stage(kt + 1, lds_b + ((kt + 1) & 1) * STAGE_B);
+    if (kt == 0 || kt == 1 || kt == 4) RRT_TRACE_MARK();   // [4,6,8] next stage issued
+    const char* As = smem + (kt & 1) * STAGE_B + rsel * (BM * ROWB);
+    const char* Bs = smem + (kt & 1) * STAGE_B + 2 * BM * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      Frag a8[MT], b8[3];
+      const int cslot = 4 * kk + lg;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int row = 64 * j + 16 * cw + lr;
+        b8[j] = *(const Frag*)(Bs + row * ROWB + ((cslot ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = i * 16 + lr;                // BM is a multiple of 16: the swizzle key of stage row rsel BM + row
+        a8[i] = *(const Frag*)(As + row * ROWB + ((cslot ^ (((rsel * BM + row) >> 1) & 7)) << 4));
+      }
+      // Q and V with the U fragment in the A slot: reg r of lane (lr, lg) = C[token 16 i + 4 lg + r][d = 16 cw + lr]
+      // (four consecutive TOKENS of one column: what the transposed images Q^T and V^T want); K with the roles
+      // swapped: reg r = K[token 16 i + lr][d = 16 cw + 4 lg + r] (the row-major K image)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        acc[i][0] = H::mfma(a8[i], b8[0], acc[i][0]);
+        acc[i][1] = H::mfma(b8[1], a8[i], acc[i][1]);
+        acc[i][2] = H::mfma(a8[i], b8[2], acc[i][2]);
+      }
+    }
+  }
+  RRT_TRACE_MARK();                                 // [9] last projection MFMA issued
+  __syncthreads();                                  // the staging ring is dead
+  RRT_TRACE_MARK();                                 // [10]
+
+  // ================================================================== phases 2 + 3, wave-local: Q^T -> stencil -> Q~, K, V^T
+  // Wave (rsel, cw) owns head-dim columns 16 cw .. 16 cw + 15 of its region: it writes those rows of Q^T, runs the
+  // stencil on exactly those rows (A operand = its own rows), and then overwrites them with its rows of V^T (same
+  // 512-byte pitch, same place) -- no barrier until the tiles are complete.
+  char* const RB = smem + rsel * REG_B;
+  char* const QT = RB;                              // Q~ [BM] x 128 B, slot XOR ((row >> 1) & 7)
+  char* const KS = RB + QT_B;                       // K  [BM] x 128 B, same swizzle
+  char* const VQ = RB + QT_B + KS_B;                // [64][512 B]: Q^T (slot XOR (d & 15)) now, V^T after the stencil
+  {
+    const float qs = q_scale * LOG2E;
+    char* const qrow = VQ + dc * VT_PITCH;
+    // 8 bytes at token position pos (a multiple of 4) of this lane's Q^T row
+    auto qaddr = [&](int pos) -> char* { return qrow + ((((pos >> 3) ^ lr) & 31) << 4) + ((pos & 4) << 1); };
+    // halo: token positions [0, H8) and [H8 + BM, BM - 16 + 32 nstep) read as zero (region edge = zero padding)
+    const uint2 z = make_uint2(0u, 0u);
+    for (int c = lg; c < (H8 >> 2); c += 4) *(uint2*)qaddr(4 * c) = z;
+    const int right0 = H8 + BM, rightn = (32 * nstep - 16 - H8) >> 2;
+    for (int c = lg; c < rightn; c += 4) *(uint2*)qaddr(right0 + 4 * c) = z;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int tok = 16 * i + 4 * lg;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (acc[i][0][r] + bq1) * qs;
+      if (i >= MT - 2) {                            // (compile time) only the last two row tiles can hold rows past the
+#pragma unroll                                      // region: zero them, branch-free
+        for (int r = 0; r < 4; ++r) v[r] = (tok + r < P) ? v[r] : 0.f;
+      }
+      *(uint2*)qaddr(H8 + tok) = pack4<PREC>(v[0], v[1], v[2], v[3]);
+      const int m = i * 16 + lr;
+      *(uint2*)(KS + m * ROWB + (((dk >> 3) ^ ((m >> 1) & 7)) << 4) + ((dk & 4) << 1)) =
+          pack4<PREC>(acc[i][1][0] + bk4.x, acc[i][1][1] + bk4.y, acc[i][1][2] + bk4.z, acc[i][1][3] + bk4.w);
+    }
+    RRT_TRACE_MARK();                               // [11] Q^T, K written
+    // band of T for this lane: B-slot row = query lr of the tile, k-slice = sources 32 s + 8 lg + e of the window that
+    // starts H8 rows before the tile: tap index (32 s + 8 lg + e - H8) - lr + k/2
+    Frag thi[3], tlo[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float tv = (s < nstep) ? taps[32 + 32 * s + 8 * lg + e - H8 - lr + half] : 0.f;
+        const E hi = (E)tv;
+        thi[s][e] = hi;
+        tlo[s][e] = (E)(tv - (float)hi);
+      }
+    // A operand: this wave's rows d = 16 cw + lr, sources 16 t + 32 s + 8 lg .. + 7 (positions; 16-byte slots)
+    // (every tile, also one that lies wholly past the region: its Q^T rows are zeros, its Q~ rows are never read as
+    //  queries -- a data-dependent exit here would keep the compiler from overlapping the tiles' reads and MFMAs)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        if (s < nstep) {
+          const int slot = 2 * t + 4 * s + lg;      // (16 t + 32 s + 8 lg) * 2 bytes / 16
+          const Frag a = *(const Frag*)(qrow + (((slot ^ lr) & 31) << 4));
+          o = H::mfma(a, thi[s], o);
+          o = H::mfma(a, tlo[s], o);
+        }
+      // o[r] = Q~[query 16 t + lr][d = 16 cw + 4 lg + r]
+      const int m = 16 * t + lr;
+      *(uint2*)(QT + m * ROWB + (((dk >> 3) ^ ((m >> 1) & 7)) << 4) + ((dk & 4) << 1)) = pack4<PREC>(o[0], o[1], o[2], o[3]);
+    }
+    RRT_TRACE_MARK();                               // [12] stencil done
+    // V^T over this wave's Q^T rows (its own reads of them are complete: LDS operations of a wave execute in order)
+    char* const VT = VQ;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      // tokens 16 i + 4 lg + r, r = 0..3 -> positions 32 (i / 2) + 8 lg + 4 (i % 2) + r of V^T row dc: 8 bytes
+      const int vslot = 4 * (i >> 1) + lg;
+      *(uint2*)(VT + dc * VT_PITCH + ((vslot ^ vt_swz(dc)) << 4) + ((i & 1) << 3)) =
+          pack4<PREC>(acc[i][2][0] + bv1, acc[i][2][1] + bv1, acc[i][2][2] + bv1, acc[i][2][3] + bv1);
+    }
+    if (MT & 1) {
+      // odd tile count: the second half of the last 32-key block has no keys; its V^T columns meet P = 0 in the MFMA
+      // and must hold finite numbers -> zeros.  The wave's 64 lanes = its 16 rows x 4 groups of 4 positions.
+      const int dd = 16 * cw + (lane >> 2), g = lane & 3;
+      const int vslot = 4 * (MT >> 1) + g;
+      *(uint2*)(VT + dd * VT_PITCH + ((vslot ^ vt_swz(dd)) << 4) + 8) = make_uint2(0u, 0u);
+    }
+  }
+  __syncthreads();
+  RRT_TRACE_MARK();                                 // [13] tiles complete
+
+  // ================================================================== phase 4: attention from LDS (as rmsa_fused16)
+  const char* const VT = VQ;
+  for (int t = cw; t < MT; t += 4) {
+    const int i0 = t * 16;
+    if (i0 >= P) break;
+    Frag bq[2];
+    {
+      const int m = i0 + lr;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) bq[kk] = *(const Frag*)(QT + m * ROWB + (((4 * kk + lg) ^ ((m >> 1) & 7)) << 4));
+    }
+    f32x4 s[MTP];
+#pragma unroll
+    for (int jt = 0; jt < MTP; ++jt) s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      Frag a[MT];
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) {
+        const int row = jt * 16 + lr;
+        a[jt] = *(const Frag*)(KS + row * ROWB + (((4 * kk + lg) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) s[jt] = H::mfma(a[jt], bq[kk], s[jt]);
+    }
+    RRT_TRACE_MARK();                               // tile: S^T issued
+    // s[jt][r] = log2e * score(query i0 + lr, key 16 jt + 4 lg + r)
+    float cmax = NEG_BIG;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+      if ((jt + 1) * 16 > P) {                                    // (wave-uniform) tiles with keys past the region
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;
+      }
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[jt][r]);
+    cmax = max_xor32(max_xor16(cmax));
+    float psum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[jt][r] - cmax);
+        s[jt][r] = p;
+        psum += p;
+      }
+    psum = sum_xor32(sum_xor16(psum));
+    const float inv = 1.0f / psum;                  // of THIS lane's query (lr): the four lg lanes agree
+    asm volatile("" :: "v"(inv));
+    RRT_TRACE_MARK();                               // tile: softmax done
+    f32x4 oacc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < MTP / 2; ++b) {
+      const Frag pb = pack8<PREC>(s[2 * b], s[2 * b + 1]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dd = 4 * lr + c;
+        const Frag vf = *(const Frag*)(VT + dd * VT_PITCH + (((4 * b + lg) ^ ((lr ^ (c << 2)) & 15)) << 4));
+        oacc[c] = H::mfma(vf, pb, oacc[c]);
+      }
+    }
+    RRT_TRACE_MARK();                               // tile: PV issued
+    // oacc[c][r] = O[query i0 + lr][d = 16 lg + 4 r + c]
+    const int i = i0 + lr;
+    if (i < P && valid) {
+      uint2 q0 = pack4<PREC>(oacc[0][0] * inv, oacc[1][0] * inv, oacc[2][0] * inv, oacc[3][0] * inv);
+      uint2 q1 = pack4<PREC>(oacc[0][1] * inv, oacc[1][1] * inv, oacc[2][1] * inv, oacc[3][1] * inv);
+      uint2 q2 = pack4<PREC>(oacc[0][2] * inv, oacc[1][2] * inv, oacc[2][2] * inv, oacc[3][2] * inv);
+      uint2 q3 = pack4<PREC>(oacc[0][3] * inv, oacc[1][3] * inv, oacc[2][3] * inv, oacc[3][3] * inv);
+      uint16_t* dst = O + (size_t)(row0 + i) * D + head * HD + 16 * lg;
+      *(uint4*)dst = make_uint4(q0.x, q0.y, q1.x, q1.y);
+      *(uint4*)(dst + 8) = make_uint4(q2.x, q2.y, q3.x, q3.y);
+    }
+    RRT_TRACE_MARK();                               // tile: O stored
+  }
+}
+
+// stencil geometry for a tap count: zero halo H8 (k/2 rounded up to 8), 32-wide MFMA steps, bytes of a Q^T row in use
+struct StencilGeo { int H8, nstep, pitch; };
+StencilGeo stencil_geo(int BM, int epeg_k) {
+  StencilGeo g;
+  const int half = epeg_k >> 1;
+  g.H8 = (half + 7) & ~7;
+  g.nstep = (16 + 2 * g.H8 + 31) / 32;
+  const int qw = BM - 16 + 32 * g.nstep;            // token positions a Q^T row holds
+  g.pitch = qw * 2;                                 // bytes of a Q^T row in use (rows sit at the V^T pitch, 512 B)
+  return g;
+}
+
+template <int MT, int PREC>
+hipError_t launch_pair(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
+                       int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
+  constexpr int BM = 16 * MT;
+  constexpr size_t RING = (size_t)2 * (2 * BM + BN) * ROWB, TILES = (size_t)2 * (2 * BM * ROWB + VQ_B);
+  constexpr size_t LDS = (RING > TILES ? RING : TILES) + 512;          // + the tap table
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  const int ek = pe_w ? epeg_k : 0;
+  const StencilGeo g = stencil_geo(BM, ek);
+  if (g.pitch > VT_PITCH || g.nstep > 3) return hipErrorInvalidValue;
+  auto kern = rmsa_pair16_kernel<MT, PREC>;
+  static OncePerDevice once;
+  if (once.first())
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+  const float q_scale = 1.0f / sqrtf((float)HD);
+  const int pairs = (n_regions + 1) / 2;
+  kern<<<dim3(heads * pairs), dim3(512), LDS, st>>>(U, W, bqkv, pe_w, O, n_regions * P, n_regions, P, D, heads, ek, q_scale,
+                                                   g.pitch, g.H8, g.nstep);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+#ifdef RRT_TRACE
+RRT_TRACE_DEFINE_READER(rrt_debug_trace_pair16)
+#endif
+
+bool rmsa_pair16_supported(int n_regions, int P, int D, int heads, int epeg_k) {
+  static const bool off = rrt_tune_env("RRT_NO_PAIR16") != nullptr;
+  if (off) return false;
+  if (!(heads > 0 && D == heads * HD && D % 64 == 0 && P > 16 && P <= 176 && epeg_k >= 0 && epeg_k <= 63 && n_regions >= 8))
+    return false;
+  const int MT = P > 144 ? 11 : P > 128 ? 9 : P > 112 ? 8 : P > 96 ? 7 : P > 64 ? 6 : P > 32 ? 4 : 2;
+  const StencilGeo g = stencil_geo(16 * MT, epeg_k);
+  return g.pitch <= VT_PITCH && g.nstep <= 3;
+}
+
+hipError_t launch_rmsa_pair16(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
+                              int n_regions, int P, int D, int heads, int epeg_k, int prec, hipStream_t st) {
+  if (prec != 1 && prec != 2) return hipErrorInvalidValue;
+#define RRT_PAIR16(MT_)                                                                                \
+  return prec == 1 ? launch_pair<MT_, 1>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st)       \
+                   : launch_pair<MT_, 2>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st);
+  if (P > 144) { RRT_PAIR16(11) }
+  if (P > 128) { RRT_PAIR16(9) }
+  if (P > 112) { RRT_PAIR16(8) }
+  if (P > 96) { RRT_PAIR16(7) }
+  if (P > 64) { RRT_PAIR16(6) }
+  if (P > 32) { RRT_PAIR16(4) }
+  RRT_PAIR16(2)
+#undef RRT_PAIR16
+}

@@ -1,6 +1,7 @@
 """GPU micro-benchmark of the stage entry points (not the judged bench).
     python tools/bench_linear.py linear M N K [M N K ...]
     python tools/bench_linear.py attn R P D heads epeg_k
+    python tools/bench_linear.py proj16 L region_num        (the 16-bit out-projection + un-partition + residual of a bag)
 """
 import sys, os
 import numpy as np, torch
@@ -35,6 +36,20 @@ def main():
             f = lambda: _lib.check(lib.rrt_linear_f32(A.data_ptr(), B.data_ptr(), bias.data_ptr(), C.data_ptr(), M, N, K, 0, 1.0, int(os.environ.get("RRT_COMPUTE", "0")), st))
             med, mn = timeit(f)
             print(f"linear M={M} N={N} K={K}: median {med:.1f} us  min {mn:.1f} us  {2.0 * M * N * K / med / 1e6:.1f} TFLOP/s (median)")
+    elif kind == "proj16":
+        import ctypes as C
+        L, rn = int(sys.argv[2]), int(sys.argv[3])
+        g = _lib.region_grid(L, rn)
+        Np, D = g.H * g.H, 512
+        A = torch.randn(Np, D, device=dev).bfloat16().view(torch.int16)
+        B = (torch.randn(D, D, device=dev) / D ** 0.5).bfloat16().view(torch.int16)
+        bias = torch.randn(D, device=dev); resid = torch.randn(L, D, device=dev); out = torch.empty(L, D, device=dev)
+        flush = torch.empty(96 << 20, device=dev)
+        def f():
+            _lib.check(lib.rrt_linear16_f32(A.data_ptr(), B.data_ptr(), bias.data_ptr(), resid.data_ptr(), out.data_ptr(), Np, D, D,
+                                            C.byref(g), 1, st))
+        med, mn = timeit(f)
+        print(f"proj16 L={L} rn={rn} (M={Np}) cfg={os.environ.get('RRT_LINEAR16_CFG', 'default')}: median {med:.1f} us  min {mn:.1f} us")
     elif kind == "attn":
         R, P, D, H, ek = map(int, sys.argv[2:7])
         qkv = torch.randn(R * P, 3 * D, device=dev) * 0.5
