@@ -26,7 +26,13 @@ Besides the contract fields the JSON line carries
   roofline     -- the dominant kernel (the fused R-MSA kernel): algorithmic FLOPs per launch / its average
                   duration, measured live with HIP events that librrt_hip records on the launch stream inside
                   the timed region (config 2: in an untimed pass of the same encoder; the one-call classifier
-                  entry takes no event array);
+                  entry takes no event array; config 4: summed over the rank's bags in an untimed pass);
+                  `traffic` = HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes of THIS config,
+                  read from profiles/r03_traffic.json (tools/pmc_to_traffic.py; never a typed-in constant);
+  roofline_kernels -- every stage of one bag's forward (LN + partition, fused R-MSA, out-projection, CR-MSA logits +
+                  combine, the representatives' MSA, dispatch + LayerNorm) with ITS bound: MFMA TFLOP/s for the matrix
+                  kernels, HBM GB/s over the stage's algorithmic bytes for the streaming ones; stage boundaries from the
+                  library's event marks in an untimed one-bag-in-flight pass;
   cpu_baseline -- the oracle's eager torch-CPU port of the reference op sequence
                   (oracle/rrt_oracle.py::forward_eager) timed on this box's host cores over a bounded sample
                   of the same workload (rank 0, N=1 only).
@@ -58,19 +64,51 @@ if ROOT not in sys.path:
 
 DIM = 512
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (f32 in / bf16 in)
-# HBM-side bytes of the dominant kernel per launch at the north star from rocprofv3 --pmc (separate FETCH_SIZE
-# and WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction)
-TRAFFIC_BYTES_PER_LAUNCH = {("f32", 9000): 88.0e6,      # profiles/r02_a_pmc_f32.txt  (2 x 33967.5 KiB + 18432 KiB)
-                            ("bf16", 9000): 31.7e6,     # profiles/r02_a_pmc_bf16.txt (2 x 10876.6 KiB +  9216 KiB)
-                            ("f32x3", 9000): 88.0e6}    # profiles/r02_b_pmc_f32x3.txt (2 x 33959.8 KiB + 18432 KiB)
+PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # tools/pmc_to_traffic.py, from the PMC passes
+
+
+# kernels that ARE the R-MSA core of a layer (one launch per layer and forward); "rmsa_fused16_kernel<4" is not in the
+# list: at the bench's bag sizes that instantiation only runs CR-MSA's inner MSA (k "regions" of 64 representatives)
+RMSA_CORE_KERNELS = ("rmsa_pair16", "rmsa_fused16_kernel<1", "rmsa_fused16_kernel<6", "rmsa_fused16_kernel<7",
+                     "rmsa_fused16_kernel<8", "rmsa_fused16_kernel<9", "rmsa_fused_kernel", "rmsa_fused_x3")
+
+
+def traffic_table(config, dtype):
+    """{kernel: {hbm_bytes, dispatches, ...}} of this (config, dtype) from the tracked PMC summary, or None."""
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            return json.load(fh).get(f"c{config}_{dtype}", {}).get("kernels")
+    except (OSError, ValueError):
+        return None
+
+
+def traffic_of(table, patterns, per_forward_of=None):
+    """HBM-side bytes of the kernels whose names contain one of `patterns`: per launch (one kernel), or -- with
+    per_forward_of = the name pattern of a kernel that runs once per forward -- summed per forward."""
+    if not table:
+        return None
+    hits = {k: v for k, v in table.items() if any(p in k for p in patterns)}
+    if not hits:
+        return None
+    if per_forward_of is None:
+        k = max(hits, key=lambda n: hits[n]["dispatches"])
+        return {"bytes": hits[k]["hbm_bytes"], "kernel": k, "source": os.path.relpath(TRAFFIC_FILE, ROOT)}
+    base = [v["dispatches"] for k, v in table.items() if any(p in k for p in per_forward_of)]
+    if not base or max(base) == 0:
+        return None
+    nfwd = float(max(base))
+    return {"bytes": int(sum(v["hbm_bytes"] * v["dispatches"] / nfwd for v in hits.values())),
+            "kernels": sorted(hits), "source": os.path.relpath(TRAFFIC_FILE, ROOT)}
 
 CONFIGS = {
     0: dict(kind="encoder", n=512, dtype="f32", enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8),
             label="BASELINE configs[0]: RRTEncoder(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8).eval() forward, "
-                  "one device-resident bag N=512 D=512 per stream per step"),
+                  "`streams_per_gpu` device-resident bags N=512 D=512 in flight per GPU (one per HIP stream) = one step"),
     1: dict(kind="encoder", n=9000, dtype="f32", enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8),
             label="BASELINE configs[1]: RRTEncoder(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8).eval() forward, "
-                  "one device-resident bag N=9000 D=512 per GPU per step, fp32, closed-form weights"),
+                  "`streams_per_gpu` device-resident bags N=9000 D=512 in flight per GPU (one per HIP stream, each an ordinary "
+                  "forward with its own workspace) = one step; fp32, closed-form weights"),
     2: dict(kind="mil", n=9000, dtype="bf16", input_dim=1024,
             enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=1, region_num=8, all_shortcut=True),
             label="BASELINE configs[2]: C16-R50 RRTMIL(input_dim=1024, epeg_k=15, crmsa_k=1, all_shortcut=True).eval() "
@@ -359,6 +397,95 @@ class EncoderWorkload:
         torch.cuda.synchronize()
         return float(np.median([self.hev.elapsed_ms(a, b) for a, b in pairs]))
 
+    def staged_pass(self, reps=12):
+        """One bag in flight, every stage boundary marked (librrt_hip records the events on the launch stream): median
+        duration of each stage of the forward in ms, plus the plain (unmarked) time per bag of the same loop."""
+        import numpy as np
+        torch, L = self.torch, self._lib
+        enc = self.enc
+        x = self.bags[0]
+        if self.mil is not None:
+            x = torch.from_numpy(__import__("rrt_mil_amd").synth.bag(self.n, DIM, tag="bench/iso")).to(self.dev)
+            need = enc._workspace(self.n, self.dev).numel()
+            ws, y = torch.empty(need, dtype=torch.uint8, device=self.dev), torch.empty_like(x)
+        else:
+            ws, y = self.wss[0], self.outs[0]
+        marks = [L.EV_START, L.EV_LN_PARTITION, L.EV_ATTN, L.EV_PROJ, L.EV_CR_COMBINE, L.EV_CR_INNER, L.EV_END]
+        sets = [[self.hev.create() for _ in marks] for _ in range(reps)]
+
+        def fwd(evs):
+            self._lib.check(self.lib.rrt_encoder_forward_events_f32(C.byref(enc._desc), C.byref(self.w), x.data_ptr(),
+                                                                    y.data_ptr(), self.n, ws.data_ptr(), ws.numel(),
+                                                                    self.streams[0], evs), "forward")
+        enc._desc.weights16_valid = 0
+        fwd(None)
+        enc._desc.weights16_valid = int(enc._desc.compute != L.COMPUTE_F32)
+        lead = 100
+        for i in range(lead + 4 * reps):
+            evs = None
+            if i >= lead and (i - lead) % 4 == 0:
+                for j in range(L.EV_COUNT):
+                    self.ev_arr[j] = None
+                for m, e in zip(marks, sets[(i - lead) // 4]):
+                    self.ev_arr[m] = e
+                evs = self.ev_arr
+            fwd(evs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(100):
+            fwd(None)
+        torch.cuda.synchronize()
+        plain_ms = (time.perf_counter() - t0) / 100 * 1e3
+        enc._desc.weights16_valid = 0
+        d = np.array([[self.hev.elapsed_ms(a, b) for a, b in zip(st[:-1], st[1:])] for st in sets])
+        return dict(zip(("ln_partition", "fused_rmsa", "out_projection", "crmsa_combine", "crmsa_inner", "dispatch_ln"),
+                        np.median(d, axis=0).tolist())), plain_ms
+
+    def kernel_table(self, args):
+        """roofline_kernels: each stage of a bag's forward against ITS roofline (north_star: MFMA utilisation for the dense
+        projections, rocprof HBM GB/s for the streaming kernels)."""
+        from rrt_mil_amd.geometry import region_grid
+        stages, plain_ms = self.staged_pass()
+        g, g8 = region_grid(self.n, self.enc_cfg["region_num"]), region_grid(self.n, 8)
+        k, D, N = self.enc_cfg["crmsa_k"], DIM, self.n
+        lowp = self.dtype in ("bf16", "f16")
+        mpeak = PEAK_TFLOPS["bf16" if lowp else "f32"]
+        es = 2 if lowp else 4                                   # bytes of a u / O element in HBM
+        sc = 1 if self.enc_cfg.get("all_shortcut") else 0
+        f_fused, _ = fused_flops(self.n, self.enc_cfg)
+        tab = traffic_table(args.config, self.dtype)
+        fused_pat = RMSA_CORE_KERNELS
+        spec = [
+            ("ln_partition", "LayerNorm + zero-pad + region partition (rrt.py:121, rmsa.py:199-200,28-39)", "hbm",
+             N * D * 4 + g.Np * D * es, ("ln_partition",)),
+            ("fused_rmsa", "qkv projection + EPEG + softmax(QK^T)V per (region, head) (rmsa.py:100-122)", "mfma", f_fused, fused_pat),
+            ("out_projection", "proj Linear + region_reverse + un-pad + residual (rmsa.py:131,41-54; rrt.py:125)", "mfma",
+             2.0 * g.Np * D * D, ("linear_ws_kernel<6, 1, 1", "linear_ws_kernel<8, 1, 1", "linear_ws_kernel<9, 1, 1")),
+            ("crmsa_combine", "LN2 + logits + region softmax / min-max + combine (rmsa.py:303-316): x1 read once", "hbm",
+             N * D * 4, ("crmsa_region4", "crmsa_logits", "crmsa_combine")),
+            ("crmsa_inner", "MSA over the 64 k representatives: qkv, 64 x 64 attention, proj (rmsa.py:322)", "mfma",
+             8.0 * k * 64 * D * D + 4.0 * k * 64 * 64 * D, ("linear_kernel<2", "region_attn64", "rmsa_fused16_kernel<4", "linear_ws_kernel<2")),
+            ("dispatch_ln", "dispatch + residual (+ shortcut) + final LayerNorm (rmsa.py:324-335; rrt.py:192-195)", "hbm",
+             N * D * 4 * (2 + sc), ("crmsa_dispatch_ln",)),
+        ]
+        out = []
+        for key, what, bound, work, pats in spec:
+            ms = stages[key]
+            if bound == "mfma":
+                ach, peak, unit = work / (ms * 1e-3) / 1e12, mpeak, "TFLOP/s"
+            else:
+                ach, peak, unit = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+            tr = traffic_of(tab, pats, per_forward_of=fused_pat)
+            out.append({"stage": key, "kernel": what, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 4), "avg_ms": round(ms, 5),
+                        "algorithmic": work, "traffic": tr["bytes"] if tr else None,
+                        "traffic_kernels": tr["kernels"] if tr else None})
+        note = ("one bag in flight, stage boundaries = the library's event marks (7 markers per instrumented forward, every "
+                f"fourth forward, median of 12); the same loop without markers takes {plain_ms:.4f} ms per bag, the marked "
+                f"stages add up to {sum(stages.values()):.4f} ms -- the difference is what the marker packets cost; "
+                "`traffic` = HBM-side bytes per forward of the stage's kernels (profiles/r03_traffic.json)")
+        return out, note, plain_ms
+
     def finish(self, args, world, rank, elapsed):
         import numpy as np
         torch = self.torch
@@ -375,6 +502,7 @@ class EncoderWorkload:
             f_proj, f_attn = 2.0 * g.Np * 1536 * DIM, 4.0 * g.Np * g.P * DIM
             peak = round(flops / (3.0 * f_proj / PEAK_TFLOPS["bf16"] + f_attn / PEAK_TFLOPS["f32"]), 1)
         iso_ms = self.isolated_fused_ms()
+        tr = traffic_of(traffic_table(args.config, self.dtype), RMSA_CORE_KERNELS)
         kernel = (f"rmsa_fused_kernel (R-MSA per (region, head): qkv projection {g.P}x192x512 + EPEG + softmax(QK^T)V "
                   f"from LDS; {2.0 * g.Np * 1536 * DIM / 1e9:.2f} + {4.0 * g.Np * g.P * DIM / 1e9:.2f} GFLOP), {self.dtype} operands"
                   + (" (projection: fp32 emulated by 3 bf16 MFMAs per product; attention: fp32 MFMA; peak = FLOPs over "
@@ -385,7 +513,7 @@ class EncoderWorkload:
             rec["roofline"] = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak,
                                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "flops_per_launch": flops,
                                "avg_launch_ms": round(ms, 5),
-                               "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((self.dtype, self.n)),
+                               "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
                                "note": f"mean over {len(self.ev_pairs)} launches of the timed region (every "
                                        f"{self.ev_every}. step, all streams; {self.S} bag(s) "
                                        "in flight per GPU: the other bag's kernels are co-resident on this launch's "
@@ -394,13 +522,16 @@ class EncoderWorkload:
         ach = flops / (iso_ms * 1e-3) / 1e12
         iso = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                "frac": round(ach / peak, 4), "flops_per_launch": flops, "avg_launch_ms": round(iso_ms, 5),
-               "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((self.dtype, self.n)),
+               "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
                "note": "same kernel, untimed pass with one bag in flight (forwards back to back on one stream after 150 "
                        "forwards of lead, every fourth one instrumented, median of 10 launches)"}
         if self.mil is None:
             rec["roofline_isolated"] = iso
         else:
             rec["roofline"] = iso
+        rec["roofline_kernels"], rec["roofline_kernels_note"], plain_ms = self.kernel_table(args)
+        rec["one_bag_in_flight"] = {"ms_per_bag": round(plain_ms, 5), "slides_per_s": round(1e3 / plain_ms, 1),
+                                    "note": "encoder forwards back to back on ONE stream (no second bag to fill the gaps)"}
         return rec
 
 
@@ -447,7 +578,53 @@ class MixWorkload:
     def finish(self, args, world, rank, elapsed):
         for o in self.outs:
             assert self.torch.isfinite(o).all()
-        return {}
+        if rank != 0 or not self.bags:
+            return {}
+        # the R-MSA core kernel of every bag of this rank, one bag in flight, untimed: sum of the algorithmic FLOPs over the
+        # sum of the launches' durations (HIP events recorded by the library around the kernel)
+        from rrt_mil_amd import _lib
+        torch, enc = self.torch, self.enc
+        lib, hev = _lib.load(), HipEvents()
+        enc._desc.compute = enc._compute_mode()
+        w = enc._weights()
+        dev = self.bags[0].device
+        ws = enc._workspace(max(b.size(0) for b in self.bags), dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        ev_arr = (C.c_void_p * _lib.EV_COUNT)()
+        pairs = []
+        enc._desc.weights16_valid = 0
+        for rep in range(2):                                        # first round warms up; the second is read
+            pairs = []
+            for b, o in zip(self.bags, self.outs):
+                a_, b_ = hev.create(), hev.create()
+                for j in range(_lib.EV_COUNT):
+                    ev_arr[j] = None
+                ev_arr[_lib.EV_LN_PARTITION], ev_arr[_lib.EV_ATTN] = a_, b_
+                _lib.check(lib.rrt_encoder_forward_events_f32(C.byref(enc._desc), C.byref(w), b.data_ptr(), o.data_ptr(),
+                                                              b.size(0), ws.data_ptr(), ws.numel(), st, ev_arr), "forward")
+                enc._desc.weights16_valid = int(enc._desc.compute != _lib.COMPUTE_F32)
+                pairs.append((a_, b_))
+            torch.cuda.synchronize()
+        enc._desc.weights16_valid = 0
+        ms = sum(hev.elapsed_ms(a_, b_) for a_, b_ in pairs)
+        flops = sum(fused_flops(b.size(0), self.enc_cfg)[0] for b in self.bags)
+        peak = PEAK_TFLOPS["bf16" if self.dtype in ("bf16", "f16") else "f32"]
+        ach = flops / (ms * 1e-3) / 1e12
+        tab = traffic_table(args.config, self.dtype)
+        tr = None
+        if tab:
+            hits = [v for k, v in tab.items() if any(p in k for p in RMSA_CORE_KERNELS)]
+            nd = sum(v["dispatches"] for v in hits)
+            if nd:
+                tr = int(sum(v["hbm_bytes"] * v["dispatches"] for v in hits) / nd)
+        return {"roofline": {"bound": "mfma", "kernel": "the R-MSA core kernel of each bag (rmsa_pair16 / rmsa_fused16 / rmsa_fused by "
+                             f"region size): qkv projection + EPEG + softmax(QK^T)V per (region, head), {self.dtype} operands",
+                             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                             "flops_per_launch": flops / len(self.bags), "avg_launch_ms": round(ms / len(self.bags), 5),
+                             "traffic": tr, "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) if tr else None,
+                             "note": f"sum over this rank's {len(self.bags)} bags (mixed sizes), one bag in flight, untimed pass "
+                                     "after the timed region: sum of FLOPs / sum of the launches' durations; flops_per_launch, "
+                                     "avg_launch_ms and traffic are means per launch"}}
 
 
 # ------------------------------------------------------------------------------------ the rank program
@@ -545,7 +722,13 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = wl.units_global * args.steps / elapsed
         enc_cfg = cfg["enc"]
+        backend = None
+        if dist:
+            backend = str(dist.get_backend())
         config = {"workload": cfg["label"] + (" [--stub-cpu: CPU stand-in, rank logic only]" if args.stub_cpu else ""),
+                  "collectives": {"backend": backend, "world": world,
+                                  "use": "barrier + MAX all-reduce of the elapsed time only (no data-path collective)"},
+                  "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                   "baseline_config_index": args.config, "dim": DIM, "bags_per_step": wl.units_global,
                   "streams_per_gpu": getattr(wl, "S", None), "untimed_ramp_steps": ramp,
                   "parallelism": f"bag-parallel x{world} (no data-path collective)"}
@@ -576,6 +759,42 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def h2d_inclusive(wl, dev, n_bags=96):
+    """slides/s when every bag starts in HOST memory: (a) pinned host bags through rrt_mil_amd.BagFeeder (copy stream +
+    events, the H2D of the next bags under the current forward), (b) pageable host bags through the feeder, (c) the
+    reference's loop: blocking bag.to(device) then forward.  One stream of forwards (the copies are the other stream)."""
+    import torch
+    from rrt_mil_amd import BagFeeder
+    enc, n = wl.enc, wl.n
+    host = [torch.randn(n, DIM) for _ in range(8)]
+    pinned = [h.pin_memory() for h in host]
+    y = torch.empty(n, DIM, device=dev)
+    res = {}
+    with torch.no_grad():
+        for name, src in (("pinned_feeder", pinned), ("pageable_feeder", host)):
+            for rep in range(2):                               # first pass warms the staging buffers / allocator
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for xb in BagFeeder((src[i % len(src)] for i in range(n_bags)), device=dev, depth=3):
+                    enc.forward_bag(xb, out=y)
+                torch.cuda.synchronize()
+                res[name] = n_bags / (time.perf_counter() - t0)
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_bags):
+                enc.forward_bag(host[i % len(host)].to(dev), out=y)      # the reference's per-iteration blocking copy
+            torch.cuda.synchronize()
+            res["blocking_to_device"] = n_bags / (time.perf_counter() - t0)
+    gb = n * DIM * 4 / 1e9
+    return {"unit": "slides/s", "pinned_feeder": round(res["pinned_feeder"], 1),
+            "pageable_feeder": round(res["pageable_feeder"], 1), "blocking_to_device": round(res["blocking_to_device"], 1),
+            "pinned_feeder_h2d_GBps": round(res["pinned_feeder"] * gb, 1), "bag_mb": round(gb * 1e3, 1), "bags": n_bags,
+            "note": "fp32 encoder, N=9000 D=512, one forward stream + the feeder's copy stream; PCIe Gen5 x16 moves ~53 GB/s, i.e. "
+                    "~2.9 k of these bags per second: with host-resident bags the link, not the encoder, is the limit "
+                    "(rrt_mil_amd/feed.py; reference loop: main.py:434)"}
 
 
 def extras(wl, dev):
@@ -623,6 +842,10 @@ def extras(wl, dev):
                     "note": "rank 0 only, 40 steps after the timed region; RRT_COMPUTE_F32X3: qkv / proj GEMMs of the R-MSA "
                             "layers as three bf16 MFMAs per product on (hi, lo) bf16 operand pairs, fp32 accumulate; attention, "
                             "LayerNorm, CR-MSA exact fp32 (`--dtype f32x3` gives the full record)"}
+
+    # PCIe-inclusive rates (the reference moves one bag per iteration with a blocking
+    # bag.to(device), main.py:434): host bags -> HBM -> encoder, fp32, 18.4 MB per bag.  Never `value`.
+    out["h2d_inclusive"] = h2d_inclusive(wl, dev)
 
     # the whole slide classifier of BASELINE configs[2] (C16-R50 shape) through the one-call path (row f1), fp32,
     # one bag in flight

@@ -43,12 +43,18 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
   using E = typename H::elem;
   constexpr int BM = 16 * MT;
   constexpr int MTP = (MT + 1) & ~1;                 // key tiles rounded up to whole 32-key MFMA blocks
-  constexpr int STAGE_B = (2 * BM + BN) * ROWB;      // bytes per pipeline stage: region A rows | region B rows | W rows
+  // two rings: U tiles (region A rows | region B rows) two stages deep, W tiles (192 rows) THREE deep where the LDS
+  // allows: the operand stream is latency-bound -- a CU gets (bytes in flight) / ~1.3 us out of L2 (tools/ubench/
+  // dma_rows.hip: 14 B/clk with 43 KB in flight, 21 with 61, 28-32 with 86) -- so whatever the tiles leave free holds a
+  // third W stage: 86 KB in flight instead of 61
+  constexpr int USTG_B = 2 * BM * ROWB, WSTG_B = BN * ROWB;
+  constexpr int NSW = (2 * USTG_B + 3 * WSTG_B + 512 <= 160 * 1024) ? 3 : 2;
   constexpr int NA = 2 * BM / 8, NB = BN / 8;        // 1-KiB DMA pieces (8 rows) per stage
   constexpr int NP = NA + NB, LP = (NP + 7) / 8;     // pieces per stage / per wave
+  static_assert(NB == 24, "every wave issues exactly three W pieces per stage (the counted wait below)");
   constexpr int QT_B = BM * ROWB, KS_B = BM * ROWB;
   constexpr int REG_B = QT_B + KS_B + VQ_B;          // per region: Q~ | K | V^T (Q^T before the stencil)
-  constexpr int RING_B = 2 * STAGE_B, TILES_B = 2 * REG_B;
+  constexpr int RING_B = 2 * USTG_B + NSW * WSTG_B, TILES_B = 2 * REG_B;
   constexpr int LDS_MAIN = RING_B > TILES_B ? RING_B : TILES_B;
   static_assert(16 * MTP * 2 <= VT_PITCH, "V^T row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -112,21 +118,31 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
       off[q] = (unsigned)wr * (unsigned)D * 2u + (unsigned)((p ^ ((wrow >> 1) & 7)) << 4);
     }
   }
-  auto stage = [&](int kt, unsigned buf) {
+  auto stage_u = [&](int kt, unsigned buf) {
     const char* ub = (const char*)U + kt * ROWB;
+#pragma unroll
+    for (int q = 0; q < LP; ++q) {
+      const int piece = q * 8 + wave;
+      if (piece < NA) dma16s(ub, off[q], buf + piece * 1024);
+    }
+  };
+  auto stage_w = [&](int kt, unsigned buf) {
     const char* wb = (const char*)W + kt * ROWB;
 #pragma unroll
     for (int q = 0; q < LP; ++q) {
       const int piece = q * 8 + wave;
-      if (piece < NP) dma16s(piece < NA ? ub : wb, off[q], buf + piece * 1024);
+      if (piece >= NA && piece < NP) dma16s(wb, off[q], buf + (piece - NA) * 1024);
     }
   };
+  const unsigned wring = lds_b + 2 * USTG_B;
   f32x4 acc[MT][3];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  stage(0, lds_b);
+  stage_u(0, lds_b);
+  stage_w(0, wring);
+  if (NSW == 3 && nk > 1) stage_w(1, wring + WSTG_B);
   // bias of this lane's columns: lands under the K loop
   const int dk = 16 * cw + 4 * lg;                  // first of the lane's 4 K columns
   const int dc = 16 * cw + lr;                      // the lane's Q / V column
@@ -137,15 +153,25 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
     bk4 = *(const float4*)(bqkv + D + head * HD + dk);
     bv1 = bqkv[2 * D + head * HD + dc];
   }
-  RRT_TRACE_MARK();                                 // [2] first stage issued
+  RRT_TRACE_MARK();                                 // [2] first stages issued
+  int wslot = 0;                                    // W ring slot of K tile kt
   for (int kt = 0; kt < nk; ++kt) {
-    wait_vm0();                                     // this wave's pieces of stage kt landed
-    __syncthreads();                                // stage kt is complete; everyone is done with stage kt - 1
+    // U tile kt and W tile kt landed; with three W stages the W tile kt + 1 -- this wave's LAST three pieces, issued
+    // after U tile kt -- may still be in flight
+    if (NSW == 3 && kt + 1 < nk) wait_vmcnt<3>(); else wait_vm0();
+    __syncthreads();                                // K tile kt is complete; everyone is done with K tile kt - 1
     if (kt == 0 || kt == 1 || kt == 4) RRT_TRACE_MARK();   // [3,5,7]
-    if (kt + 1 < nk) stage(kt + 1, lds_b + ((kt + 1) & 1) * STAGE_B);
-    if (kt == 0 || kt == 1 || kt == 4) RRT_TRACE_MARK();   // [4,6,8] next stage issued
-    const char* As = smem + (kt & 1) * STAGE_B + rsel * (BM * ROWB);
-    const char* Bs = smem + (kt & 1) * STAGE_B + 2 * BM * ROWB;
+    if (kt + 1 < nk) stage_u(kt + 1, lds_b + ((kt + 1) & 1) * USTG_B);
+    {
+      const int nw = kt + NSW - 1;                  // W tile to issue now: into the slot K tile kt - 1 just left
+      int ns = wslot + NSW - 1;
+      ns = ns >= NSW ? ns - NSW : ns;
+      if (nw < nk) stage_w(nw, wring + ns * WSTG_B);
+    }
+    if (kt == 0 || kt == 1 || kt == 4) RRT_TRACE_MARK();   // [4,6,8] next stages issued
+    const char* As = smem + (kt & 1) * USTG_B + rsel * (BM * ROWB);
+    const char* Bs = smem + 2 * USTG_B + wslot * WSTG_B;
+    wslot = wslot + 1 == NSW ? 0 : wslot + 1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       Frag a8[MT], b8[3];
@@ -358,7 +384,9 @@ template <int MT, int PREC>
 hipError_t launch_pair(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
                        int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
   constexpr int BM = 16 * MT;
-  constexpr size_t RING = (size_t)2 * (2 * BM + BN) * ROWB, TILES = (size_t)2 * (2 * BM * ROWB + VQ_B);
+  constexpr size_t USTG = (size_t)2 * BM * ROWB, WSTG = (size_t)BN * ROWB;
+  constexpr size_t RING = 2 * USTG + ((2 * USTG + 3 * WSTG + 512 <= 160 * 1024) ? 3 : 2) * WSTG;
+  constexpr size_t TILES = (size_t)2 * (2 * BM * ROWB + VQ_B);
   constexpr size_t LDS = (RING > TILES ? RING : TILES) + 512;          // + the tap table
   static_assert(LDS <= 160 * 1024, "LDS budget");
   const int ek = pe_w ? epeg_k : 0;

@@ -228,6 +228,30 @@ class _EncoderFunction(torch.autograd.Function):
         return (None, dx) + tuple(grads)      # (the stash lives as long as the graph node: retain_graph works)
 
 
+_HWQ_WARNED = False
+
+
+def _warn_hw_queues(streams):
+    """HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; it is
+    read once, when the HIP runtime initialises.  With torch's own streams and RCCL's in the process, two of the
+    executor's streams can land on ONE queue and serialise (measured: the one-stream rate, -15 %).  The library cannot
+    see the setting from inside HIP, so the host side checks the environment and says so -- once."""
+    global _HWQ_WARNED
+    if _HWQ_WARNED or streams < 2:
+        return
+    import os
+    import warnings
+    try:
+        q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        q = 4
+    if q < 2 * streams + 4:
+        _HWQ_WARNED = True
+        warnings.warn(f"rrt_mil_amd: {streams} bags in flight but GPU_MAX_HW_QUEUES={q} (HIP default 4): the executor's "
+                      "streams may share a hardware queue and serialise.  Export GPU_MAX_HW_QUEUES=16 before the "
+                      "process initialises HIP (before `import torch`); see INTEGRATION.md section 5.", RuntimeWarning)
+
+
 class RRTEncoder(nn.Module):
     def __init__(self, mlp_dim=512, pos_pos=0, pos='none', peg_k=7, attn='rmsa', region_num=8,
                  drop_out=0.1, n_layers=2, n_heads=8, drop_path=0., ffn=False, ffn_act='gelu',
@@ -579,6 +603,7 @@ class RRTEncoder(nn.Module):
             xs.append(x2.contiguous())
         ys = [torch.empty_like(x) for x in xs] if outs is None else outs
         self._desc.compute = self._compute_mode()
+        _warn_hw_queues(int(streams))
         ex = self._executor(int(streams), max(x.size(0) for x in xs), dev)
         arr = (_lib.Bag * len(xs))()
         for i, (x, y) in enumerate(zip(xs, ys)):

@@ -35,10 +35,12 @@ def assign_bags(sizes: Sequence[int], world_size: int, **cost_kw) -> List[List[i
 
 
 def max_over_ranks(value: float, device=None) -> float:
-    """MAX-reduce a python float over the default process group (no-op without one)."""
+    """MAX-reduce a python float over the default process group (no-op without one).  With a group of ONE rank the
+    collective still runs: `torch.distributed.run --nproc-per-node 1` then exercises RCCL end to end (init, a device
+    all-reduce, teardown) on one GPU -- what tests/test_multigpu_plumbing.py relies on."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

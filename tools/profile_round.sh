@@ -1,19 +1,48 @@
 #!/bin/bash
-# Round evidence: bench lines + rocprofv3 kernel stats (fp32: default 2-stream bench and 1-stream; bf16: 1-stream) + PMC
-# passes (separate --pmc runs with --kernel-trace only, each under its own timeout).  Run on the GPU box from the repo root:
-#     tools/profile_round.sh <tag>        -> gpurun_out/<tag>_*.{txt,json}
+# Round evidence: bench lines + rocprofv3 kernel stats (fp32: default 2-stream bench and 1-stream; bf16 / configs 3: 1-stream)
+# + PMC passes (separate --pmc runs with --kernel-trace only, each under its own timeout) -> profiles-ready files.
+# Run on the GPU box from the repo root:
+#     tools/profile_round.sh <tag>        -> gpurun_out/<tag>_*.{txt,json} and gpurun_out/<tag>_traffic.json
+# Order: the PMC passes first (they produce <tag>_traffic.json, which bench.py reads as profiles/r03_traffic.json when it
+# is copied there BEFORE the bench lines are taken -- the script does that copy on the box so one call gives a consistent set).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_*
-timeout 600 python $R/bench.py > $OUT/${TAG}_bench_default.bench.json 2> /tmp/bench.err || tail -5 /tmp/bench.err
+rm -rf /tmp/prof_* /tmp/pmc_*
+X="--no-cpu-baseline --no-extras"
+rm -f $OUT/${TAG}_traffic.json
+for spec in "c1_f32:--config 1 --dtype f32" "c1_bf16:--config 1 --dtype bf16" "c1_f32x3:--config 1 --dtype f32x3" \
+            "c2_bf16:--config 2" "c3_bf16:--config 3" "c4_bf16:--config 4"; do
+  key=${spec%%:*}; args=${spec#*:}
+  for pmc in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $pmc -d /tmp/pmc_${key}_$pmc -o p -- python $R/bench.py $args --streams 1 --steps 5 --warmup 2 $X > /tmp/pmc.log 2>&1 || echo "pmc pass $key $pmc failed/timeout"
+  done
+  if [ -f /tmp/pmc_${key}_FETCH_SIZE/p_results.db ] && [ -f /tmp/pmc_${key}_WRITE_SIZE/p_results.db ]; then
+    python $R/tools/pmc_to_traffic.py $key /tmp/pmc_${key}_FETCH_SIZE/p_results.db /tmp/pmc_${key}_WRITE_SIZE/p_results.db $OUT/${TAG}_traffic.json "bench.py $args --streams 1 --steps 5 --warmup 2"
+  fi
+done
+cp $OUT/${TAG}_traffic.json $R/profiles/r03_traffic.json 2>/dev/null
+for dt in f32 bf16; do
+  for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+    rm -rf /tmp/pmc_x
+    timeout 300 rocprofv3 --kernel-trace --pmc $pmc -d /tmp/pmc_x -o p -- python $R/bench.py --dtype $dt --streams 1 --steps 5 --warmup 2 $X > /tmp/pmc.log 2>&1 || echo "pmc pass $dt ($pmc) failed/timeout"
+    if [ -f /tmp/pmc_x/p_results.db ]; then
+      echo "# pass: --dtype $dt --pmc $pmc" >> $OUT/${TAG}_pmc_$dt.txt
+      python $R/tools/pmc_summary.py /tmp/pmc_x/p_results.db >> $OUT/${TAG}_pmc_$dt.txt
+    fi
+  done
+done
+timeout 900 python $R/bench.py > $OUT/${TAG}_bench_default.bench.json 2> /tmp/bench.err || tail -5 /tmp/bench.err
 timeout 600 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_cmd.bench.json 2>/dev/null
 for c in 2 3 4; do timeout 300 python $R/bench.py --config $c --no-cpu-baseline --steps 100 > $OUT/${TAG}_bench_config$c.bench.json 2>/dev/null; done
 timeout 300 python $R/bench.py --dtype bf16 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_config1_bf16.bench.json 2>/dev/null
-X="--no-cpu-baseline --no-extras"
+timeout 300 python $R/bench.py --dtype f32x3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_config1_f32x3.bench.json 2>/dev/null
+timeout 300 python $R/bench.py --streams 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_1stream.bench.json 2>/dev/null
+timeout 300 python $R/bench.py --streams 4 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_4streams.bench.json 2>/dev/null
+timeout 300 python $R/bench.py --dtype bf16 --streams 3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_config1_bf16_3streams.bench.json 2>/dev/null
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o a -- python $R/bench.py $X > /tmp/a.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_a/a_results.db > $OUT/${TAG}_bench_default_2streams.kernel_stats.txt
 python $R/tools/rocprof_timeline.py /tmp/prof_a/a_results.db 48 < /dev/null | cut -c1-130 > $OUT/${TAG}_timeline_2streams.txt
@@ -23,23 +52,12 @@ timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_c -o c -- python $R/be
 python $R/tools/rocprof_summary.py /tmp/prof_c/c_results.db > $OUT/${TAG}_bench_bf16_1stream.kernel_stats.txt
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_d -o d -- python $R/bench.py --config 3 --streams 1 --steps 50 $X > /tmp/d.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_d/d_results.db > $OUT/${TAG}_bench_config3_bf16_1stream.kernel_stats.txt
-for dt in f32 bf16; do
-  i=0
-  for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
-    i=$((i+1))
-    timeout 300 rocprofv3 --kernel-trace --pmc $pmc -d /tmp/prof_${dt}_p$i -o p -- python $R/bench.py --dtype $dt --streams 1 --steps 5 --warmup 2 $X > /tmp/p$i.log 2>&1 || echo "pmc pass $dt $i ($pmc) failed/timeout"
-    if [ -f /tmp/prof_${dt}_p$i/p_results.db ]; then
-      echo "# pass: --dtype $dt --pmc $pmc" >> $OUT/${TAG}_pmc_$dt.txt
-      python $R/tools/pmc_summary.py /tmp/prof_${dt}_p$i/p_results.db >> $OUT/${TAG}_pmc_$dt.txt
-    fi
-  done
-done
-timeout 300 python $R/bench.py --dtype f32x3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_config1_f32x3.bench.json 2>/dev/null
-timeout 300 python $R/bench.py --streams 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_1stream.bench.json 2>/dev/null
-timeout 300 python $R/bench.py --streams 4 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_4streams.bench.json 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o e -- python $R/bench.py --config 4 --streams 1 --steps 10 $X > /tmp/e.log 2>&1
+python $R/tools/rocprof_summary.py /tmp/prof_e/e_results.db > $OUT/${TAG}_bench_config4_bf16_1stream.kernel_stats.txt
 if [ -f $R/tools/_abl/librrt_trace.so ]; then
-  RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_fused.py > $OUT/${TAG}_trace_fused_f32_wave_timeline.txt 2>/dev/null
+  RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_fused.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_fused_f32_wave_timeline.txt
+  RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_pair16.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_pair16_wave_timeline.txt
 fi
-[ -x $R/tools/_abl/mfma_valu_overlap ] && timeout 120 $R/tools/_abl/mfma_valu_overlap > $OUT/${TAG}_ubench_mfma_valu_overlap.txt 2>&1
-tail -1 $OUT/${TAG}_bench_default.bench.json | cut -c1-200
+[ -x $R/tools/_abl/dma_rows ] && timeout 120 $R/tools/_abl/dma_rows > $OUT/${TAG}_ubench_dma_rows.txt 2>&1
+tail -1 $OUT/${TAG}_bench_default.bench.json | cut -c1-300
 head -14 $OUT/${TAG}_bench_1stream.kernel_stats.txt
