@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 20
+#define RRT_ABI_VERSION 21
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -91,7 +91,7 @@ typedef struct rrt_encoder_desc {
   int32_t pos_pos;         /* -1: before the first layer; 0: before layer index 1 (needs n_layers >= 3), rrt.py:181-187 */
   int32_t peg_k;           /* odd, <= 11 */
   int32_t peg_1d;          /* 1: (k, 1) kernels (peg_1d / conv_1d) */
-  /* EPEG ablations (rmsa.py:76-85,106-129; inference only, unfused path): */
+  /* EPEG ablations (rmsa.py:76-85,106-129; unfused path, forward and backward): */
   int32_t epeg_2d;         /* 1: k x k kernel -- over the score map ('attn') or over v's sqrt(P) x sqrt(P) image ('value_*') */
   int32_t epeg_type;       /* RRT_EPEG_ATTN (default) / RRT_EPEG_VALUE_BF / RRT_EPEG_VALUE_AF */
   /* Reduced-precision modes (BF16 / F16 / F32X3) keep 16-bit images of the R-MSA weights at the START of the workspace
@@ -404,7 +404,9 @@ typedef struct rrt_attn_grads {
   float *norm;                 /* [2, dim] */
   float *qkv_w, *qkv_b;        /* qkv_b NULL when qkv_bias = False */
   float *proj_w, *proj_b;
-  float *pe_w;                 /* [heads, epeg_k] or NULL */
+  float *pe_w;                 /* [heads, epeg_k] or NULL (epeg_2d: [heads, k, k]; epeg_type value_*: [dim, k] / [dim, k, k]) */
+  float *pe_b;                 /* epeg_type value_* with a conv bias: [dim]; NULL otherwise (the 'attn' conv bias has an
+                                  exactly zero gradient: it cancels in the softmax) */
   float *norm2;                /* ffn = 1: [2, dim] */
   float *fc1_w, *fc1_b;        /* ffn = 1: [ffn_hidden, dim], [ffn_hidden] */
   float *fc2_w, *fc2_b;        /* ffn = 1: [dim, ffn_hidden], [dim] */

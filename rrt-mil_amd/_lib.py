@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _f32p = C.POINTER(C.c_float)
 
@@ -46,7 +46,7 @@ class EncoderWeights(C.Structure):
 
 
 class AttnGrads(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("norm", "qkv_w", "qkv_b", "proj_w", "proj_b", "pe_w", "norm2",
+    _fields_ = [(n, C.c_void_p) for n in ("norm", "qkv_w", "qkv_b", "proj_w", "proj_b", "pe_w", "pe_b", "norm2",
                                           "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
 
 

@@ -28,6 +28,7 @@ struct Workspace {
   float *uo, *qkv, *xa, *xb, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2, *v8, *hid;
   float *ffn_ln, *ffn_hid, *xp;
   float* pe_out;     // value-EPEG ablation: the conv's output [Np, D]
+  float* smap;       // 2-D 'attn' EPEG on regions whose [P, P] score map does not fit the LDS: the maps [R * heads][P][P]
   uint16_t* w16;     // reduced-precision modes: 16-bit copies of the R-MSA layers' qkv / proj weights (4 D^2 per layer)
   uint16_t* wcr16;   // ... and of CR-MSA's inner qkv / proj weights (4 D^2), bf16 / fp16 modes
   uint16_t *rep16, *repo16;   // 16-bit representatives [k * 64, D] and their attention output (the fused 16-bit inner MSA)
@@ -60,6 +61,10 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     w.xa = take((size_t)N * D);
     if (d.n_rmsa_layers > 1 || d.ffn) w.xb = take((size_t)N * D);
     if (d.epeg && d.epeg_type != RRT_EPEG_ATTN) w.pe_out = take(Np * D);
+    if (d.epeg && d.epeg_2d && d.epeg_type == RRT_EPEG_ATTN) {
+      const size_t sm = attn_scoremap_scratch_floats(g.regions_side * g.regions_side, g.s * g.s, d.n_heads, d.epeg_k, 1);
+      if (sm) w.smap = take(sm);
+    }
   }
   if (d.ffn) {
     if (!w.xa) w.xa = take((size_t)N * D);
@@ -105,7 +110,6 @@ int check_desc(const rrt_encoder_desc* d, int64_t N) {
     if (d->region_size <= 0 && d->region_num <= 0) return unsupported("region_num must be positive");
   }
   if (d->cr_msa) {
-    if (d->crmsa_mlp && d->dim % 128 != 0) return unsupported("crmsa_mlp needs dim % 128 == 0 (hidden dim/4 is a GEMM K)");
     if (d->crmsa_k <= 0 || d->crmsa_k > RRT_MAX_CRMSA_K) return unsupported("crmsa_k must be in [1,8]");
     if (d->crmsa_heads <= 0 || d->dim % d->crmsa_heads != 0) return unsupported("crmsa_heads must divide dim");
   }
@@ -440,9 +444,8 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
         RRT_TRY(launch_linear(ws.uo, lw.qkv_w, ws.qkv, gd.Np, 3 * D, D, ep, st));
       }
       if (desc->epeg_type == RRT_EPEG_ATTN) {           // epeg_2d: k x k stencil over the score map
-        if (attn_scoremap_lds(gd.P, desc->epeg_k) > 160 * 1024)
-          return unsupported("epeg_2d: the [P, P] score map of a region must fit the CU's LDS (regions of <= ~180 tokens)");
-        RRT_TRY(launch_attn_scoremap(ws.qkv, lw.pe_w, ws.uo, nreg, gd.P, D, desc->n_heads, desc->epeg_k, st));
+        // (regions of more than ~180 tokens: the score maps live in the workspace instead of the LDS)
+        RRT_TRY(launch_attn_scoremap(ws.qkv, lw.pe_w, ws.uo, ws.smap, nreg, gd.P, D, desc->n_heads, desc->epeg_k, st));
       } else {
         RRT_TRY(launch_value_pe(ws.qkv, lw.pe_w, lw.pe_b, ws.pe_out, nreg, gd.P, gd.s, D, desc->n_heads, desc->epeg_k,
                                 desc->epeg_2d, st));
@@ -1207,6 +1210,8 @@ struct Stash {
   // xcr = CR-MSA's output before its FFN; hscr = one scratch for act(hpre)
   float *ffn_u[RRT_MAX_RMSA_LAYERS + 1], *ffn_hpre[RRT_MAX_RMSA_LAYERS + 1], *xf[RRT_MAX_RMSA_LAYERS + 1];
   float *xcr, *hscr, *xp;     // xp: output of the PEG / PPEG stage (pos != none)
+  float *pe[RRT_MAX_RMSA_LAYERS];   // value-EPEG ablations: the conv's output per layer
+  float *smap;                // 2-D 'attn' EPEG: score-map scratch of the forward (large regions only)
   size_t bytes;
 };
 
@@ -1225,6 +1230,11 @@ Stash carve_stash(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const
     s.qkv[l] = take(Np * 3 * D);
     s.o[l] = take(Np * D);
     s.xout[l] = take((size_t)N * D);
+    if (d.epeg && d.epeg_type != RRT_EPEG_ATTN) s.pe[l] = take(Np * D);
+  }
+  if (d.n_rmsa_layers > 0 && d.epeg && d.epeg_2d && d.epeg_type == RRT_EPEG_ATTN) {
+    const size_t sm = attn_scoremap_scratch_floats(g.regions_side * g.regions_side, g.s * g.s, d.n_heads, d.epeg_k, 1);
+    if (sm) s.smap = take(sm);
   }
   if (d.cr_msa) {
     s.mean_rstd = take((size_t)N * 2);
@@ -1258,7 +1268,7 @@ Stash carve_stash(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const
 
 struct BwdWs {
   float *dx2, *dxa, *dxb, *dz, *dO, *dqkv, *lnpart, *attnpart, *dWd, *dC, *dlg, *Cw, *d_rep2, *d_rep_o,
-      *d_rep_qkv, *d_rep, *rows, *dxpart, *th, *dhid, *dvphi, *w1t, *tnscratch, *fh, *fdh, *fdu, *attnpart_cr;
+      *d_rep_qkv, *d_rep, *rows, *dxpart, *th, *dhid, *dvphi, *w1t, *tnscratch, *fh, *fdh, *fdu, *attnpart_cr, *dpe, *smap;
   char *lin, *pegws;
   size_t bytes;
 };
@@ -1284,7 +1294,14 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     w.dO = take(Np * D);
     w.dqkv = take(Np * 3 * D);
     const int R = g.regions_side * g.regions_side;
-    w.attnpart = take(attn_bwd_workspace(R, g.s * g.s, (int)D, d.n_heads, d.epeg ? d.epeg_k : 0) / sizeof(float));
+    const bool e2d = d.epeg && d.epeg_2d && d.epeg_type == RRT_EPEG_ATTN, evalue = d.epeg && d.epeg_type != RRT_EPEG_ATTN;
+    if (e2d) {       // 2-D 'attn' EPEG: its own backward kernel (three [P, P] maps per (region, head) + the tap partials)
+      w.smap = take(attn_scoremap_scratch_floats(R, g.s * g.s, d.n_heads, d.epeg_k, 3) + (size_t)R * d.n_heads * d.epeg_k * d.epeg_k);
+      w.attnpart = take(64);
+    } else {
+      w.attnpart = take(attn_bwd_workspace(R, g.s * g.s, (int)D, d.n_heads, (d.epeg && !evalue) ? d.epeg_k : 0) / sizeof(float));
+    }
+    if (evalue) w.dpe = take(Np * D);
     lin = linear_bwd_workspace((int)Np, 3 * (int)D, (int)D);
     const size_t l2 = linear_bwd_workspace((int)Np, (int)D, (int)D);
     if (l2 > lin) lin = l2;
@@ -1334,13 +1351,13 @@ int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8)
   if (rc) return rc;
   if (d->compute == RRT_COMPUTE_F32X3) return unsupported("training: RRT_COMPUTE_F32X3 is an inference mode (train in F32 or under autocast)");
   if (d->dim > 1024) return unsupported("training: dim > 1024");
-  if (d->epeg && d->n_rmsa_layers > 0 && (d->epeg_2d || d->epeg_type != RRT_EPEG_ATTN))
-    return unsupported("training: the EPEG ablations (epeg_2d, epeg_type = value_*) are inference-only on the HIP path");
   memset(g, 0, sizeof(*g));
   if (d->n_rmsa_layers > 0) {
     rc = rrt_region_grid(N, d->region_num, d->region_size, d->min_region_num, d->min_region_ratio, g);
     if (rc) return rc;
-    if (!attn_bwd_supported(g->s * g->s, d->dim, d->n_heads, d->epeg ? d->epeg_k : 0))
+    const bool e2d = d->epeg && d->epeg_2d && d->epeg_type == RRT_EPEG_ATTN, evalue = d->epeg && d->epeg_type != RRT_EPEG_ATTN;
+    // (the 2-D 'attn' EPEG has its own backward kernel, any head dim; the value variants run the plain attention backward)
+    if (!e2d && !attn_bwd_supported(g->s * g->s, d->dim, d->n_heads, (d->epeg && !evalue) ? d->epeg_k : 0))
       return unsupported("training: R-MSA needs head dim 64 and regions of <= 208 tokens (N <= 12544 at region_num=8)");
   }
   rc = rrt_region_grid(N, 8, 0, 0, 0.f, g8);
@@ -1479,6 +1496,17 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     ep.q_cols = D;
     ep.q_scale = 1.0f / sqrtf((float)(D / desc->n_heads));
     RRT_TRY(launch_linear(s.u[li], lw.qkv_w, s.qkv[li], gd.Np, 3 * D, D, ep, st));
+    const bool e2d = desc->epeg && desc->epeg_2d && desc->epeg_type == RRT_EPEG_ATTN;
+    const bool evalue = desc->epeg && desc->epeg_type != RRT_EPEG_ATTN;
+    if (e2d) {                                            // rmsa.py:78-79,106-108
+      RRT_TRY(launch_attn_scoremap(s.qkv[li], lw.pe_w, s.o[li], s.smap, gd.rs * gd.rs, gd.P, D, desc->n_heads, desc->epeg_k, st));
+    } else if (evalue) {                                  // rmsa.py:80-85,114-129; the stash keeps pe, v' = v + pe ('bf') and o + pe ('af')
+      RRT_TRY(launch_value_pe(s.qkv[li], lw.pe_w, lw.pe_b, s.pe[li], gd.rs * gd.rs, gd.P, gd.s, D, desc->n_heads, desc->epeg_k,
+                              desc->epeg_2d, st));
+      if (desc->epeg_type == RRT_EPEG_VALUE_BF) RRT_TRY(launch_add_cols(s.qkv[li] + 2 * D, s.pe[li], (size_t)gd.Np, D, 3 * D, st));
+      RRT_TRY(launch_region_attention(s.qkv[li], nullptr, s.o[li], gd.rs * gd.rs, gd.P, D, desc->n_heads, 0, st));
+      if (desc->epeg_type == RRT_EPEG_VALUE_AF) RRT_TRY(launch_add_cols(s.o[li], s.pe[li], (size_t)gd.Np, D, D, st));
+    } else
     RRT_TRY(launch_region_attention(s.qkv[li], desc->epeg ? lw.pe_w : nullptr, s.o[li], gd.rs * gd.rs, gd.P, D,
                                     desc->n_heads, desc->epeg ? desc->epeg_k : 0, st));
     LinearEpilogue ep2{};
@@ -1661,10 +1689,14 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
       RRT_TRY(launch_crmsa_mlp_bwd_hidden(s.hid, b.dlg, w->phi2_w, b.th, b.dhid, (size_t)gd8.Np, hdim, k, st));
       RRT_TRY(launch_gemm_tn(b.dlg, b.th, gr->phi2_w, b.tnscratch, gd8.Np, k, hdim, st));          // dW2 [k, D/4]
       RRT_TRY(launch_gemm_tn(b.dhid, s.v8, gr->phi0_w, b.tnscratch, gd8.Np, hdim, D, st));         // dW1 [D/4, D]
-      RRT_TRY(launch_transpose(w->phi0_w, b.w1t, hdim, D, st));                                    // W1^T [D, D/4]
-      LinearEpilogue ev{};
-      ev.prec = desc->compute;
-      RRT_TRY(launch_linear(b.dhid, b.w1t, b.dvphi, gd8.Np, D, hdim, ev, st));                     // d v_phi = d hid . W1
+      if (hdim % 32 == 0) {
+        RRT_TRY(launch_transpose(w->phi0_w, b.w1t, hdim, D, st));                                  // W1^T [D, D/4]
+        LinearEpilogue ev{};
+        ev.prec = desc->compute;
+        RRT_TRY(launch_linear(b.dhid, b.w1t, b.dvphi, gd8.Np, D, hdim, ev, st));                   // d v_phi = d hid . W1
+      } else {                                             // hidden width not a GEMM K tile (dim % 128 != 0)
+        RRT_TRY(launch_small_k_matmul(b.dhid, w->phi0_w, b.dvphi, gd8.Np, D, hdim, st));
+      }
       RRT_TRY(launch_crmsa_bwd_dx(x1, up, s.mean_rstd, cw.norm_w, cw.norm_b, b.dvphi, b.Cw, b.dlg, b.d_rep, dx1,
                                   b.rows, b.dxpart, D, k, gd8, true, st));
       RRT_TRY(hipMemcpyAsync(cg.norm, b.rows, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1691,6 +1723,30 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     }
     RRT_TRY(launch_partition_rows(cur, b.dz, D, gd, dc.thresh, dc.seed(drop_seed, li), dc.scale * br.attn[li], st));
     RRT_TRY(launch_linear_backward(b.dz, s.o[li], lw.proj_w, b.dO, lg.proj_w, lg.proj_b, gd.Np, D, D, desc->compute, b.lin, st));
+    const bool e2d = desc->epeg && desc->epeg_2d && desc->epeg_type == RRT_EPEG_ATTN;
+    const bool evalue = desc->epeg && desc->epeg_type != RRT_EPEG_ATTN;
+    if (e2d) {
+      RRT_TRY(launch_attn_scoremap_backward(s.qkv[li], lw.pe_w, b.dO, b.dqkv, lg.pe_w, b.smap, gd.rs * gd.rs, gd.P, D,
+                                            desc->n_heads, desc->epeg_k, st));
+    } else if (evalue) {
+      if (lw.pe_b && !lg.pe_b) return RRT_E_INVALID;
+      const int nreg = gd.rs * gd.rs;
+      if (desc->epeg_type == RRT_EPEG_VALUE_BF) {
+        // attention ran on v' = v + pe: its backward gives dv' (v columns of dqkv) = d pe; the conv read v = v' - pe
+        RRT_TRY(launch_attention_backward(s.qkv[li], nullptr, s.o[li], b.dO, b.dqkv, nullptr, b.attnpart, nreg, gd.P, D,
+                                          desc->n_heads, 0, st));
+        RRT_TRY(launch_copy_cols(b.dpe, b.dqkv, (size_t)gd.Np, D, 3 * D, 2 * D, st));
+        RRT_TRY(launch_value_pe_backward(b.dpe, s.qkv[li], s.pe[li], lw.pe_w, b.dqkv, lg.pe_w, lw.pe_b ? lg.pe_b : nullptr, nreg,
+                                         gd.P, gd.s, D, desc->n_heads, desc->epeg_k, desc->epeg_2d, st));
+      } else {
+        // proj read o + pe: d pe = dO; the attention's own output is (o + pe) - pe (into dz, dead since the proj backward)
+        RRT_TRY(launch_sub(b.dz, s.o[li], s.pe[li], (size_t)gd.Np * D, st));
+        RRT_TRY(launch_attention_backward(s.qkv[li], nullptr, b.dz, b.dO, b.dqkv, nullptr, b.attnpart, nreg, gd.P, D,
+                                          desc->n_heads, 0, st));
+        RRT_TRY(launch_value_pe_backward(b.dO, s.qkv[li], nullptr, lw.pe_w, b.dqkv, lg.pe_w, lw.pe_b ? lg.pe_b : nullptr, nreg,
+                                         gd.P, gd.s, D, desc->n_heads, desc->epeg_k, desc->epeg_2d, st));
+      }
+    } else
     RRT_TRY(launch_attention_backward(s.qkv[li], desc->epeg ? lw.pe_w : nullptr, s.o[li], b.dO, b.dqkv,
                                       desc->epeg ? lg.pe_w : nullptr, b.attnpart, gd.rs * gd.rs, gd.P, D,
                                       desc->n_heads, desc->epeg ? desc->epeg_k : 0, st));

@@ -100,11 +100,23 @@ hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqk
 
 // EPEG ablations (epeg_variants.hip): 2-D 'attn' EPEG over the score map; value EPEG over v's token image
 size_t attn_scoremap_lds(int P, int k);
-hipError_t launch_attn_scoremap(const float* qkv, const float* pe_w, float* o, int n_regions, int P, int dim, int heads,
-                                int k, hipStream_t st);
+// floats of global scratch for `maps` [P, P] maps per (region, head) when they do not fit the LDS (0: they fit)
+size_t attn_scoremap_scratch_floats(int n_regions, int P, int heads, int k, int maps);
+hipError_t launch_attn_scoremap(const float* qkv, const float* pe_w, float* o, float* smap, int n_regions, int P, int dim,
+                                int heads, int k, hipStream_t st);
 hipError_t launch_value_pe(const float* qkv, const float* w, const float* bias, float* pe, int n_regions, int P, int s,
                            int dim, int heads, int k, int two_d, hipStream_t st);
 hipError_t launch_add_cols(float* dst, const float* src, size_t rows, int dim, int ld, hipStream_t st);
+// backward of the ablations (epeg_variants.hip)
+hipError_t launch_value_pe_backward(const float* dpe, const float* qkv, const float* vsub, const float* w, float* dqkv, float* dw,
+                                    float* db, int n_regions, int P, int s, int dim, int heads, int k, int two_d,
+                                    hipStream_t st);
+hipError_t launch_copy_cols(float* dst, const float* src, size_t rows, int dim, int ld, int off, hipStream_t st);
+hipError_t launch_sub(float* dst, const float* a, const float* b, size_t n, hipStream_t st);
+// C [M, N] = A [M, Kd] . W [Kd, N] (row-major W), any small Kd
+hipError_t launch_small_k_matmul(const float* A, const float* W, float* Cm, int M, int N, int Kd, hipStream_t st);
+hipError_t launch_attn_scoremap_backward(const float* qkv, const float* pe_w, const float* dO, float* dqkv, float* dpe_w,
+                                         float* scratch, int n_regions, int P, int dim, int heads, int k, hipStream_t st);
 
 hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float* beta,
                                const float* phi, float* mean_rstd, float* logits, int dim, int k,

@@ -399,7 +399,12 @@ class RRTEncoder(nn.Module):
                 by_name[prefix + "attn.attn.pe.weight"] = gw
                 ag.pe_w = gw.data_ptr()
                 if ia.pe.bias is not None:
-                    by_name[prefix + "attn.attn.pe.bias"] = torch.zeros_like(ia.pe.bias)
+                    if ia.epeg_type == 'attn':          # a per-head constant on every score: cancels in the softmax
+                        by_name[prefix + "attn.attn.pe.bias"] = torch.zeros_like(ia.pe.bias)
+                    else:                               # value_bf / value_af: the conv output is added to v / x
+                        gb = torch.empty_like(ia.pe.bias)
+                        by_name[prefix + "attn.attn.pe.bias"] = gb
+                        ag.pe_b = gb.data_ptr()
             if layer.ffn:
                 ag.norm2 = ln(prefix + "norm2")
                 for nm in ("fc1", "fc2"):

@@ -56,6 +56,16 @@ GRAD_CASES = {
     "nsclc_plip_mlp_n1800": (1800, dict(mlp_dim=512, epeg_k=13, crmsa_k=3, crmsa_heads=1, all_shortcut=True,
                                         crmsa_mlp=True)),
     "ffn_gelu_n1200": (1200, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, ffn=True, mlp_ratio=2.0)),
+    # round 3: the EPEG ablations train too (modules/rmsa.py:76-85,106-129 are differentiable in the reference)
+    "d128_n300_attn2d": (300, dict(mlp_dim=128, n_heads=2, crmsa_heads=2, epeg_k=7, crmsa_k=3, epeg_2d=True)),
+    "d128_n500_valuebf": (500, dict(mlp_dim=128, n_heads=2, crmsa_heads=2, epeg_k=9, crmsa_k=3, epeg_type="value_bf")),
+    "d128_n400_valueaf2d_l3": (400, dict(mlp_dim=128, n_heads=2, crmsa_heads=2, epeg_k=5, crmsa_k=3, epeg_type="value_af",
+                                         epeg_2d=True, n_layers=3)),
+    "attn2d_n1500_k9": (1500, dict(mlp_dim=512, epeg_k=9, crmsa_k=3, epeg_2d=True)),
+    "valuebf2d_n2000_k5": (2000, dict(mlp_dim=512, epeg_k=5, crmsa_k=3, epeg_type="value_bf", epeg_2d=True)),
+    "valueaf_n1500_nobias": (1500, dict(mlp_dim=512, epeg_k=15, crmsa_k=1, epeg_type="value_af", epeg_bias=False)),
+    # regions of 144 tokens: the 2-D EPEG backward's three [P, P] maps per (region, head) no longer fit the LDS
+    "d128_n8000_attn2d_k5": (8000, dict(mlp_dim=128, n_heads=2, crmsa_heads=2, epeg_k=5, crmsa_k=3, epeg_2d=True)),
 }
 
 FULL_LIMIT = 20000      # elements: tensors up to this size are stored whole
@@ -157,6 +167,8 @@ EPEG_CASES = {
     "valueaf_d512_n9000": (9000, dict(mlp_dim=512, epeg_k=15, crmsa_k=3, epeg_type="value_af")),
     "valueaf2d_d512_n1000_nobias": (1000, dict(mlp_dim=512, epeg_k=7, crmsa_k=1, epeg_type="value_af", epeg_2d=True,
                                                epeg_bias=False)),
+    # round 3: regions of 225 tokens -- the forward's score map no longer fits the LDS (it lives in the workspace)
+    "attn2d_d512_n13000_k7": (13000, dict(mlp_dim=512, epeg_k=7, crmsa_k=3, epeg_2d=True)),
 }
 
 
