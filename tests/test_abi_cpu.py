@@ -48,9 +48,11 @@ def test_workspace_and_errors(lib):
     # u/o + qkv + x1 dominate: (9216*512*4 + 9000*512) floats
     assert n.value >= (9216 * 512 * 4 + 9000 * 512) * 4
     assert lib.rrt_encoder_workspace_size(C.byref(enc._desc), 0, C.byref(n)) == -1
-    bad = RRTEncoder(mlp_dim=64, crmsa_mlp=True)
+    ok = RRTEncoder(mlp_dim=64, crmsa_mlp=True)              # (rounds 1-2: unsupported; round 3 runs any width)
+    assert lib.rrt_encoder_workspace_size(C.byref(ok._desc), 100, C.byref(n)) == 0
+    bad = RRTEncoder(mlp_dim=512, crmsa_k=9)                  # more representatives than RRT_MAX_CRMSA_K
     rc = lib.rrt_encoder_workspace_size(C.byref(bad._desc), 100, C.byref(n))
-    assert rc == -2 and b"crmsa_mlp" in lib.rrt_strerror(rc)
+    assert rc == -2 and b"crmsa_k" in lib.rrt_strerror(rc)
     with pytest.raises(NotImplementedError):
         _lib.check(rc, "x")
     assert lib.rrt_region_grid(0, 8, 0, 0, 0.0, C.byref(_lib.Grid())) == -1
