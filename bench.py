@@ -318,6 +318,7 @@ class EncoderWorkload:
             self.wss = [torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(S)]   # one workspace per bag in flight
             self.outs = [torch.empty_like(self.bags[0]) for _ in range(S)]
         self.enc._desc.compute = self.compute
+        self.enc._desc.solo = int(S == 1)        # scheduling hint: with S > 1 the bags share the GPU (rrt_encoder_desc.solo)
         self.w = self.enc._weights()
         # one event pair per launch of the dominant kernel in the timed region: every step, every stream
         # (an event pair costs the stream two marker packets: measured ~5 us per forward, 2 % of an fp32 bag and 10 % of a
@@ -418,6 +419,7 @@ class EncoderWorkload:
                                                                     y.data_ptr(), self.n, ws.data_ptr(), ws.numel(),
                                                                     self.streams[0], evs), "forward")
         enc._desc.weights16_valid = 0
+        solo_was, enc._desc.solo = enc._desc.solo, 1      # this pass IS one bag in flight
         fwd(None)
         enc._desc.weights16_valid = int(enc._desc.compute != L.COMPUTE_F32)
         lead = 100
@@ -437,6 +439,7 @@ class EncoderWorkload:
         torch.cuda.synchronize()
         plain_ms = (time.perf_counter() - t0) / 100 * 1e3
         enc._desc.weights16_valid = 0
+        enc._desc.solo = solo_was
         d = np.array([[self.hev.elapsed_ms(a, b) for a, b in zip(st[:-1], st[1:])] for st in sets])
         return dict(zip(("ln_partition", "fused_rmsa", "out_projection", "crmsa_combine", "crmsa_inner", "dispatch_ln"),
                         np.median(d, axis=0).tolist())), plain_ms

@@ -101,6 +101,12 @@ typedef struct rrt_encoder_desc {
    * the two calls need not match.  The library keeps no state: 0 is always right, 1 is the caller's promise
    * (rrt_mil_amd tracks parameter versions). */
   int32_t weights16_valid;
+  /* Scheduling hint, no effect on results.  0 (default): other work may share the GPU with this forward (more bags in
+   * flight on other streams): every kernel of the latency-bound CR-MSA tail keeps a footprint that fits NEXT TO a block
+   * of the other bag's fused R-MSA kernel (<= 4 waves, <= 40 KiB LDS).  1: the forward has the GPU to itself (one bag in
+   * flight): the representatives' small GEMMs may take whole CUs (16-wave blocks, K split inside the block: 10 -> 6-7 us
+   * each).  The executor sets it to (n_streams == 1) itself. */
+  int32_t solo;
 } rrt_encoder_desc;
 
 /* One TransLayer's parameters: InnerAttention, modules/rmsa.py:57-89 (+ the optional FFN).  Row-major, fp32.

@@ -29,7 +29,8 @@ class EncoderDesc(C.Structure):
                 ("crmsa_mlp", C.c_int32), ("all_shortcut", C.c_int32), ("compute", C.c_int32),
                 ("ffn", C.c_int32), ("ffn_act", C.c_int32), ("ffn_hidden", C.c_int32),
                 ("pos", C.c_int32), ("pos_pos", C.c_int32), ("peg_k", C.c_int32), ("peg_1d", C.c_int32),
-                ("epeg_2d", C.c_int32), ("epeg_type", C.c_int32), ("weights16_valid", C.c_int32)]
+                ("epeg_2d", C.c_int32), ("epeg_type", C.c_int32), ("weights16_valid", C.c_int32),
+                ("solo", C.c_int32)]
 
 
 class AttnWeights(C.Structure):

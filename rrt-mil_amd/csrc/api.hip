@@ -129,10 +129,11 @@ int check_desc(const rrt_encoder_desc* d, int64_t N) {
 }
 
 hipError_t inner_attention(const float* u, int n_regions, int P, const rrt_attn_weights& w, int dim,
-                           int heads, int epeg_k, float* qkv, float* o, int prec, hipStream_t st) {
+                           int heads, int epeg_k, float* qkv, float* o, int prec, bool solo, hipStream_t st) {
   const int M = n_regions * P;
   LinearEpilogue ep{};
   ep.prec = prec;
+  ep.solo = solo;
   ep.bias = w.qkv_b;
   ep.q_cols = dim;
   ep.q_scale = 1.0f / sqrtf((float)(dim / heads));   // head_dim ** -0.5, modules/rmsa.py:65,103
@@ -588,10 +589,11 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     ep.bias = cw.proj_b;
     RRT_TRY(launch_linear16(ws.repo16, ws.wcr16 + (size_t)3 * D * D, ws.rep2, k * R8, D, D, ep, st));
   } else {
-    RRT_TRY(inner_attention(ws.rep, k, R8, cw, D, desc->crmsa_heads, 0, ws.rep_qkv, ws.rep_o, desc->compute, st));
+    RRT_TRY(inner_attention(ws.rep, k, R8, cw, D, desc->crmsa_heads, 0, ws.rep_qkv, ws.rep_o, desc->compute, desc->solo != 0, st));
     LinearEpilogue ep{};
     ep.prec = desc->compute;
     ep.bias = cw.proj_b;
+    ep.solo = desc->solo != 0;
     RRT_TRY(launch_linear(ws.rep_o, cw.proj_w, ws.rep2, k * R8, D, D, ep, st));
   }
   RRT_MARK(RRT_EV_CR_INNER);
@@ -1126,6 +1128,7 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
       ex->w16_version[s] = 0;
     }
     rrt_encoder_desc d = ex->desc;
+    d.solo = S == 1;
     d.weights16_valid = w->version != 0 && ex->w16_version[s] == w->version && ex->w16_compute[s] == d.compute;
     rc = encoder_forward(&d, w, b.x, b.y, b.n_tokens, ex->ws[s], ex->ws_bytes[s], ex->streams[s], nullptr,
                          gated ? &ex->gate : nullptr);

@@ -50,6 +50,8 @@ struct LinearEpilogue {
   // side job: block 0 zeroes 64 ints (the CR-MSA region kernel's arrival counters: they must be 0 when it starts,
   // and some kernel earlier in the same forward has to do it -- the workspace is the caller's, uninitialised)
   int* zero64;
+  // scheduling hint (rrt_encoder_desc.solo): this GEMM may use whole CUs (small-M GEMMs: split K inside a 16-wave block)
+  bool solo;
 };
 hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
                          const LinearEpilogue& ep, hipStream_t st);

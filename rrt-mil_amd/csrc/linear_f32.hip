@@ -504,6 +504,23 @@ __global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void
       for (int r = 0; r < 4; ++r) bz[j][r] = (ep.bias && nb + r < N) ? ep.bias[nb + r] : 0.f;
     }
   };
+  // deferred un-partition epilogue: the next slice's residual row, requested a K iteration ahead (full 16-byte columns
+  // only; q_scale does not apply to this epilogue)
+  const bool pref_ok = MODE == MODE_UNPART && N % (64 * NT) == 0 && ep.q_cols == 0;
+  float4 rq[NT];
+  long rrow = -1;
+  auto resid_prefetch = [&](int mbase, int nbase) {
+    const int m = mbase + lr;
+    rrow = -1;
+    if (m < M) {
+      const int t = slot_to_token(m, ep.g);
+      if (t < ep.g.L) rrow = t;
+    }
+    if (rrow >= 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) rq[j] = *(const float4*)(ep.resid + (size_t)rrow * N + nbase + wave * (16 * NT) + j * 16 + 4 * lg);
+    }
+  };
   for (int tile = first; tile < ntiles; tile += G) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -615,7 +632,22 @@ __global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void
       // (static register indexing: always slice 0, then rotate the remaining slices down)
       if constexpr (DEFER) {
         if (have_prev && kt < MT) {
-          store_slice<MT, NT, MODE, 0>(prev, pbias, C, M, N, pm0 + kt * 16, pn0, wave, lr, lg, ep);
+          if (MODE == MODE_UNPART && pref_ok) {
+            // the slice's residual row was requested one K iteration ago (the load's ~1 us round trip sat on the critical
+            // path of every iteration: the wave waited for it before it could issue the store -- and the next MFMAs)
+            if (rrow >= 0) {
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                const int nb = pn0 + wave * (16 * NT) + j * 16 + 4 * lg;
+                const float4 q = rq[j];
+                *(float4*)(C + (size_t)rrow * N + nb) = make_float4(prev[0][j][0] + pbias[j][0] + q.x, prev[0][j][1] + pbias[j][1] + q.y,
+                                                                    prev[0][j][2] + pbias[j][2] + q.z, prev[0][j][3] + pbias[j][3] + q.w);
+              }
+            }
+            if (kt + 1 < MT) resid_prefetch(pm0 + (kt + 1) * 16, pn0);
+          } else {
+            store_slice<MT, NT, MODE, 0>(prev, pbias, C, M, N, pm0 + kt * 16, pn0, wave, lr, lg, ep);
+          }
 #pragma unroll
           for (int i = 0; i + 1 < MT; ++i)
 #pragma unroll
@@ -653,12 +685,123 @@ __global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void
     pm0 = m0;
     pn0 = n0;
     have_prev = true;
+    if (MODE == MODE_UNPART && pref_ok) resid_prefetch(pm0, pn0);      // slice 0 of the tile just handed over
     RRT_TRACE_MARK();
     }
   }
   // the block's last tile has no successor to hide behind
   if constexpr (DEFER)
     if (have_prev) store_all_slices<MT, NT, MODE>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Small-M GEMMs (the 64 k representatives of CR-MSA: M = 192..512 rows): split K INSIDE the block.
+// linear_kernel's K loop is a chain of K / 32 dependent steps (DMA round trip + 16 MFMAs each): at M = 192 a launch
+// is 144 blocks of one 32 x 64 tile that spend ~6 us walking sixteen K tiles one after the other, on top of a ~4 us
+// launch floor.  Here a block is KG groups of four waves; group g multiplies the K tiles g, g + KG, ... of the SAME
+// output tile with its own two-stage ring (all groups step in lockstep, so the block barrier still works), the KG
+// partial accumulators are summed through LDS in a fixed order and group 0 runs the epilogue.  Four times fewer
+// dependent steps; the MFMA work per SIMD is unchanged (wave g * 4 + c sits on SIMD c).  Exact fp32, plain epilogue
+// (bias, q-scale): what the inner MSA's qkv and proj need.
+template <int MT, int KG>
+__global__ __launch_bounds__(256 * KG, 1) void linear_splitk_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                     float* __restrict__ C, int M, int N, int K, int tiles_n,
+                                                                     LinearEpilogue ep) {
+  constexpr int BM = 16 * MT, BN = 64;
+  constexpr int STAGE = (BM + BN) * BK;             // floats per stage
+  constexpr int NA = BM / 8, NB = BN / 8;
+  constexpr int QA = (NA + 3) / 4, QB = NB / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kg = wave >> 2, cw = wave & 3;          // K group; 16-column tile
+  const int lr = lane & 15, lg = lane >> 4;
+  float* lds = (float*)smem + kg * 2 * STAGE;       // this group's ring
+  const unsigned lds_b = lds_addr_of(lds);
+  const int tile = blockIdx.x;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  unsigned aoff[QA], boff[QB];
+#pragma unroll
+  for (int qi = 0; qi < QA; ++qi) {
+    const int S = (qi * 4 + cw) * 64 + lane, row = S >> 3, p = S & 7;
+    int gr = m0 + row;
+    gr = gr < M ? gr : M - 1;
+    aoff[qi] = (unsigned)(gr - m0) * (unsigned)K * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    const int S = (qi * 4 + cw) * 64 + lane, row = S >> 3, p = S & 7;
+    int gr = n0 + row;
+    gr = gr < N ? gr : N - 1;
+    boff[qi] = (unsigned)(gr - n0) * (unsigned)K * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+  }
+  const float* abase = A + (size_t)m0 * K;
+  const float* bbase = B + (size_t)n0 * K;
+  auto stage = [&](int kt, unsigned buf) {
+#pragma unroll
+    for (int qi = 0; qi < QA; ++qi)
+      if (qi * 4 + cw < NA) dma16s(abase + kt * BK, aoff[qi], buf + (qi * 4 + cw) * 1024);
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) dma16s(bbase + kt * BK, boff[qi], buf + BM * BK * 4 + (qi * 4 + cw) * 1024);
+  };
+  const int nk = K / BK, nkg = (nk + KG - 1) / KG;  // K tiles of this group: kg, kg + KG, ...
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (kg < nk) stage(kg, lds_b);
+  for (int it = 0; it < nkg; ++it) {
+    const int kt = kg + it * KG;
+    wait_vm0();
+    __syncthreads();
+    if (kt + KG < nk) stage(kt + KG, lds_b + ((it + 1) & 1) * STAGE * 4);
+    if (kt < nk) {
+      const float* As = lds + (it & 1) * STAGE;
+      const float* Bs = As + BM * BK;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int cslot = 4 * kk + lg;
+        const int brow = cw * 16 + lr;
+        const float4 bf = *(const float4*)(Bs + brow * BK + ((cslot ^ ((brow >> 1) & 7)) << 2));
+        float4 af[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = i * 16 + lr;
+          af[i] = *(const float4*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.x, af[i].x, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.y, af[i].y, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.z, af[i].z, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.w, af[i].w, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();                                  // the rings are dead: they carry the partial tiles now
+  f32x4* red = (f32x4*)smem;                        // [KG - 1][4 column waves][MT][64 lanes]
+  if (kg > 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) red[(((kg - 1) * 4 + cw) * MT + i) * 64 + lane] = acc[i];
+  }
+  __syncthreads();
+  if (kg == 0) {
+    f32x4 out[MT][1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      f32x4 a = acc[i];
+#pragma unroll
+      for (int g = 1; g < KG; ++g) {                // fixed order: bit-reproducible
+        const f32x4 b = red[(((g - 1) * 4 + cw) * MT + i) * 64 + lane];
+        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+      }
+      out[i][0] = a;
+    }
+    RRT_TRACE_INIT(1 << 30);
+    store_tile<MT, 1, MODE_PLAIN>(out, C, M, N, m0, n0, cw, lr, lg, ep RRT_EPI_TRACE_PASS);
+  }
 }
 
 // > 64 KiB of dynamic LDS needs the attribute, once per kernel per device: the static lives at the call site (inside
@@ -823,6 +966,7 @@ hipError_t launch_linear16(const void* A, const void* B, float* C, int M, int N,
                                 {4, 1, 512}, {2, 1, 512}};
     long best_cost = -1;
     for (const Cfg& c : cands) {
+      if (c.mt < 6 && M > 1024) continue;           // small tiles re-stream B too often to pay on a bag-sized GEMM
       long tiles = (long)((M + 16 * c.mt - 1) / (16 * c.mt)) * ((N + 64 * c.nt - 1) / (64 * c.nt));
       long grid = tiles < c.cap ? tiles : c.cap;
       long cost = ((tiles + grid - 1) / grid) * ((grid + 255) / 256) * c.mt * c.nt;
@@ -857,6 +1001,27 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
                          const LinearEpilogue& ep, hipStream_t st) {
   const bool u = ep.resid != nullptr;
   if (ep.drop_on && (ep.prec != PREC_F32 || ep.act)) return hipErrorInvalidValue;   // dropout: fp32 training only
+  // the GEMMs of CR-MSA's representatives (M = 64 k <= 512 rows), when the forward has the GPU to itself: K split inside
+  // the block (linear_splitk_kernel; its 16-wave, 80-96 KiB blocks do not fit next to another bag's fused R-MSA block)
+  static const bool no_splitk = rrt_tune_env("RRT_NO_SPLITK") != nullptr;
+  if (!no_splitk && ep.solo && ep.prec == PREC_F32 && !u && !ep.act && !ep.drop_on && !ep.zero64 && M <= 512 && K % (4 * BK) == 0 && K >= 256) {
+    constexpr int KG = 4;
+    const int tiles_n = (N + 63) / 64;
+    if (N >= 1024) {                                // qkv: 32-row tiles (6 x 24 = 144 blocks at k = 3)
+      constexpr int MT = 2;
+      constexpr int LDS_BYTES = KG * 2 * (16 * MT + 64) * BK * 4;
+      auto kern = linear_splitk_kernel<MT, KG>;
+      RRT_ALLOW_LDS(kern, LDS_BYTES);
+      kern<<<dim3(((M + 16 * MT - 1) / (16 * MT)) * tiles_n), dim3(256 * KG), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ep);
+    } else {                                        // proj: 16-row tiles (12 x 8 = 96 blocks)
+      constexpr int MT = 1;
+      constexpr int LDS_BYTES = KG * 2 * (16 * MT + 64) * BK * 4;
+      auto kern = linear_splitk_kernel<MT, KG>;
+      RRT_ALLOW_LDS(kern, LDS_BYTES);
+      kern<<<dim3(((M + 16 * MT - 1) / (16 * MT)) * tiles_n), dim3(256 * KG), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ep);
+    }
+    return hipGetLastError();
+  }
   const Cfg c = choose(M, N, ep.prec);
 #define RRT_CASE(MT_, NT_)                                                                          \
   if (c.mt == MT_ && c.nt == NT_) {                                                                 \

@@ -495,6 +495,9 @@ class RRTEncoder(nn.Module):
             # the 16-bit weight images at the head of this workspace are still those of these weights?
             key = (ws.data_ptr(), self._desc.compute, w.version, stream)
             self._desc.weights16_valid = int(self._desc.compute != _lib.COMPUTE_F32 and key == getattr(self, "_w16_key", None))
+            # scheduling hint (no effect on results): a plain forward is the reference's loop, one bag at a time; callers
+            # that keep several forwards in flight on their own streams set enc.solo = False
+            self._desc.solo = int(getattr(self, "solo", True))
             rc = lib.rrt_encoder_forward_f32(C.byref(self._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
                                              ws.data_ptr(), ws.numel(), stream)
             self._desc.weights16_valid = 0
@@ -558,6 +561,7 @@ class RRTEncoder(nn.Module):
     def _executor(self, n_streams, max_tokens, device):
         key = (n_streams, device)
         ex = getattr(self, "_ex", None)
+        self._desc.weights16_valid, self._desc.solo = 0, 0      # per-call fields: the executor sets its own
         if ex is not None and self._ex_key == key and bytes(self._ex_desc) == bytes(self._desc):
             return ex
         self._drop_executor()
