@@ -556,6 +556,8 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int reg = blockIdx.x / NB, q = blockIdx.x - reg * NB, R = g.rs * g.rs;
+  RRT_TRACE_INIT(blockIdx.x * NW + wave);
+  RRT_TRACE_MARK();                                 // [1] entry
   const int ri = reg / g.rs, rj = reg - ri * g.rs;
   const int PQ = (g.P + NB - 1) / NB;               // rows per part ("quarter": NB = 4)
   float4 r[NR][2];
@@ -581,6 +583,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
     phi_t[n * DIM + d] = phi[idx];
   }
   __syncthreads();
+  RRT_TRACE_MARK();                                 // [2] rows requested, phi in LDS
   const float inv_d = 1.0f / (float)DIM;
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
@@ -619,8 +622,12 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
       if (real && mean_rstd) { mean_rstd[2 * (size_t)tokv[j]] = mean; mean_rstd[2 * (size_t)tokv[j] + 1] = rstd; }
     }
   }
+  RRT_TRACE_MARK();                                 // [3] LayerNorm statistics + logits of this wave's rows
   __syncthreads();
   const int nrow = min(PQ, g.P - q * PQ);           // rows of this quarter (>= 1: P >= 4 is checked by the launcher)
+  // wave n < k owns representative n: local max / min / sum of exp over the quarter's rows, the combine coefficients
+  // c * rstd of every row, and the two LayerNorm-fold sums (Identity 3) -- five wave reductions on k waves, one barrier
+  // (round 2 did the sums on all NW waves behind a second barrier: 4.3 K cycles of mostly idle reductions)
   if (wave < k) {
     const int n = wave;
     float mx = -3.0e38f, mn = 3.0e38f;
@@ -631,36 +638,26 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
     }
     mx = wave_max(mx);
     mn = wave_min(mn);
-    float se = 0.f;
-    for (int p = lane; p < nrow; p += 64) se += __expf(s_lg[p * KM + n] - mx);
-    se = wave_sum(se);
-    if (lane == 0) { s_stat[n][0] = mx; s_stat[n][1] = mn; s_stat[n][2] = se; }
-  }
-  __syncthreads();
-  {
-    float c0[KM], c1[KM];
-#pragma unroll
-    for (int n = 0; n < KM; ++n) c0[n] = c1[n] = 0.f;
-    for (int p = tid; p < nrow; p += 64 * NW) {
+    float se = 0.f, c0 = 0.f, c1 = 0.f;
+    for (int p = lane; p < nrow; p += 64) {
+      const float e = __expf(s_lg[p * KM + n] - mx);
+      se += e;
       const float mean = s_mr[2 * p], rstd = s_mr[2 * p + 1];
-      const bool real = rstd != 0.f;
-#pragma unroll
-      for (int n = 0; n < KM; ++n)
-        if (n < k) {
-          const float c = real ? __expf(s_lg[p * KM + n] - s_stat[n][0]) : 0.f;   // unnormalised, local max
-          s_w[p * KM + n] = c * rstd;
-          c0[n] += c * rstd * mean;
-          c1[n] += c;
-        }
+      const float c = rstd != 0.f ? e : 0.f;        // pad rows (rstd = 0): in the softmax sum, not in the contraction
+      s_w[p * KM + n] = c * rstd;
+      c0 += c * rstd * mean;
+      c1 += c;
     }
-#pragma unroll
-    for (int n = 0; n < KM; ++n)
-      if (n < k) {
-        const float a = wave_sum(c0[n]), b = wave_sum(c1[n]);
-        if (lane == 0) { s_c0[n][wave] = a; s_c1[n][wave] = b; }
-      }
+    se = wave_sum(se);
+    c0 = wave_sum(c0);
+    c1 = wave_sum(c1);
+    if (lane == 0) {
+      s_stat[n][0] = mx; s_stat[n][1] = mn; s_stat[n][2] = se;
+      s_c0[n][0] = c0; s_c1[n][0] = c1;
+    }
   }
   __syncthreads();
+  RRT_TRACE_MARK();                                 // [4] local softmax statistics + coefficients
   float4 acc[KM][2];
 #pragma unroll
   for (int n = 0; n < KM; ++n) acc[n][0] = acc[n][1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -676,6 +673,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
         acc[n][1].x += w * r[j][1].x; acc[n][1].y += w * r[j][1].y; acc[n][1].z += w * r[j][1].z; acc[n][1].w += w * r[j][1].w;
       }
   }
+  RRT_TRACE_MARK();                                 // [5] contraction of this wave's rows
   constexpr int HW = NW / 2;
   // ---- this quarter's record -> workspace: the NW per-wave partials summed through LDS in a fixed order, KC
   // representatives at a time
@@ -720,18 +718,19 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   }
   if (tid < k) {
     const int n = tid;
-    float c0 = 0.f, c1 = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { c0 += s_c0[n][w]; c1 += s_c1[n][w]; }
+    const float c0 = s_c0[n][0], c1 = s_c1[n][0];
     float* st = rec + n * (DIM + 8) + DIM;
     st_agent(st, s_stat[n][0]); st_agent(st + 1, s_stat[n][1]); st_agent(st + 2, s_stat[n][2]);
     st_agent(st + 3, c0); st_agent(st + 4, c1);
   }
+  RRT_TRACE_MARK();                                 // [6] record stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record (and the logits) are in memory ...
   __syncthreads();
+  RRT_TRACE_MARK();                                 // [7] record in memory (write-through stores acknowledged)
   if (tid == 0)                                     // ... before this quarter counts as arrived
     s_last = __hip_atomic_fetch_add(counters + reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NB - 1;
   __syncthreads();
+  RRT_TRACE_MARK();                                 // [8] arrival counted
   if (!s_last) return;
   if (tid == 0) __hip_atomic_store(counters + reg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next forward
   const float* rec0 = part_g + (size_t)(reg * NB) * R4_REC;
@@ -776,6 +775,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
       *(uint2*)d16 = prec16 == 2 ? r4_pack4<2>(out) : r4_pack4<1>(out);
     }
   }
+  RRT_TRACE_MARK();                                 // [9] (last arrival) records merged, rep written
   // dispatch weights of the whole region (rmsa.py:310-314, :324-325) from the four quarters' logits
   for (int p = tid; p < g.P; p += 64 * NW) {
     float v[KM], e[KM];
@@ -793,6 +793,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
       if (n < k)
         wdisp[((size_t)reg * g.P + p) * k + n] = (v[n] - s_mm[n][0]) / (s_mm[n][1] - s_mm[n][0] + 1e-8f) * (e[n] * inv);
   }
+  RRT_TRACE_MARK();                                 // [10] dispatch weights written
 }
 
 template <int NV, bool CRMSA, bool FULL>   // FULL: dim == NV * 256, no lane predication (see ln_partition.hip)
@@ -943,6 +944,10 @@ hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
 }
 
 }  // namespace
+
+#ifdef RRT_TRACE
+RRT_TRACE_DEFINE_READER(rrt_debug_trace_crmsa)
+#endif
 
 hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float* beta,
                                const float* phi, float* mean_rstd, float* logits, int dim, int k,

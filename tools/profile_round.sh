@@ -56,6 +56,7 @@ timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o e -- python $R/be
 python $R/tools/rocprof_summary.py /tmp/prof_e/e_results.db > $OUT/${TAG}_bench_config4_bf16_1stream.kernel_stats.txt
 if [ -f $R/tools/_abl/librrt_trace.so ]; then
   RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_fused.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_fused_f32_wave_timeline.txt
+  RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_linear.py proj 9000 8 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_out_projection_f32_wave_timeline.txt
   RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_pair16.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_pair16_wave_timeline.txt
 fi
 [ -x $R/tools/_abl/dma_rows ] && timeout 120 $R/tools/_abl/dma_rows > $OUT/${TAG}_ubench_dma_rows.txt 2>&1
