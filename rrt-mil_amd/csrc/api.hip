@@ -1556,6 +1556,7 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     ep.bias = cw.qkv_b;
     ep.q_cols = D;
     ep.q_scale = 1.0f / sqrtf((float)(D / desc->crmsa_heads));
+    ep.solo = true;
     RRT_TRY(launch_linear(s.rep, cw.qkv_w, s.rep_qkv, k * R8, 3 * D, D, ep, st));
     RRT_TRY(launch_region_attention(s.rep_qkv, nullptr, s.rep_o, k, R8, D, desc->crmsa_heads, 0, st));
     LinearEpilogue ep2{};

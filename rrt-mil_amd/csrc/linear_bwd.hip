@@ -37,8 +37,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // pitch of 144 floats puts the four groups on disjoint bank ranges.
 constexpr int TN_BN = 128, TN_BK = 128, TN_BM = 32, TN_PITCH = 144;
 
+// dbpart (may be null): the blocks of the first k column also sum the columns of their A rows -- db[n] = sum_m dY[m][n]
+// of nn.Linear's backward -- into dbpart[s][n] (the rows are in LDS anyway: one launch and one pass over dY fewer)
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                      float* __restrict__ part, int M, int N, int K,
+                                                      float* __restrict__ part, float* __restrict__ dbpart, int M, int N, int K,
                                                       int rows_per_chunk) {
   __shared__ __attribute__((aligned(16))) float As[TN_BM * TN_PITCH];
   __shared__ __attribute__((aligned(16))) float Bs[TN_BM * TN_PITCH];
@@ -55,6 +57,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_db = dbpart != nullptr && blockIdx.y == 0;
+  float colsum = 0.f;                               // column n0 + tid of this block's rows (tid < 128)
 
   for (int m0 = m_begin; m0 < m_end; m0 += TN_BM) {
     // stage 32 rows x 128 columns of each operand: 1024 float4 per operand, 4 per thread
@@ -85,6 +89,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
       *(float4*)(Bs + row * TN_PITCH + c4) = vb;
     }
     __syncthreads();
+    if (do_db && tid < TN_BN) {
+      float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < TN_BM; r += 2) { c0 += As[r * TN_PITCH + tid]; c1 += As[(r + 1) * TN_PITCH + tid]; }
+      colsum += c0 + c1;
+    }
 #pragma unroll
     for (int kk = 0; kk < TN_BM / 4; ++kk) {
       float a[4], b[4];
@@ -99,6 +109,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     }
     __syncthreads();
   }
+  if (do_db && tid < TN_BN && n0 + tid < N) dbpart[(size_t)s * N + n0 + tid] = colsum;
   // D[i = 4 lg + r][j = lr] of every 16 x 16 tile
   float* out = part + (size_t)s * N * K;
 #pragma unroll
@@ -116,11 +127,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 //      waves split the S partials (wave w takes s = w, w + 4, ...) with up to 12 independent 16-byte loads in flight
 //      each, then combine through LDS in wave order.  (The plain per-thread loop was a chain of S memory round
 //      trips: 131 us for 16 x 3 MB; 8 loads in flight: 37 us; this: one or two trips.)
+// Optional second segment (part2 / out2 / n2; blocks past the first segment's): the bias gradient's partials ride in the
+// same launch as the weight gradient's.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              int S, size_t n) {
+                                                              int S, size_t n, const float* __restrict__ part2,
+                                                              float* __restrict__ out2, size_t n2, unsigned nb1) {
   __shared__ float4 comb[3][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t i = ((size_t)blockIdx.x * 64 + lane) * 4;
+  unsigned blk = blockIdx.x;
+  if (blk >= nb1) { blk -= nb1; part = part2; out = out2; n = n2; }
+  const size_t i = ((size_t)blk * 64 + lane) * 4;
   const bool vec = (n & 3) == 0 && i + 3 < n;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n) {
@@ -209,7 +225,8 @@ hipError_t launch_transpose(const float* in, float* out, int R, int C, hipStream
 }
 
 hipError_t launch_reduce_partials(const float* part, float* out, int S, size_t n, hipStream_t st) {
-  reduce_partials_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(part, out, S, n);
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  reduce_partials_kernel<<<dim3(nb), 256, 0, st>>>(part, out, S, n, nullptr, nullptr, 0, nb);
   return hipGetLastError();
 }
 
@@ -219,10 +236,24 @@ hipError_t launch_gemm_tn(const float* dY, const float* X, float* dW, float* scr
   int rpc;
   const int S = linear_bwd_chunks(M, N, K, &rpc);
   dim3 grid((N + TN_BN - 1) / TN_BN, (K + TN_BK - 1) / TN_BK, S);
-  gemm_tn_kernel<<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, M, N, K, rpc);
+  gemm_tn_kernel<<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, nullptr, M, N, K, rpc);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || S == 1) return e;
   return launch_reduce_partials(scratch, dW, S, (size_t)N * K, st);
+}
+
+// ... and db[N] = column sums of dY in the same two launches (dbscratch: S * N floats)
+static hipError_t launch_gemm_tn_db(const float* dY, const float* X, float* dW, float* db, float* scratch, float* dbscratch, int M,
+                                    int N, int K, hipStream_t st) {
+  int rpc;
+  const int S = linear_bwd_chunks(M, N, K, &rpc);
+  dim3 grid((N + TN_BN - 1) / TN_BN, (K + TN_BK - 1) / TN_BK, S);
+  gemm_tn_kernel<<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, S == 1 ? db : dbscratch, M, N, K, rpc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || S == 1) return e;
+  const unsigned nb1 = (unsigned)(((size_t)N * K + 255) / 256), nb2 = (unsigned)((N + 255) / 256);
+  reduce_partials_kernel<<<dim3(nb1 + nb2), 256, 0, st>>>(scratch, dW, S, (size_t)N * K, dbscratch, db, (size_t)N, nb1);
+  return hipGetLastError();
 }
 
 hipError_t launch_colsum(const float* Y, float* out, float* scratch, int M, int N, hipStream_t st) {
@@ -248,14 +279,17 @@ hipError_t launch_linear_backward(const float* dY, const float* X, const float* 
     if (e != hipSuccess) return e;
     LinearEpilogue ep{};
     ep.prec = prec;
+    ep.solo = true;                                           // (a training step has the GPU to itself: small-M GEMMs split K in the block)
     e = launch_linear(dY, WT, dX, M, K, N, ep, st);           // dX[M,K] = dY[M,N] . WT[K,N]^T
     if (e != hipSuccess) return e;
   }
-  if (dW) {
+  if (dW && db) {                                              // the usual case: bias gradient inside the dW product
+    e = launch_gemm_tn_db(dY, X, dW, db, scratch, cs, M, N, K, st);
+    if (e != hipSuccess) return e;
+  } else if (dW) {
     e = launch_gemm_tn(dY, X, dW, scratch, M, N, K, st);
     if (e != hipSuccess) return e;
-  }
-  if (db) {
+  } else if (db) {
     e = launch_colsum(dY, db, cs, M, N, st);
     if (e != hipSuccess) return e;
   }
