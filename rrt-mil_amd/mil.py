@@ -26,6 +26,61 @@ def _act(name):
     return {"gelu": nn.GELU, "relu": nn.ReLU, "tanh": nn.Tanh}.get(name)
 
 
+class _LibLinear(torch.autograd.Function):
+    """nn.Linear on the library's GEMM kernels with a graph (round 3: the classifier's big products -- patch_to_emb
+    (N x input_dim -> 512) and DAttention's first Linear(512, 128) -- no longer go through torch / rocBLAS in training):
+    forward = rrt_linear_f32, backward = rrt_linear_backward_f32 (dX via the forward GEMM on W^T, dW as the split-K TN
+    product with the bias gradient summed inside it).  Operand precision follows autocast like the encoder."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, compute):
+        lib = _lib.load()
+        x2d = x2d.float().contiguous()
+        M, K = x2d.shape
+        N = weight.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+        with torch.cuda.device(x2d.device):
+            st = torch.cuda.current_stream(x2d.device).cuda_stream
+            _lib.check(lib.rrt_linear_f32(x2d.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                          y.data_ptr(), M, N, K, 0, 1.0, compute, st), "rrt_linear_f32")
+        ctx.save_for_backward(x2d, weight)
+        ctx.has_bias, ctx.compute = bias is not None, compute
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2d, weight = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        M, K = x2d.shape
+        N = weight.shape[0]
+        need = C.c_size_t()
+        _lib.check(lib.rrt_linear_backward_workspace_size(M, N, K, C.byref(need)), "rrt_linear_backward_workspace_size")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dy.device)
+        dx = torch.empty_like(x2d) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        db = torch.empty(N, dtype=torch.float32, device=dy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        with torch.cuda.device(dy.device):
+            st = torch.cuda.current_stream(dy.device).cuda_stream
+            _lib.check(lib.rrt_linear_backward_f32(dy.data_ptr(), x2d.data_ptr(), weight.data_ptr(),
+                                                   dx.data_ptr() if dx is not None else None,
+                                                   dw.data_ptr() if dw is not None else None,
+                                                   db.data_ptr() if db is not None else None, M, N, K, ctx.compute,
+                                                   ws.data_ptr(), ws.numel(), st), "rrt_linear_backward_f32")
+        return dx, dw, db, None
+
+
+def lib_linear(lin, x, compute):
+    """x (..., K) through nn.Linear `lin` on the library kernels when they apply (HIP tensor, fp32 parameters, K a
+    multiple of 32 and -- for the input gradient -- N too); otherwise the torch op."""
+    ok = (x.is_cuda and lin.weight.is_cuda and lin.weight.dtype == torch.float32 and lin.in_features % 32 == 0
+          and (not x.requires_grad or lin.out_features % 32 == 0) and x.numel() > 0)
+    if not ok:
+        return lin(x)
+    y = _LibLinear.apply(x.reshape(-1, x.shape[-1]), lin.weight, lin.bias, compute)
+    return y.reshape(*x.shape[:-1], lin.out_features)
+
+
 class Attention(nn.Module):
     """modules/datten.py:5-38."""
 
@@ -215,11 +270,43 @@ class RRTMIL(nn.Module):
         return self._forward_layers(x, return_attn, no_norm)
 
     def _forward_layers(self, x, return_attn=False, no_norm=False):
-        x = self.dp(self.patch_to_emb(x))                 # (1, N, 512)
-        x = self.online_encoder(x)                        # feature re-embedding: the HIP path
-        if return_attn:
-            x, a = self.pool_fn(x, return_attn=True, no_norm=no_norm)
+        enc = self.online_encoder
+        if x.is_cuda:
+            # the two bag-sized products of the classifier on the library's GEMMs (forward and backward), the
+            # activation / dropout / softmax glue as torch ops under autograd
+            compute = enc._compute_mode()
+            compute = _lib.COMPUTE_F32 if compute == _lib.COMPUTE_F32X3 else compute
+            h = lib_linear(self.patch_to_emb[0], x, compute)
+            for m in list(self.patch_to_emb)[1:]:
+                h = m(h)
+            x = self.dp(h.float())                        # (1, N, 512)
         else:
-            x = self.pool_fn(x)
+            x = self.dp(self.patch_to_emb(x))
+        x = enc(x)                                        # feature re-embedding: the HIP path
+        x, a = self._pool(x, no_norm)
         logits = self.predictor(x)
         return (logits, a) if return_attn else logits
+
+    def _pool(self, x, no_norm):
+        """DAttention (modules/datten.py:28-38, :69-83) with its Linear(512, 128) layers on the library GEMMs"""
+        att = self.pool_fn.attention
+        if not x.is_cuda:
+            return self.pool_fn(x, return_attn=True, no_norm=no_norm)
+        compute = self.online_encoder._compute_mode()
+        compute = _lib.COMPUTE_F32 if compute == _lib.COMPUTE_F32X3 else compute
+
+        def seq(mods, t):
+            t = lib_linear(mods[0], t, compute)
+            for m in list(mods)[1:]:
+                t = m(t)
+            return t
+        if self.pool_fn.gated:
+            s = att.attention_c(seq(att.attention_a, x).mul(seq(att.attention_b, x)))
+        else:
+            mods = list(att.attention)
+            s = mods[-1](seq(mods[:-1], x))
+        s = s.transpose(-1, -2)                           # K x N
+        a_raw = s.clone()
+        a = F.softmax(s, dim=-1)
+        pooled = torch.matmul(a, x).squeeze(1)
+        return pooled, (a_raw if no_norm else a).squeeze(1)
