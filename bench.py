@@ -663,8 +663,10 @@ def main():
                          "matrix cores, RRT_COMPUTE_F32X3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational extra records of the default run")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("RRT_BENCH_STREAMS", "2")),
-                    help="bags in flight per GPU (one HIP stream + workspace each); a step = this many bags")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("RRT_BENCH_STREAMS", "0")),
+                    help="bags in flight per GPU (one HIP stream + workspace each); a step = this many bags.  Default: 2 for "
+                         "fp32 arithmetic (the MFMA-bound kernels time-slice beyond that), 3 for bf16 / fp16 (their kernels are "
+                         "bound by operand-stream and launch latency: a third bag in flight fills more of it, +8 %)")
     ap.add_argument("--stub-cpu", action="store_true", help="rank logic only: CPU stand-in workload over gloo (tests)")
     args = ap.parse_args()
 
@@ -694,6 +696,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # RCCL
 
     cfg = CONFIGS[args.config]
+    if args.streams <= 0:
+        args.streams = 3 if (args.dtype or cfg["dtype"]) in ("bf16", "f16") else 2
     if args.stub_cpu:
         wl = StubWorkload(args, rank, world, dev)
     elif cfg["kind"] == "mix":
