@@ -353,7 +353,11 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
   bool x3 = false;
   if (want_x3 && desc->n_rmsa_layers > 0 && !epeg_variant) {
     const GridDev gd = to_dev(g);
-    x3 = rmsa_fused_x3_supported(gd.P, D, desc->n_heads, desc->epeg ? desc->epeg_k : 0) && rmsa_fused_supported_rows(gd.Np, D);
+    // dim % 256 == 0 only: at other widths the LayerNorm-type kernels keep their lane-predicated column guards, and those
+    // mis-summed now and then with split-kernel waves co-resident (root cause not established) -- such
+    // widths get the exact fp32 kernels instead (more accurate than what was asked for)
+    x3 = D % 256 == 0 && rmsa_fused_x3_supported(gd.P, D, desc->n_heads, desc->epeg ? desc->epeg_k : 0) &&
+         rmsa_fused_supported_rows(gd.Np, D);
     Cast16Jobs jobs{};
     for (int li = 0; li < desc->n_rmsa_layers; ++li) {
       const rrt_attn_weights& lw = w->rmsa[li];
