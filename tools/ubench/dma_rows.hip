@@ -70,9 +70,10 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(const char* __restrict__
 }
 
 
-// The same stream through REGISTERS: global_load_dwordx4 (fire and forget: the wave goes on) + ds_write_b128 one or two
-// K tiles later.  The LDS-DMA instruction blocks its wave until the piece is accepted (~300-500 cycles per KiB at
-// these rates): a wave that also has MFMAs to issue serialises the two.  DEPTH = K tiles a load runs ahead of its use.
+// The same stream through REGISTERS: global_load_dwordx4 (fire and forget: the wave goes on) + ds_write_b128 one K tile
+// later.  The LDS-DMA instruction blocks its wave until the piece is accepted (~300-500 cycles per KiB at these rates): a
+// wave that also has MFMAs to issue serialises the two.  (Statically indexed staging registers: a first version indexed
+// them with kt & 1 and the compiler put them in scratch -- 5 B/clk.)  DEPTH is ignored (1 tile ahead).
 template <int DEPTH>
 __global__ __launch_bounds__(512, 2) void stream_reg_kernel(const char* __restrict__ U, const char* __restrict__ W, int BM, int D,
                                                            int heads, unsigned* sink) {
@@ -83,39 +84,29 @@ __global__ __launch_bounds__(512, 2) void stream_reg_kernel(const char* __restri
   const int reg = grp * 8 + xcd, head = idx - grp * heads;
   const int rows = BM + 192, npieces = rows / 8, stage_b = rows * 128, nk = D * 2 / 128;
   constexpr int LP = 8;                              // pieces per wave per stage, at most (rows <= 512)
-  size_t off[LP];
+  const char* src[LP];
   int dst[LP];
 #pragma unroll
   for (int q = 0; q < LP; ++q) {
-    const int p = q * 8 + wave;
+    int p = q * 8 + wave;
+    p = p < npieces ? p : npieces - 1;               // (ragged tail: re-load the last piece, same destination)
     const int row = p * 8 + (lane >> 3), s = lane & 7, sw = s ^ ((row >> 1) & 7);
-    size_t base;
-    if (row < BM) base = (size_t)(reg * BM + row) * D * 2;
-    else { const int r = row - BM; base = (size_t)((r >> 6) * D + head * 64 + (r & 63)) * D * 2 + ((size_t)1 << 62); }
-    off[q] = base + (sw << 4);
+    if (row < BM) src[q] = U + (size_t)(reg * BM + row) * D * 2 + (sw << 4);
+    else { const int r = row - BM; src[q] = W + (size_t)((r >> 6) * D + head * 64 + (r & 63)) * D * 2 + (sw << 4); }
     dst[q] = p * 1024 + lane * 16;
   }
-  uint4 r[DEPTH][LP];
-  auto load = [&](int kt, int d) {
+  uint4 r[LP];
 #pragma unroll
-    for (int q = 0; q < LP; ++q)
-      if (q * 8 + wave < npieces) {
-        const bool isw = (off[q] >> 62) & 1;
-        const char* src = (isw ? W : U) + (off[q] & (((size_t)1 << 62) - 1)) + (size_t)kt * 128;
-        r[d][q] = *(const uint4*)src;
-      }
-  };
-  load(0, 0);
-  if (DEPTH == 2 && nk > 1) load(1, 1);
+  for (int q = 0; q < LP; ++q) r[q] = *(const uint4*)(src[q]);
   unsigned acc = 0;
-#pragma unroll 2
   for (int kt = 0; kt < nk; ++kt) {
-    const int d = DEPTH == 2 ? (kt & 1) : 0;
     char* buf = smem + (kt & 1) * stage_b;
 #pragma unroll
-    for (int q = 0; q < LP; ++q)
-      if (q * 8 + wave < npieces) *(uint4*)(buf + dst[q]) = r[d][q];      // (the compiler waits for the loads of tile kt here)
-    if (kt + DEPTH < nk) load(kt + DEPTH, d);
+    for (int q = 0; q < LP; ++q) *(uint4*)(buf + dst[q]) = r[q];       // waits for the loads of tile kt
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int q = 0; q < LP; ++q) r[q] = *(const uint4*)(src[q] + (size_t)(kt + 1) * 128);
+    }
     __syncthreads();
     acc += *(const unsigned*)(buf + ((tid * 16) % stage_b));
   }
@@ -186,10 +177,8 @@ int main() {
     {
       float us = run_reg<1>(U, W, R, BM, D, heads, 100 * 1024, sink, 20);
       printf("  %-62s %7.1f us  %6.1f B/clk/CU\n", "registers (global_load + ds_write), 1 tile ahead, 1 block/CU", us, mb * 1e6 / (us * 1e-6) / 2.4e9 / 256);
-      us = run_reg<2>(U, W, R, BM, D, heads, 100 * 1024, sink, 20);
-      printf("  %-62s %7.1f us  %6.1f B/clk/CU\n", "registers, 2 tiles ahead, 1 block/CU", us, mb * 1e6 / (us * 1e-6) / 2.4e9 / 256);
-      us = run_reg<2>(U, W, R, BM, D, heads, 2 * s128, sink, 20);
-      printf("  %-62s %7.1f us  %6.1f B/clk/CU\n", "registers, 2 tiles ahead, 2 blocks/CU if they fit", us, mb * 1e6 / (us * 1e-6) / 2.4e9 / 256);
+      us = run_reg<1>(U, W, R, BM, D, heads, 2 * s128, sink, 20);
+      printf("  %-62s %7.1f us  %6.1f B/clk/CU\n", "registers, 1 tile ahead, 2 blocks/CU if they fit", us, mb * 1e6 / (us * 1e-6) / 2.4e9 / 256);
     }
     hipFree(U); hipFree(W); hipFree(sink);
   }
