@@ -50,6 +50,18 @@ def main():
                                             C.byref(g), 1, st))
         med, mn = timeit(f)
         print(f"proj16 L={L} rn={rn} (M={Np}) cfg={os.environ.get('RRT_LINEAR16_CFG', 'default')}: median {med:.1f} us  min {mn:.1f} us")
+    elif kind == "proj32":
+        import ctypes as C
+        L, rn = int(sys.argv[2]), int(sys.argv[3])
+        g = _lib.region_grid(L, rn)
+        Np, D = g.H * g.H, 512
+        A = torch.randn(Np, D, device=dev); B = torch.randn(D, D, device=dev) / D ** 0.5
+        bias = torch.randn(D, device=dev); resid = torch.randn(L, D, device=dev); out = torch.empty(L, D, device=dev)
+        f = lambda: _lib.check(lib.rrt_linear_unpartition_residual_f32(A.data_ptr(), B.data_ptr(), bias.data_ptr(), resid.data_ptr(),
+                                                                       out.data_ptr(), D, D, C.byref(g), 0, st))
+        med, mn = timeit(f)
+        print(f"proj32 L={L} rn={rn} (M={Np}) cfg={os.environ.get('RRT_LINEAR_CFG_BIG', 'default')}: median {med:.1f} us  min {mn:.1f} us  "
+              f"{2.0 * Np * D * D / med / 1e6:.1f} TFLOP/s")
     elif kind == "attn":
         R, P, D, H, ek = map(int, sys.argv[2:7])
         qkv = torch.randn(R * P, 3 * D, device=dev) * 0.5
