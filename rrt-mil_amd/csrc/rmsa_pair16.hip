@@ -28,30 +28,35 @@
 namespace {
 using namespace f16k;
 
-constexpr int VQ_B = 64 * VT_PITCH;     // per region: V^T [64][512 B]; before that, Q^T [64][512 B] for the stencil
+constexpr int VQ_B = 64 * VT_PITCH;
+constexpr bool PAIR16_NH2_DEFAULT = true;    // sixteen-wave form for 6..9 row tiles: see launch_rmsa_pair16     // per region: V^T [64][512 B]; before that, Q^T [64][512 B] for the stencil
 
-template <int MT, int PREC>
-__global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __restrict__ U,
-                                                             const uint16_t* __restrict__ W,
-                                                             const float* __restrict__ bqkv,
-                                                             const float* __restrict__ pe_w,
-                                                             uint16_t* __restrict__ O, int n_rows, int n_regions, int P,
-                                                             int D, int heads_rt, int epeg_k, float q_scale,
-                                                             int qs_pitch, int H8, int nstep) {
+// NH = 1: eight waves, wave (region, c) owns all row tiles of its region for its 16-column tile of Q / K / V.
+// NH = 2: sixteen waves (<= 128 VGPRs), wave (region, row half, c) owns half the row tiles: twice the issuing waves for the
+//         DMA pieces (the stream's rate grows with them) and eighteen query tiles on sixteen waves instead of eight.
+template <int MT, int PREC, int NH>
+__global__ __launch_bounds__(512 * NH, 1) void rmsa_pair16_kernel(const uint16_t* __restrict__ U,
+                                                                  const uint16_t* __restrict__ W,
+                                                                  const float* __restrict__ bqkv,
+                                                                  const float* __restrict__ pe_w,
+                                                                  uint16_t* __restrict__ O, int n_rows, int n_regions, int P,
+                                                                  int D, int heads_rt, int epeg_k, float q_scale,
+                                                                  int qs_pitch, int H8, int nstep) {
   using H = H16<PREC>;
   using Frag = typename H::frag;
   using E = typename H::elem;
   constexpr int BM = 16 * MT;
   constexpr int MTP = (MT + 1) & ~1;                 // key tiles rounded up to whole 32-key MFMA blocks
+  constexpr int NWV = 8 * NH;                        // waves per block
+  constexpr int MTH = (MT + NH - 1) / NH;            // row tiles a wave owns (the last half may own one fewer)
   // two rings: U tiles (region A rows | region B rows) two stages deep, W tiles (192 rows) THREE deep where the LDS
-  // allows: the operand stream is latency-bound -- a CU gets (bytes in flight) / ~1.3 us out of L2 (tools/ubench/
-  // dma_rows.hip: 14 B/clk with 43 KB in flight, 21 with 61, 28-32 with 86) -- so whatever the tiles leave free holds a
-  // third W stage: 86 KB in flight instead of 61
+  // allows and every wave issues the same number of W pieces (NH = 1; measured equal to two: the stream is bound by
+  // how many waves issue, not by bytes in flight -- tools/ubench/dma_rows.hip)
   constexpr int USTG_B = 2 * BM * ROWB, WSTG_B = BN * ROWB;
-  constexpr int NSW = (2 * USTG_B + 3 * WSTG_B + 512 <= 160 * 1024) ? 3 : 2;
+  constexpr int NSW = (NH == 1 && 2 * USTG_B + 3 * WSTG_B + 512 <= 160 * 1024) ? 3 : 2;
   constexpr int NA = 2 * BM / 8, NB = BN / 8;        // 1-KiB DMA pieces (8 rows) per stage
-  constexpr int NP = NA + NB, LP = (NP + 7) / 8;     // pieces per stage / per wave
-  static_assert(NB == 24, "every wave issues exactly three W pieces per stage (the counted wait below)");
+  constexpr int NP = NA + NB, LP = (NP + NWV - 1) / NWV;   // pieces per stage / per wave
+  static_assert(NB == 24, "with eight waves every wave issues exactly three W pieces per stage (the counted wait below)");
   constexpr int QT_B = BM * ROWB, KS_B = BM * ROWB;
   constexpr int REG_B = QT_B + KS_B + VQ_B;          // per region: Q~ | K | V^T (Q^T before the stencil)
   constexpr int RING_B = 2 * USTG_B + NSW * WSTG_B, TILES_B = 2 * REG_B;
@@ -62,7 +67,9 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rsel = wave >> 2, cw = wave & 3;         // which region of the pair; which 16-column tile of Q / K / V
+  const int rsel = wave / (4 * NH), rh = (wave >> 2) % NH, cw = wave & 3;   // region of the pair; row half; 16-column tile
+  const int i_base = rh * MTH;                       // first row tile of this wave
+  const int nt = (MT - i_base) < MTH ? (MT - i_base) : MTH;   // row tiles it owns
   const int lr = lane & 15, lg = lane >> 4;
   const unsigned lds_b = lds_addr_of(smem);
   // XCD-aware block -> (pair, head) map: the head-blocks of a pair sit on ONE XCD (its U panels are fetched from HBM
@@ -88,22 +95,33 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
   const int row0 = (valid ? reg : 2 * pair) * P;
   const int nk = D / 64;
   const int half = epeg_k >> 1;
-  // the stencil's band, tap(i) = w_h[i] + [i == k/2] for i in [0, k), else 0, at index i + 32 of a 128-entry table
-  float* const taps = (float*)(smem + LDS_MAIN);
-  if (tid < 128) {
-    const int t = tid - 32;
-    float wt = (pe_w != nullptr && t >= 0 && t < epeg_k) ? pe_w[head * epeg_k + t] : 0.f;
-    if (t == half) wt += 1.0f;
-    taps[tid] = wt;
+  // the stencil's band as ready-made MFMA B operands, built once per block while the first K tiles are in flight:
+  // tfrag[s][hi | lo][lane] (16 bytes each) = the eight taps tap(32 s + 8 lg + e - H8 - lr + k/2), e = 0..7, of lane
+  // (lr, lg) -- tap(i) = w_h[i] + [i == k/2] for i in [0, k), else 0 -- split into a 16-bit value and its 16-bit remainder
+  Frag* const tfrag = (Frag*)(smem + LDS_MAIN);
+  if (tid < 192) {
+    const int s_ = tid >> 6, l_ = tid & 63, lr_ = l_ & 15, lg_ = l_ >> 4;
+    Frag hi8, lo8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int t = 32 * s_ + 8 * lg_ + e - H8 - lr_ + half;
+      float tv = (pe_w != nullptr && t >= 0 && t < epeg_k && s_ < nstep) ? pe_w[head * epeg_k + t] : 0.f;
+      if (t == half && s_ < nstep) tv += 1.0f;
+      const E hi = (E)tv;
+      hi8[e] = hi;
+      lo8[e] = (E)(tv - (float)hi);
+    }
+    tfrag[(s_ * 2) * 64 + l_] = hi8;
+    tfrag[(s_ * 2 + 1) * 64 + l_] = lo8;
   }
-  RRT_TRACE_INIT(blockIdx.x * 8 + wave);
+  RRT_TRACE_INIT(blockIdx.x * NWV + wave);
   RRT_TRACE_MARK();                                 // [1] entry
 
   // ================================================================== phase 1: projection, both regions against one W tile
   unsigned off[LP];
 #pragma unroll
   for (int q = 0; q < LP; ++q) {
-    const int piece = q * 8 + wave;
+    const int piece = q * NWV + wave;
     const int p = lane & 7;
     if (piece < NA) {
       const int srow = piece * 8 + (lane >> 3);     // row of the stage's A part: [0, BM) region A, [BM, 2 BM) region B
@@ -122,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
     const char* ub = (const char*)U + kt * ROWB;
 #pragma unroll
     for (int q = 0; q < LP; ++q) {
-      const int piece = q * 8 + wave;
+      const int piece = q * NWV + wave;
       if (piece < NA) dma16s(ub, off[q], buf + piece * 1024);
     }
   };
@@ -130,14 +148,14 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
     const char* wb = (const char*)W + kt * ROWB;
 #pragma unroll
     for (int q = 0; q < LP; ++q) {
-      const int piece = q * 8 + wave;
+      const int piece = q * NWV + wave;
       if (piece >= NA && piece < NP) dma16s(wb, off[q], buf + (piece - NA) * 1024);
     }
   };
   const unsigned wring = lds_b + 2 * USTG_B;
-  f32x4 acc[MT][3];
+  f32x4 acc[MTH][3];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MTH; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   stage_u(0, lds_b);
@@ -169,12 +187,12 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
       if (nw < nk) stage_w(nw, wring + ns * WSTG_B);
     }
     if (kt == 0 || kt == 1 || kt == 4) RRT_TRACE_MARK();   // [4,6,8] next stages issued
-    const char* As = smem + (kt & 1) * USTG_B + rsel * (BM * ROWB);
+    const char* As = smem + (kt & 1) * USTG_B + (rsel * BM + i_base * 16) * ROWB;
     const char* Bs = smem + 2 * USTG_B + wslot * WSTG_B;
     wslot = wslot + 1 == NSW ? 0 : wslot + 1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      Frag a8[MT], b8[3];
+      Frag a8[MTH], b8[3];
       const int cslot = 4 * kk + lg;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -182,15 +200,17 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
         b8[j] = *(const Frag*)(Bs + row * ROWB + ((cslot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = i * 16 + lr;                // BM is a multiple of 16: the swizzle key of stage row rsel BM + row
-        a8[i] = *(const Frag*)(As + row * ROWB + ((cslot ^ (((rsel * BM + row) >> 1) & 7)) << 4));
+      for (int i = 0; i < MTH; ++i) {
+        if (NH > 1 && i >= nt) continue;            // (wave-uniform: the short half has one row tile fewer)
+        const int row = i * 16 + lr;                // BM and 16 i_base are multiples of 16: swizzle key of the stage row
+        a8[i] = *(const Frag*)(As + row * ROWB + ((cslot ^ (((rsel * BM + i_base * 16 + row) >> 1) & 7)) << 4));
       }
       // Q and V with the U fragment in the A slot: reg r of lane (lr, lg) = C[token 16 i + 4 lg + r][d = 16 cw + lr]
       // (four consecutive TOKENS of one column: what the transposed images Q^T and V^T want); K with the roles
       // swapped: reg r = K[token 16 i + lr][d = 16 cw + 4 lg + r] (the row-major K image)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
+      for (int i = 0; i < MTH; ++i) {
+        if (NH > 1 && i >= nt) continue;
         acc[i][0] = H::mfma(a8[i], b8[0], acc[i][0]);
         acc[i][1] = H::mfma(b8[1], a8[i], acc[i][1]);
         acc[i][2] = H::mfma(a8[i], b8[2], acc[i][2]);
@@ -201,10 +221,12 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
   __syncthreads();                                  // the staging ring is dead
   RRT_TRACE_MARK();                                 // [10]
 
-  // ================================================================== phases 2 + 3, wave-local: Q^T -> stencil -> Q~, K, V^T
-  // Wave (rsel, cw) owns head-dim columns 16 cw .. 16 cw + 15 of its region: it writes those rows of Q^T, runs the
-  // stencil on exactly those rows (A operand = its own rows), and then overwrites them with its rows of V^T (same
-  // 512-byte pitch, same place) -- no barrier until the tiles are complete.
+  // ================================================================== phases 2 + 3: Q^T -> stencil -> Q~, K, V^T
+  // Wave (region, half, c) owns head-dim columns 16 c .. 16 c + 15 of its region for ITS row tiles: it writes those rows
+  // of Q^T, runs the stencil for its query tiles on those rows, and then overwrites them with its part of V^T (same
+  // 512-byte pitch, same place).  NH = 1: everything a wave reads it wrote itself -- no barrier until the tiles are
+  // complete.  NH = 2: the stencil's sources cross the row halves, so the two halves meet at a block barrier before the
+  // stencil and before V^T goes over Q^T.
   char* const RB = smem + rsel * REG_B;
   char* const QT = RB;                              // Q~ [BM] x 128 B, slot XOR ((row >> 1) & 7)
   char* const KS = RB + QT_B;                       // K  [BM] x 128 B, same swizzle
@@ -216,42 +238,46 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
     auto qaddr = [&](int pos) -> char* { return qrow + ((((pos >> 3) ^ lr) & 31) << 4) + ((pos & 4) << 1); };
     // halo: token positions [0, H8) and [H8 + BM, BM - 16 + 32 nstep) read as zero (region edge = zero padding)
     const uint2 z = make_uint2(0u, 0u);
-    for (int c = lg; c < (H8 >> 2); c += 4) *(uint2*)qaddr(4 * c) = z;
-    const int right0 = H8 + BM, rightn = (32 * nstep - 16 - H8) >> 2;
-    for (int c = lg; c < rightn; c += 4) *(uint2*)qaddr(right0 + 4 * c) = z;
+    if (rh == 0)
+      for (int c = lg; c < (H8 >> 2); c += 4) *(uint2*)qaddr(4 * c) = z;
+    if (rh == NH - 1) {
+      const int right0 = H8 + BM, rightn = (32 * nstep - 16 - H8) >> 2;
+      for (int c = lg; c < rightn; c += 4) *(uint2*)qaddr(right0 + 4 * c) = z;
+    }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int tok = 16 * i + 4 * lg;
+    for (int i = 0; i < MTH; ++i) {
+      if (NH > 1 && i >= nt) continue;
+      const int ig = i_base + i;                    // row tile of the region
+      const int tok = 16 * ig + 4 * lg;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (acc[i][0][r] + bq1) * qs;
-      if (i >= MT - 2) {                            // (compile time) only the last two row tiles can hold rows past the
-#pragma unroll                                      // region: zero them, branch-free
+      if (NH > 1 || i >= MT - 2) {                  // only the last two row tiles can hold rows past the region: zero
+#pragma unroll                                      // them, branch-free (NH = 1: decided at compile time)
         for (int r = 0; r < 4; ++r) v[r] = (tok + r < P) ? v[r] : 0.f;
       }
       *(uint2*)qaddr(H8 + tok) = pack4<PREC>(v[0], v[1], v[2], v[3]);
-      const int m = i * 16 + lr;
+      const int m = ig * 16 + lr;
       *(uint2*)(KS + m * ROWB + (((dk >> 3) ^ ((m >> 1) & 7)) << 4) + ((dk & 4) << 1)) =
           pack4<PREC>(acc[i][1][0] + bk4.x, acc[i][1][1] + bk4.y, acc[i][1][2] + bk4.z, acc[i][1][3] + bk4.w);
     }
+    if (NH > 1) __syncthreads();                    // the other half's Q^T columns (the stencil reads across the halves)
     RRT_TRACE_MARK();                               // [11] Q^T, K written
-    // band of T for this lane: B-slot row = query lr of the tile, k-slice = sources 32 s + 8 lg + e of the window that
-    // starts H8 rows before the tile: tap index (32 s + 8 lg + e - H8) - lr + k/2
+    // band of T for this lane (B-slot row = query lr of the tile, k-slice = sources 32 s + 8 lg + e of the window that
+    // starts H8 rows before the tile), prepared at the top of the kernel
     Frag thi[3], tlo[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 3; ++s) {
+      thi[s] = tfrag[(s * 2) * 64 + lane];
+      tlo[s] = tfrag[(s * 2 + 1) * 64 + lane];
+    }
+    // A operand: rows d = 16 cw + lr, sources 16 t + 32 s + 8 lg .. + 7 (positions; 16-byte slots).
+    // (every tile of the wave, also one that lies wholly past the region: its Q^T rows are zeros, its Q~ rows are never
+    //  read as queries -- a data-dependent exit here would keep the compiler from overlapping the tiles' reads and MFMAs)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float tv = (s < nstep) ? taps[32 + 32 * s + 8 * lg + e - H8 - lr + half] : 0.f;
-        const E hi = (E)tv;
-        thi[s][e] = hi;
-        tlo[s][e] = (E)(tv - (float)hi);
-      }
-    // A operand: this wave's rows d = 16 cw + lr, sources 16 t + 32 s + 8 lg .. + 7 (positions; 16-byte slots)
-    // (every tile, also one that lies wholly past the region: its Q^T rows are zeros, its Q~ rows are never read as
-    //  queries -- a data-dependent exit here would keep the compiler from overlapping the tiles' reads and MFMAs)
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
+    for (int i = 0; i < MTH; ++i) {
+      if (NH > 1 && i >= nt) continue;
+      const int t = i_base + i;
       f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 3; ++s)
@@ -265,17 +291,20 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
       const int m = 16 * t + lr;
       *(uint2*)(QT + m * ROWB + (((dk >> 3) ^ ((m >> 1) & 7)) << 4) + ((dk & 4) << 1)) = pack4<PREC>(o[0], o[1], o[2], o[3]);
     }
+    if (NH > 1) __syncthreads();                    // every read of Q^T is done (both halves): its place becomes V^T
     RRT_TRACE_MARK();                               // [12] stencil done
-    // V^T over this wave's Q^T rows (its own reads of them are complete: LDS operations of a wave execute in order)
+    // V^T over the Q^T rows (NH = 1: the wave's own reads of them are complete, LDS operations of a wave execute in order)
     char* const VT = VQ;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      // tokens 16 i + 4 lg + r, r = 0..3 -> positions 32 (i / 2) + 8 lg + 4 (i % 2) + r of V^T row dc: 8 bytes
-      const int vslot = 4 * (i >> 1) + lg;
-      *(uint2*)(VT + dc * VT_PITCH + ((vslot ^ vt_swz(dc)) << 4) + ((i & 1) << 3)) =
+    for (int i = 0; i < MTH; ++i) {
+      if (NH > 1 && i >= nt) continue;
+      const int ig = i_base + i;
+      // tokens 16 ig + 4 lg + r, r = 0..3 -> positions 32 (ig / 2) + 8 lg + 4 (ig % 2) + r of V^T row dc: 8 bytes
+      const int vslot = 4 * (ig >> 1) + lg;
+      *(uint2*)(VT + dc * VT_PITCH + ((vslot ^ vt_swz(dc)) << 4) + ((ig & 1) << 3)) =
           pack4<PREC>(acc[i][2][0] + bv1, acc[i][2][1] + bv1, acc[i][2][2] + bv1, acc[i][2][3] + bv1);
     }
-    if (MT & 1) {
+    if ((MT & 1) && rh == NH - 1) {
       // odd tile count: the second half of the last 32-key block has no keys; its V^T columns meet P = 0 in the MFMA
       // and must hold finite numbers -> zeros.  The wave's 64 lanes = its 16 rows x 4 groups of 4 positions.
       const int dd = 16 * cw + (lane >> 2), g = lane & 3;
@@ -288,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
 
   // ================================================================== phase 4: attention from LDS (as rmsa_fused16)
   const char* const VT = VQ;
-  for (int t = cw; t < MT; t += 4) {
+  for (int t = rh * 4 + cw; t < MT; t += 4 * NH) {
     const int i0 = t * 16;
     if (i0 >= P) break;
     Frag bq[2];
@@ -302,14 +331,20 @@ __global__ __launch_bounds__(512, 2) void rmsa_pair16_kernel(const uint16_t* __r
     for (int jt = 0; jt < MTP; ++jt) s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      Frag a[MT];
+      constexpr int CH = NH > 1 ? (MT + 1) / 2 : MT;  // K fragments in flight (sixteen waves: 128 VGPRs)
 #pragma unroll
-      for (int jt = 0; jt < MT; ++jt) {
-        const int row = jt * 16 + lr;
-        a[jt] = *(const Frag*)(KS + row * ROWB + (((4 * kk + lg) ^ ((row >> 1) & 7)) << 4));
+      for (int j0 = 0; j0 < MT; j0 += CH) {
+        Frag a[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int jt = j0 + u < MT ? j0 + u : MT - 1;
+          const int row = jt * 16 + lr;
+          a[u] = *(const Frag*)(KS + row * ROWB + (((4 * kk + lg) ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (j0 + u < MT) s[j0 + u] = H::mfma(a[u], bq[kk], s[j0 + u]);
       }
-#pragma unroll
-      for (int jt = 0; jt < MT; ++jt) s[jt] = H::mfma(a[jt], bq[kk], s[jt]);
     }
     RRT_TRACE_MARK();                               // tile: S^T issued
     // s[jt][r] = log2e * score(query i0 + lr, key 16 jt + 4 lg + r)
@@ -380,26 +415,26 @@ StencilGeo stencil_geo(int BM, int epeg_k) {
   return g;
 }
 
-template <int MT, int PREC>
+template <int MT, int PREC, int NH>
 hipError_t launch_pair(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
                        int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
   constexpr int BM = 16 * MT;
   constexpr size_t USTG = (size_t)2 * BM * ROWB, WSTG = (size_t)BN * ROWB;
-  constexpr size_t RING = 2 * USTG + ((2 * USTG + 3 * WSTG + 512 <= 160 * 1024) ? 3 : 2) * WSTG;
+  constexpr size_t RING = 2 * USTG + ((NH == 1 && 2 * USTG + 3 * WSTG + 512 <= 160 * 1024) ? 3 : 2) * WSTG;
   constexpr size_t TILES = (size_t)2 * (2 * BM * ROWB + VQ_B);
-  constexpr size_t LDS = (RING > TILES ? RING : TILES) + 512;          // + the tap table
+  constexpr size_t LDS = (RING > TILES ? RING : TILES) + 6 * 1024;     // + the stencil's operand table
   static_assert(LDS <= 160 * 1024, "LDS budget");
   const int ek = pe_w ? epeg_k : 0;
   const StencilGeo g = stencil_geo(BM, ek);
   if (g.pitch > VT_PITCH || g.nstep > 3) return hipErrorInvalidValue;
-  auto kern = rmsa_pair16_kernel<MT, PREC>;
+  auto kern = rmsa_pair16_kernel<MT, PREC, NH>;
   static OncePerDevice once;
   if (once.first())
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
   const float q_scale = 1.0f / sqrtf((float)HD);
   const int pairs = (n_regions + 1) / 2;
-  kern<<<dim3(heads * pairs), dim3(512), LDS, st>>>(U, W, bqkv, pe_w, O, n_regions * P, n_regions, P, D, heads, ek, q_scale,
-                                                   g.pitch, g.H8, g.nstep);
+  kern<<<dim3(heads * pairs), dim3(512 * NH), LDS, st>>>(U, W, bqkv, pe_w, O, n_regions * P, n_regions, P, D, heads, ek, q_scale,
+                                                        g.pitch, g.H8, g.nstep);
   return hipGetLastError();
 }
 
@@ -422,9 +457,14 @@ bool rmsa_pair16_supported(int n_regions, int P, int D, int heads, int epeg_k) {
 hipError_t launch_rmsa_pair16(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
                               int n_regions, int P, int D, int heads, int epeg_k, int prec, hipStream_t st) {
   if (prec != 1 && prec != 2) return hipErrorInvalidValue;
-#define RRT_PAIR16(MT_)                                                                                \
-  return prec == 1 ? launch_pair<MT_, 1>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st)       \
-                   : launch_pair<MT_, 2>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st);
+  // sixteen waves (two row halves per region) where a wave still has >= 3 row tiles; RRT_PAIR16_NH=1|2 in a tuning build
+  static const int nh_env = rrt_tune_env("RRT_PAIR16_NH") ? atoi(rrt_tune_env("RRT_PAIR16_NH")) : 0;
+#define RRT_PAIR16(MT_)                                                                                       \
+  if ((nh_env ? nh_env == 2 : PAIR16_NH2_DEFAULT) && MT_ >= 6 && MT_ <= 9)                                               \
+    return prec == 1 ? launch_pair<MT_, 1, 2>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st)         \
+                     : launch_pair<MT_, 2, 2>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st);        \
+  return prec == 1 ? launch_pair<MT_, 1, 1>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st)           \
+                   : launch_pair<MT_, 2, 1>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st);
   if (P > 144) { RRT_PAIR16(11) }
   if (P > 128) { RRT_PAIR16(9) }
   if (P > 112) { RRT_PAIR16(8) }

@@ -26,7 +26,7 @@ t = buf.reshape(WAVES, EV)
 idx = np.arange(WAVES)
 live = t[:, 1] > 0
 print(f"R={R} P={P} D={D} heads={H} epeg_k={ek}: {int(live.sum())} traced waves (first {WAVES // 8} blocks)")
-for role, sel in (("waves cw=0 (3 query tiles at MT=9)", live & (idx % 4 == 0)), ("waves cw=1..3", live & (idx % 4 > 0))):
+for role, sel in (("waves cw=0", live & (idx % 4 == 0)), ("waves cw=1..3", live & (idx % 4 > 0))):
     ts = t[sel][:, 1:].astype(np.int64)
     nev = int(np.median((ts > 0).sum(1)))
     ok = (ts[:, :nev] > 0).all(1)
