@@ -252,8 +252,8 @@ __global__ __launch_bounds__(512 * NH, 1) void rmsa_pair16_kernel(const uint16_t
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (acc[i][0][r] + bq1) * qs;
-      if (NH > 1 || i >= MT - 2) {                  // only the last two row tiles can hold rows past the region: zero
-#pragma unroll                                      // them, branch-free (NH = 1: decided at compile time)
+      if (ig >= MT - 2) {                           // only the last two row tiles can hold rows past the region: zero them
+#pragma unroll                                      // (NH = 1: decided at compile time; NH = 2: a wave-uniform branch)
         for (int r = 0; r < 4; ++r) v[r] = (tok + r < P) ? v[r] : 0.f;
       }
       *(uint2*)qaddr(H8 + tok) = pack4<PREC>(v[0], v[1], v[2], v[3]);
