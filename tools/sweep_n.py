@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """ms per bag of the encoder forward (fp32, one bag in flight) over bag sizes; run once plain and once with
-RRT_NO_FUSED=1 to compare the fused R-MSA kernel with the unfused linear + attention pair."""
+RRT_NO_FUSED=1 -- on a -DRRT_TUNING library (tools/build_ablation.sh tune -DRRT_TUNING; RRT_HIP_LIB=tools/_abl/librrt_tune.so:
+the product library does not read the environment) -- to compare the fused R-MSA kernel with the unfused linear + attention
+pair."""
 import os
 import sys
 import time
