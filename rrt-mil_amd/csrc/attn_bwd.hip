@@ -204,8 +204,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
       for (int c = 0; c < 4; ++c)
         dsum += (fg[c].x * fo[c].x + fg[c].y * fo[c].y) + (fg[c].z * fo[c].z + fg[c].w * fo[c].w);
     }
-    dsum += __shfl_xor(dsum, 16);
-    dsum += __shfl_xor(dsum, 32);
+    dsum = sum_xor32(sum_xor16(dsum));     // VALU lane swaps (common.h), not ds_bpermute
     f32x4 s[MT];
     tile_scores<MT>(Ks, fq, lr, lg, s);            // s[jt][r] = S2[query lr][key 16 jt + 4 lg + r]
     float cmax = NEG_BIG;
@@ -216,8 +215,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
         if (jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;
         cmax = fmaxf(cmax, s[jt][r]);
       }
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    cmax = max_xor32(max_xor16(cmax));
     float psum = 0.f;
 #pragma unroll
     for (int jt = 0; jt < MT; ++jt)
@@ -227,8 +225,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
         s[jt][r] = p;
         psum += p;
       }
-    psum += __shfl_xor(psum, 16);
-    psum += __shfl_xor(psum, 32);
+    psum = sum_xor32(sum_xor16(psum));     // VALU lane swaps (common.h), not ds_bpermute
     const float inv = 1.0f / psum;
     if (lg == 0) {
       lse[m] = cmax + __builtin_amdgcn_logf(psum);   // v_log_f32 = log2
@@ -478,8 +475,7 @@ __global__ __launch_bounds__(384) void attn_bwd_q_kernel(const float* __restrict
       dsum += (fg[c].x * o4.x + fg[c].y * o4.y) + (fg[c].z * o4.z + fg[c].w * o4.w);
     }
   }
-  dsum += __shfl_xor(dsum, 16);
-  dsum += __shfl_xor(dsum, 32);
+  dsum = sum_xor32(sum_xor16(dsum));     // VALU lane swaps (common.h), not ds_bpermute
   // sweep 1: online row max / sum over the key chunks
   float mrun = NEG_BIG, lrun = 0.f;
   for (int r0 = 0; r0 < P; r0 += CK) {
@@ -497,16 +493,14 @@ __global__ __launch_bounds__(384) void attn_bwd_q_kernel(const float* __restrict
           if (r0 + jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;
           cmax = fmaxf(cmax, s[jt][r]);
         }
-      cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-      cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+      cmax = max_xor32(max_xor16(cmax));
       const float mnew = fmaxf(mrun, cmax);
       float psum = 0.f;
 #pragma unroll
       for (int jt = 0; jt < CT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) psum += __builtin_amdgcn_exp2f(s[jt][r] - mnew);
-      psum += __shfl_xor(psum, 16);
-      psum += __shfl_xor(psum, 32);
+      psum = sum_xor32(sum_xor16(psum));     // VALU lane swaps (common.h), not ds_bpermute
       lrun = lrun * __builtin_amdgcn_exp2f(mrun - mnew) + psum;
       mrun = mnew;
     }
