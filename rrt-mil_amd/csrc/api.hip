@@ -1502,9 +1502,18 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     ep.bias = lw.qkv_b;
     ep.q_cols = D;
     ep.q_scale = 1.0f / sqrtf((float)(D / desc->n_heads));
-    RRT_TRY(launch_linear(s.u[li], lw.qkv_w, s.qkv[li], gd.Np, 3 * D, D, ep, st));
     const bool e2d = desc->epeg && desc->epeg_2d && desc->epeg_type == RRT_EPEG_ATTN;
     const bool evalue = desc->epeg && desc->epeg_type != RRT_EPEG_ATTN;
+    // the inference path's fused kernel (projection + EPEG + attention per (region, head)) with the q | k | v tiles
+    // also written to the stash, where the bag's regions fit it; else projection to the stash + attention from it
+    const int ekf = desc->epeg ? desc->epeg_k : 0;
+    const bool fused = !e2d && !evalue && desc->compute == RRT_COMPUTE_F32 &&
+                       rmsa_fused_supported(gd.P, D, desc->n_heads, ekf) && rmsa_fused_supported_rows(gd.Np, D);
+    if (fused) {
+      RRT_TRY(launch_rmsa_fused(s.u[li], lw.qkv_w, lw.qkv_b, desc->epeg ? lw.pe_w : nullptr, s.o[li], gd.rs * gd.rs, gd.P, D,
+                                desc->n_heads, ekf, RRT_COMPUTE_F32, st, s.qkv[li]));
+    } else {
+    RRT_TRY(launch_linear(s.u[li], lw.qkv_w, s.qkv[li], gd.Np, 3 * D, D, ep, st));
     if (e2d) {                                            // rmsa.py:78-79,106-108
       RRT_TRY(launch_attn_scoremap(s.qkv[li], lw.pe_w, s.o[li], s.smap, gd.rs * gd.rs, gd.P, D, desc->n_heads, desc->epeg_k, st));
     } else if (evalue) {                                  // rmsa.py:80-85,114-129; the stash keeps pe, v' = v + pe ('bf') and o + pe ('af')
@@ -1516,6 +1525,7 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     } else
     RRT_TRY(launch_region_attention(s.qkv[li], desc->epeg ? lw.pe_w : nullptr, s.o[li], gd.rs * gd.rs, gd.P, D,
                                     desc->n_heads, desc->epeg ? desc->epeg_k : 0, st));
+    }
     LinearEpilogue ep2{};
     ep2.bias = lw.proj_b;
     ep2.resid = xin;

@@ -107,6 +107,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
   const int reg = blockIdx.x / heads, head = blockIdx.x - reg * heads;
   const size_t row0 = (size_t)reg * P;
   const int ld = 3 * D;
+  RRT_TRACE_INIT(blockIdx.x * 8 + wave);
+  RRT_TRACE_MARK();                                 // [1] entry
 
   // ---- phase 0: q, k, v tiles -> LDS (XOR-swizzled 16-byte slots, rows >= P are zeros)
   for (int idx = tid; idx < BM * 16; idx += NW * 64) {
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     *(float4*)(Xs + off) = v4;
   }
   __syncthreads();
+  RRT_TRACE_MARK();                                 // [2] q, k, v in LDS
 
   // ---- phase 1: Q~ = log2(e) * (I + T_w) q, in place (the forward's sliding-window stencil)
   constexpr int RUN = (BM * 16 + NW * 64 - 1) / (NW * 64);
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     }
   }
   __syncthreads();
+  RRT_TRACE_MARK();                                 // [3] Q~ built
 
   // tile -> wave schedule of the forward fused kernel (balanced per SIMD; at most three tiles per wave)
   auto tile_of = [&](int pass) {
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
         dsum += (fg[c].x * fo[c].x + fg[c].y * fo[c].y) + (fg[c].z * fo[c].z + fg[c].w * fo[c].w);
     }
     dsum = sum_xor32(sum_xor16(dsum));     // VALU lane swaps (common.h), not ds_bpermute
+    if (ps == 0) RRT_TRACE_MARK();                  // [4] first tile: dO / O rows here, D_i
     f32x4 s[MT];
     tile_scores<MT>(Ks, fq, lr, lg, s);            // s[jt][r] = S2[query lr][key 16 jt + 4 lg + r]
     float cmax = NEG_BIG;
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
       lse[m] = cmax + __builtin_amdgcn_logf(psum);   // v_log_f32 = log2
       dd[m] = dsum;
     }
+    if (ps == 0) RRT_TRACE_MARK();                  // [5] first tile: scores + softmax
     {
       f32x4 da[MT];
       tile_scores<MT>(Xs, fg, lr, lg, da);          // dA[query lr][key]  (Xs = V)
@@ -239,6 +245,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[jt][r] = s[jt][r] * inv * (da[jt][r] - dsum);   // dS (masked keys: A = 0)
     }
+    if (ps == 0) RRT_TRACE_MARK();                  // [6] first tile: dA, dS
     f32x4 dqt[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) dqt[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -248,7 +255,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
       const int i = i0 + 4 * lg + r;
       if (i < P) *(float4*)(dq_park + (row0 + i) * ld + (lr << 2)) = make_float4(dqt[0][r], dqt[1][r], dqt[2][r], dqt[3][r]);
     }
+    if (ps == 0) RRT_TRACE_MARK();                  // [7] first tile: dQ~ parked
   }
+  RRT_TRACE_MARK();                                 // [8] pass A done (this wave)
   __syncthreads();                                  // V is dead: the third tile becomes dO
   for (int idx = tid; idx < BM * 16; idx += NW * 64) {
     const int m = idx >> 4, s = idx & 15;
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     *(float4*)(Xs + m * HD + ((s ^ (m & 15)) << 2)) = g4;
   }
   __syncthreads();
+  RRT_TRACE_MARK();                                 // [9] dO tile in LDS
 
   // ---- pass B: key tiles.  dV = A^T dO, dK = dS^T Q~ (Q~ carries log2 e: x ln 2)
 #pragma unroll 1
@@ -270,6 +280,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     f32x4 a[MT], ds[MT];
     tile_scores<MT>(Qt, fk, lr, lg, a);             // a[it][r] = S2[query 16 it + 4 lg + r][key lr]
     tile_scores<MT>(Xs, fv, lr, lg, ds);            // dA[query][key lr]  (Xs = dO)
+    if (ps == 0) RRT_TRACE_MARK();                  // [10] first key tile: S^T, dA^T
 #pragma unroll
     for (int it = 0; it < MT; ++it)
 #pragma unroll
@@ -280,6 +291,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
         a[it][r] = p;
         ds[it][r] = q < P ? p * (ds[it][r] - dd[q]) : 0.f;
       }
+    if (ps == 0) RRT_TRACE_MARK();                  // [11] first key tile: A, dS
     f32x4 dv[4], dk[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) dv[c] = dk[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -294,17 +306,27 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
         *(float4*)(dst + 2 * D) = make_float4(dv[0][r], dv[1][r], dv[2][r], dv[3][r]);
       }
     }
+    if (ps == 0) RRT_TRACE_MARK();                  // [12] first key tile: dV, dK stored
   }
+  RRT_TRACE_MARK();                                 // [13] pass B done (this wave)
   __syncthreads();                                  // every read of the dO tile is done; parked dQ~ rows are visible
 
   // ---- parked dQ~ rows -> LDS over the dead dO tile (rows >= P: zeros)
+  // ... and the stashed q rows back over the dead Q~ tile: the tap gradients pair dQ~ rows with q rows k/2 apart
   float* Gs = Xs;
   for (int idx = tid; idx < BM * 16; idx += NW * 64) {
     const int m = idx >> 4, s = idx & 15;
-    const float4 g4 = m < P ? *(const float4*)(dq_park + (row0 + m) * ld + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-    *(float4*)(Gs + m * HD + ((s ^ (m & 15)) << 2)) = g4;
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), q4 = g4;
+    if (m < P) {
+      g4 = *(const float4*)(dq_park + (row0 + m) * ld + 4 * s);
+      if (epeg_k > 0) q4 = *(const float4*)(qkv + (row0 + m) * ld + head * HD + 4 * s);
+    }
+    const int off = m * HD + ((s ^ (m & 15)) << 2);
+    *(float4*)(Gs + off) = g4;
+    *(float4*)(Qt + off) = q4;
   }
   __syncthreads();
+  RRT_TRACE_MARK();                                 // [14] dQ~ tile in LDS
 
   // ---- dq_raw = q_scale * (I + T_w)^T dQ~ : the stencil with flipped taps; rows stay inside the region
   {
@@ -343,30 +365,62 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     }
   }
 
-  // ---- tap gradients: dw[t] = sum_i <dQ~_i, q_{i + t - half}>   (q as stashed, read back from global / L2)
+  RRT_TRACE_MARK();                                 // [15] dq written
+  // ---- tap gradients: dw[t] = sum_i <dQ~_i, q_{i + t - half}>, both tiles in LDS.  Thread = (16-byte slot s, run of RUN
+  // rows) as in the stencils: its dQ~ rows stay in registers, the q rows r0 - k/2 .. slide past them once, and source
+  // row jj meets output o with tap t = jj - o -- compile-time indices into a 16-tap register window (taps in chunks
+  // of 16).  Per chunk: lane sums over the 4 row groups of a wave (lane swaps), one [16 slots][16 taps] record per
+  // wave in the dead K tile, 16 threads per tap add the NW x 16 partials in a fixed order.
+  // (First version: a serial loop over the taps with q re-read from global / L2 and a wave reduction per tap --
+  // 49.6 K of a block's 238 K cycles, traced.)
   if (epeg_k > 0) {
-    const int s = tid & 15;
-    for (int t = 0; t < epeg_k; ++t) {
-      float acc = 0.f;
-      for (int i = tid >> 4; i < P; i += NW * 4) {
-        const int j = i + t - half;
-        if (j >= 0 && j < P) {
-          const float4 g4 = *(const float4*)(Gs + i * HD + ((s ^ (i & 15)) << 2));
-          const float4 q4 = *(const float4*)(qkv + (row0 + j) * ld + head * HD + 4 * s);
-          acc += (g4.x * q4.x + g4.y * q4.y) + (g4.z * q4.z + g4.w * q4.w);
+    const int s = tid & 15, g = tid >> 4;
+    const int r0 = g * RUN;
+    float* const rec = Ks;                          // [NW][16 slots][16 taps]
+    float4 gq[RUN];
+#pragma unroll
+    for (int o = 0; o < RUN; ++o) {
+      const int i = r0 + o;
+      gq[o] = i < BM ? *(const float4*)(Gs + i * HD + ((s ^ (i & 15)) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int t0 = 0; t0 < epeg_k; t0 += 16) {
+      float acc[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 16 + RUN - 1; ++jj) {   // source row r0 + t0 - half + jj
+        const int j = r0 + t0 - half + jj;
+        const bool ok = j >= 0 && j < P;
+        const int jc = ok ? j : 0;
+        float4 q4 = *(const float4*)(Qt + jc * HD + ((s ^ (jc & 15)) << 2));
+        if (!ok) q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < RUN; ++o) {
+          const int u = jj - o;                     // tap t0 + u
+          if (u >= 0 && u < 16)
+            acc[u] += (gq[o].x * q4.x + gq[o].y * q4.y) + (gq[o].z * q4.z + gq[o].w * q4.w);
         }
       }
-      acc = wave_sum(acc);
-      if (lane == 0) wred[wave * 64 + t] = acc;
-    }
-    __syncthreads();
-    if (tid < epeg_k) {
-      float a = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < NW; ++wv) a += wred[wv * 64 + tid];
-      dpe_part[((size_t)reg * heads + head) * epeg_k + tid] = a;
+      for (int u = 0; u < 16; ++u) acc[u] = sum_xor32(sum_xor16(acc[u]));
+      if (t0 > 0) __syncthreads();                  // the previous chunk's records have been read
+      if (lane < 16) {
+#pragma unroll
+        for (int u = 0; u < 16; u += 4)
+          *(float4*)(rec + (wave * 16 + lane) * 16 + u) = make_float4(acc[u], acc[u + 1], acc[u + 2], acc[u + 3]);
+      }
+      __syncthreads();
+      if (tid < 256) {                              // thread = (tap u, slot group of NW records)
+        const int u = tid >> 4, sl = tid & 15;
+        float a = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) a += rec[(wv * 16 + sl) * 16 + u];
+        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+        if (sl == 0 && t0 + u < epeg_k) dpe_part[((size_t)reg * heads + head) * epeg_k + t0 + u] = a;
+      }
     }
   }
+  RRT_TRACE_MARK();                                 // [16] tap gradients
 }
 
 template <int MT>
@@ -784,6 +838,10 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const float* __re
 }
 
 }  // namespace
+
+#ifdef RRT_TRACE
+RRT_TRACE_DEFINE_READER(rrt_debug_trace_attn_bwd)
+#endif
 
 // MFMA path: head dim 64, P <= 208.  Generic path: any head dim that is a multiple of 4, no EPEG, P <= 128.
 bool attn_bwd_supported(int P, int D, int heads, int epeg_k) {

@@ -98,7 +98,7 @@ bool rmsa_fused_supported(int P, int D, int heads, int epeg_k);
 bool rmsa_fused_supported_rows(long n_rows, int D);
 hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w,
                              float* O, int n_regions, int P, int D, int heads, int epeg_k, int prec,
-                             hipStream_t st);
+                             hipStream_t st, float* stash = nullptr);   // stash: [rows, 3 D] q | k | v for the backward
 
 // EPEG ablations (epeg_variants.hip): 2-D 'attn' EPEG over the score map; value EPEG over v's token image
 size_t attn_scoremap_lds(int P, int k);

@@ -39,7 +39,11 @@ constexpr int TN_BN = 128, TN_BK = 128, TN_BM = 32, TN_PITCH = 144;
 
 // dbpart (may be null): the blocks of the first k column also sum the columns of their A rows -- db[n] = sum_m dY[m][n]
 // of nn.Linear's backward -- into dbpart[s][n] (the rows are in LDS anyway: one launch and one pass over dY fewer)
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
+// FAST: N and K are multiples of the 128-wide tile (every nn.Linear of the encoder at dim = 128 n): plain 16-byte loads with
+// the row clamped and zeroed at the LDS write -- no predicated fallback loads, whose merges made the compiler wait for
+// the prefetch (s_waitcnt vmcnt(0)) in front of the MFMAs it was meant to run under.
+template <bool FAST>
+__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       float* __restrict__ part, float* __restrict__ dbpart, int M, int N, int K,
                                                       int rows_per_chunk) {
   __shared__ __attribute__((aligned(16))) float As[TN_BM * TN_PITCH];
@@ -60,8 +64,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   const bool do_db = dbpart != nullptr && blockIdx.y == 0;
   float colsum = 0.f;                               // column n0 + tid of this block's rows (tid < 128)
 
-  for (int m0 = m_begin; m0 < m_end; m0 += TN_BM) {
-    // stage 32 rows x 128 columns of each operand: 1024 float4 per operand, 4 per thread
+  // Stage = 32 rows x 128 columns of each operand: 1024 float4 per operand, 4 per thread.  The rows of stage s + 1 are
+  // requested into registers BEFORE the 128 MFMAs of stage s and written to LDS behind them: a block covers its own
+  // global-memory latency (the first version loaded, waited, computed: 0.55 of the fp32 MFMA rate on the qkv weight
+  // gradient, the matrix pipe waiting for whichever co-resident block had rows).
+  float4 ra[4], rb[4];
+  auto fetch = [&](const int m0) {
+    if constexpr (FAST) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 5, c4 = (idx & 31) * 4;
+        const int m = min(m0 + row, m_end - 1);     // rows past the chunk: re-read, zeroed in publish()
+        ra[i] = *(const float4*)(A + (size_t)m * N + n0 + c4);
+        rb[i] = *(const float4*)(B + (size_t)m * K + k0 + c4);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i;
@@ -85,28 +104,55 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
           if (k + 3 < K) vb.w = B[(size_t)m * K + k + 3];
         }
       }
-      *(float4*)(As + row * TN_PITCH + c4) = va;
-      *(float4*)(Bs + row * TN_PITCH + c4) = vb;
+      ra[i] = va;
+      rb[i] = vb;
     }
-    __syncthreads();
+  };
+  auto publish = [&](const int m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 5, c4 = (idx & 31) * 4;
+      if (FAST && m0 + row >= m_end) ra[i] = rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(As + row * TN_PITCH + c4) = ra[i];
+      *(float4*)(Bs + row * TN_PITCH + c4) = rb[i];
+    }
+  };
+  if (m_begin < m_end) {
+    fetch(m_begin);
+    publish(m_begin);
+  }
+  __syncthreads();
+  for (int m0 = m_begin; m0 < m_end; m0 += TN_BM) {
+    const bool more = m0 + TN_BM < m_end;
+    if (more) fetch(m0 + TN_BM);
     if (do_db && tid < TN_BN) {
       float c0 = 0.f, c1 = 0.f;
 #pragma unroll
       for (int r = 0; r < TN_BM; r += 2) { c0 += As[r * TN_PITCH + tid]; c1 += As[(r + 1) * TN_PITCH + tid]; }
       colsum += c0 + c1;
     }
+    // fragments of k step kk + 1 are read under the 16 MFMAs of step kk (two register sets)
+    float a[2][4], b[2][4];
+    auto frags = [&](const int kk, float (&fa)[4], float (&fb)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = As[(4 * kk + lg) * TN_PITCH + wn * 64 + i * 16 + lr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = Bs[(4 * kk + lg) * TN_PITCH + wk * 64 + j * 16 + lr];
+    };
+    frags(0, a[0], b[0]);
 #pragma unroll
     for (int kk = 0; kk < TN_BM / 4; ++kk) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[(4 * kk + lg) * TN_PITCH + wn * 64 + i * 16 + lr];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[(4 * kk + lg) * TN_PITCH + wk * 64 + j * 16 + lr];
+      if (kk + 1 < TN_BM / 4) frags(kk + 1, a[(kk + 1) & 1], b[(kk + 1) & 1]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();                                // every wave is done reading this stage
+    if (more) publish(m0 + TN_BM);
     __syncthreads();
   }
   if (do_db && tid < TN_BN && n0 + tid < N) dbpart[(size_t)s * N + n0 + tid] = colsum;
@@ -236,7 +282,8 @@ hipError_t launch_gemm_tn(const float* dY, const float* X, float* dW, float* scr
   int rpc;
   const int S = linear_bwd_chunks(M, N, K, &rpc);
   dim3 grid((N + TN_BN - 1) / TN_BN, (K + TN_BK - 1) / TN_BK, S);
-  gemm_tn_kernel<<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, nullptr, M, N, K, rpc);
+  if (N % TN_BN == 0 && K % TN_BK == 0) gemm_tn_kernel<true><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, nullptr, M, N, K, rpc);
+  else gemm_tn_kernel<false><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, nullptr, M, N, K, rpc);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || S == 1) return e;
   return launch_reduce_partials(scratch, dW, S, (size_t)N * K, st);
@@ -248,7 +295,9 @@ static hipError_t launch_gemm_tn_db(const float* dY, const float* X, float* dW, 
   int rpc;
   const int S = linear_bwd_chunks(M, N, K, &rpc);
   dim3 grid((N + TN_BN - 1) / TN_BN, (K + TN_BK - 1) / TN_BK, S);
-  gemm_tn_kernel<<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, S == 1 ? db : dbscratch, M, N, K, rpc);
+  if (N % TN_BN == 0 && K % TN_BK == 0)
+    gemm_tn_kernel<true><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, S == 1 ? db : dbscratch, M, N, K, rpc);
+  else gemm_tn_kernel<false><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, S == 1 ? db : dbscratch, M, N, K, rpc);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || S == 1) return e;
   const unsigned nb1 = (unsigned)(((size_t)N * K + 255) / 256), nb2 = (unsigned)((N + 255) / 256);

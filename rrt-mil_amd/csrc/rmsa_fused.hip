@@ -76,7 +76,8 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
                                                             const float* __restrict__ bqkv,
                                                             const float* __restrict__ pe_w,
                                                             float* __restrict__ O, int n_rows, int P,
-                                                            int D, int heads_rt, int epeg_k, float q_scale) {
+                                                            int D, int heads_rt, int epeg_k, float q_scale,
+                                                            float* __restrict__ stash) {
   constexpr int BM = 16 * MT;
   constexpr int STAGE = (BM + BN) * BK;            // floats per pipeline stage
   constexpr int TILE = BM * HD;                    // floats of one Q / K / V tile
@@ -368,6 +369,19 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
   if (wave >= 4) __syncthreads();                   // loader side of the "staging ring is dead" barrier
   __syncthreads();                                  // Q / K / V tiles complete
   RRT_TRACE_MARK();                                 // [6] Q/K/V in LDS
+  // Training forward (rrt_encoder_forward_train): the backward kernels read q (scaled, + bias), k and v rows from a
+  // [rows, 3 D] stash -- written here from the three tiles (the only time qkv reaches HBM: 256-byte row segments,
+  // fire and forget) instead of running the unfused projection + attention pair for the sake of that tensor.
+  if (stash != nullptr) {
+    for (int idx = tid; idx < BM * 16 * 3; idx += 512) {
+      const int c = idx / (BM * 16), rem = idx - c * (BM * 16);
+      const int m = rem >> 4, sl = rem & 15;
+      if (m < P) {
+        const float4 v = *(const float4*)(lds + c * TILE + m * HD + ((sl ^ (m & 15)) << 2));
+        *(float4*)(stash + (size_t)(row0 + m) * (3 * D) + c * D + head * HD + 4 * sl) = v;
+      }
+    }
+  }
 
   // ================================================================== phase 3: EPEG stencil -> Q~
   // thread = (slot s of 16, run g of RUN consecutive query rows); all eight waves take part
@@ -742,7 +756,7 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
 
 template <int MT, int PREC>
 hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w, float* O,
-                     int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
+                     int n_regions, int P, int D, int heads, int epeg_k, float* stash, hipStream_t st) {
   constexpr int BM = 16 * MT;
   constexpr size_t STG = (size_t)2 * (BM + BN) * BK * 4, QKV = (size_t)3 * BM * HD * 4;
   // staging ring / Q, K, V; tap table (512 B) + bias (768 B); partials of the shared-out tile (MT = 9)
@@ -755,7 +769,7 @@ hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
   const float q_scale = 1.0f / sqrtf((float)HD);
   kern<<<dim3(heads * n_regions), dim3(512), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D, heads,
-                                                      pe_w ? epeg_k : 0, q_scale);
+                                                      pe_w ? epeg_k : 0, q_scale, stash);
   return hipGetLastError();
 }
 
@@ -780,12 +794,12 @@ bool rmsa_fused_supported_rows(long n_rows, int D) {   // 32-bit DMA byte offset
 
 hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w,
                              float* O, int n_regions, int P, int D, int heads, int epeg_k, int prec,
-                             hipStream_t st) {
+                             hipStream_t st, float* stash) {
 #define RRT_FUSED(MT_)                                                                              \
   switch (prec) {                                                                                   \
-    case 1: return launch_mt<MT_, PREC_BF16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st); \
-    case 2: return launch_mt<MT_, PREC_F16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st);  \
-    default: return launch_mt<MT_, PREC_F32>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, st); \
+    case 1: return launch_mt<MT_, PREC_BF16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, stash, st); \
+    case 2: return launch_mt<MT_, PREC_F16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, stash, st);  \
+    default: return launch_mt<MT_, PREC_F32>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, stash, st); \
   }
   if (P > 176) { RRT_FUSED(13) }
   if (P > 144) { RRT_FUSED(11) }
