@@ -1277,6 +1277,7 @@ struct BwdWs {
   float *dx2, *dxa, *dxb, *dz, *dO, *dqkv, *lnpart, *attnpart, *dWd, *dC, *dlg, *Cw, *d_rep2, *d_rep_o,
       *d_rep_qkv, *d_rep, *rows, *dxpart, *th, *dhid, *dvphi, *w1t, *tnscratch, *fh, *fdh, *fdu, *attnpart_cr, *dpe, *smap;
   char *lin, *pegws;
+  float *wt_qkv[RRT_MAX_RMSA_LAYERS], *wt_proj[RRT_MAX_RMSA_LAYERS], *wt_cr_qkv, *wt_cr_proj;   // W^T images, made in one launch
   size_t bytes;
 };
 
@@ -1349,6 +1350,14 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
   }
   w.lin = takeb(lin ? lin : 256);
   if (d.pos) w.pegws = takeb(peg_bwd_workspace((int)N, (int)D, d.peg_k, d.pos == RRT_POS_PPEG));
+  for (int li = 0; li < d.n_rmsa_layers; ++li) {
+    w.wt_qkv[li] = take(3 * D * D);
+    w.wt_proj[li] = take(D * D);
+  }
+  if (d.cr_msa) {
+    w.wt_cr_qkv = take(3 * D * D);
+    w.wt_cr_proj = take(D * D);
+  }
   w.bytes = off;
   return w;
 }
@@ -1628,6 +1637,24 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     if (e != hipSuccess) return (int)e; \
   } while (0)
   if (!gr->norm) return RRT_E_INVALID;
+  {
+    // W^T of every attention Linear, for the dX products (dX = dY . W as the forward GEMM on W^T): one launch up front
+    TransposeJobs tj{};
+    auto add = [&](const float* wsrc, float* wt, int n_out, int k_in) {
+      if (!wsrc || tj.n >= TRANSPOSE_MAX_JOBS) return;
+      tj.in[tj.n] = wsrc; tj.out[tj.n] = wt; tj.R[tj.n] = n_out; tj.C[tj.n] = k_in;
+      ++tj.n;
+    };
+    for (int li = 0; li < desc->n_rmsa_layers; ++li) {
+      add(w->rmsa[li].qkv_w, b.wt_qkv[li], 3 * D, D);
+      add(w->rmsa[li].proj_w, b.wt_proj[li], D, D);
+    }
+    if (desc->cr_msa) {
+      add(w->crmsa.qkv_w, b.wt_cr_qkv, 3 * D, D);
+      add(w->crmsa.proj_w, b.wt_cr_proj, D, D);
+    }
+    RRT_TRY(launch_transpose_batch(tj, st));
+  }
   // final LayerNorm
   RRT_TRY(launch_ln_backward(dy, s.x2, w->norm_w, nullptr, b.dx2, gr->norm, b.lnpart, N, D, nullptr, st));
   const float* cur = b.dx2;   // gradient w.r.t. the activations entering the stage being undone
@@ -1692,11 +1719,11 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     RRT_TRY(launch_apply_drop_mask(b.d_rep2, k * R8, D, dc.thresh, dc.seed(drop_seed, DROP_LAYER_CRMSA),
                                    dc.scale * br.attn[L], st));
     RRT_TRY(launch_linear_backward(b.d_rep2, s.rep_o, cw.proj_w, b.d_rep_o, cg.proj_w, cg.proj_b, k * R8, D, D, desc->compute,
-                                   b.lin, st));
+                                   b.lin, st, b.wt_cr_proj));
     RRT_TRY(launch_attention_backward(s.rep_qkv, nullptr, s.rep_o, b.d_rep_o, b.d_rep_qkv, nullptr, b.attnpart_cr, k,
                                       R8, D, desc->crmsa_heads, 0, st));
     RRT_TRY(launch_linear_backward(b.d_rep_qkv, s.rep, cw.qkv_w, b.d_rep, cg.qkv_w, cg.qkv_b, k * R8, 3 * D, D, desc->compute,
-                                   b.lin, st));
+                                   b.lin, st, b.wt_cr_qkv));
     RRT_TRY(launch_crmsa_tokdot(x1, s.mean_rstd, cw.norm_w, cw.norm_b, b.d_rep, b.dC, D, k, gd8, st));
     RRT_TRY(launch_crmsa_bwd_region(s.logits, b.dC, b.dWd, b.dlg, b.Cw, k, gd8, st));
     if (desc->crmsa_mlp) {
@@ -1740,7 +1767,8 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
       if (rc) return rc;
     }
     RRT_TRY(launch_partition_rows(cur, b.dz, D, gd, dc.thresh, dc.seed(drop_seed, li), dc.scale * br.attn[li], st));
-    RRT_TRY(launch_linear_backward(b.dz, s.o[li], lw.proj_w, b.dO, lg.proj_w, lg.proj_b, gd.Np, D, D, desc->compute, b.lin, st));
+    RRT_TRY(launch_linear_backward(b.dz, s.o[li], lw.proj_w, b.dO, lg.proj_w, lg.proj_b, gd.Np, D, D, desc->compute, b.lin, st,
+                                   b.wt_proj[li]));
     const bool e2d = desc->epeg && desc->epeg_2d && desc->epeg_type == RRT_EPEG_ATTN;
     const bool evalue = desc->epeg && desc->epeg_type != RRT_EPEG_ATTN;
     if (e2d) {
@@ -1769,7 +1797,7 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
                                       desc->epeg ? lg.pe_w : nullptr, b.attnpart, gd.rs * gd.rs, gd.P, D,
                                       desc->n_heads, desc->epeg ? desc->epeg_k : 0, st));
     RRT_TRY(launch_linear_backward(b.dqkv, s.u[li], lw.qkv_w, b.dz, lg.qkv_w, lg.qkv_b, gd.Np, 3 * D, D, desc->compute, b.lin,
-                                   st));                                       // dU -> dz (dead)
+                                   st, b.wt_qkv[li]));                         // dU -> dz (dead)
     float* nxt = (cur == b.dxa) ? b.dxb : b.dxa;
     RRT_TRY(launch_ln_backward(b.dz, xin, lw.norm_w, cur, nxt, lg.norm, b.lnpart, N, D, &gd, st));
     cur = nxt;

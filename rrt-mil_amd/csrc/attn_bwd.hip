@@ -174,12 +174,13 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
 
   // tile -> wave schedule of the forward fused kernel (balanced per SIMD; at most three tiles per wave)
   auto tile_of = [&](int pass) {
+    if (NW == MT) return pass == 0 ? wave : MT;     // a wave per tile: no second pass
     if (NW == 4) return wave + 4 * pass;            // 4 waves, one per SIMD: tiles round-robin
     if (pass == 0) return wave;
     if (pass == 1) return wave >= 2 ? wave + 4 : (wave == 0 ? 12 : MT);
     return (wave == 2 || wave == 3) ? wave + 8 : MT;
   };
-  constexpr int NPASS = NW == 4 ? (MT + 3) / 4 : 3;
+  constexpr int NPASS = NW == MT ? 1 : NW == 4 ? (MT + 3) / 4 : 3;
   // fragment rows of a [rows, D]-strided global tensor: lane (lr, lg) <- row[4*(4c + lg) .. +3]
   auto global_frags = [&](const float* base, size_t stride, int m, float4 (&f)[4]) {
 #pragma unroll
@@ -426,11 +427,17 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
 template <int MT>
 hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, const float* dO, float* dqkv,
                          float* dpe_part, int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
-  constexpr size_t LDS = ((size_t)3 * 16 * MT * HD + 2 * 16 * MT + 6 * 64) * sizeof(float);
+  constexpr size_t LDS = ((size_t)3 * 16 * MT * HD + 2 * 16 * MT + 9 * 64) * sizeof(float);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   const float q_scale = 1.0f / sqrtf((float)HD);
   static const bool six = rrt_tune_env("RRT_ATTN_BWD_NW6") != nullptr;     // tuning hook (A/B of the two schedules)
-  if (MT >= 11 && !six) {           // measured: 9 tiles 221 (6 waves) vs 241 us; 11: 350 vs 291; 13: 516 vs 400
+  if (MT == 9 && !six) {            // a wave per tile, three waves per SIMD at <= 168 VGPRs
+    auto kern = attn_bwd_kernel<MT, MT == 9 ? 9 : 6>;
+    static OncePerDevice once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    kern<<<dim3(n_regions * heads), dim3(576), LDS, st>>>(qkv, pe_w, O, dO, dqkv, dpe_part, P, D, heads,
+                                                          pe_w ? epeg_k : 0, q_scale);
+  } else if (MT >= 11 && !six) {           // measured: 9 tiles 221 (6 waves) vs 241 us; 11: 350 vs 291; 13: 516 vs 400
     auto kern = attn_bwd_kernel<MT, 4>;
     static OncePerDevice once;
     if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);

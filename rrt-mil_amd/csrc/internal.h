@@ -162,8 +162,16 @@ hipError_t launch_pool_merge(const float* part, const float* a_raw, const float*
 // nn.Linear backward: dX = dY W (forward GEMM on a transposed W), dW = dY^T X (split-K TN kernel), db = colsum(dY)
 size_t linear_bwd_workspace(int M, int N, int K);
 hipError_t launch_linear_backward(const float* dY, const float* X, const float* W, float* dX, float* dW, float* db,
-                                  int M, int N, int K, int prec, void* ws, hipStream_t st);
+                                  int M, int N, int K, int prec, void* ws, hipStream_t st, const float* WT_ready = nullptr);
 hipError_t launch_transpose(const float* in, float* out, int R, int C, hipStream_t st);
+constexpr int TRANSPOSE_MAX_JOBS = 2 * RRT_MAX_RMSA_LAYERS + 2;
+struct TransposeJobs {           // out[j] [C, R] = in[j] [R, C]^T, one launch (blk0: filled by the launcher)
+  const float* in[TRANSPOSE_MAX_JOBS];
+  float* out[TRANSPOSE_MAX_JOBS];
+  int R[TRANSPOSE_MAX_JOBS], C[TRANSPOSE_MAX_JOBS], blk0[TRANSPOSE_MAX_JOBS];
+  int n;
+};
+hipError_t launch_transpose_batch(TransposeJobs& jobs, hipStream_t st);
 hipError_t launch_reduce_partials(const float* part, float* out, int S, size_t n, hipStream_t st);
 hipError_t launch_gemm_tn(const float* dY, const float* X, float* dW, float* scratch, int M, int N, int K,
                           hipStream_t st);

@@ -30,6 +30,33 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   }
 }
 
+// ---- several transposes in one launch (the weight matrices of a backward pass: their W^T images do not depend on the
+//      gradients, so they are all made up front instead of one 5 us launch in front of every dX product)
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeJobs jobs) {
+  __shared__ float tile[32][33];
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < TRANSPOSE_MAX_JOBS; ++q)
+    if (q < jobs.n && (int)blockIdx.x >= jobs.blk0[q]) j = q;
+  const float* __restrict__ in = jobs.in[j];
+  float* __restrict__ out = jobs.out[j];
+  const int R = jobs.R[j], C = jobs.C[j];
+  const int b = blockIdx.x - jobs.blk0[j], nbx = (C + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = (b % nbx) * 32, r0 = (b / nbx) * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < C && r < R) out[(size_t)c * R + r] = tile[tx][ty + 8 * i];
+  }
+}
+
 // ---- split-K TN product: part[s][n][k] = sum_{m in chunk s} A[m][n] * B[m][k]
 // block = 4 waves (2 x 2), tile 128 (n) x 128 (k), 32 rows of both operands per step.  Rows are staged in LDS
 // as they lie in memory (coalesced 16-byte loads); the MFMA fragments are read "down the columns":
@@ -175,10 +202,14 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
 //      trips: 131 us for 16 x 3 MB; 8 loads in flight: 37 us; this: one or two trips.)
 // Optional second segment (part2 / out2 / n2; blocks past the first segment's): the bias gradient's partials ride in the
 // same launch as the weight gradient's.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+// NWV waves per block: 4, or 16 when there are many partials of a short vector (LayerNorm's 512 x [2, dim], the taps'
+// [regions][heads, k]: a handful of blocks, each wave walking S / 4 partials twelve at a time, was a chain of ~11
+// memory round trips = 8 us for 2 MB).
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               int S, size_t n, const float* __restrict__ part2,
                                                               float* __restrict__ out2, size_t n2, unsigned nb1) {
-  __shared__ float4 comb[3][64];
+  __shared__ float4 comb[NWV - 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned blk = blockIdx.x;
   if (blk >= nb1) { blk -= nb1; part = part2; out = out2; n = n2; }
@@ -187,11 +218,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n) {
     if (vec) {
-      for (int s0 = wave; s0 < S; s0 += 48) {
+      for (int s0 = wave; s0 < S; s0 += 12 * NWV) {
         float4 b[12];
 #pragma unroll
         for (int u = 0; u < 12; ++u) {
-          const int s = s0 + 4 * u;
+          const int s = s0 + NWV * u;
           b[u] = s < S ? *(const float4*)(part + (size_t)s * n + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -199,7 +230,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
       }
     } else {
       float t[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int s = wave; s < S; s += 4)
+      for (int s = wave; s < S; s += NWV)
         for (int e = 0; e < 4; ++e)
           if (i + e < n) t[e] += part[(size_t)s * n + i + e];
       a = make_float4(t[0], t[1], t[2], t[3]);
@@ -209,7 +240,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   __syncthreads();
   if (wave == 0 && i < n) {
 #pragma unroll
-    for (int w = 0; w < 3; ++w) {
+    for (int w = 0; w < NWV - 1; ++w) {
       const float4 o = comb[w][lane];
       a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
     }
@@ -270,9 +301,21 @@ hipError_t launch_transpose(const float* in, float* out, int R, int C, hipStream
   return hipGetLastError();
 }
 
+hipError_t launch_transpose_batch(TransposeJobs& jobs, hipStream_t st) {
+  if (jobs.n == 0) return hipSuccess;
+  int nb = 0;
+  for (int j = 0; j < jobs.n; ++j) {
+    jobs.blk0[j] = nb;
+    nb += ((jobs.C[j] + 31) / 32) * ((jobs.R[j] + 31) / 32);
+  }
+  transpose_batch_kernel<<<dim3(nb), 256, 0, st>>>(jobs);
+  return hipGetLastError();
+}
+
 hipError_t launch_reduce_partials(const float* part, float* out, int S, size_t n, hipStream_t st) {
   const unsigned nb = (unsigned)((n + 255) / 256);
-  reduce_partials_kernel<<<dim3(nb), 256, 0, st>>>(part, out, S, n, nullptr, nullptr, 0, nb);
+  if (S >= 64 && nb <= 64) reduce_partials_kernel<16><<<dim3(nb), 1024, 0, st>>>(part, out, S, n, nullptr, nullptr, 0, nb);
+  else reduce_partials_kernel<4><<<dim3(nb), 256, 0, st>>>(part, out, S, n, nullptr, nullptr, 0, nb);
   return hipGetLastError();
 }
 
@@ -301,7 +344,7 @@ static hipError_t launch_gemm_tn_db(const float* dY, const float* X, float* dW, 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || S == 1) return e;
   const unsigned nb1 = (unsigned)(((size_t)N * K + 255) / 256), nb2 = (unsigned)((N + 255) / 256);
-  reduce_partials_kernel<<<dim3(nb1 + nb2), 256, 0, st>>>(scratch, dW, S, (size_t)N * K, dbscratch, db, (size_t)N, nb1);
+  reduce_partials_kernel<4><<<dim3(nb1 + nb2), 256, 0, st>>>(scratch, dW, S, (size_t)N * K, dbscratch, db, (size_t)N, nb1);
   return hipGetLastError();
 }
 
@@ -315,7 +358,7 @@ hipError_t launch_colsum(const float* Y, float* out, float* scratch, int M, int 
 
 // Full nn.Linear backward.  dX may be null (first layer).  ws: linear_bwd_workspace(M, N, K) bytes.
 hipError_t launch_linear_backward(const float* dY, const float* X, const float* W, float* dX, float* dW, float* db,
-                                  int M, int N, int K, int prec, void* ws, hipStream_t st) {
+                                  int M, int N, int K, int prec, void* ws, hipStream_t st, const float* WT_ready) {
   char* base = (char*)ws;
   float* WT = (float*)base;
   float* scratch = (float*)(base + align256((size_t)N * K * 4));
@@ -324,8 +367,11 @@ hipError_t launch_linear_backward(const float* dY, const float* X, const float* 
   float* cs = (float*)((char*)scratch + align256((size_t)S * N * K * 4));
   hipError_t e;
   if (dX) {
-    e = launch_transpose(W, WT, N, K, st);                    // WT [K, N]
-    if (e != hipSuccess) return e;
+    if (WT_ready) WT = const_cast<float*>(WT_ready);          // made up front (launch_transpose_batch)
+    else {
+      e = launch_transpose(W, WT, N, K, st);                  // WT [K, N]
+      if (e != hipSuccess) return e;
+    }
     LinearEpilogue ep{};
     ep.prec = prec;
     ep.solo = true;                                           // (a training step has the GPU to itself: small-M GEMMs split K in the block)
