@@ -882,7 +882,7 @@ struct Cfg { int mt, nt, cap; };
 //   grid = min(tiles, cap), rounds = ceil(tiles / grid), blocks per CU = ceil(grid / 256)
 //   cost = rounds * blocks_per_cu * MT * NT      [co-resident blocks share the CU's matrix pipes]
 // Candidates are ordered by preference; a later one must be strictly cheaper to win.
-Cfg choose(int M, int N, int prec = PREC_F32) {
+Cfg choose(int M, int N, int prec = PREC_F32, int K = 0) {
   if (const char* e = rrt_tune_env("RRT_LINEAR_CFG_BIG")) {   // tuning hook for the bag-sized GEMMs only: "mt,nt,cap"
     Cfg c{};
     if (M > 1024 && sscanf(e, "%d,%d,%d", &c.mt, &c.nt, &c.cap) == 3) return c;
@@ -894,6 +894,28 @@ Cfg choose(int M, int N, int prec = PREC_F32) {
   if (prec == PREC_F32 && N == 512) {
     const long t96 = (long)((M + 95) / 96) * 8;
     if (t96 >= 640 && t96 <= 768) return Cfg{6, 1, 768};
+  }
+  // Round 3: the out-projection of every other bag size (N = K = 512, fp32), from a sweep of all shapes x caps over bags of
+  // 3 k .. 15 k tokens (tools/sweep_proj_cfg.py).  What the numbers say: a block alone on a CU is latency-bound (~19 us +
+  // 1.2 us per row tile whatever its size), k co-resident blocks of one tile each take max(that, k * MT * 2.6 us), and
+  // a second tile behind the first costs a whole extra round (the block runs it alone).  So: the single-round shape with the
+  // least max(floor, k * MT), 64-row tiles first (32 KiB of LDS: four per CU, and the best fit next to another bag's fused
+  // block); bags with more tiles than any shape can keep resident take 64-row tiles four per CU (two even rounds).
+  // The rounds x blocks-per-CU estimate below picked 32-row tiles of the plain kernel at 12 k tokens (83 us; now 66)
+  // and 128-row tiles at 13-15 k (95; now 76).
+  if (prec == PREC_F32 && N == 512 && K == 512 && M >= 2048) {
+    static const Cfg single[] = {{4, 1, 1024}, {8, 1, 768}, {6, 1, 1024}, {9, 1, 768}};
+    Cfg best{4, 1, 1024};
+    float best_cost = -1.f;
+    for (const Cfg& c : single) {
+      const long tiles = (long)((M + 16 * c.mt - 1) / (16 * c.mt)) * 8;
+      if (tiles > c.cap) continue;
+      const float k = (float)((tiles + 255) / 256);
+      const float floor_us = 19.f + 1.2f * c.mt, busy_us = k * c.mt * 2.6f;
+      const float cost = floor_us > busy_us ? floor_us : busy_us;
+      if (best_cost < 0.f || cost < best_cost - 0.05f) { best = c; best_cost = cost; }
+    }
+    return best;
   }
   if (const char* e = rrt_tune_env("RRT_LINEAR_CFG")) {   // tuning hook: "mt,nt,cap"
     Cfg c{};
@@ -973,6 +995,20 @@ hipError_t launch_linear16(const void* A, const void* B, float* C, int M, int N,
       if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
     }
   }
+  // Round 3: the bag-sized out-projection (N = K = 512) by rule, from the same sweep as the fp32 one
+  // (SWEEP_BF16=1 tools/sweep_proj_cfg.py): the smallest tile whose blocks are all resident at once -- 64-row tiles four
+  // per CU up to 8 k rows, 96-row up to 12 k, 144-row up to 13.8 k, then 128 / 144 x 128 tiles two per CU up to 18 k --
+  // and 128-row tiles in rounds beyond.  (The rounds x blocks estimate above cost 10.5-12 k-token bags 28 us instead of
+  // 21-23 and kept the 64-row tiles, the best shape below 8 k tokens, out of bag-sized products altogether.)
+  if (N == 512 && K == 512 && M >= 2048) {
+    auto tiles = [&](int mt, int nt) { return (long)((M + 16 * mt - 1) / (16 * mt)) * (8 / nt); };
+    if (tiles(4, 1) <= 1024) best = Cfg{4, 1, 1024};
+    else if (tiles(6, 1) <= 1024) best = Cfg{6, 1, tiles(6, 1) <= 768 ? 768 : 1024};
+    else if (tiles(9, 1) <= 768) best = Cfg{9, 1, 768};
+    else if (tiles(8, 2) <= 512) best = Cfg{8, 2, 512};
+    else if (tiles(9, 2) <= 512) best = Cfg{9, 2, 512};
+    else best = Cfg{8, 1, 512};
+  }
   if (const char* e = rrt_tune_env("RRT_LINEAR16_CFG")) {   // tuning hook: "mt,nt,cap"
     Cfg q{};
     if (sscanf(e, "%d,%d,%d", &q.mt, &q.nt, &q.cap) == 3) best = q;
@@ -1022,7 +1058,7 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
     }
     return hipGetLastError();
   }
-  const Cfg c = choose(M, N, ep.prec);
+  const Cfg c = choose(M, N, ep.prec, K);
 #define RRT_CASE(MT_, NT_)                                                                          \
   if (c.mt == MT_ && c.nt == NT_) {                                                                 \
     if (ep.prec == PREC_BF16) return RRT_MODES(MT_, NT_, PREC_BF16);                                \
