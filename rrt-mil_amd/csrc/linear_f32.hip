@@ -924,6 +924,9 @@ Cfg choose(int M, int N, int prec = PREC_F32, int K = 0) {
   // operands rounded to 16 bits after LDS (fp32 bytes through the DMA path, 1/16 of the MFMA time): the K loop is bound
   // by DMA issue, and three 96-row blocks per CU keep more of it in flight than two 144-row ones (patch_to_emb at
   // N = 9000 x 1024 -> 512: 36.3 -> ~31 us)
+  // (round 3, tools/sweep_linear_cfg.py: where one 144 x 128 block per CU covers the product -- patch_to_emb of a 9 k bag --
+  //  that shape streams B half as often: 31.8 us against 35.1)
+  if (prec != PREC_F32 && N % 128 == 0 && K >= 1024 && (long)((M + 143) / 144) * (N / 128) <= 256 && M >= 4096) return Cfg{9, 2, 256};
   if (prec != PREC_F32 && (M + 95) / 96 * ((N + 63) / 64) >= 512) return Cfg{6, 1, 768};
   static const Cfg cands[] = {{9, 1, 512}, {8, 1, 512}, {9, 2, 512}, {8, 2, 512}, {9, 2, 256},
                               {8, 2, 256}, {4, 1, 512}, {2, 1, 512}};

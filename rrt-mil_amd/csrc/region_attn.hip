@@ -270,6 +270,159 @@ __global__ __launch_bounds__(256) void region_attn_kernel(const float* __restric
   }
 }
 
+// ---- regions of 209..256 tokens (bags of ~12.6-16 k tokens at region_num = 8), whole region resident ------------------
+// The streaming kernel above re-stages K and V once per 64 queries and rescales its accumulators at every 48-key chunk
+// behind a block-wide barrier (P = 256: 99 us, 0.55 of the fp32 MFMA rate, the DMA round trip of the next chunk not
+// covered by one chunk's 96 MFMAs).  Here a block = one (region, head), sixteen waves = sixteen 16-query tiles, and the
+// tiles live in two 64 KiB halves of LDS:  Q | K  ->  (Q~ fragments to registers, barrier)  ->  V | K.  The scores of a
+// query tile against ALL keys stay in registers (s[MT] = 64 VGPRs), so the softmax is single-pass, there is no
+// rescaling and no barrier inside the products; the V image lands over Q while S^T = K Q~^T runs.  One block per CU,
+// four waves per SIMD (<= 128 VGPRs).  Same transposed-score layout, swizzle and DMA path as above.
+template <int MT>
+__global__ __launch_bounds__(1024) void region_attn_resident_kernel(const float* __restrict__ qkv,
+                                                                   const float* __restrict__ pe_w,
+                                                                   float* __restrict__ o, int P, int dim, int epeg_k) {
+  constexpr int BM = 16 * MT;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const Xs = (float*)smem;                  // Q, then V (row-contiguous, not swizzled)
+  float* const Ks = Xs + BM * HD;                  // K, XOR-swizzled 16-byte slots
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int head = blockIdx.x, reg = blockIdx.y;
+  const int ld = 3 * dim;
+  const size_t rbase = (size_t)reg * P;
+  const float* qbase = qkv + rbase * ld + head * HD;
+  const float* kbase = qbase + dim;
+  const float* vbase = qbase + 2 * dim;
+  const unsigned xs_b = lds_addr_of(Xs), ks_b = lds_addr_of(Ks);
+  // one wave-instruction = 4 rows of 256 bytes; rows >= P re-read the last row (masked / never used below)
+  for (int q = wave; q < BM / 4; q += 16) {
+    const int S = q * 64 + lane, row = S >> 4, p = S & 15;
+    const int j = row < P ? row : P - 1;
+    dma16(qbase + (size_t)j * ld + ((p ^ (row & 15)) << 2), xs_b + q * 1024);
+    dma16(kbase + (size_t)j * ld + ((p ^ (row & 15)) << 2), ks_b + q * 1024);
+  }
+  wait_vm0();
+  __syncthreads();
+  const int i0 = wave * 16;
+  const bool active = wave < MT && i0 < P;
+  const int qi = i0 + lr;
+  float4 bq[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active && qi < P) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bq[c] = *(const float4*)(Xs + qi * HD + (((4 * c + lg) ^ (qi & 15)) << 2));
+    if (epeg_k > 0) {
+      const float* w = pe_w + head * epeg_k;
+      const int half = epeg_k >> 1;
+      for (int t = 0; t < epeg_k; ++t) {
+        const int r = qi + t - half;
+        if (r >= 0 && r < P) {
+          const float wt = w[t];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float4 v = *(const float4*)(Xs + r * HD + (((4 * c + lg) ^ (r & 15)) << 2));
+            bq[c].x += wt * v.x; bq[c].y += wt * v.y; bq[c].z += wt * v.z; bq[c].w += wt * v.w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { bq[c].x *= LOG2E; bq[c].y *= LOG2E; bq[c].z *= LOG2E; bq[c].w *= LOG2E; }
+  }
+  __syncthreads();                                  // every wave has its Q~ fragments: the Q image is dead
+  for (int q = wave; q < BM / 4; q += 16) {        // V over Q, rows as they lie in memory
+    const int S = q * 64 + lane, row = S >> 4, p = S & 15;
+    const int j = row < P ? row : P - 1;
+    dma16(vbase + (size_t)j * ld + (p << 2), xs_b + q * 1024);
+  }
+  // S^T tiles against every key tile: s[jt][r] = score(query lr, key 16 jt + 4 lg + r), log2 units
+  f32x4 s[MT];
+#pragma unroll
+  for (int jt = 0; jt < MT; ++jt) s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (active) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int j0 = 0; j0 < MT; j0 += 4) {          // four key tiles' fragments in flight (16 VGPRs)
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = (j0 + u < MT ? j0 + u : MT - 1) * 16 + lr;
+          a[u] = *(const float4*)(Ks + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + u < MT) s[j0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, bq[c].x, s[j0 + u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + u < MT) s[j0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, bq[c].y, s[j0 + u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + u < MT) s[j0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, bq[c].z, s[j0 + u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + u < MT) s[j0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, bq[c].w, s[j0 + u], 0, 0, 0);
+      }
+    }
+    if (P < BM) {
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (jt * 16 + 4 * lg + r >= P) s[jt][r] = NEG_BIG;     // keys past the region
+    }
+  }
+  float inv = 0.f;
+  if (active) {
+    float cmax = NEG_BIG;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, s[jt][r]);
+    cmax = max_xor32(max_xor16(cmax));
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[jt][r] - cmax);
+        s[jt][r] = e;
+        a4[r] += e;
+      }
+    inv = 1.0f / sum_xor32(sum_xor16((a4[0] + a4[1]) + (a4[2] + a4[3])));
+  }
+  wait_vm0();
+  __syncthreads();                                  // V image complete
+  if (!active) return;
+  f32x4 oacc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = jt * 16 + 4 * lg + r;
+      const float4 v = *(const float4*)(Xs + row * HD + (lr << 2));
+      const float p = s[jt][r];
+      oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.x, oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.y, oacc[1], 0, 0, 0);
+      oacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.z, oacc[2], 0, 0, 0);
+      oacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, v.w, oacc[3], 0, 0, 0);
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float ir = __shfl(inv, 4 * lg + r);
+    const int i = i0 + 4 * lg + r;
+    if (i < P)
+      *(float4*)(o + (rbase + i) * dim + head * HD + (lr << 2)) =
+          make_float4(oacc[0][r] * ir, oacc[1][r] * ir, oacc[2][r] * ir, oacc[3][r] * ir);
+  }
+}
+
 // Generic head-dim fallback (hd != 64: e.g. crmsa_heads=1 -> hd=dim, or dim=64 -> hd=8).
 // One wave per query; VALU only (the published TCGA-BRCA-R50 / NSCLC-PLIP configs run CR-MSA's inner attention
 // with crmsa_heads=1: 3 x 64 queries of head dim 512).
@@ -474,6 +627,23 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
     region_attn64_kernel<<<dim3(heads, n_regions), 256, 0, st>>>(qkv, o, dim);
     return hipGetLastError();
   }
+  static const bool no_resident = rrt_tune_env("RRT_NO_ATTN_RESIDENT") != nullptr;
+  if (P > 208 && P <= 256 && !no_resident) {        // whole region resident, single-pass softmax
+    if (P > 240) {
+      auto kern = region_attn_resident_kernel<16>;
+      constexpr int LDS = 2 * 256 * HD * 4;
+      static OncePerDevice once;
+      if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      kern<<<dim3(heads, n_regions), 1024, LDS, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+    } else {
+      auto kern = region_attn_resident_kernel<15>;
+      constexpr int LDS = 2 * 240 * HD * 4;
+      static OncePerDevice once;
+      if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      kern<<<dim3(heads, n_regions), 1024, LDS, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+    }
+    return hipGetLastError();
+  }
   const int ntiles = (P + 15) / 16;
   // waves per block: avoid idle waves (P=144 -> 9 tiles -> 3 waves x 3 blocks)
   int nw = 4;
@@ -488,7 +658,7 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
   int tc_force = 0;
   if (const char* e = rrt_tune_env("RRT_ATTN_CFG")) {   // tuning hook: "tc,nw" (rejected if the Q rows do not fit)
     int a = 0, b = 0;
-    if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= 3 && b >= 1 && b <= 4) {
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= 4 && b >= 1 && b <= 4) {
       const int need = P < 16 * b + epeg_k - 1 ? P : 16 * b + epeg_k - 1;
       if (epeg_k <= 0 || need <= 2 * 16 * a) { tc_force = a; nw = b; }
     }
@@ -503,6 +673,11 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
     if (direct == 1) region_attn_kernel<1, true><<<grid, block, lds, st>>>(qkv, pe_w, o, P, dim, epeg_k);
     else if (direct == 2) region_attn_kernel<2, true><<<grid, block, lds, st>>>(qkv, pe_w, o, P, dim, epeg_k);
     else region_attn_kernel<3, true><<<grid, block, lds, st>>>(qkv, pe_w, o, P, dim, epeg_k);
+  } else if (tc_force == 4) {
+    auto kern = region_attn_kernel<4, false>;
+    static OncePerDevice once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * HD * 4);
+    kern<<<grid, block, 2 * 2 * 64 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
   } else if (tc_force == 2) {
     region_attn_kernel<2, false><<<grid, block, 2 * 2 * 32 * HD * 4, st>>>(qkv, pe_w, o, P, dim, epeg_k);
   } else if (tc_force == 1) {
