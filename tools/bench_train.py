@@ -34,18 +34,23 @@ print(f"  under bf16 autocast: train step {timeit(enc_step_amp):.3f} ms")
 mem0 = torch.cuda.max_memory_allocated() / 1e6
 print(f"  peak device memory so far {mem0:.0f} MB")
 
-mil = RRTMIL(input_dim=1024, n_classes=2, epeg_k=15, crmsa_k=1, all_shortcut=True, trans_dropout=0., dropout=0.25).to(dev).train()
-opt = torch.optim.Adam(mil.parameters(), lr=2e-4)
 feats = torch.from_numpy(synth.bag(N, 1024, tag="btm", nonneg=True)).to(dev).unsqueeze(0)
-with torch.no_grad():
-    label = mil.eval()(feats).argmin(-1)      # the class the fresh model likes least: a loss worth descending
-mil.train()
-def mil_step():
-    opt.zero_grad(set_to_none=True)
-    loss = torch.nn.functional.cross_entropy(mil(feats), label)
-    loss.backward()
-    opt.step()
-    return loss
-l0 = float(mil_step())
-print(f"RRTMIL (C16-R50 config) N={N}: train step (fwd+bwd+Adam) {timeit(mil_step):.3f} ms")
-print(f"  loss {l0:.4f} at the first step -> {float(mil_step()):.6f} after 36 Adam steps on the same bag")
+# The step launches ~240 kernels, 160 of them the seven element-wise kernels per parameter of torch's default (foreach-less)
+# Adam: with that optimizer the step is bound by the host's launch rate (1.7-2.5 ms from box to box, GPU kernel time 1.85 ms
+# under rocprofv3), so the fused optimizer is timed beside it.
+for fused in (False, True):
+    torch.manual_seed(0)
+    mil = RRTMIL(input_dim=1024, n_classes=2, epeg_k=15, crmsa_k=1, all_shortcut=True, trans_dropout=0., dropout=0.25).to(dev).train()
+    opt = torch.optim.Adam(mil.parameters(), lr=2e-4, fused=fused)
+    with torch.no_grad():
+        label = mil.eval()(feats).argmin(-1)      # the class the fresh model likes least: a loss worth descending
+    mil.train()
+    def mil_step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(mil(feats), label)
+        loss.backward()
+        opt.step()
+        return loss
+    l0 = mil_step().item()
+    print(f"RRTMIL (C16-R50 config) N={N}: train step (fwd+bwd+Adam{', fused=True' if fused else ''}) {timeit(mil_step):.3f} ms")
+    print(f"  loss {l0:.4f} at the first step -> {mil_step().item():.6f} after 36 Adam steps on the same bag")
