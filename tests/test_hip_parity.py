@@ -100,7 +100,10 @@ def test_linear_transpose_detecting():
     assert np.array_equal(got, B.T)
 
 
-@pytest.mark.parametrize("L,rn", [(9000, 8), (300, 8), (30000, 16), (50, 8)])
+# 5000 .. 15000: one bag size per branch of the out-projection's tile-shape rule (linear_f32.hip::choose, round 3: 64-row tiles
+# single round / 128-row / 96-row four per CU / 144-row / 64-row in rounds), each with a ragged last row tile
+@pytest.mark.parametrize("L,rn", [(9000, 8), (300, 8), (30000, 16), (50, 8), (5000, 8), (7000, 8), (10500, 8), (12000, 8), (13000, 8),
+                                  (15000, 8)])
 def test_linear_unpartition_residual(L, rn):
     from hip_util import dev, p, stream, DEV
     lib = _lib.load()
@@ -1018,7 +1021,8 @@ def test_linear16(M, N, K, compute):
     _cmp(C_.cpu().numpy(), A @ B.T + bias, 2e-5, f"linear16 {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("L,rn", [(9000, 8), (30000, 16), (3000, 8)])
+# (one size per rung of launch_linear16's row-count ladder: 64 / 96 / 144-row tiles, 128 x 128, 144 x 128, 128-row rounds)
+@pytest.mark.parametrize("L,rn", [(9000, 8), (30000, 16), (3000, 8), (7000, 8), (10500, 8), (12000, 8), (15000, 8), (17000, 8), (20000, 16)])
 def test_linear16_unpartition_residual(L, rn):
     from hip_util import dev, p, stream
     lib = _lib.load()
