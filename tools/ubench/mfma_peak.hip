@@ -58,6 +58,11 @@ int main() {
     run<false>("f32", 256, f32_its[t] * 2, out);
     run<false>("f32", 512, f32_its[t], out);
   }
+  // the headline kernel's FLOPs as nothing but MFMAs: rmsa_fused_kernel at N = 9000 does 17.21 GFLOP per launch (512 blocks of
+  // 8 waves; here 256 blocks x 8 waves x 513 x 8 MFMAs = 17.2 GFLOP) -- what a launch of that size can reach at all
+  printf("-- a launch with the fused fp32 R-MSA kernel's FLOPs (17.2 G), and the 16-bit pair kernel's as bf16 MFMAs:\n");
+  run<false>("f32", 512, 513, out);
+  run<true>("bf16", 512, 64, out);
   for (int t = 0; t < 3; ++t) {
     run<true>("bf16", 256, bf_its[t] * 2, out);
     run<true>("bf16", 512, bf_its[t], out);
