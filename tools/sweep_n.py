@@ -17,6 +17,8 @@ cfg = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)
 enc = RRTEncoder(**cfg).eval()
 enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.encoder_state(**cfg).items()}, strict=True)
 enc = enc.to(dev)
+if os.environ.get("SWEEP_DTYPE"):                   # "bf16" / "f16" / "f32x3": the reduced modes' one-bag times
+    enc.compute_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32x3": "f32x3"}[os.environ["SWEEP_DTYPE"]]
 big = torch.from_numpy(synth.bag(16000, 512, tag="sweep")).to(dev)
 for n in [int(a) for a in sys.argv[1:]] or [2500, 3000, 4096, 5000, 6000, 7000, 8000, 9000, 10500, 12000, 15000]:
     x = big[:n].contiguous()
