@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
   const int reg = blockIdx.x / heads, head = blockIdx.x - reg * heads;
   const size_t row0 = (size_t)reg * P;
   const int ld = 3 * D;
-  RRT_TRACE_INIT(blockIdx.x * 8 + wave);
+  RRT_TRACE_INIT(blockIdx.x * 16 + wave);            // (up to nine waves per block; 512 blocks fill the trace buffer)
   RRT_TRACE_MARK();                                 // [1] entry
 
   // ---- phase 0: q, k, v tiles -> LDS (XOR-swizzled 16-byte slots, rows >= P are zeros)
