@@ -15,6 +15,7 @@
 // MFMA helpers with the roles of Q~ and K exchanged) produces dK and dV.  Scores are in base-2 units (log2(e)
 // folded into Q~).  Requires head dim 64 and P <= 208.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "internal.h"
 
@@ -82,6 +83,47 @@ __device__ __forceinline__ void tile_apply(const float* X, const f32x4 (&p)[MT],
     }
 }
 
+// the same two products over a run of N consecutive row tiles starting at tile t0: the passes below walk the "other" operand in
+// runs of three tiles so that only a run's scores are live next to the accumulators (nine tiles at once: 72 VGPRs of scores in
+// pass B, and the register allocator serialised every LDS read with its use)
+template <int N>
+__device__ __forceinline__ void run_scores(const float* X, const float4 (&f)[4], int lr, int lg, int t0, f32x4 (&s)[N]) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) s[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float4 a[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const int row = (t0 + u) * 16 + lr;
+      a[u] = *(const float4*)(X + row * HD + (((4 * c + lg) ^ (row & 15)) << 2));
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) s[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, f[c].x, s[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) s[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, f[c].y, s[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) s[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, f[c].z, s[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) s[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, f[c].w, s[u], 0, 0, 0);
+  }
+}
+template <int N>
+__device__ __forceinline__ void run_apply(const float* X, const f32x4 (&p)[N], int lr, int lg, int t0, f32x4 (&o)[4]) {
+#pragma unroll
+  for (int u = 0; u < N; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = (t0 + u) * 16 + 4 * lg + r;
+      const float4 v = *(const float4*)(X + row * HD + ((lr ^ (row & 15)) << 2));
+      const float w = p[u][r];
+      o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v.x, o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v.y, o[1], 0, 0, 0);
+      o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v.z, o[2], 0, 0, 0);
+      o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v.w, o[3], 0, 0, 0);
+    }
+}
+
 // NW waves per block: 6 (the forward fused kernel's schedule) up to 9 row tiles; 4 for 11 / 13 row tiles -- one wave
 // per SIMD owns the whole 512-entry register file, and the two [MT]-long score arrays no longer spill.
 template <int MT, int NW>
@@ -110,6 +152,22 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
   RRT_TRACE_INIT(blockIdx.x * 16 + wave);            // (up to nine waves per block; 512 blocks fill the trace buffer)
   RRT_TRACE_MARK();                                 // [1] entry
 
+  // Tap tables of the two stencils in LDS (index t + RUN - 1; zero outside [0, k)): forward log2(e) (w[t] + [t == k/2]), adjoint
+  // q_scale (w[k - 1 - t] + [t == k/2]).  (The stencils fetched w[t] from global inside their row loops -- one dependent vector
+  // load per source row, as the forward kernel once did: 8.7 K and 7.6 K cycles for two phases with ~3 K of work each.)
+  constexpr int RUN = (BM * 16 + NW * 64 - 1) / (NW * 64);
+  static_assert(2 * RUN + 62 < 128, "tap table range");
+  const int half = epeg_k >> 1;
+  const float* w = pe_w + head * epeg_k;
+  float* const tapsF = wred;
+  float* const tapsA = wred + 128;
+  if (tid < 128) {
+    const int t = tid - (RUN - 1);
+    const bool in = epeg_k > 0 && t >= 0 && t < epeg_k;
+    const float id = t == half ? 1.0f : 0.f;
+    tapsF[tid] = ((in ? w[t] : 0.f) + id) * LOG2E;
+    tapsA[tid] = ((in ? w[epeg_k - 1 - t] : 0.f) + id) * q_scale;
+  }
   // ---- phase 0: q, k, v tiles -> LDS (XOR-swizzled 16-byte slots, rows >= P are zeros)
   for (int idx = tid; idx < BM * 16; idx += NW * 64) {
     const int m = idx >> 4, s = idx & 15;
@@ -127,17 +185,23 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
   }
   __syncthreads();
   RRT_TRACE_MARK();                                 // [2] q, k, v in LDS
+  // The first tile's dO and O fragment rows (every schedule gives wave w tile w first) are requested HERE, under the stencil
+  // (at the head of pass A all waves of the block waited ~9 K cycles for them together, traced; in front of the LDS fill they
+  // only delayed it: vector-memory loads return in order).
+  float4 fg0[4], fo0[4];
+  {
+    const int m = wave * 16 + lr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool ok = wave < MT && m < P;
+      fg0[c] = ok ? *(const float4*)(dO + (row0 + m) * D + head * HD + 4 * (4 * c + lg)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      fo0[c] = ok ? *(const float4*)(O + (row0 + m) * D + head * HD + 4 * (4 * c + lg)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
 
   // ---- phase 1: Q~ = log2(e) * (I + T_w) q, in place (the forward's sliding-window stencil)
-  constexpr int RUN = (BM * 16 + NW * 64 - 1) / (NW * 64);
-  const int half = epeg_k >> 1;
-  const float* w = pe_w + head * epeg_k;
   {
-    auto tap = [&](int t) {
-      float wt = (t >= 0 && t < epeg_k) ? w[t] : 0.f;
-      if (t == half) wt += 1.0f;
-      return wt * LOG2E;
-    };
+    auto tap = [&](int t) { return tapsF[t + RUN - 1]; };
     const int s = tid & 15, g = tid >> 4;
     const int r0 = g * RUN;
     float4 out[RUN];
@@ -199,12 +263,17 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     const int m = i0 + lr;
     float4 fq[4], fg[4];
     load_frags(Qt, m, lg, fq);
-    global_frags(dO, (size_t)D, m, fg);
     // D_i = <dO_i, O_i>: this lane's 16 of the 64 dims, then across the 4 lane groups
     float dsum = 0.f;
     {
       float4 fo[4];
-      global_frags(O, (size_t)D, m, fo);
+      if (ps == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { fg[c] = fg0[c]; fo[c] = fo0[c]; }
+      } else {
+        global_frags(dO, (size_t)D, m, fg);
+        global_frags(O, (size_t)D, m, fo);
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         dsum += (fg[c].x * fo[c].x + fg[c].y * fo[c].y) + (fg[c].z * fo[c].z + fg[c].w * fo[c].w);
@@ -239,12 +308,20 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     }
     if (ps == 0) RRT_TRACE_MARK();                  // [5] first tile: scores + softmax
     {
-      f32x4 da[MT];
-      tile_scores<MT>(Xs, fg, lr, lg, da);          // dA[query lr][key]  (Xs = V)
+      // dA[query lr][key] = dO . V^T in runs of three key tiles (Xs = V), folded into dS as each run arrives
+      auto krun = [&](auto nc, const int t0) {
+        constexpr int N = decltype(nc)::value;
+        f32x4 da[N];
+        run_scores<N>(Xs, fg, lr, lg, t0, da);
 #pragma unroll
-      for (int jt = 0; jt < MT; ++jt)
+        for (int u = 0; u < N; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[jt][r] = s[jt][r] * inv * (da[jt][r] - dsum);   // dS (masked keys: A = 0)
+          for (int r = 0; r < 4; ++r) s[t0 + u][r] = s[t0 + u][r] * inv * (da[u][r] - dsum);   // dS (masked keys: A = 0)
+      };
+#pragma unroll
+      for (int t0 = 0; t0 + 3 <= MT; t0 += 3) krun(std::integral_constant<int, 3>{}, t0);
+      if constexpr (MT % 3 == 1) krun(std::integral_constant<int, 1>{}, MT - 1);
+      if constexpr (MT % 3 == 2) krun(std::integral_constant<int, 2>{}, MT - 2);
     }
     if (ps == 0) RRT_TRACE_MARK();                  // [6] first tile: dA, dS
     f32x4 dqt[4];
@@ -259,6 +336,14 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     if (ps == 0) RRT_TRACE_MARK();                  // [7] first tile: dQ~ parked
   }
   RRT_TRACE_MARK();                                 // [8] pass A done (this wave)
+  float4 fv0[4];                                    // pass B's first tile: its V rows, requested under the barrier + dO refill
+  {
+    const int m = wave * 16 + lr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      fv0[c] = (wave < MT && m < P) ? *(const float4*)(qkv + 2 * D + (row0 + m) * ld + head * HD + 4 * (4 * c + lg))
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();                                  // V is dead: the third tile becomes dO
   for (int idx = tid; idx < BM * 16; idx += NW * 64) {
     const int m = idx >> 4, s = idx & 15;
@@ -277,27 +362,40 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     const int m = j0 + lr;
     float4 fk[4], fv[4];
     load_frags(Ks, m, lg, fk);
-    global_frags(qkv + 2 * D, (size_t)ld, m, fv);
-    f32x4 a[MT], ds[MT];
-    tile_scores<MT>(Qt, fk, lr, lg, a);             // a[it][r] = S2[query 16 it + 4 lg + r][key lr]
-    tile_scores<MT>(Xs, fv, lr, lg, ds);            // dA[query][key lr]  (Xs = dO)
-    if (ps == 0) RRT_TRACE_MARK();                  // [10] first key tile: S^T, dA^T
+    if (ps == 0) {
 #pragma unroll
-    for (int it = 0; it < MT; ++it)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = it * 16 + 4 * lg + r;
-        // rows past the region: lse / dd were never written there (0 x garbage would be NaN)
-        const float p = q < P ? __builtin_amdgcn_exp2f(a[it][r] - lse[q]) : 0.f;
-        a[it][r] = p;
-        ds[it][r] = q < P ? p * (ds[it][r] - dd[q]) : 0.f;
-      }
-    if (ps == 0) RRT_TRACE_MARK();                  // [11] first key tile: A, dS
+      for (int c = 0; c < 4; ++c) fv[c] = fv0[c];
+    } else {
+      global_frags(qkv + 2 * D, (size_t)ld, m, fv);
+    }
     f32x4 dv[4], dk[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) dv[c] = dk[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tile_apply<MT>(Xs, a, lr, lg, dv);              // dV[key 4 lg + r][d = 4 lr + c]
-    tile_apply<MT>(Qt, ds, lr, lg, dk);
+    // query tiles in runs of three: S^T and dA^T of the run, A and dS from them, the run's share of dV and dK
+    auto qrun = [&](auto nc, const int t0) {
+      constexpr int N = decltype(nc)::value;
+      f32x4 a[N], ds[N];
+      run_scores<N>(Qt, fk, lr, lg, t0, a);         // a[u][r] = S2[query 16 (t0 + u) + 4 lg + r][key lr]
+      run_scores<N>(Xs, fv, lr, lg, t0, ds);        // dA[query][key lr]  (Xs = dO)
+#pragma unroll
+      for (int u = 0; u < N; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = (t0 + u) * 16 + 4 * lg + r;
+          // rows past the region: lse / dd were never written there (0 x garbage would be NaN)
+          const float p = q < P ? __builtin_amdgcn_exp2f(a[u][r] - lse[q]) : 0.f;
+          a[u][r] = p;
+          ds[u][r] = q < P ? p * (ds[u][r] - dd[q]) : 0.f;
+        }
+      run_apply<N>(Xs, a, lr, lg, t0, dv);          // dV[key 4 lg + r][d = 4 lr + c]
+      run_apply<N>(Qt, ds, lr, lg, t0, dk);
+    };
+#pragma unroll
+    for (int t0 = 0; t0 + 3 <= MT; t0 += 3) qrun(std::integral_constant<int, 3>{}, t0);
+    if constexpr (MT % 3 == 1) qrun(std::integral_constant<int, 1>{}, MT - 1);
+    if constexpr (MT % 3 == 2) qrun(std::integral_constant<int, 2>{}, MT - 2);
+    if (ps == 0) RRT_TRACE_MARK();                  // [10] first key tile: S^T, dA^T ... (runs)
+    if (ps == 0) RRT_TRACE_MARK();                  // [11]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = j0 + 4 * lg + r;
@@ -331,12 +429,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
 
   // ---- dq_raw = q_scale * (I + T_w)^T dQ~ : the stencil with flipped taps; rows stay inside the region
   {
-    auto tapf = [&](int t) {                        // weight of source row j for output row i, t = j - i + half
-      const int tt = epeg_k - 1 - t;                // flipped
-      float wt = (t >= 0 && t < epeg_k && tt >= 0) ? w[tt] : 0.f;
-      if (t == half) wt += 1.0f;
-      return wt * q_scale;
-    };
+    auto tapf = [&](int t) { return tapsA[t + RUN - 1]; };   // weight of source row j for output row i, t = j - i + half (flipped taps)
     const int s = tid & 15, g = tid >> 4;
     const int r0 = g * RUN;
     if (r0 < P) {
