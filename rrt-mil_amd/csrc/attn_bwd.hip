@@ -141,7 +141,15 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
   float* Xs = Ks + TILE;                // V (pass A), dO (pass B), dQ~ (stencil adjoint)
   float* lse = Xs + TILE;               // [BM] row log-sum-exp, base 2
   float* dd = lse + BM;                 // [BM] D_i
-  float* wred = dd + BM;                // [6][64] wave partials of the tap gradients
+  float* wred = dd + BM;                // [9][64]: the stencils' tap tables (256 floats)
+  // Nine row tiles on four SIMDs are 3 : 2 : 2 : 2 whichever wave takes the ninth (traced: both passes waited ~20 K cycles
+  // for SIMD 0).  HELP (MT = 9, NW = 12): waves 0..7 own tiles 0..7, and the ninth is SHARED OUT to waves 8..11 -- one per
+  // SIMD -- by key tiles in pass A (its row statistics merged through LDS behind one extra barrier) and by query tiles in
+  // pass B; the four partial dQ~ / dK / dV tiles are summed in wave order (fixed order: bit-reproducible).
+  constexpr bool HELP = MT == 9 && NW == 12;
+  constexpr int XT = MT - 1;
+  float* const hstat = wred + 9 * 64;   // [4][32]: local max [16], local sum [16] of the shared-out tile's queries
+  float* const hpart = hstat + 128;     // [4][2][16 x 64] partial tiles
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
   const int reg = blockIdx.x / heads, head = blockIdx.x - reg * heads;
   const size_t row0 = (size_t)reg * P;
   const int ld = 3 * D;
-  RRT_TRACE_INIT(blockIdx.x * 16 + wave);            // (up to nine waves per block; 512 blocks fill the trace buffer)
+  RRT_TRACE_INIT(blockIdx.x * 16 + wave);            // (up to twelve waves per block; 512 blocks fill the trace buffer)
   RRT_TRACE_MARK();                                 // [1] entry
 
   // Tap tables of the two stencils in LDS (index t + RUN - 1; zero outside [0, k)): forward log2(e) (w[t] + [t == k/2]), adjoint
@@ -190,10 +198,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
   // only delayed it: vector-memory loads return in order).
   float4 fg0[4], fo0[4];
   {
-    const int m = wave * 16 + lr;
+    const int m = (HELP && wave >= XT ? XT : wave) * 16 + lr;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const bool ok = wave < MT && m < P;
+      const bool ok = (HELP || wave < MT) && m < P;
       fg0[c] = ok ? *(const float4*)(dO + (row0 + m) * D + head * HD + 4 * (4 * c + lg)) : make_float4(0.f, 0.f, 0.f, 0.f);
       fo0[c] = ok ? *(const float4*)(O + (row0 + m) * D + head * HD + 4 * (4 * c + lg)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -238,13 +246,14 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
 
   // tile -> wave schedule of the forward fused kernel (balanced per SIMD; at most three tiles per wave)
   auto tile_of = [&](int pass) {
+    if (HELP) return (pass == 0 && wave < XT) ? wave : MT;   // waves 8..11: the shared-out tile, below
     if (NW == MT) return pass == 0 ? wave : MT;     // a wave per tile: no second pass
     if (NW == 4) return wave + 4 * pass;            // 4 waves, one per SIMD: tiles round-robin
     if (pass == 0) return wave;
     if (pass == 1) return wave >= 2 ? wave + 4 : (wave == 0 ? 12 : MT);
     return (wave == 2 || wave == 3) ? wave + 8 : MT;
   };
-  constexpr int NPASS = NW == MT ? 1 : NW == 4 ? (MT + 3) / 4 : 3;
+  constexpr int NPASS = (HELP || NW == MT) ? 1 : NW == 4 ? (MT + 3) / 4 : 3;
   // fragment rows of a [rows, D]-strided global tensor: lane (lr, lg) <- row[4*(4c + lg) .. +3]
   auto global_frags = [&](const float* base, size_t stride, int m, float4 (&f)[4]) {
 #pragma unroll
@@ -307,6 +316,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
       dd[m] = dsum;
     }
     if (ps == 0) RRT_TRACE_MARK();                  // [5] first tile: scores + softmax
+    if (HELP) __syncthreads();                      // barrier X: the shared-out tile's local statistics are in LDS
     {
       // dA[query lr][key] = dO . V^T in runs of three key tiles (Xs = V), folded into dS as each run arrives
       auto krun = [&](auto nc, const int t0) {
@@ -335,16 +345,99 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     }
     if (ps == 0) RRT_TRACE_MARK();                  // [7] first tile: dQ~ parked
   }
+  if constexpr (HELP) {
+    if (wave >= XT) {                               // the ninth query tile against this wave's key tiles
+      const int hq = wave - XT;
+      const int m = XT * 16 + lr;
+      float4 fq[4];
+      load_frags(Qt, m, lg, fq);
+      float dsum = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        dsum += (fg0[c].x * fo0[c].x + fg0[c].y * fo0[c].y) + (fg0[c].z * fo0[c].z + fg0[c].w * fo0[c].w);
+      dsum = sum_xor32(sum_xor16(dsum));
+      auto share = [&](auto nc, const int t0) {
+        constexpr int N = decltype(nc)::value;
+        f32x4 sc[N];
+        run_scores<N>(Ks, fq, lr, lg, t0, sc);
+        float cmax = NEG_BIG;
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if ((t0 + u) * 16 + 4 * lg + r >= P) sc[u][r] = NEG_BIG;
+            cmax = fmaxf(cmax, sc[u][r]);
+          }
+        cmax = max_xor32(max_xor16(cmax));
+        float psum = 0.f;
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(sc[u][r] - cmax);
+            sc[u][r] = e;
+            psum += e;
+          }
+        psum = sum_xor32(sum_xor16(psum));
+        if (lg == 0) {
+          hstat[hq * 32 + lr] = cmax;
+          hstat[hq * 32 + 16 + lr] = psum;
+        }
+        __syncthreads();                            // barrier X
+        float M = NEG_BIG;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) M = fmaxf(M, hstat[w4 * 32 + lr]);
+        float L = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) L += hstat[w4 * 32 + 16 + lr] * __builtin_amdgcn_exp2f(hstat[w4 * 32 + lr] - M);
+        if (hq == 0 && lg == 0) {
+          lse[m] = M + __builtin_amdgcn_logf(L);    // v_log_f32 = log2
+          dd[m] = dsum;
+        }
+        const float scale = __builtin_amdgcn_exp2f(cmax - M) / L;
+        f32x4 da[N];
+        run_scores<N>(Xs, fg0, lr, lg, t0, da);     // dA[query lr][key]  (Xs = V)
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[u][r] = sc[u][r] * scale * (da[u][r] - dsum);
+        f32x4 dqt[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dqt[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        run_apply<N>(Ks, sc, lr, lg, t0, dqt);
+        float* const mine = hpart + hq * 2048;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *(float4*)(mine + (4 * lg + r) * HD + 4 * lr) = make_float4(dqt[0][r], dqt[1][r], dqt[2][r], dqt[3][r]);
+      };
+      if (hq == 0) share(std::integral_constant<int, 3>{}, 0);
+      else share(std::integral_constant<int, 2>{}, 1 + 2 * hq);
+    }
+  }
   RRT_TRACE_MARK();                                 // [8] pass A done (this wave)
   float4 fv0[4];                                    // pass B's first tile: its V rows, requested under the barrier + dO refill
   {
-    const int m = wave * 16 + lr;
+    const int m = (HELP && wave >= XT ? XT : wave) * 16 + lr;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      fv0[c] = (wave < MT && m < P) ? *(const float4*)(qkv + 2 * D + (row0 + m) * ld + head * HD + 4 * (4 * c + lg))
+      fv0[c] = ((HELP || wave < MT) && m < P) ? *(const float4*)(qkv + 2 * D + (row0 + m) * ld + head * HD + 4 * (4 * c + lg))
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();                                  // V is dead: the third tile becomes dO
+  if constexpr (HELP) {                             // the shared-out tile's dQ~: four partials in wave order, parked
+    if (tid < 256) {
+      const int row = tid >> 4, sl = tid & 15;
+      if (XT * 16 + row < P) {
+        float4 a = *(const float4*)(hpart + row * HD + 4 * sl);
+#pragma unroll
+        for (int w4 = 1; w4 < 4; ++w4) {
+          const float4 b = *(const float4*)(hpart + w4 * 2048 + row * HD + 4 * sl);
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        *(float4*)(dq_park + (row0 + XT * 16 + row) * ld + 4 * sl) = a;
+      }
+    }
+  }
   for (int idx = tid; idx < BM * 16; idx += NW * 64) {
     const int m = idx >> 4, s = idx & 15;
     const float4 g4 = m < P ? *(const float4*)(dO + (row0 + m) * D + head * HD + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -407,8 +500,61 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
     }
     if (ps == 0) RRT_TRACE_MARK();                  // [12] first key tile: dV, dK stored
   }
+  if constexpr (HELP) {
+    if (wave >= XT) {                               // the ninth key tile against this wave's query tiles
+      const int hq = wave - XT;
+      const int m = XT * 16 + lr;
+      float4 fk[4];
+      load_frags(Ks, m, lg, fk);
+      auto share = [&](auto nc, const int t0) {
+        constexpr int N = decltype(nc)::value;
+        f32x4 a[N], ds[N];
+        run_scores<N>(Qt, fk, lr, lg, t0, a);
+        run_scores<N>(Xs, fv0, lr, lg, t0, ds);
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = (t0 + u) * 16 + 4 * lg + r;
+            const float p = q < P ? __builtin_amdgcn_exp2f(a[u][r] - lse[q]) : 0.f;
+            a[u][r] = p;
+            ds[u][r] = q < P ? p * (ds[u][r] - dd[q]) : 0.f;
+          }
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dv[c] = dk[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        run_apply<N>(Xs, a, lr, lg, t0, dv);
+        run_apply<N>(Qt, ds, lr, lg, t0, dk);
+        float* const mine = hpart + hq * 2048;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          *(float4*)(mine + (4 * lg + r) * HD + 4 * lr) = make_float4(dv[0][r], dv[1][r], dv[2][r], dv[3][r]);
+          *(float4*)(mine + 1024 + (4 * lg + r) * HD + 4 * lr) = make_float4(dk[0][r], dk[1][r], dk[2][r], dk[3][r]);
+        }
+      };
+      if (hq == 0) share(std::integral_constant<int, 3>{}, 0);
+      else share(std::integral_constant<int, 2>{}, 1 + 2 * hq);
+    }
+  }
   RRT_TRACE_MARK();                                 // [13] pass B done (this wave)
   __syncthreads();                                  // every read of the dO tile is done; parked dQ~ rows are visible
+  if constexpr (HELP) {                             // the shared-out tile's dV / dK: four partials in wave order
+    if (tid < 512) {
+      const int which = tid >> 8, row = (tid & 255) >> 4, sl = tid & 15;
+      const int key = XT * 16 + row;
+      if (key < P) {
+        float4 a = *(const float4*)(hpart + which * 1024 + row * HD + 4 * sl);
+#pragma unroll
+        for (int w4 = 1; w4 < 4; ++w4) {
+          const float4 b = *(const float4*)(hpart + w4 * 2048 + which * 1024 + row * HD + 4 * sl);
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float* dst = dqkv + (row0 + key) * ld + head * HD + 4 * sl;
+        if (which == 0) *(float4*)(dst + 2 * D) = a;
+        else *(float4*)(dst + D) = make_float4(a.x * LN2, a.y * LN2, a.z * LN2, a.w * LN2);
+      }
+    }
+  }
 
   // ---- parked dQ~ rows -> LDS over the dead dO tile (rows >= P: zeros)
   // ... and the stashed q rows back over the dead Q~ tile: the tap gradients pair dQ~ rows with q rows k/2 apart
@@ -520,11 +666,18 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
 template <int MT>
 hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, const float* dO, float* dqkv,
                          float* dpe_part, int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st) {
-  constexpr size_t LDS = ((size_t)3 * 16 * MT * HD + 2 * 16 * MT + 9 * 64) * sizeof(float);
+  constexpr size_t LDS = ((size_t)3 * 16 * MT * HD + 2 * 16 * MT + 9 * 64 + (MT == 9 ? 128 + 4 * 2048 : 0)) * sizeof(float);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   const float q_scale = 1.0f / sqrtf((float)HD);
   static const bool six = rrt_tune_env("RRT_ATTN_BWD_NW6") != nullptr;     // tuning hook (A/B of the two schedules)
-  if (MT == 9 && !six) {            // a wave per tile, three waves per SIMD at <= 168 VGPRs
+  static const bool nine = rrt_tune_env("RRT_ATTN_BWD_NW9") != nullptr;      // tuning hook: a wave per tile, no helpers
+  if (MT == 9 && !six && !nine) {   // eight tile waves + four helper waves sharing the ninth tile (three waves per SIMD)
+    auto kern = attn_bwd_kernel<MT, MT == 9 ? 12 : 6>;
+    static OncePerDevice once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    kern<<<dim3(n_regions * heads), dim3(768), LDS, st>>>(qkv, pe_w, O, dO, dqkv, dpe_part, P, D, heads,
+                                                          pe_w ? epeg_k : 0, q_scale);
+  } else if (MT == 9 && !six) {     // a wave per tile, three waves per SIMD at <= 168 VGPRs
     auto kern = attn_bwd_kernel<MT, MT == 9 ? 9 : 6>;
     static OncePerDevice once;
     if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
