@@ -220,6 +220,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
       float wr[RUN];
 #pragma unroll
       for (int o = 0; o < RUN; ++o) wr[o] = tap(lo - r0 - o + half);
+#pragma unroll 4
       for (int rr = lo; rr <= hi; ++rr) {
         const float4 v = *(const float4*)(Qt + rr * HD + ((s ^ (rr & 15)) << 2));
         const float wnext = tap(rr + 1 - r0 + half);
@@ -586,6 +587,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_kernel(const float* __res
       float wr[RUN];
 #pragma unroll
       for (int o = 0; o < RUN; ++o) wr[o] = tapf(lo - r0 - o + half);
+#pragma unroll 4
       for (int rr = lo; rr <= hi; ++rr) {
         const float4 v = *(const float4*)(Gs + rr * HD + ((s ^ (rr & 15)) << 2));
         const float wnext = tapf(rr + 1 - r0 + half);
