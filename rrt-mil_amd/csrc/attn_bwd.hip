@@ -685,6 +685,13 @@ hipError_t launch_bwd_mt(const float* qkv, const float* pe_w, const float* O, co
     if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     kern<<<dim3(n_regions * heads), dim3(576), LDS, st>>>(qkv, pe_w, O, dO, dqkv, dpe_part, P, D, heads,
                                                           pe_w ? epeg_k : 0, q_scale);
+  } else if ((MT == 7 || MT == 8 || MT == 11) && !six && !nine) {   // a wave per tile (P = 121 / 128: 146 -> ? us with eight waves, two per SIMD)
+    constexpr int NWT = (MT == 7 || MT == 8 || MT == 11) ? MT : 6;
+    auto kern = attn_bwd_kernel<MT, NWT>;
+    static OncePerDevice once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    kern<<<dim3(n_regions * heads), dim3(NWT * 64), LDS, st>>>(qkv, pe_w, O, dO, dqkv, dpe_part, P, D, heads,
+                                                               pe_w ? epeg_k : 0, q_scale);
   } else if (MT >= 11 && !six) {           // measured: 9 tiles 221 (6 waves) vs 241 us; 11: 350 vs 291; 13: 516 vs 400
     auto kern = attn_bwd_kernel<MT, 4>;
     static OncePerDevice once;
