@@ -1003,6 +1003,118 @@ __global__ __launch_bounds__(256) void attn_adjoint_kernel(const float* __restri
   }
 }
 
+// The same adjoint step with both tiles in LDS, for regions of up to 256 tokens (the streaming path's P = 225 / 256: bags of
+// 12.6-16 k tokens at region_num = 8): block = (region, head), eight waves; dQ~ rows (parked in the dq columns) and the stashed
+// q rows staged once as XOR-swizzled [BM][64] tiles, the stencil's flipped taps from an LDS table, the tap gradients in one
+// sliding pass with a fixed-order reduction -- the resident kernel's last two phases.  (attn_adjoint_kernel above walks global
+// memory: every output row re-reads its k source rows, every tap its q row: 170 us at P = 256, 21 % of that backward.)
+__global__ __launch_bounds__(512) void attn_adjoint_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ pe_w,
+                                                               float* __restrict__ dqkv, float* __restrict__ dpe_part, int P,
+                                                               int D, int heads, int epeg_k, float q_scale) {
+  constexpr int BM = 256, NW = 8, RUN = BM * 16 / (NW * 64);      // 8 rows per thread
+  static_assert(2 * RUN + 62 < 128, "tap table range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const Gs = (float*)smem;                   // dQ~ tile
+  float* const Qs = Gs + BM * HD;                   // q tile (as stashed: scaled, + bias)
+  float* const tapsA = Qs + BM * HD;                // [128]
+  float* const rec = tapsA + 128;                   // [NW][16 slots][16 taps]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.x, reg = blockIdx.y;
+  const size_t row0 = (size_t)reg * P;
+  const int ld = 3 * D, half = epeg_k >> 1;
+  if (tid < 128) {
+    const int t = tid - (RUN - 1);
+    const bool in = epeg_k > 0 && t >= 0 && t < epeg_k;
+    tapsA[tid] = ((in ? pe_w[head * epeg_k + epeg_k - 1 - t] : 0.f) + (t == half ? 1.0f : 0.f)) * q_scale;
+  }
+  for (int idx = tid; idx < BM * 16; idx += NW * 64) {
+    const int m = idx >> 4, sl = idx & 15;
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), q4 = g4;
+    if (m < P) {
+      g4 = *(const float4*)(dqkv + (row0 + m) * ld + head * HD + 4 * sl);
+      if (epeg_k > 0) q4 = *(const float4*)(qkv + (row0 + m) * ld + head * HD + 4 * sl);
+    }
+    const int off = m * HD + ((sl ^ (m & 15)) << 2);
+    *(float4*)(Gs + off) = g4;
+    *(float4*)(Qs + off) = q4;
+  }
+  __syncthreads();
+  const int s = tid & 15, g = tid >> 4;
+  const int r0 = g * RUN;
+  // dq_raw = q_scale (I + T_w)^T dQ~
+  if (r0 < P) {
+    float4 out[RUN];
+#pragma unroll
+    for (int o = 0; o < RUN; ++o) out[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int lo = max(r0 - half, 0), hi = min(r0 + RUN - 1 + half, P - 1);
+    float wr[RUN];
+#pragma unroll
+    for (int o = 0; o < RUN; ++o) wr[o] = tapsA[lo - r0 - o + half + RUN - 1];
+#pragma unroll 4
+    for (int rr = lo; rr <= hi; ++rr) {
+      const float4 v = *(const float4*)(Gs + rr * HD + ((s ^ (rr & 15)) << 2));
+      const float wnext = tapsA[rr + 1 - r0 + half + RUN - 1];
+#pragma unroll
+      for (int o = 0; o < RUN; ++o) {
+        out[o].x += wr[o] * v.x; out[o].y += wr[o] * v.y; out[o].z += wr[o] * v.z; out[o].w += wr[o] * v.w;
+      }
+#pragma unroll
+      for (int o = RUN - 1; o > 0; --o) wr[o] = wr[o - 1];
+      wr[0] = wnext;
+    }
+#pragma unroll
+    for (int o = 0; o < RUN; ++o) {
+      const int i = r0 + o;
+      if (i < P) *(float4*)(dqkv + (row0 + i) * ld + head * HD + 4 * s) = out[o];
+    }
+  }
+  // tap gradients: dw[t] = sum_i <dQ~_i, q_{i + t - half}>
+  if (epeg_k > 0) {
+    float4 gq[RUN];
+#pragma unroll
+    for (int o = 0; o < RUN; ++o) {
+      const int i = r0 + o;
+      gq[o] = *(const float4*)(Gs + i * HD + ((s ^ (i & 15)) << 2));     // rows >= P are zero in the tile
+    }
+    for (int t0 = 0; t0 < epeg_k; t0 += 16) {
+      float acc[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 16 + RUN - 1; ++jj) {
+        const int j = r0 + t0 - half + jj;
+        const bool ok = j >= 0 && j < P;
+        const int jc = ok ? j : 0;
+        float4 q4 = *(const float4*)(Qs + jc * HD + ((s ^ (jc & 15)) << 2));
+        if (!ok) q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < RUN; ++o) {
+          const int u = jj - o;
+          if (u >= 0 && u < 16)
+            acc[u] += (gq[o].x * q4.x + gq[o].y * q4.y) + (gq[o].z * q4.z + gq[o].w * q4.w);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] = sum_xor32(sum_xor16(acc[u]));
+      if (t0 > 0) __syncthreads();
+      if (lane < 16) {
+#pragma unroll
+        for (int u = 0; u < 16; u += 4)
+          *(float4*)(rec + (wave * 16 + lane) * 16 + u) = make_float4(acc[u], acc[u + 1], acc[u + 2], acc[u + 3]);
+      }
+      __syncthreads();
+      if (tid < 256) {
+        const int u = tid >> 4, sl = tid & 15;
+        float a = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) a += rec[(wv * 16 + sl) * 16 + u];
+        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+        if (sl == 0 && t0 + u < epeg_k) dpe_part[((size_t)reg * heads + head) * epeg_k + t0 + u] = a;
+      }
+    }
+  }
+}
+
 // ---- any head dim (crmsa_heads = 1 -> head dim = dim), no EPEG, short sequences: CR-MSA's inner attention over
 // the k x 64 representatives.  VALU only: one block per (sequence, head), a wave per query / key row, the head dim
 // across the lanes; A and dS [P, P] in LDS.  (Published TCGA-BRCA-R50 / NSCLC-PLIP configs: 3 x 64 rows.)
@@ -1158,8 +1270,16 @@ hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const 
     }
     attn_bwd_q_kernel<<<dim3(heads, n_regions, groups), 384, lq, st>>>(qkv, qt, O, dO, dqkv, lse_g, dd_g, P, D, heads);
     attn_bwd_kv_kernel<<<dim3(heads, n_regions, groups), 384, lkv, st>>>(qkv, qt, dO, lse_g, dd_g, dqkv, P, D, heads);
-    attn_adjoint_kernel<<<dim3(heads, n_regions), 256, 0, st>>>(qkv, pe_w, dqkv, tmp, dpe_part, P, D, heads, epeg_k,
-                                                                 q_scale);
+    if (P <= 256) {
+      constexpr int LADJ = (2 * 256 * HD + 128 + 8 * 256) * sizeof(float);
+      static OncePerDevice once2;
+      if (once2.first())
+        (void)hipFuncSetAttribute((const void*)attn_adjoint_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LADJ);
+      attn_adjoint_lds_kernel<<<dim3(heads, n_regions), 512, LADJ, st>>>(qkv, pe_w, dqkv, dpe_part, P, D, heads, epeg_k, q_scale);
+    } else {
+      attn_adjoint_kernel<<<dim3(heads, n_regions), 256, 0, st>>>(qkv, pe_w, dqkv, tmp, dpe_part, P, D, heads, epeg_k,
+                                                                   q_scale);
+    }
     e = hipGetLastError();
   } else if (P > 176) e = launch_bwd_mt<13>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   else if (P > 144) e = launch_bwd_mt<11>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);

@@ -906,7 +906,7 @@ def test_layernorm_backward(L, D, rn):
                                             (3, 169, 512, 8, 15), (2, 196, 512, 8, 21), (2, 208, 512, 8, 0),
                                             (3, 177, 256, 4, 9),
                                             # streaming variant: regions beyond the resident kernel's 208 tokens
-                                            (2, 256, 512, 8, 15), (1, 484, 512, 8, 21), (2, 324, 256, 4, 0),
+                                            (2, 256, 512, 8, 15), (2, 225, 512, 8, 21), (3, 240, 512, 8, 0), (1, 484, 512, 8, 21), (2, 324, 256, 4, 0),
                                             (3, 209, 512, 8, 9),
                                             # generic head dims (crmsa_heads = 1: head dim = dim), no EPEG
                                             (3, 64, 512, 1, 0), (5, 64, 512, 2, 0), (3, 64, 96, 1, 0), (1, 100, 64, 8, 0)])
