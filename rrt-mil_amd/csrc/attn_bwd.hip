@@ -760,7 +760,7 @@ __device__ __forceinline__ void load_chunk(float* dst, const float* src, size_t 
   }
 }
 
-__global__ __launch_bounds__(384) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ qt,
+__global__ __launch_bounds__(384, 3) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ qt,
                                                          const float* __restrict__ O, const float* __restrict__ dO,
                                                          float* __restrict__ dqkv, float* __restrict__ lse_g,
                                                          float* __restrict__ dd_g, int P, int D, int heads) {
@@ -832,21 +832,26 @@ __global__ __launch_bounds__(384) void attn_bwd_q_kernel(const float* __restrict
     load_chunk(Vs, qkv + 2 * D + head * HD, (size_t)ld, row0, r0, P, tid);
     __syncthreads();
     if (active) {
-      f32x4 s[CT];
-      tile_scores<CT>(Ks, fq, lr, lg, s);
-      {
-        f32x4 da[CT];
-        tile_scores<CT>(Vs, fg, lr, lg, da);
+      // the chunk's key tiles in runs of three (as in the resident kernel: a run's scores are all that is live)
+      auto krun = [&](auto nc, const int t0) {
+        constexpr int N = decltype(nc)::value;
+        f32x4 sc[N], da[N];
+        run_scores<N>(Ks, fq, lr, lg, t0, sc);
+        run_scores<N>(Vs, fg, lr, lg, t0, da);
 #pragma unroll
-        for (int jt = 0; jt < CT; ++jt)
+        for (int u = 0; u < N; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = r0 + jt * 16 + 4 * lg + r < P;
-            const float p = ok ? __builtin_amdgcn_exp2f(s[jt][r] - lse) : 0.f;
-            s[jt][r] = p * (da[jt][r] - dsum);
+            const bool ok = r0 + (t0 + u) * 16 + 4 * lg + r < P;
+            const float p = ok ? __builtin_amdgcn_exp2f(sc[u][r] - lse) : 0.f;
+            sc[u][r] = p * (da[u][r] - dsum);
           }
-      }
-      tile_apply<CT>(Ks, s, lr, lg, dqt);
+        run_apply<N>(Ks, sc, lr, lg, t0, dqt);
+      };
+      static_assert(CT == 8, "runs below assume eight row tiles per chunk");
+      krun(std::integral_constant<int, 3>{}, 0);
+      krun(std::integral_constant<int, 3>{}, 3);
+      krun(std::integral_constant<int, 2>{}, 6);
     }
   }
   if (active) {
@@ -903,21 +908,27 @@ __global__ __launch_bounds__(384) void attn_bwd_kv_kernel(const float* __restric
     }
     __syncthreads();
     if (active) {
-      f32x4 a[CT], ds[CT];
-      tile_scores<CT>(Qs, fk, lr, lg, a);
-      tile_scores<CT>(Gs, fv, lr, lg, ds);
+      auto qrun = [&](auto nc, const int t0) {
+        constexpr int N = decltype(nc)::value;
+        f32x4 a[N], ds[N];
+        run_scores<N>(Qs, fk, lr, lg, t0, a);
+        run_scores<N>(Gs, fv, lr, lg, t0, ds);
 #pragma unroll
-      for (int it = 0; it < CT; ++it)
+        for (int u = 0; u < N; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = it * 16 + 4 * lg + r;
-          const bool ok = r0 + q < P;
-          const float p = ok ? __builtin_amdgcn_exp2f(a[it][r] - lse[q]) : 0.f;
-          a[it][r] = p;
-          ds[it][r] = ok ? p * (ds[it][r] - dd[q]) : 0.f;
-        }
-      tile_apply<CT>(Gs, a, lr, lg, dv);
-      tile_apply<CT>(Qs, ds, lr, lg, dk);
+          for (int r = 0; r < 4; ++r) {
+            const int q = (t0 + u) * 16 + 4 * lg + r;
+            const bool ok = r0 + q < P;
+            const float p = ok ? __builtin_amdgcn_exp2f(a[u][r] - lse[q]) : 0.f;
+            a[u][r] = p;
+            ds[u][r] = ok ? p * (ds[u][r] - dd[q]) : 0.f;
+          }
+        run_apply<N>(Gs, a, lr, lg, t0, dv);
+        run_apply<N>(Qs, ds, lr, lg, t0, dk);
+      };
+      qrun(std::integral_constant<int, 3>{}, 0);
+      qrun(std::integral_constant<int, 3>{}, 3);
+      qrun(std::integral_constant<int, 2>{}, 6);
     }
   }
   if (active) {
