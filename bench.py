@@ -65,7 +65,26 @@ if ROOT not in sys.path:
 DIM = 512
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (f32 in / bf16 in)
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # tools/pmc_to_traffic.py, from the PMC passes
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")   # tools/pmc_to_traffic.py, from the PMC passes
+ROCPROF_FILE = os.path.join(ROOT, "profiles", "r04_rocprof_dominant.json")   # tools/rocprof_union.py, from --kernel-trace runs
+if not os.path.exists(TRAFFIC_FILE):
+    TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+
+
+def rocprof_record(config, dtype, streams):
+    """The dominant kernel's duration in the committed rocprofv3 kernel trace of this (config, dtype, streams): mean
+    dispatch duration and union-of-intervals per launch (tools/rocprof_union.py writes the file), or None."""
+    try:
+        with open(ROCPROF_FILE) as fh:
+            r = json.load(fh).get(f"c{config}_{dtype}_s{streams}")
+    except (OSError, ValueError):
+        return None
+    if not r:
+        return None
+    r = dict(r)
+    r["source"] = os.path.relpath(ROCPROF_FILE, ROOT)
+    return r
+
 
 
 # kernels that ARE the R-MSA core of a layer (one launch per layer and forward); "rmsa_fused16_kernel<4" is not in the
@@ -319,12 +338,16 @@ class EncoderWorkload:
             self.outs = [torch.empty_like(self.bags[0]) for _ in range(S)]
         self.enc._desc.compute = self.compute
         self.enc._desc.solo = int(S == 1)        # scheduling hint: with S > 1 the bags share the GPU (rrt_encoder_desc.solo)
+        if os.environ.get("RRT_BENCH_SOLO") in ("0", "1"):     # (experiments only)
+            self.enc._desc.solo = int(os.environ["RRT_BENCH_SOLO"])
         self.w = self.enc._weights()
-        # one event pair per launch of the dominant kernel in the timed region: every step, every stream
-        # (an event pair costs the stream two marker packets: measured ~5 us per forward, 2 % of an fp32 bag and 10 % of a
-        #  bf16 one -- so every EV_EVERY-th step is instrumented, at least 8 steps)
-        self.ev_every = max(1, min(4, args.steps // 8))
-        self.ev_pairs = [(self.hev.create(), self.hev.create()) for _ in range(((args.steps + self.ev_every - 1) // self.ev_every) * S)]
+        # one event pair per launch of the dominant kernel over a WINDOW of consecutive steps in the middle of the timed
+        # region, every stream (an event pair costs the stream two marker packets: measured ~5 us per forward, 2 % of an
+        # fp32 bag and 10 % of a bf16 one -- so the window is 6 steps, not the whole region).  Consecutive steps, all
+        # streams: the launches' intervals can then be merged into the time during which the kernel was running at all.
+        self.ev_win = min(6, args.steps)
+        self.ev_w0 = (args.steps - self.ev_win) // 2
+        self.ev_pairs = [(self.hev.create(), self.hev.create()) for _ in range(self.ev_win * S)]
         self.ev_arr = (C.c_void_p * _lib.EV_COUNT)()
         # optional phase gate (RRT_BENCH_GATE=1): the bags' MFMA-bound R-MSA cores take turns instead of time-slicing.
         # Off by default since round 2: with the denser kernels free-running streams are faster at every S
@@ -356,7 +379,8 @@ class EncoderWorkload:
                 _lib.check(rc, "rrt_mil_forward_f32")
                 continue
             # mark the dominant kernel: [after LN+partition, after the fused R-MSA core]
-            evs = self._mark(*self.ev_pairs[(i // self.ev_every) * self.S + s_]) if (timed and i % self.ev_every == 0) else None
+            evs = (self._mark(*self.ev_pairs[(i - self.ev_w0) * self.S + s_])
+                   if (timed and self.ev_w0 <= i < self.ev_w0 + self.ev_win) else None)
             # reduced-precision modes: this stream's workspace keeps the 16-bit weight images of the (unchanged)
             # weights from its first call on, as rrt_mil_amd.RRTEncoder does between forwards (weights16_valid)
             mode = self.enc._desc.compute
@@ -511,17 +535,36 @@ class EncoderWorkload:
                   + (" (projection: fp32 emulated by 3 bf16 MFMAs per product; attention: fp32 MFMA; peak = FLOPs over "
                      "3 x projection / 2.5 PFLOP/s + attention / 157.3 TFLOP/s)" if self.dtype == "f32x3" else ""))
         if self.mil is None:
-            ms = float(np.mean([self.hev.elapsed_ms(a, b) for a, b in self.ev_pairs]))
+            # all events against the window's first one: [start, end] of every launch on one clock
+            ref = self.ev_pairs[0][0]
+            iv = sorted((self.hev.elapsed_ms(ref, a), self.hev.elapsed_ms(ref, b)) for a, b in self.ev_pairs)
+            raw_ms = float(np.mean([e - s for s, e in iv]))
+            busy, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+            for s_, e_ in iv[1:]:
+                if s_ > cur_e:
+                    busy += cur_e - cur_s
+                    cur_s, cur_e = s_, e_
+                else:
+                    cur_e = max(cur_e, e_)
+            busy += cur_e - cur_s
+            ms = busy / len(iv)            # time the kernel was running at all, per launch
             ach = flops / (ms * 1e-3) / 1e12
+            rp = rocprof_record(args.config, self.dtype, self.S)
             rec["roofline"] = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak,
                                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "flops_per_launch": flops,
-                               "avg_launch_ms": round(ms, 5),
+                               "avg_launch_ms": round(ms, 5), "raw_interval_ms": round(raw_ms, 5),
+                               "launches": len(iv), "bags_in_flight": self.S,
                                "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
-                               "note": f"mean over {len(self.ev_pairs)} launches of the timed region (every "
-                                       f"{self.ev_every}. step, all streams; {self.S} bag(s) "
-                                       "in flight per GPU: the other bag's kernels are co-resident on this launch's "
-                                       "CUs for its whole duration and take issue slots from it -- the kernel's own "
-                                       "number is roofline_isolated)"}
+                               "rocprof": rp,
+                               "note": f"{len(iv)} launches = {self.ev_win} consecutive steps x {self.S} stream(s) in the middle of "
+                                       "the timed region, one HIP event pair per launch (recorded by librrt_hip on the launch "
+                                       "stream).  avg_launch_ms = the UNION of the launches' [start, end] intervals / launches: "
+                                       "with several bags in flight launches of different streams overlap and time-slice the "
+                                       "matrix cores, so the mean raw interval (raw_interval_ms) counts the same wall time "
+                                       "several times; the union is the time during which this kernel was running at all "
+                                       "(it still contains whatever the other bags' kernels took from it: the kernel's own "
+                                       "number is roofline_isolated).  `rocprof` = the same two numbers from the committed "
+                                       "rocprofv3 --kernel-trace table of this command (tools/rocprof_union.py)"}
         ach = flops / (iso_ms * 1e-3) / 1e12
         iso = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                "frac": round(ach / peak, 4), "flops_per_launch": flops, "avg_launch_ms": round(iso_ms, 5),
@@ -722,6 +765,18 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, device=None if args.stub_cpu else dev)   # whole-job time = slowest rank
 
+    # run-to-run spread: three more repeats of the same K steps, same bracketing, after the contract's timed region
+    # (rank-local clocks, informational: `value` is the first region, the only one bracketed by the barriers' MAX)
+    spread = []
+    if not args.stub_cpu:
+        for _ in range(3):
+            wl.sync()
+            ts = time.perf_counter()
+            for i in range(args.steps):
+                wl.step(i, False)
+            wl.sync()
+            spread.append(wl.units_global * args.steps / (time.perf_counter() - ts))
+
     rec_extra = wl.finish(args, world, rank, elapsed)
 
     if rank == 0:
@@ -756,9 +811,19 @@ def main():
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
                "scaling": wl.scaling, "vs_baseline": None, "dtype": dtype,
                "data": "stub" if args.stub_cpu else "synthetic", "config": config}
+        if spread:
+            allv = [value] + spread
+            rec["value_spread"] = {"values": [round(v, 1) for v in allv], "min": round(min(allv), 1), "max": round(max(allv), 1),
+                                   "rel": round((max(allv) - min(allv)) / value, 4),
+                                   "note": f"the timed region's value followed by 3 repeats of the same {args.steps} steps "
+                                           "(this rank's clock, no barrier between them)"}
         rec.update(rec_extra)
+        if not args.stub_cpu and world == 1 and cfg["kind"] == "encoder" and not args.no_extras:
+            rec["module_call"] = module_call(wl, dev)
         if not args.stub_cpu and args.config == 1 and world == 1 and not args.no_extras:
             rec.update(extras(wl, dev))
+            for c in (0, 2, 3, 4):
+                rec[f"config{c}"] = config_record(c, dev)
         if not args.stub_cpu and world == 1 and not args.no_cpu_baseline:
             n_cpu = cfg["n"] or 9000          # config 4: the typical bag of the mix
             rec["cpu_baseline"] = cpu_baseline(n_cpu, enc_cfg)
@@ -802,6 +867,92 @@ def h2d_inclusive(wl, dev, n_bags=96):
             "note": "fp32 encoder, N=9000 D=512, one forward stream + the feeder's copy stream; PCIe Gen5 x16 moves ~53 GB/s, i.e. "
                     "~2.9 k of these bags per second: with host-resident bags the link, not the encoder, is the limit "
                     "(rrt_mil_amd/feed.py; reference loop: main.py:434)"}
+
+
+def module_call(wl, dev, n_bags=64):
+    """The boundary the reference exposes is the nn.Module (modules/rrt.py:133-202), not the C ABI the timed region calls:
+    the same bags through `enc(bag)` one at a time (the reference's loop, main.py:466-467; one bag in flight) and through
+    `enc.forward_bags(bags, streams=S)` (S in flight), with the host's own time per forward (the Python + ctypes cost of one
+    call, measured while the GPU queue is far from full, i.e. not waiting for the device)."""
+    import torch
+    enc, S = wl.enc, wl.S
+    bags3 = [b.unsqueeze(0) for b in wl.bags]
+    mode_was, solo_was = enc.compute_dtype, enc.__dict__.get("solo", True)
+    enc.compute_dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "f32x3": "f32x3"}[wl.dtype]
+    out = {"unit": "slides/s", "dtype": wl.dtype, "n_tokens": wl.n}
+    with torch.no_grad():
+        enc.solo = True
+        for i in range(16):
+            y = enc(bags3[i % len(bags3)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_bags):
+            y = enc(bags3[i % len(bags3)])
+        host = time.perf_counter() - t0               # enqueue only: n_bags forwards are ~600 packets, the queue does not fill
+        torch.cuda.synchronize()
+        t1 = time.perf_counter() - t0
+        out["module_loop"] = round(n_bags / t1, 1)
+        out["host_us_per_bag"] = round(host / n_bags * 1e6, 1)
+        batch = [bags3[i % len(bags3)] for i in range(n_bags)]
+        outs = [torch.empty_like(b[0]) for b in batch]
+        enc.forward_bags(batch[:2 * S], streams=S, outs=outs[:2 * S])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enc.forward_bags(batch, streams=S, outs=outs)
+        host_b = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t1 = time.perf_counter() - t0
+        out["forward_bags"] = round(n_bags / t1, 1)
+        out["forward_bags_streams"] = S
+        out["forward_bags_host_us_per_bag"] = round(host_b / n_bags * 1e6, 1)
+        assert torch.isfinite(y).all() and torch.isfinite(outs[-1]).all()
+    enc.compute_dtype, enc.solo = mode_was, solo_was
+    enc._desc.compute = wl.compute
+    out["note"] = (f"{n_bags} device-resident bags: `for bag in bags: enc(bag)` under no_grad through nn.Module.__call__ (one bag "
+                   f"in flight, the reference's loop) and enc.forward_bags(bags, streams={S}) (one executor call); host_us_per_bag "
+                   "= host thread time per forward while the device queue is not full; compare module_loop with "
+                   "one_bag_in_flight.slides_per_s and forward_bags with `value` (both taken at the C ABI)")
+    return out
+
+
+def config_record(c, dev, steps=None):
+    """A bounded single-GPU record of BASELINE configs[c] inside the default run (rank 0, after the timed region): the same
+    workload classes, warm-up + clock-ramp guard + a short timed region; the full record is `bench.py --config c`."""
+    import torch
+    cfg = CONFIGS[c]
+    S = 3 if cfg["dtype"] in ("bf16", "f16") else 2
+    steps = steps or {0: 200, 2: 60, 3: 30, 4: 8}[c]
+    a = argparse.Namespace(config=c, dtype=None, streams=S, steps=steps, warmup=5)
+    t_all = time.perf_counter()
+    wl = (MixWorkload if cfg["kind"] == "mix" else EncoderWorkload)(a, 0, 1, dev)
+    for i in range(a.warmup):
+        wl.step(i, False)
+    wl.sync()
+    stabilise(wl, steps, max_s=1.5)
+    wl.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        wl.step(i, True)
+    wl.sync()
+    el = time.perf_counter() - t0
+    fin = wl.finish(a, 1, 0, el)
+    rec = {"value": round(wl.units_global * steps / el, 1), "unit": "slides/s", "dtype": wl.dtype, "n_gpus": 1,
+           "streams_per_gpu": S, "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
+           "workload": cfg["label"]}
+    roof = fin.get("roofline_isolated") or fin.get("roofline")
+    if roof:
+        rec["dominant_kernel"] = {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms") if k in roof}
+    if "roofline_kernels" in fin:       # every stage against its own bound: HBM GB/s for the streaming stages
+        rec["stages"] = [{k: st[k] for k in ("stage", "bound", "achieved", "peak", "unit", "frac", "avg_ms")}
+                         for st in fin["roofline_kernels"]]
+    if "one_bag_in_flight" in fin:
+        rec["one_bag_in_flight_ms"] = fin["one_bag_in_flight"]["ms_per_bag"]
+    rec.update({k: v for k, v in wl.extra.items() if k in ("tokens_per_step", "cost_imbalance")})
+    del wl
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    rec["wall_s"] = round(time.perf_counter() - t_all, 2)
+    return rec
 
 
 def extras(wl, dev):

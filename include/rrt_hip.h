@@ -101,7 +101,11 @@ typedef struct rrt_encoder_desc {
    * the two calls need not match.  The library keeps no state: 0 is always right, 1 is the caller's promise
    * (rrt_mil_amd tracks parameter versions). */
   int32_t weights16_valid;
-  /* Scheduling hint, no effect on results.  0 (default): other work may share the GPU with this forward (more bags in
+  /* Scheduling hint.  Results are deterministic for a given setting and equal between the two settings up to fp32 summation
+   * order: with 1 the representatives' two small GEMMs sum K in four interleaved groups (linear_splitk), so low-order
+   * bits of the output may differ from a solo = 0 forward of the same bag (both within ~1e-6 of the float64 oracle);
+   * callers that compare bits across entry points use one setting (RRTEncoder.solo; the executor uses 0 unless it has
+   * exactly one stream).  0 (default): other work may share the GPU with this forward (more bags in
    * flight on other streams): every kernel of the latency-bound CR-MSA tail keeps a footprint that fits NEXT TO a block
    * of the other bag's fused R-MSA kernel (<= 4 waves, <= 40 KiB LDS).  1: the forward has the GPU to itself (one bag in
    * flight): the representatives' small GEMMs may take whole CUs (16-wave blocks, K split inside the block: 10 -> 6-7 us

@@ -1374,7 +1374,7 @@ int check_train(const rrt_encoder_desc* d, int64_t N, rrt_grid* g, rrt_grid* g8)
     const bool e2d = d->epeg && d->epeg_2d && d->epeg_type == RRT_EPEG_ATTN, evalue = d->epeg && d->epeg_type != RRT_EPEG_ATTN;
     // (the 2-D 'attn' EPEG has its own backward kernel, any head dim; the value variants run the plain attention backward)
     if (!e2d && !attn_bwd_supported(g->s * g->s, d->dim, d->n_heads, (d->epeg && !evalue) ? d->epeg_k : 0))
-      return unsupported("training: R-MSA needs head dim 64 and regions of <= 208 tokens (N <= 12544 at region_num=8)");
+      return unsupported("training: the R-MSA attention backward needs head dim 64 (any region size, epeg_k <= 63); other head dims only without EPEG on regions of <= 128 tokens, or with epeg_2d");
   }
   rc = rrt_region_grid(N, 8, 0, 0, 0.f, g8);
   if (rc) return rc;
@@ -1640,8 +1640,10 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
   {
     // W^T of every attention Linear, for the dX products (dX = dY . W as the forward GEMM on W^T): one launch up front
     TransposeJobs tj{};
+    // (a NULL weight or a full table used to drop the job silently: the dX product then read an unwritten W^T image)
+    bool tj_bad = false;
     auto add = [&](const float* wsrc, float* wt, int n_out, int k_in) {
-      if (!wsrc || tj.n >= TRANSPOSE_MAX_JOBS) return;
+      if (!wsrc || !wt || tj.n >= TRANSPOSE_MAX_JOBS) { tj_bad = true; return; }
       tj.in[tj.n] = wsrc; tj.out[tj.n] = wt; tj.R[tj.n] = n_out; tj.C[tj.n] = k_in;
       ++tj.n;
     };
@@ -1653,6 +1655,7 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
       add(w->crmsa.qkv_w, b.wt_cr_qkv, 3 * D, D);
       add(w->crmsa.proj_w, b.wt_cr_proj, D, D);
     }
+    if (tj_bad) return RRT_E_INVALID;
     RRT_TRY(launch_transpose_batch(tj, st));
   }
   // final LayerNorm

@@ -116,6 +116,25 @@ __device__ __forceinline__ float wave_min(float v) {
   return fminf(fminf(rrt_readlane(v, 0), rrt_readlane(v, 16)), fminf(rrt_readlane(v, 32), rrt_readlane(v, 48)));
 }
 
+// Streaming accesses of the bag-sized row kernels (LayerNorm + partition, CR-MSA statistics, dispatch + LayerNorm): rows
+// that are read or written ONCE by the kernel.  -DRRT_NT marks them non-temporal (nt: streamed through the caches
+// instead of displacing another kernel's resident operand panels in the XCD's L2).
+#ifdef RRT_NT
+__device__ __forceinline__ float4 ldg_stream(const float* p) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 v = __builtin_nontemporal_load((const f4*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stg_stream(float* p, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store((f4){v.x, v.y, v.z, v.w}, (f4*)p);
+}
+#else
+__device__ __forceinline__ float4 ldg_stream(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ void stg_stream(float* p, float4 v) { *(float4*)p = v; }
+#endif
+#define RRT_LDG_STREAM 1
+
 // 16-byte global -> LDS DMA (global_load_lds_dwordx4): the LDS destination is the
 // wave-uniform byte address `lds_addr` (held in M0) + lane*16; the global source is per lane.
 // Issued through inline asm on purpose: with the builtin, hipcc drains vmcnt(0) before the

@@ -345,8 +345,8 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
     }
     tokv[j] = t;
     const float* src = x1 + (size_t)(t < 0 ? 0 : t) * DIM;
-    r[j][0] = *(const float4*)(src + lane * 4);
-    r[j][1] = *(const float4*)(src + 256 + lane * 4);
+    r[j][0] = ldg_stream(src + lane * 4);
+    r[j][1] = ldg_stream(src + 256 + lane * 4);
   }
   const float4 gm0 = *(const float4*)(gamma + lane * 4), gm1 = *(const float4*)(gamma + 256 + lane * 4);
   const float4 bt0 = *(const float4*)(beta + lane * 4), bt1 = *(const float4*)(beta + 256 + lane * 4);
@@ -573,8 +573,8 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
     }
     tokv[j] = t;
     const float* src = x1 + (size_t)(t < 0 ? 0 : t) * DIM;
-    r[j][0] = *(const float4*)(src + lane * 4);
-    r[j][1] = *(const float4*)(src + 256 + lane * 4);
+    r[j][0] = ldg_stream(src + lane * 4);
+    r[j][1] = ldg_stream(src + 256 + lane * 4);
   }
   const float4 gm0 = *(const float4*)(gamma + lane * 4), gm1 = *(const float4*)(gamma + 256 + lane * 4);
   const float4 bt0 = *(const float4*)(beta + lane * 4), bt1 = *(const float4*)(beta + 256 + lane * 4);
@@ -814,9 +814,9 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      r[i][v] = (FULL || c < dim) ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r[i][v] = (FULL || c < dim) ? ldg_stream(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (x0 && (FULL || c < dim)) {
-        float4 s = *(const float4*)(x0 + (size_t)t * dim + c);
+        float4 s = ldg_stream(x0 + (size_t)t * dim + c);
         r[i][v].x += s.x; r[i][v].y += s.y; r[i][v].z += s.z; r[i][v].w += s.w;
       }
     }
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         int c = (v * 64 + lane) * 4;
-        if (FULL || c < dim) *(float4*)(y + (size_t)(t0 + i) * dim + c) = r[i][v];
+        if (FULL || c < dim) stg_stream(y + (size_t)(t0 + i) * dim + c, r[i][v]);
       }
     }
     return;
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
           o.y = (r[i][v].y - mean[i]) * rstd[i] * gm.y + bt.y;
           o.z = (r[i][v].z - mean[i]) * rstd[i] * gm.z + bt.z;
           o.w = (r[i][v].w - mean[i]) * rstd[i] * gm.w + bt.w;
-          *(float4*)(y + (size_t)(t0 + i) * dim + c) = o;
+          stg_stream(y + (size_t)(t0 + i) * dim + c, o);
         }
     }
   }

@@ -12,6 +12,7 @@ rrt_encoder_backward_f32 (train() adds proj dropout and stochastic depth, eval()
 There is no PyTorch/CPU fallback: CPU tensors and configurations outside the HIP path raise.
 """
 import warnings
+import contextlib
 import ctypes as C
 import math
 
@@ -252,6 +253,9 @@ def _warn_hw_queues(streams):
                       "process initialises HIP (before `import torch`); see INTEGRATION.md section 5.", RuntimeWarning)
 
 
+_NULL_CTX = contextlib.nullcontext()
+
+
 class RRTEncoder(nn.Module):
     def __init__(self, mlp_dim=512, pos_pos=0, pos='none', peg_k=7, attn='rmsa', region_num=8,
                  drop_out=0.1, n_layers=2, n_heads=8, drop_path=0., ffn=False, ffn_act='gelu',
@@ -336,23 +340,47 @@ class RRTEncoder(nn.Module):
         return w
 
     def _weights_version(self):
-        """A number that changes whenever an R-MSA qkv / proj weight does (storage pointer or autograd version counter:
+        """A number that changes whenever ANY parameter of the encoder does (storage pointer or autograd version counter:
         optimizer steps, load_state_dict, .to(), in-place ops all bump one of them; writes through ``p.data`` do not --
         call invalidate_weight_cache() after those).  Lets the library keep the 16-bit weight images of the
-        reduced-precision modes across calls (rrt_encoder_desc.weights16_valid, rrt_encoder_weights.version)."""
-        fp = tuple((p.data_ptr(), p._version) for layer in self.layers.children()
-                   for p in (layer.attn.attn.qkv.weight, layer.attn.attn.proj.weight))
-        if fp != getattr(self, "_w_fp", None):
-            self._w_fp, self._w_ver = fp, getattr(self, "_w_ver", 0) + 1
+        reduced-precision modes across calls (rrt_encoder_desc.weights16_valid, rrt_encoder_weights.version) -- the
+        R-MSA layers' qkv / proj images AND CR-MSA's inner qkv / proj images (round-3 advisor finding: the fingerprint
+        used to cover the R-MSA layers only, so a CR-MSA-only update, or any update at n_layers = 1, kept stale images) --
+        and lets this module keep its ctypes weight struct between calls."""
+        slots = self.__dict__.get("_plist")
+        if slots is None:
+            # (the modules' own parameter dicts, not the Parameter objects: assigning a new nn.Parameter to an existing
+            #  submodule is then seen too; replacing a whole submodule needs invalidate_weight_cache())
+            slots = self.__dict__["_plist"] = [(m._parameters, k) for m in self.modules() for k in m._parameters
+                                               if m._parameters[k] is not None]
+        fp = tuple([(d[k].data_ptr(), d[k]._version) for d, k in slots])
+        if fp != self.__dict__.get("_w_fp"):
+            self.__dict__["_w_fp"], self.__dict__["_w_ver"] = fp, self.__dict__.get("_w_ver", 0) + 1
+            self.__dict__["_w_struct"] = None
         return self._w_ver
 
     def invalidate_weight_cache(self):
-        """Forget the cached 16-bit weight images (needed only after writing weights through ``.data``)."""
-        self._w_fp, self._w16_key = None, None
+        """Forget the cached 16-bit weight images and the cached pointer struct (needed only after writing weights
+        through ``.data`` or replacing a parameter object)."""
+        self.__dict__["_w_fp"], self.__dict__["_w16_key"] = None, None
+        self.__dict__["_w_struct"], self.__dict__["_plist"] = None, None
+
+    def _apply(self, fn, *a, **kw):
+        # .to() / .cuda() / .float() may REPLACE parameter objects: drop the cached list with them
+        r = super()._apply(fn, *a, **kw)
+        self.__dict__["_plist"] = None
+        self.__dict__["_w_struct"] = None
+        return r
 
     def _weights(self):
+        """The C struct of parameter pointers (rrt_encoder_weights).  Cached between calls while no parameter changed
+        storage or version (the struct holds raw pointers: it is rebuilt whenever the fingerprint moves)."""
+        ver = self._weights_version()
+        w = self.__dict__.get("_w_struct")
+        if w is not None:
+            return w
         w = _lib.EncoderWeights()
-        w.version = self._weights_version()
+        w.version = ver
         for i, layer in enumerate(self.layers.children()):
             w.rmsa[i] = self._attn_weights(layer)
         if self._desc.cr_msa:
@@ -368,6 +396,7 @@ class RRTEncoder(nn.Module):
                 conv = getattr(self.pos_embedding, name, None)
                 if conv is not None:
                     w.pos_w[i], w.pos_b[i] = self._ptr(conv.weight), self._ptr(conv.bias)
+        self.__dict__["_w_struct"] = w
         return w
 
     def _grad_buffers(self, device):
@@ -452,13 +481,23 @@ class RRTEncoder(nn.Module):
         return grads, gs
 
     def _workspace(self, n_tokens, device):
-        lib = _lib.load()
-        need = C.c_size_t()
-        _lib.check(lib.rrt_encoder_workspace_size(C.byref(self._desc), n_tokens, C.byref(need)),
-                   "rrt_encoder_workspace_size")
-        if self._ws is None or self._ws.device != device or self._ws.numel() < need.value:
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
-        return self._ws
+        # the size query is a C call + a geometry computation: remembered per (bag size, arithmetic) -- every other field
+        # of the descriptor is fixed at construction
+        cache = self.__dict__.setdefault("_ws_need", {})
+        key = (int(n_tokens), int(self._desc.compute))
+        need = cache.get(key)
+        if need is None:
+            lib = _lib.load()
+            c_need = C.c_size_t()
+            _lib.check(lib.rrt_encoder_workspace_size(C.byref(self._desc), n_tokens, C.byref(c_need)),
+                       "rrt_encoder_workspace_size")
+            need = cache[key] = int(c_need.value)
+            if len(cache) > 4096:
+                cache.clear()
+        ws = self._ws
+        if ws is None or ws.device != device or ws.numel() < need:
+            ws = self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return ws
 
     def _compute_mode(self):
         dt = self.compute_dtype
@@ -487,22 +526,29 @@ class RRTEncoder(nn.Module):
             # reference still applies proj dropout and stochastic depth; same kernels as the training forward, the
             # stash is scratch
             return self._forward_bag_stochastic(x2d, y)
+        desc, d_ = self._desc, self.__dict__
+        mode = desc.compute = self._compute_mode()
         ws = self._workspace(n, x2d.device)
         w = self._weights()
-        self._desc.compute = self._compute_mode()
-        with torch.cuda.device(x2d.device):      # kernels launch on the bag's device, whatever the current one is
-            stream = torch.cuda.current_stream(x2d.device).cuda_stream
+        dev = x2d.device
+        # kernels launch on the bag's device, whatever the current one is (the context switch is skipped when it already is)
+        ctx = torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else _NULL_CTX
+        with ctx:
+            stream = torch.cuda.current_stream(dev).cuda_stream
             # the 16-bit weight images at the head of this workspace are still those of these weights?
-            key = (ws.data_ptr(), self._desc.compute, w.version, stream)
-            self._desc.weights16_valid = int(self._desc.compute != _lib.COMPUTE_F32 and key == getattr(self, "_w16_key", None))
-            # scheduling hint (no effect on results): a plain forward is the reference's loop, one bag at a time; callers
-            # that keep several forwards in flight on their own streams set enc.solo = False
-            self._desc.solo = int(getattr(self, "solo", True))
-            rc = lib.rrt_encoder_forward_f32(C.byref(self._desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
+            lowp = mode != _lib.COMPUTE_F32
+            key = (ws.data_ptr(), mode, w.version, stream) if lowp else None
+            desc.weights16_valid = int(lowp and key == d_.get("_w16_key"))
+            # scheduling hint (rrt_hip.h: deterministic for a given setting, low-order bits may differ between settings):
+            # a plain forward is the reference's loop, one bag at a time; callers that keep several forwards in flight on
+            # their own streams set enc.solo = False
+            desc.solo = int(d_.get("solo", True))
+            rc = lib.rrt_encoder_forward_f32(C.byref(desc), C.byref(w), x2d.data_ptr(), y.data_ptr(), n,
                                              ws.data_ptr(), ws.numel(), stream)
-            self._desc.weights16_valid = 0
-            self._w16_key = key if rc == 0 and self._desc.compute != _lib.COMPUTE_F32 else None
-        _lib.check(rc, "rrt_encoder_forward_f32")
+            desc.weights16_valid = 0
+            d_["_w16_key"] = key if rc == 0 else None
+        if rc:
+            _lib.check(rc, "rrt_encoder_forward_f32")
         return y
 
     def _stochastic(self):

@@ -71,10 +71,13 @@ class _LibLinear(torch.autograd.Function):
 
 
 def lib_linear(lin, x, compute):
-    """x (..., K) through nn.Linear `lin` on the library kernels when they apply (HIP tensor, fp32 parameters, K a
-    multiple of 32 and -- for the input gradient -- N too); otherwise the torch op."""
-    ok = (x.is_cuda and lin.weight.is_cuda and lin.weight.dtype == torch.float32 and lin.in_features % 32 == 0
-          and (not x.requires_grad or lin.out_features % 32 == 0) and x.numel() > 0)
+    """x (..., K) through nn.Linear `lin` on the library kernels when they apply (a plain nn.Linear without forward
+    hooks, HIP tensor on the weight's device, fp32 parameters, fp32 / 16-bit input, K a multiple of 32 and -- for the
+    input gradient -- N too); otherwise the torch op (a replaced / hooked submodule keeps its own forward)."""
+    ok = (type(lin) is nn.Linear and not lin._forward_hooks and not lin._forward_pre_hooks
+          and x.is_cuda and lin.weight.device == x.device and lin.weight.dtype == torch.float32
+          and x.dtype in (torch.float32, torch.bfloat16, torch.float16)       # (float64 bags keep torch's arithmetic)
+          and lin.in_features % 32 == 0 and (not x.requires_grad or lin.out_features % 32 == 0) and x.numel() > 0)
     if not ok:
         return lin(x)
     y = _LibLinear.apply(x.reshape(-1, x.shape[-1]), lin.weight, lin.bias, compute)

@@ -98,6 +98,36 @@ def test_default_param_count():
     assert len(enc.state_dict()) == 17
 
 
+@pytest.mark.parametrize("n_layers", [1, 2, 3])
+def test_weight_fingerprint_covers_every_parameter(n_layers):
+    """The version that guards the cached 16-bit weight images (rrt_encoder_weights.version, weights16_valid) moves when
+    ANY parameter of the encoder changes -- CR-MSA's included, and with no R-MSA layer at all (round-3 advisor finding) --
+    and the cached ctypes pointer struct is rebuilt with it (host logic only: no GPU needed)."""
+    enc = RRTEncoder(mlp_dim=64, n_layers=n_layers)
+    w0 = enc._weights()
+    v0 = w0.version
+    assert enc._weights() is w0 and enc._weights_version() == v0          # nothing changed: the cached struct
+    seen = {v0}
+    for name, p in enc.named_parameters():
+        with torch.no_grad():
+            p.add_(1.0)                                                     # optimizer-style in-place update
+        v = enc._weights_version()
+        assert v not in seen, name
+        seen.add(v)
+    w1 = enc._weights()
+    assert w1 is not w0 and w1.version == max(seen)
+    # load_state_dict copies in place (version counters move); a new Parameter object is seen through its data_ptr
+    enc.load_state_dict(enc.state_dict())
+    assert enc._weights_version() not in seen
+    seen.add(enc._weights_version())
+    enc.cr_msa.attn.attn.qkv.weight = torch.nn.Parameter(enc.cr_msa.attn.attn.qkv.weight.detach().clone())
+    w2 = enc._weights()
+    assert w2.version not in seen and w2.crmsa.qkv_w == enc.cr_msa.attn.attn.qkv.weight.data_ptr()
+    # .float() / .to() may replace parameter objects: the pointer struct follows
+    enc = enc.double().float()
+    assert enc._weights().crmsa.qkv_w == enc.cr_msa.attn.attn.qkv.weight.data_ptr()
+
+
 def test_need_init_matches_reference_rule():
     enc = RRTEncoder(mlp_dim=64, need_init=True)
     assert float(enc.layers[0].attn.attn.qkv.bias.abs().max()) == 0.0

@@ -1172,6 +1172,47 @@ def test_weight_image_cache_follows_the_parameters(mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_layers", [2, 1])
+def test_weight_image_cache_follows_the_crmsa_parameters(n_layers):
+    """Round-3 advisor finding (high): CR-MSA's inner qkv / proj weights have cached 16-bit images too, but the validity
+    fingerprint covered the R-MSA layers only -- an update of a cr_msa weight alone (frozen R-MSA layers), or ANY update
+    at n_layers = 1 (no R-MSA layer: the fingerprint was the empty tuple), left the inner MSA on the first call's
+    weights.  The fingerprint now covers every parameter of the encoder; module path and executor path."""
+    from hip_util import encoder_from_state, dev
+    cfg = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8, n_layers=n_layers)
+    st = synth.encoder_state(**{k: v for k, v in cfg.items() if k != "region_num"})
+    xb = dev(synth.bag(3000, 512, tag="w16/crmsa")).unsqueeze(0)
+
+    def make(state):
+        e = encoder_from_state(state, cfg)
+        e.compute_dtype = torch.bfloat16
+        e.solo = False
+        return e
+    enc = make(st)
+    y1 = enc(xb).clone()
+    assert torch.equal(enc(xb), y1) and enc._w16_key is not None          # cached images, same bits
+    for name in ("cr_msa.attn.attn.qkv.weight", "cr_msa.attn.attn.proj.weight"):
+        with torch.no_grad():
+            dict(enc.named_parameters())[name].mul_(1.5)
+        st = {k: (v * 1.5 if k == name else v) for k, v in st.items()}
+        y2 = enc(xb).clone()
+        want = make(st)(xb)
+        torch.cuda.synchronize()
+        assert torch.equal(y2, want) and not torch.equal(y2, y1), name
+        outs = enc.forward_bags([xb, xb], streams=2)                      # executor: rrt_encoder_weights.version
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], want) and torch.equal(outs[1], want), name
+        y1 = y2
+    # a NEW Parameter object assigned to an existing submodule is seen as well (its data_ptr differs)
+    enc.cr_msa.attn.attn.proj.weight = torch.nn.Parameter(enc.cr_msa.attn.attn.proj.weight.detach() * 0.5)
+    st = {k: (v * 0.5 if k == "cr_msa.attn.attn.proj.weight" else v) for k, v in st.items()}
+    y3 = enc(xb)
+    want = make(st)(xb)
+    torch.cuda.synchronize()
+    assert torch.equal(y3, want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,big", [(torch.bfloat16, 20000), ("f32x3", 10500), ("f32x3", 20000)])
 def test_weight_image_cache_survives_a_bag_that_skips_the_16bit_kernels(mode, big):
     """Round-2 advisor finding: the validity key of the cached weight images did not say whether the call had written
