@@ -18,7 +18,7 @@ quoted on; the N = 1 line of that config is what the driver records):
   4  TCGA-NSCLC mix: 64 bags, N ~ randint(3000, 15001) (seed 2021), epeg_k=21 crmsa_k=5; the batch is split over
      the ranks by cost (sharding.assign_bags, longest-processing-time first) and each rank runs its share through
      the batch-of-bags executor; a step = one pass over the whole batch ("scaling": "strong")
-In configs 0-3 a step = `--streams` (default 2) independent bags per GPU, each an ordinary forward on its own HIP
+In configs 0-3 a step = `--streams` (default 4 in fp32, 3 in bf16) independent bags per GPU, each an ordinary forward on its own HIP
 stream with its own workspace (bags are independent units), and every rank owns its own bags
 ("scaling": "weak").  No data-path collective anywhere: RCCL carries the barrier and a MAX of the elapsed time.
 
@@ -128,7 +128,7 @@ CONFIGS = {
             label="BASELINE configs[1]: RRTEncoder(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8).eval() forward, "
                   "`streams_per_gpu` device-resident bags N=9000 D=512 in flight per GPU (one per HIP stream, each an ordinary "
                   "forward with its own workspace) = one step; fp32, closed-form weights"),
-    2: dict(kind="mil", n=9000, dtype="bf16", input_dim=1024,
+    2: dict(kind="mil", n=9000, dtype="bf16", input_dim=1024, streams=4,
             enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=1, region_num=8, all_shortcut=True),
             label="BASELINE configs[2]: C16-R50 RRTMIL(input_dim=1024, epeg_k=15, crmsa_k=1, all_shortcut=True).eval() "
                   "forward, N=9000 x 1024 non-negative features -> logits (rrt_mil_forward_f32: fc + ReLU, encoder, "
@@ -305,6 +305,8 @@ class EncoderWorkload:
         self.lib = _lib.load()
         self.hev = HipEvents()
         tstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+        if os.environ.get("RRT_BENCH_NO_NULL") == "1":       # (experiment: no bag on the process's default stream)
+            tstreams = [torch.cuda.Stream(dev) for _ in range(S)]
         self._tstreams = tstreams
         self.streams = [t.cuda_stream for t in tstreams]
         self.mil = None
@@ -707,9 +709,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational extra records of the default run")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("RRT_BENCH_STREAMS", "0")),
-                    help="bags in flight per GPU (one HIP stream + workspace each); a step = this many bags.  Default: 2 for "
-                         "fp32 arithmetic (the MFMA-bound kernels time-slice beyond that), 3 for bf16 / fp16 (their kernels are "
-                         "bound by operand-stream and launch latency: a third bag in flight fills more of it, +8 %)")
+                    help="bags in flight per GPU (one HIP stream + workspace each); a step = this many bags.  Default: 4 for "
+                         "fp32 arithmetic, 3 for bf16 / fp16 (measured optima, see the comment in main())")
     ap.add_argument("--stub-cpu", action="store_true", help="rank logic only: CPU stand-in workload over gloo (tests)")
     args = ap.parse_args()
 
@@ -740,7 +741,13 @@ def main():
 
     cfg = CONFIGS[args.config]
     if args.streams <= 0:
-        args.streams = 3 if (args.dtype or cfg["dtype"]) in ("bf16", "f16") else 2
+        # fp32: measured on MI355X (round 4, profiles/r04_streams_sweep.txt): 2 -> 4.84 k, 3 -> 4.90 k, 4 -> 5.10 k, 5 -> 4.78 k,
+        # 6 -> 4.85 k, 8 -> 5.07 k slides/s.  Kernels of different bags do not overlap on this chip in any way that saves
+        # time (tools/corun_matrix.py: a kernel beside the fused R-MSA launch costs that launch the kernel's own solo
+        # duration) -- what more bags in flight buy is the latency-bound CR-MSA chains of DIFFERENT bags running next to
+        # each other; four streams = one per hardware pipe
+        # bf16: 3 (17.8 k; 4: 17.7 k, 5: 14.4 k); the bf16 classifier of configs[2] (a longer chain per bag): 4 (9.7 k vs 9.1 k)
+        args.streams = cfg.get("streams") or (3 if (args.dtype or cfg["dtype"]) in ("bf16", "f16") else 4)
     if args.stub_cpu:
         wl = StubWorkload(args, rank, world, dev)
     elif cfg["kind"] == "mix":
@@ -823,7 +830,7 @@ def main():
         if not args.stub_cpu and args.config == 1 and world == 1 and not args.no_extras:
             rec.update(extras(wl, dev))
             for c in (0, 2, 3, 4):
-                rec[f"config{c}"] = config_record(c, dev)
+                rec[f"config{c}"] = config_record(c)
         if not args.stub_cpu and world == 1 and not args.no_cpu_baseline:
             n_cpu = cfg["n"] or 9000          # config 4: the typical bag of the mix
             rec["cpu_baseline"] = cpu_baseline(n_cpu, enc_cfg)
@@ -893,7 +900,8 @@ def module_call(wl, dev, n_bags=64):
         t1 = time.perf_counter() - t0
         out["module_loop"] = round(n_bags / t1, 1)
         out["host_us_per_bag"] = round(host / n_bags * 1e6, 1)
-        batch = [bags3[i % len(bags3)] for i in range(n_bags)]
+        n_batch = 4 * n_bags                          # one executor call = one fork / join: the longer the batch, the less it weighs
+        batch = [bags3[i % len(bags3)] for i in range(n_batch)]
         outs = [torch.empty_like(b[0]) for b in batch]
         enc.forward_bags(batch[:2 * S], streams=S, outs=outs[:2 * S])
         torch.cuda.synchronize()
@@ -902,56 +910,51 @@ def module_call(wl, dev, n_bags=64):
         host_b = time.perf_counter() - t0
         torch.cuda.synchronize()
         t1 = time.perf_counter() - t0
-        out["forward_bags"] = round(n_bags / t1, 1)
+        out["forward_bags"] = round(n_batch / t1, 1)
         out["forward_bags_streams"] = S
-        out["forward_bags_host_us_per_bag"] = round(host_b / n_bags * 1e6, 1)
+        out["forward_bags_batch"] = n_batch
+        out["forward_bags_host_us_per_bag"] = round(host_b / n_batch * 1e6, 1)
         assert torch.isfinite(y).all() and torch.isfinite(outs[-1]).all()
     enc.compute_dtype, enc.solo = mode_was, solo_was
     enc._desc.compute = wl.compute
     out["note"] = (f"{n_bags} device-resident bags: `for bag in bags: enc(bag)` under no_grad through nn.Module.__call__ (one bag "
-                   f"in flight, the reference's loop) and enc.forward_bags(bags, streams={S}) (one executor call); host_us_per_bag "
+                   f"in flight, the reference's loop) and enc.forward_bags({n_batch} bags, streams={S}) (one executor call); host_us_per_bag "
                    "= host thread time per forward while the device queue is not full; compare module_loop with "
                    "one_bag_in_flight.slides_per_s and forward_bags with `value` (both taken at the C ABI)")
     return out
 
 
-def config_record(c, dev, steps=None):
-    """A bounded single-GPU record of BASELINE configs[c] inside the default run (rank 0, after the timed region): the same
-    workload classes, warm-up + clock-ramp guard + a short timed region; the full record is `bench.py --config c`."""
-    import torch
-    cfg = CONFIGS[c]
-    S = 3 if cfg["dtype"] in ("bf16", "f16") else 2
-    steps = steps or {0: 200, 2: 60, 3: 30, 4: 8}[c]
-    a = argparse.Namespace(config=c, dtype=None, streams=S, steps=steps, warmup=5)
-    t_all = time.perf_counter()
-    wl = (MixWorkload if cfg["kind"] == "mix" else EncoderWorkload)(a, 0, 1, dev)
-    for i in range(a.warmup):
-        wl.step(i, False)
-    wl.sync()
-    stabilise(wl, steps, max_s=1.5)
-    wl.sync()
+def config_record(c):
+    """A bounded single-GPU record of BASELINE configs[c] inside the default run (rank 0, after the timed region):
+    `bench.py --config c` with a short timed region, run as a CHILD PROCESS while this one idles -- HIP maps streams to
+    hardware queues in creation order, and a process that has already created this run's streams (four bags in flight, the
+    feeder's copy stream, the executor's own) no longer gives a new workload the queues a fresh process gets (measured:
+    configs[4] 7.8 k slides/s in-process vs 14.5 k in its own process)."""
+    import subprocess
+    steps = {0: 200, 2: 80, 3: 40, 4: 12}[c]
     t0 = time.perf_counter()
-    for i in range(steps):
-        wl.step(i, True)
-    wl.sync()
-    el = time.perf_counter() - t0
-    fin = wl.finish(a, 1, 0, el)
-    rec = {"value": round(wl.units_global * steps / el, 1), "unit": "slides/s", "dtype": wl.dtype, "n_gpus": 1,
-           "streams_per_gpu": S, "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
-           "workload": cfg["label"]}
-    roof = fin.get("roofline_isolated") or fin.get("roofline")
-    if roof:
-        rec["dominant_kernel"] = {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms") if k in roof}
-    if "roofline_kernels" in fin:       # every stage against its own bound: HBM GB/s for the streaming stages
-        rec["stages"] = [{k: st[k] for k in ("stage", "bound", "achieved", "peak", "unit", "frac", "avg_ms")}
-                         for st in fin["roofline_kernels"]]
-    if "one_bag_in_flight" in fin:
-        rec["one_bag_in_flight_ms"] = fin["one_bag_in_flight"]["ms_per_bag"]
-    rec.update({k: v for k, v in wl.extra.items() if k in ("tokens_per_step", "cost_imbalance")})
-    del wl
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()
-    rec["wall_s"] = round(time.perf_counter() - t_all, 2)
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--steps", str(steps), "--warmup", "5",
+           "--no-extras", "--no-cpu-baseline"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:                      # the headline line must not die with a side record
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    rec = {"value": r["value"], "unit": r["unit"], "dtype": r["dtype"], "n_gpus": 1, "steps": r["steps"],
+           "ms_per_step": r["ms_per_step"], "streams_per_gpu": r["config"].get("streams_per_gpu"),
+           "bags_per_step": r["config"].get("bags_per_step"), "workload": r["config"]["workload"],
+           "whole_path_tflops": r["config"].get("whole_path_tflops"), "value_spread": (r.get("value_spread") or {}).get("values")}
+    for key in ("roofline", "roofline_isolated"):
+        if key in r:
+            rec[key] = {k: r[key][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "traffic")
+                        if k in r[key]}
+    if "roofline_kernels" in r:                 # every stage against its own bound: HBM GB/s for the streaming stages
+        rec["stages"] = [{k: st[k] for k in ("stage", "bound", "achieved", "peak", "unit", "frac", "avg_ms", "traffic")}
+                         for st in r["roofline_kernels"]]
+    if "one_bag_in_flight" in r:
+        rec["one_bag_in_flight_ms"] = r["one_bag_in_flight"]["ms_per_bag"]
+    rec["command"] = "bench.py " + " ".join(cmd[2:])
+    rec["wall_s"] = round(time.perf_counter() - t0, 1)
     return rec
 
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 21
+#define RRT_ABI_VERSION 22
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -193,6 +193,18 @@ int rrt_encoder_forward_gated_f32(const rrt_encoder_desc *desc, const rrt_encode
                                   void *workspace, size_t workspace_bytes, void *stream,
                                   rrt_phase_gate *gate, void **events);
 
+/* Batch > 1: RRTEncoder.forward on (B, N, D) input (modules/rrt.py:165-202), inference.  x, y: [batch, n_tokens, dim]
+ * contiguous.  At B > 1 the reference's region_partition puts the regions of all bags on one axis (rmsa.py:28-39): the R-MSA
+ * layers still treat the bags independently, but CR-MSA's inner attention runs over the 64 * B representatives of ALL bags
+ * (rmsa.py:316-322) -- the outputs of a batch differ from the outputs of its bags taken one at a time, and this entry point
+ * reproduces exactly that.  (Independent bags -- what every reference trainer feeds, batch_size = 1 -- go through
+ * rrt_encoder_forward_f32 / rrt_executor_forward.)  Correctness path: the R-MSA layers bag by bag, one inner MSA for the
+ * batch; workspace from rrt_encoder_batch_workspace_size. */
+int rrt_encoder_batch_workspace_size(const rrt_encoder_desc *desc, int32_t batch, int64_t n_tokens, size_t *bytes);
+int rrt_encoder_forward_batch_f32(const rrt_encoder_desc *desc, const rrt_encoder_weights *w,
+                                  const float *x, float *y, int32_t batch, int64_t n_tokens,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- stage entry points (what the fused path is built from; used by the parity tests) ---- */
 
 /* LayerNorm (modules/rrt.py:121-123) + zero-pad (rmsa.py:199-200) + region_partition
@@ -326,6 +338,22 @@ typedef struct rrt_mil_weights {
   const float *pool_c_w, *pool_c_b;   /* [1, pool_hidden], [1] */
   const float *pred_w, *pred_b;       /* predictor [n_classes, dim], [n_classes] */
 } rrt_mil_weights;
+
+/* The pooling alone (datten.py:28-38 / :69-83 AFTER the first Linear + activation; training keeps those as autograd-visible
+ * layers): s_n = c_w . h_n + c_b with h = hid_a (or hid_a * hid_b, gated), attn = softmax_n(s), pooled = sum_n attn_n y_n.
+ * Outputs pooled [dim], attn [N] (normalised), a_raw [N] (the scores).  ... and its adjoint: given d_pooled [dim] (and
+ * optionally d_attn [N] with c_ext = sum_n attn_n d_attn_n as a device scalar, d_raw [N]) ->
+ * dy [N, dim] = attn_n d_pooled, dhid_a / dhid_b [N, hidden], dwcb [hidden + 4] = d c_w | d c_b (at [hidden]).
+ * workspace: rrt_attn_pool_workspace_size bytes (either call). */
+int rrt_attn_pool_workspace_size(int64_t n_tokens, int32_t dim, int32_t hidden, size_t *bytes);
+int rrt_attn_pool_f32(const float *y, const float *hid_a, const float *hid_b, const float *c_w, const float *c_b,
+                      float *pooled, float *attn, float *a_raw, int64_t n_tokens, int32_t dim, int32_t hidden,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int rrt_attn_pool_backward_f32(const float *y, const float *hid_a, const float *hid_b, const float *c_w,
+                               const float *attn, const float *pooled, const float *d_pooled,
+                               const float *d_attn, const float *d_raw, const float *c_ext, float *dy,
+                               float *dhid_a, float *dhid_b, float *dwcb, int64_t n_tokens, int32_t dim,
+                               int32_t hidden, void *workspace, size_t workspace_bytes, void *stream);
 
 int rrt_mil_workspace_size(const rrt_mil_desc *desc, int64_t n_tokens, size_t *bytes);
 

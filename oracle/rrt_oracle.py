@@ -405,7 +405,8 @@ def forward_f64(x, state, cfg=None, taps=None, lowp=None):
 # --------------------------------------------------------------------------- eager-equivalent torch/CPU port
 def forward_eager(x, state, cfg=None, grad=False, drop=None, autocast=None, branch=None):
     """torch fp32 CPU port issuing the reference's aten op sequence; x: (N, D)
-    torch tensor or array -> torch (N, D).  Used as the timed CPU baseline.
+    torch tensor or array -> torch (N, D); or (B, N, D) -> (B, N, D): at B > 1 the reference couples the bags
+    inside CR-MSA (its inner attention runs over the regions of all bags, rmsa.py:296-322).  Used as the timed CPU baseline.
     grad=True: float64 leaves with requires_grad (x and every parameter) and a recorded graph -- torch autograd
     then yields the reference's gradients (the oracle of the backward, row f2); returns (y, x_leaf, params).
     drop = (p, {layer: keep mask [rows, D]}): train-mode proj_drop (rmsa.py:132) with GIVEN masks (layer index, or
@@ -425,7 +426,9 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None, autocast=None, bran
         st = {k_: v_.double().requires_grad_(True) for k_, v_ in st.items()}
         x = x.double().requires_grad_(True)
         x_leaf = x
-    x = x.unsqueeze(0)                                                       # (1,N,D), modules/rrt.py:166-175
+    batched = x.dim() == 3                                                   # (B,N,D): returned with its batch axis
+    if not batched:
+        x = x.unsqueeze(0)                                                   # (1,N,D), modules/rrt.py:166-175
     B, N, D = x.shape
     x0 = x
 
@@ -547,8 +550,8 @@ def forward_eager(x, state, cfg=None, grad=False, drop=None, autocast=None, bran
             x = x + x0
         x = F.layer_norm(x, (D,), st["norm.weight"], st["norm.bias"], 1e-5)
     if grad:
-        return x.squeeze(0), x_leaf, st
-    return x.squeeze(0)
+        return (x if batched else x.squeeze(0)), x_leaf, st
+    return x if batched else x.squeeze(0)
 
 
 # --------------------------------------------------------------------------- RRTMIL (row f1) in float64

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _f32p = C.POINTER(C.c_float)
 
@@ -87,6 +87,9 @@ SIGNATURES = {
     "rrt_encoder_forward_events_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p,
                                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p,
                                                  C.POINTER(C.c_void_p)]),
+    "rrt_encoder_batch_workspace_size": (C.c_int, [C.POINTER(EncoderDesc), C.c_int32, C.c_int64, C.POINTER(C.c_size_t)]),
+    "rrt_encoder_forward_batch_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p,
+                                                C.c_int32, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rrt_phase_gate_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "rrt_phase_gate_destroy": (C.c_int, [C.c_void_p]),
     "rrt_encoder_forward_gated_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p,
@@ -131,6 +134,10 @@ SIGNATURES = {
     "rrt_pool_workspace_size": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "rrt_pool_predict_f32": (C.c_int, [C.c_void_p] * 12 + [C.c_int32, C.c_int64] + [C.c_int32] * 5 +
                              [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rrt_attn_pool_workspace_size": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "rrt_attn_pool_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rrt_attn_pool_backward_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                                                 C.c_void_p]),
     "rrt_executor_create": (C.c_int, [C.POINTER(EncoderDesc), C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "rrt_executor_forward": (C.c_int, [C.c_void_p, C.POINTER(EncoderWeights), C.POINTER(Bag), C.c_int32,
                                        C.c_void_p]),

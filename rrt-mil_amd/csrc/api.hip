@@ -157,6 +157,7 @@ GridDev to_dev(const rrt_grid& g) {
   d.inv_s = 1.0f / (float)d.s;
   d.inv_rs = 1.0f / (float)d.rs;
   d.inv_P = 1.0f / (float)d.P;
+  d.Rt = d.rs * d.rs;
   return d;
 }
 
@@ -228,9 +229,41 @@ struct rrt_phase_gate {
   bool armed;
 };
 
+// TransLayer's optional FFN (rrt.py:127-129): xo = xi + fc2(act(fc1(LN2(xi)))).  LN2 -> GEMM with the activation in its
+// epilogue -> GEMM with the residual in its epilogue (identity slot -> token map).
+static int ffn_apply(const rrt_encoder_desc* desc, const rrt_attn_weights& lw, const float* xi, float* xo,
+                     const Workspace& ws, int64_t N, hipStream_t st) {
+  if (!lw.norm2_w || !lw.norm2_b || !lw.fc1_w || !lw.fc1_b || !lw.fc2_w || !lw.fc2_b) return RRT_E_INVALID;
+  const int D = desc->dim;
+  GridDev gid{};
+  const int Hs = (int)ceil_sqrt(N);
+  gid.L = (int)N;
+  gid.H = gid.s = Hs;
+  gid.rs = 1;
+  gid.P = gid.Np = Hs * Hs;
+  gid.inv_H = gid.inv_s = 1.0f / (float)Hs;
+  gid.inv_rs = 1.0f;
+  gid.inv_P = 1.0f / (float)gid.P;
+  gid.Rt = 1;
+  hipError_t fe = launch_layernorm(xi, nullptr, lw.norm2_w, lw.norm2_b, ws.ffn_ln, (int)N, D, st);
+  if (fe != hipSuccess) return (int)fe;
+  LinearEpilogue e1{};
+  e1.prec = desc->compute;
+  e1.bias = lw.fc1_b;
+  e1.act = desc->ffn_act;
+  fe = launch_linear(ws.ffn_ln, lw.fc1_w, ws.ffn_hid, (int)N, desc->ffn_hidden, D, e1, st);
+  if (fe != hipSuccess) return (int)fe;
+  LinearEpilogue e2{};
+  e2.prec = desc->compute;
+  e2.bias = lw.fc2_b;
+  e2.resid = xi;
+  e2.g = gid;
+  return (int)launch_linear(ws.ffn_hid, lw.fc2_w, xo, (int)N, D, desc->ffn_hidden, e2, st);
+}
+
 static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_weights* w, const float* x,
                            float* y, int64_t n_tokens, void* workspace, size_t workspace_bytes,
-                           void* stream, void** events, rrt_phase_gate* gate = nullptr) {
+                           void* stream, void** events, rrt_phase_gate* gate = nullptr, float* rmsa_out = nullptr) {
   if (!desc_in || !w || !x || !y || x == y) return RRT_E_INVALID;
   int rc = check_desc(desc_in, n_tokens);
   if (rc) return rc;
@@ -268,35 +301,8 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
   } while (0)
   RRT_MARK(RRT_EV_START);
 
-  // TransLayer's optional FFN (rrt.py:127-129): xo = xi + fc2(act(fc1(LN2(xi)))).  LN2 -> GEMM with the
-  // activation in its epilogue -> GEMM with the residual in its epilogue (identity slot->token map).
-  GridDev gid{};
-  {
-    const int Hs = (int)ceil_sqrt(N);
-    gid.L = (int)N;
-    gid.H = gid.s = Hs;
-    gid.rs = 1;
-    gid.P = gid.Np = Hs * Hs;
-    gid.inv_H = gid.inv_s = 1.0f / (float)Hs;
-    gid.inv_rs = 1.0f;
-    gid.inv_P = 1.0f / (float)gid.P;
-  }
   auto ffn_block = [&](const rrt_attn_weights& lw, const float* xi, float* xo) -> int {
-    if (!lw.norm2_w || !lw.norm2_b || !lw.fc1_w || !lw.fc1_b || !lw.fc2_w || !lw.fc2_b) return RRT_E_INVALID;
-    hipError_t fe = launch_layernorm(xi, nullptr, lw.norm2_w, lw.norm2_b, ws.ffn_ln, (int)N, D, st);
-    if (fe != hipSuccess) return (int)fe;
-    LinearEpilogue e1{};
-    e1.prec = desc->compute;
-    e1.bias = lw.fc1_b;
-    e1.act = desc->ffn_act;
-    fe = launch_linear(ws.ffn_ln, lw.fc1_w, ws.ffn_hid, (int)N, desc->ffn_hidden, D, e1, st);
-    if (fe != hipSuccess) return (int)fe;
-    LinearEpilogue e2{};
-    e2.prec = desc->compute;
-    e2.bias = lw.fc2_b;
-    e2.resid = xi;
-    e2.g = gid;
-    return (int)launch_linear(ws.ffn_hid, lw.fc2_w, xo, (int)N, D, desc->ffn_hidden, e2, st);
+    return ffn_apply(desc, lw, xi, xo, ws, N, st);
   };
 
   const float* xin = x;   // current activations [N, D]
@@ -379,7 +385,10 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     if (desc->epeg && !lw.pe_w) return RRT_E_INVALID;
     const GridDev gd = to_dev(g);
     // without FFN the layers ping-pong xa / xb; with it attention writes xa and the FFN writes xb
-    float* xout = desc->ffn ? ws.xa : ((li & 1) ? ws.xb : ws.xa);
+    // (rmsa_out: the batch entry point takes the R-MSA layers' result of each bag in its own buffer)
+    const bool to_out = rmsa_out != nullptr && li == desc->n_rmsa_layers - 1;
+    float* xout = desc->ffn ? ws.xa : (to_out ? rmsa_out : ((li & 1) ? ws.xb : ws.xa));
+    float* const fout = to_out ? rmsa_out : ws.xb;      // the layer's FFN output
     const int ek = desc->epeg ? desc->epeg_k : 0;
     if (lowp16) {
       // u (16-bit) in the uo buffer, O (16-bit) in the qkv buffer; qkv, scores and probabilities never leave the CU
@@ -404,9 +413,9 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;
       if (desc->ffn) {
-        rc = ffn_block(lw, xout, ws.xb);
+        rc = ffn_block(lw, xout, fout);
         if (rc) return rc;
-        xin = ws.xb;
+        xin = fout;
       }
       continue;
     }
@@ -430,9 +439,9 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;
       if (desc->ffn) {
-        rc = ffn_block(lw, xout, ws.xb);
+        rc = ffn_block(lw, xout, fout);
         if (rc) return rc;
-        xin = ws.xb;
+        xin = fout;
       }
       continue;
     }
@@ -469,9 +478,9 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       RRT_TRY(launch_linear(ws.uo, lw.proj_w, xout, gd.Np, D, D, ep, st));
       xin = xout;
       if (desc->ffn) {
-        rc = ffn_block(lw, xout, ws.xb);
+        rc = ffn_block(lw, xout, fout);
         if (rc) return rc;
-        xin = ws.xb;
+        xin = fout;
       }
       continue;
     }
@@ -500,9 +509,9 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;
       if (desc->ffn) {
-        rc = ffn_block(lw, xout, ws.xb);
+        rc = ffn_block(lw, xout, fout);
         if (rc) return rc;
-        xin = ws.xb;
+        xin = fout;
       }
       continue;
     }
@@ -528,10 +537,14 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     if (li == 0) RRT_MARK(RRT_EV_PROJ);
     xin = xout;
     if (desc->ffn) {
-      rc = ffn_block(lw, xout, ws.xb);
+      rc = ffn_block(lw, xout, fout);
       if (rc) return rc;
-      xin = ws.xb;
+      xin = fout;
     }
+  }
+  if (rmsa_out != nullptr) {           // batch entry point: stop here, the R-MSA result of this bag in rmsa_out
+    if (xin != rmsa_out) RRT_TRY(hipMemcpyAsync(rmsa_out, xin, (size_t)N * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return RRT_OK;
   }
   const float* x0 = desc->all_shortcut ? x : nullptr;
   if (!w->norm_w || !w->norm_b) return RRT_E_INVALID;
@@ -655,6 +668,159 @@ int rrt_encoder_forward_events_f32(const rrt_encoder_desc* desc, const rrt_encod
                                    const float* x, float* y, int64_t n_tokens, void* workspace,
                                    size_t workspace_bytes, void* stream, void** events) {
   return encoder_forward(desc, w, x, y, n_tokens, workspace, workspace_bytes, stream, events);
+}
+
+// ---- batch > 1 (modules/rrt.py:165-202 on (B, N, D) input).  The reference's region_partition puts the regions of all
+// bags of the batch on one leading axis (rmsa.py:28-39), so the R-MSA layers treat the bags independently, but CR-MSA's
+// inner attention runs over the 64 B representatives of ALL bags (rmsa.py:316-322: batch = k, sequence = B * 64): the bags
+// are coupled there and only there.  Here: the R-MSA layers bag by bag (the single-bag path, results in x1 [B, N, D]),
+// statistics + combine per bag into rep [k, 64 B, D] (region b * 64 + w), ONE inner MSA over sequences of 64 B tokens, the
+// dispatch + final LayerNorm per bag.  Correctness path for the literal drop-in contract (every reference trainer uses
+// B = 1): the chip-wide two-kernel statistics / combine and the generic attention kernel, fp32 data; inference only.
+namespace {
+struct BatchWs {
+  Workspace one;          // the single-bag workspace (R-MSA layers, FFN / MLP-phi temporaries), reused bag after bag
+  float *x1, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2;
+  size_t bytes;
+};
+BatchWs carve_batch(const rrt_encoder_desc& d, int64_t B, int64_t N, const rrt_grid& g, const rrt_grid& g8, char* base) {
+  BatchWs w{};
+  w.one = carve(d, N, g, g8, base);
+  size_t off = align_up(w.one.bytes, 256);
+  auto take = [&](size_t nfloat) {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off = align_up(off + nfloat * sizeof(float), 256);
+    return p;
+  };
+  const size_t D = d.dim, Np8 = (size_t)g8.H * g8.H, R8 = (size_t)g8.regions_side * g8.regions_side, k = d.crmsa_k;
+  w.x1 = take((size_t)B * N * D);
+  if (d.cr_msa) {
+    w.mean_rstd = take((size_t)B * N * 2);
+    w.logits = take((size_t)B * Np8 * k);
+    w.wdisp = take((size_t)B * Np8 * k);
+    w.rep = take(k * R8 * B * D);
+    w.rep_qkv = take(k * R8 * B * 3 * D);
+    w.rep_o = take(k * R8 * B * D);
+    w.rep2 = take(k * R8 * B * D);
+  }
+  w.bytes = off;
+  return w;
+}
+}  // namespace
+
+int rrt_encoder_batch_workspace_size(const rrt_encoder_desc* desc, int32_t batch, int64_t n_tokens, size_t* bytes) {
+  if (!bytes || batch <= 0) return RRT_E_INVALID;
+  int rc = check_desc(desc, n_tokens);
+  if (rc) return rc;
+  rrt_grid g{}, g8{};
+  if (desc->n_rmsa_layers > 0) {
+    rc = rrt_region_grid(n_tokens, desc->region_num, desc->region_size, desc->min_region_num, desc->min_region_ratio, &g);
+    if (rc) return rc;
+  }
+  rc = rrt_region_grid(n_tokens, 8, 0, 0, 0.f, &g8);
+  if (rc) return rc;
+  *bytes = carve_batch(*desc, batch, n_tokens, g, g8, nullptr).bytes;
+  return RRT_OK;
+}
+
+int rrt_encoder_forward_batch_f32(const rrt_encoder_desc* desc_in, const rrt_encoder_weights* w, const float* x, float* y,
+                                  int32_t batch, int64_t n_tokens, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!desc_in || !w || !x || !y || x == y || batch <= 0) return RRT_E_INVALID;
+  int rc = check_desc(desc_in, n_tokens);
+  if (rc) return rc;
+  if (batch > 1024) return unsupported("batch > 1024");
+  rrt_encoder_desc dloc = *desc_in;
+  dloc.weights16_valid = 0;     // (the first bag writes the images; the later bags of THIS call may reuse them, below)
+  dloc.solo = 0;
+  const rrt_encoder_desc* const desc = &dloc;
+  const int64_t N = n_tokens, B = batch;
+  const int D = desc->dim;
+  hipStream_t st = (hipStream_t)stream;
+  rrt_grid g{}, g8{};
+  if (desc->n_rmsa_layers > 0) {
+    rc = rrt_region_grid(N, desc->region_num, desc->region_size, desc->min_region_num, desc->min_region_ratio, &g);
+    if (rc) return rc;
+  }
+  rc = rrt_region_grid(N, 8, 0, 0, 0.f, &g8);
+  if (rc) return rc;
+  BatchWs bw = carve_batch(*desc, B, N, g, g8, nullptr);
+  if (!workspace || workspace_bytes < bw.bytes) return RRT_E_WORKSPACE;
+  bw = carve_batch(*desc, B, N, g, g8, (char*)workspace);
+  hipError_t e = hipSuccess;
+#define RRT_TRY(call)                   \
+  do {                                  \
+    e = (call);                         \
+    if (e != hipSuccess) return (int)e; \
+  } while (0)
+  // ---- positional encoder + R-MSA layers, bag by bag -> x1 [B, N, D]
+  for (int64_t b = 0; b < B; ++b) {
+    rc = encoder_forward(&dloc, w, x + (size_t)b * N * D, y + (size_t)b * N * D, N, workspace, bw.one.bytes, stream, nullptr,
+                         nullptr, bw.x1 + (size_t)b * N * D);
+    if (rc) return rc;
+    dloc.weights16_valid = 1;   // same workspace, same weights, same mode: the images of bag 0 stand
+  }
+  dloc.weights16_valid = 0;
+  if (!w->norm_w || !w->norm_b) return RRT_E_INVALID;
+  if (!desc->cr_msa) {
+    for (int64_t b = 0; b < B; ++b)
+      RRT_TRY(launch_layernorm(bw.x1 + (size_t)b * N * D, desc->all_shortcut ? x + (size_t)b * N * D : nullptr, w->norm_w,
+                               w->norm_b, y + (size_t)b * N * D, (int)N, D, st));
+    return RRT_OK;
+  }
+  // ---- CR-MSA over the batch (rmsa.py:290-337)
+  const rrt_attn_weights& cw = w->crmsa;
+  if (!cw.norm_w || !cw.norm_b || !cw.qkv_w || !cw.proj_w || !cw.proj_b) return RRT_E_INVALID;
+  if (desc->crmsa_mlp ? (!w->phi0_w || !w->phi2_w) : !w->phi) return RRT_E_INVALID;
+  GridDev gd8 = to_dev(g8);
+  const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
+  gd8.Rt = R8 * (int)B;                                  // rep / rep2 rows: [k][B * R8]
+  const size_t Np8 = (size_t)gd8.Np;
+  // (F32X3 concerns the R-MSA projections only; CR-MSA's GEMMs round their operands in the bf16 / fp16 modes)
+  const int prec = desc->compute == RRT_COMPUTE_F32X3 ? RRT_COMPUTE_F32 : desc->compute;
+  for (int64_t b = 0; b < B; ++b) {
+    const float* xb1 = bw.x1 + (size_t)b * N * D;
+    float* lg = bw.logits + (size_t)b * Np8 * k;
+    float* wd = bw.wdisp + (size_t)b * Np8 * k;
+    float* repb = bw.rep + (size_t)b * R8 * D;          // region 0 of bag b in every representative's row
+    if (desc->crmsa_mlp) {
+      RRT_TRY(launch_ln_partition(xb1, cw.norm_w, cw.norm_b, bw.one.v8, D, gd8, st));
+      LinearEpilogue ep{};
+      ep.prec = prec;
+      RRT_TRY(launch_linear(bw.one.v8, w->phi0_w, bw.one.hid, gd8.Np, D / 4, D, ep, st));
+      RRT_TRY(launch_crmsa_mlp_logits(bw.one.hid, w->phi2_w, lg, gd8.Np, D / 4, k, st));
+      RRT_TRY(launch_crmsa_combine(bw.one.v8, nullptr, nullptr, nullptr, lg, wd, repb, nullptr, 0, D, k, gd8, st));
+    } else {
+      float* mr = bw.mean_rstd + (size_t)b * N * 2;
+      RRT_TRY(launch_crmsa_logits(xb1, cw.norm_w, cw.norm_b, w->phi, mr, lg, D, k, gd8, st));
+      RRT_TRY(launch_crmsa_combine(xb1, cw.norm_w, cw.norm_b, mr, lg, wd, repb, nullptr, 0, D, k, gd8, st));
+    }
+  }
+  // inner MSA: batch = k, sequence = the B * R8 representatives of all bags, no EPEG (rmsa.py:322)
+  RRT_TRY(inner_attention(bw.rep, k, R8 * (int)B, cw, D, desc->crmsa_heads, 0, bw.rep_qkv, bw.rep_o, prec, false, st));
+  {
+    LinearEpilogue ep{};
+    ep.prec = prec;
+    ep.bias = cw.proj_b;
+    RRT_TRY(launch_linear(bw.rep_o, cw.proj_w, bw.rep2, k * R8 * (int)B, D, D, ep, st));
+  }
+  for (int64_t b = 0; b < B; ++b) {
+    const float* xb1 = bw.x1 + (size_t)b * N * D;
+    const float* x0 = desc->all_shortcut ? x + (size_t)b * N * D : nullptr;
+    const float* wd = bw.wdisp + (size_t)b * Np8 * k;
+    const float* rep2b = bw.rep2 + (size_t)b * R8 * D;
+    float* yb = y + (size_t)b * N * D;
+    if (desc->ffn) {
+      // x2 = x1 + dispatch (no LayerNorm yet) -> FFN -> (+ shortcut) -> final LayerNorm
+      RRT_TRY(launch_crmsa_dispatch_ln(xb1, nullptr, wd, rep2b, nullptr, nullptr, bw.one.xa, D, k, gd8, st));
+      rc = ffn_apply(desc, cw, bw.one.xa, bw.one.xb, bw.one, N, st);
+      if (rc) return rc;
+      RRT_TRY(launch_layernorm(bw.one.xb, x0, w->norm_w, w->norm_b, yb, (int)N, D, st));
+    } else {
+      RRT_TRY(launch_crmsa_dispatch_ln(xb1, x0, wd, rep2b, w->norm_w, w->norm_b, yb, D, k, gd8, st));
+    }
+  }
+#undef RRT_TRY
+  return RRT_OK;
 }
 
 // ------------------------------------------------------------------ stage entry points
@@ -968,6 +1134,49 @@ int rrt_pool_predict_f32(const float* y, const float* a_w, const float* a_b, con
                       dim, hidden, act, n_classes, compute, ws, (hipStream_t)stream);
 }
 
+// ---- the pooling alone, forward and backward (training: the first Linear + activation stay autograd-visible layers)
+int rrt_attn_pool_workspace_size(int64_t n_tokens, int32_t dim, int32_t hidden, size_t* bytes) {
+  if (!bytes) return RRT_E_INVALID;
+  int rc = check_pool(n_tokens, dim, hidden, RRT_ACT_NONE, 1);
+  if (rc) return rc;
+  const size_t nb = (size_t)(n_tokens + POOL_CHUNK - 1) / POOL_CHUNK;
+  const size_t fwd = align_up(nb * ((size_t)dim + 4) * sizeof(float), 256);
+  const size_t bwd = align_up(pool_backward_part_floats((int)n_tokens, hidden) * sizeof(float), 256);
+  *bytes = fwd > bwd ? fwd : bwd;
+  return RRT_OK;
+}
+
+int rrt_attn_pool_f32(const float* y, const float* hid_a, const float* hid_b, const float* c_w, const float* c_b,
+                      float* pooled, float* attn, float* a_raw, int64_t n_tokens, int32_t dim, int32_t hidden,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!y || !hid_a || !c_w || !pooled || !attn || !a_raw) return RRT_E_INVALID;
+  int rc = check_pool(n_tokens, dim, hidden, RRT_ACT_NONE, 1);
+  if (rc) return rc;
+  size_t need = 0;
+  (void)rrt_attn_pool_workspace_size(n_tokens, dim, hidden, &need);
+  if (!workspace || workspace_bytes < need) return RRT_E_WORKSPACE;
+  hipError_t e = launch_pool_partial(y, hid_a, hid_b, c_w, c_b, a_raw, (float*)workspace, (int)n_tokens, dim, hidden,
+                                     (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  return (int)launch_pool_merge((const float*)workspace, a_raw, nullptr, nullptr, pooled, nullptr, attn, 0, (int)n_tokens, dim, 0,
+                                (hipStream_t)stream);
+}
+
+int rrt_attn_pool_backward_f32(const float* y, const float* hid_a, const float* hid_b, const float* c_w, const float* attn,
+                               const float* pooled, const float* d_pooled, const float* d_attn, const float* d_raw,
+                               const float* c_ext, float* dy, float* dhid_a, float* dhid_b, float* dwcb, int64_t n_tokens,
+                               int32_t dim, int32_t hidden, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!y || !hid_a || !c_w || !attn || !pooled || !d_pooled || !dy || !dhid_a || !dwcb || (hid_b && !dhid_b)) return RRT_E_INVALID;
+  int rc = check_pool(n_tokens, dim, hidden, RRT_ACT_NONE, 1);
+  if (rc) return rc;
+  if (d_attn && !c_ext) return RRT_E_INVALID;     // c_ext = sum_n attn_n d_attn_n (device scalar) goes with d_attn
+  size_t need = 0;
+  (void)rrt_attn_pool_workspace_size(n_tokens, dim, hidden, &need);
+  if (!workspace || workspace_bytes < need) return RRT_E_WORKSPACE;
+  return (int)launch_pool_backward(y, hid_a, hid_b, c_w, attn, pooled, d_pooled, d_attn, d_raw, c_ext, dy, dhid_a, dhid_b, dwcb,
+                                   (float*)workspace, (int)n_tokens, dim, hidden, (hipStream_t)stream);
+}
+
 int rrt_mil_workspace_size(const rrt_mil_desc* desc, int64_t n_tokens, size_t* bytes) {
   if (!bytes) return RRT_E_INVALID;
   int rc = check_mil(desc, n_tokens);
@@ -1067,7 +1276,21 @@ int rrt_executor_create(const rrt_encoder_desc* desc, int32_t n_streams, int64_t
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->gate.done, hipEventDisableTiming);
   for (int s = 0; s < n_streams && e == hipSuccess; ++s) {
-    e = hipStreamCreateWithFlags(&ex->streams[s], hipStreamNonBlocking);
+    static const char* smode = rrt_tune_env("RRT_EXEC_STREAMS");     // tuning build: how the executor's streams are made
+    if (smode && smode[0] == 'p') {                                   // "prio": priorities spread over the device's range
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      const int span = lo - hi + 1;
+      e = hipStreamCreateWithPriority(&ex->streams[s], hipStreamNonBlocking, hi + (span > 0 ? s % span : 0));
+    } else if (smode && smode[0] == 'h') {                            // "hi": all at the highest priority
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      e = hipStreamCreateWithPriority(&ex->streams[s], hipStreamNonBlocking, hi);
+    } else if (smode && smode[0] == 'd') {                            // "default": blocking streams
+      e = hipStreamCreate(&ex->streams[s]);
+    } else {
+      e = hipStreamCreateWithFlags(&ex->streams[s], hipStreamNonBlocking);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->join[s], hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&ex->ws[s], need);
     if (e == hipSuccess) ex->ws_bytes[s] = need;

@@ -17,6 +17,8 @@ struct GridDev {
   int P;    // tokens per region (s*s)
   int Np;   // H*H
   float inv_H, inv_s, inv_rs, inv_P;   // reciprocals for the division-free index maps
+  int Rt;   // CR-MSA: regions per representative row of rep / rep2 [k, Rt, D] (rs * rs; B * rs * rs when the bags of a
+            // batch share one inner attention, rrt_encoder_forward_batch_f32 -- the bag's pointer is offset by the caller)
 };
 
 // n / d for 0 <= n < 2^24 via a float reciprocal + one correction step (exact; ~6 VALU
@@ -115,25 +117,6 @@ __device__ __forceinline__ float wave_min(float v) {
   v = fminf(v, RRT_DPP_ROR(v, 1));
   return fminf(fminf(rrt_readlane(v, 0), rrt_readlane(v, 16)), fminf(rrt_readlane(v, 32), rrt_readlane(v, 48)));
 }
-
-// Streaming accesses of the bag-sized row kernels (LayerNorm + partition, CR-MSA statistics, dispatch + LayerNorm): rows
-// that are read or written ONCE by the kernel.  -DRRT_NT marks them non-temporal (nt: streamed through the caches
-// instead of displacing another kernel's resident operand panels in the XCD's L2).
-#ifdef RRT_NT
-__device__ __forceinline__ float4 ldg_stream(const float* p) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const f4 v = __builtin_nontemporal_load((const f4*)p);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void stg_stream(float* p, float4 v) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  __builtin_nontemporal_store((f4){v.x, v.y, v.z, v.w}, (f4*)p);
-}
-#else
-__device__ __forceinline__ float4 ldg_stream(const float* p) { return *(const float4*)p; }
-__device__ __forceinline__ void stg_stream(float* p, float4 v) { *(float4*)p = v; }
-#endif
-#define RRT_LDG_STREAM 1
 
 // 16-byte global -> LDS DMA (global_load_lds_dwordx4): the LDS destination is the
 // wave-uniform byte address `lds_addr` (held in M0) + lane*16; the global source is per lane.

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
   __shared__ float s_c0[KMAX][4], s_c1[KMAX][4];    // per-wave partials of c0, c1
   const int reg = blockIdx.x, slab = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int R = g.rs * g.rs;
+  const int R = g.Rt;
   const float* lg = logits + (size_t)reg * g.P * k;
 
   // region statistics: wave n handles representative n (k <= 8, 4 waves -> 2 rounds)
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
   __shared__ float s_stat[KM][3];
   __shared__ float s_c0[KM][16], s_c1[KM][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int reg = blockIdx.x, R = g.rs * g.rs;
+  const int reg = blockIdx.x, R = g.Rt;
   const int ri = reg / g.rs, rj = reg - ri * g.rs;
   for (int idx = tid; idx < DIM * k; idx += 1024) {
     const int d = idx / k, n = idx - d * k;
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
     }
     tokv[j] = t;
     const float* src = x1 + (size_t)(t < 0 ? 0 : t) * DIM;
-    r[j][0] = ldg_stream(src + lane * 4);
-    r[j][1] = ldg_stream(src + 256 + lane * 4);
+    r[j][0] = *(const float4*)(src + lane * 4);
+    r[j][1] = *(const float4*)(src + 256 + lane * 4);
   }
   const float4 gm0 = *(const float4*)(gamma + lane * 4), gm1 = *(const float4*)(gamma + 256 + lane * 4);
   const float4 bt0 = *(const float4*)(beta + lane * 4), bt1 = *(const float4*)(beta + 256 + lane * 4);
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   __shared__ float s_mm[KM][2];                     // region min, max
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int reg = blockIdx.x / NB, q = blockIdx.x - reg * NB, R = g.rs * g.rs;
+  const int reg = blockIdx.x / NB, q = blockIdx.x - reg * NB, R = g.Rt;
   RRT_TRACE_INIT(blockIdx.x * NW + wave);
   RRT_TRACE_MARK();                                 // [1] entry
   const int ri = reg / g.rs, rj = reg - ri * g.rs;
@@ -573,8 +573,8 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
     }
     tokv[j] = t;
     const float* src = x1 + (size_t)(t < 0 ? 0 : t) * DIM;
-    r[j][0] = ldg_stream(src + lane * 4);
-    r[j][1] = ldg_stream(src + 256 + lane * 4);
+    r[j][0] = *(const float4*)(src + lane * 4);
+    r[j][1] = *(const float4*)(src + 256 + lane * 4);
   }
   const float4 gm0 = *(const float4*)(gamma + lane * 4), gm1 = *(const float4*)(gamma + 256 + lane * 4);
   const float4 bt0 = *(const float4*)(beta + lane * 4), bt1 = *(const float4*)(beta + 256 + lane * 4);
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
   const int lane = threadIdx.x & 63;
   const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
   if (t0 >= L) return;
-  const int R = g.rs * g.rs;
+  const int R = g.Rt;
   float4 r[RW][NV];
   // issue every row load first (x1, shortcut), then the dispatch weights
 #pragma unroll
@@ -814,9 +814,9 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      r[i][v] = (FULL || c < dim) ? ldg_stream(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r[i][v] = (FULL || c < dim) ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (x0 && (FULL || c < dim)) {
-        float4 s = ldg_stream(x0 + (size_t)t * dim + c);
+        float4 s = *(const float4*)(x0 + (size_t)t * dim + c);
         r[i][v].x += s.x; r[i][v].y += s.y; r[i][v].z += s.z; r[i][v].w += s.w;
       }
     }
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         int c = (v * 64 + lane) * 4;
-        if (FULL || c < dim) stg_stream(y + (size_t)(t0 + i) * dim + c, r[i][v]);
+        if (FULL || c < dim) *(float4*)(y + (size_t)(t0 + i) * dim + c) = r[i][v];
       }
     }
     return;
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
           o.y = (r[i][v].y - mean[i]) * rstd[i] * gm.y + bt.y;
           o.z = (r[i][v].z - mean[i]) * rstd[i] * gm.z + bt.z;
           o.w = (r[i][v].w - mean[i]) * rstd[i] * gm.w + bt.w;
-          stg_stream(y + (size_t)(t0 + i) * dim + c, o);
+          *(float4*)(y + (size_t)(t0 + i) * dim + c) = o;
         }
     }
   }

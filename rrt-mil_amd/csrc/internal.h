@@ -158,6 +158,13 @@ hipError_t launch_pool_merge(const float* part, const float* a_raw, const float*
                              float* pooled, float* logits, float* attn, int no_norm, int N, int dim,
                              int n_classes, hipStream_t st);
 
+// backward of the pooling (mil_pool.hip): dy [N, dim], dhid_a / dhid_b [N, hid], dwcb [hid + 4] = d wc | d bc
+size_t pool_backward_part_floats(int N, int hid);
+hipError_t launch_pool_backward(const float* y, const float* hid_a, const float* hid_b, const float* wc, const float* attn,
+                                const float* pooled, const float* d_pooled, const float* d_attn, const float* d_raw,
+                                const float* c_ext, float* dy, float* dhid_a, float* dhid_b, float* dwcb, float* part, int N,
+                                int dim, int hid, hipStream_t st);
+
 // ---- row f2 building blocks (backward)
 // nn.Linear backward: dX = dY W (forward GEMM on a transposed W), dW = dY^T X (split-K TN kernel), db = colsum(dY)
 size_t linear_bwd_workspace(int M, int N, int K);

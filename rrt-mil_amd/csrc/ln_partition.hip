@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restri
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      if (FULL || c < dim) stg_stream(dst + c, make_float4(0.f, 0.f, 0.f, 0.f));
+      if (FULL || c < dim) *(float4*)(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
   }
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restri
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    r[v] = (FULL || c < dim) ? ldg_stream(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[v] = (FULL || c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     sum += (r[v].x + r[v].y) + (r[v].z + r[v].w);
   }
   const float inv_d = 1.0f / (float)dim;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restri
       o.y = (r[v].y - mean) * rstd * gm.y + bt.y;
       o.z = (r[v].z - mean) * rstd * gm.z + bt.z;
       o.w = (r[v].w - mean) * rstd * gm.w + bt.w;
-      stg_stream(dst + c, o);
+      *(float4*)(dst + c) = o;
     }
   }
 }

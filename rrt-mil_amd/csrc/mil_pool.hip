@@ -203,7 +203,95 @@ __global__ __launch_bounds__(1024) void pool_merge_kernel(const float* __restric
   }
 }
 
+// ---- backward of the pooling (training of the slide classifier; adjoint of datten.py:28-38 / :69-83 after the first Linear):
+//     s_n = wc . h_n + bc ,  A = softmax_n(s) ,  pooled = sum_n A_n y_n         (h = hid_a, or hid_a * hid_b when gated)
+// given d pooled [dim] (and optionally d A [N], d s [N] for callers that use the returned attention / raw scores):
+//     dA_n = y_n . dpooled (+ dA_ext_n)      ds_n = A_n (dA_n - c) (+ ds_ext_n) ,  c = sum_m A_m dA_m = pooled . dpooled (+ c_ext)
+//     dy_n = A_n dpooled      dh_n = ds_n wc      d wc = sum_n ds_n h_n      d bc = sum_n ds_n
+// One wave per token, POOL_BWD_ROWS tokens per block; per-block partials of (d wc | d bc) -> launch_reduce_partials.
+constexpr int POOL_BWD_ROWS = 32;
+__global__ __launch_bounds__(256) void pool_backward_kernel(const float* __restrict__ y, const float* __restrict__ hid_a,
+                                                            const float* __restrict__ hid_b, const float* __restrict__ wc,
+                                                            const float* __restrict__ attn, const float* __restrict__ pooled,
+                                                            const float* __restrict__ d_pooled, const float* __restrict__ d_attn,
+                                                            const float* __restrict__ d_raw, const float* __restrict__ c_ext,
+                                                            float* __restrict__ dy, float* __restrict__ dhid_a,
+                                                            float* __restrict__ dhid_b, float* __restrict__ part, int N, int dim,
+                                                            int hid) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_dp = (float*)smem;                        // d pooled [dim]
+  float* s_acc = s_dp + dim;                         // [4 waves][hid + 4]: this block's d wc | d bc partial
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float cpart = 0.f;
+  for (int c = tid; c < dim; c += 256) {
+    const float v = d_pooled[c];
+    s_dp[c] = v;
+    cpart += v * pooled[c];
+  }
+  for (int c = tid; c < 4 * (hid + 4); c += 256) s_acc[c] = 0.f;
+  __shared__ float s_c[4];
+  cpart = wave_sum(cpart);
+  if (lane == 0) s_c[wave] = cpart;
+  __syncthreads();
+  const float cc = (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]) + (c_ext ? c_ext[0] : 0.f);
+  float* myacc = s_acc + wave * (hid + 4);
+  const int n0 = blockIdx.x * POOL_BWD_ROWS;
+  float dbc = 0.f;
+  for (int t = wave; t < POOL_BWD_ROWS; t += 4) {
+    const int n = n0 + t;
+    if (n >= N) break;
+    const float a = attn[n];
+    const float* yr = y + (size_t)n * dim;
+    float da = 0.f;
+    for (int c = lane * 4; c < dim; c += 256) {
+      const float4 v = *(const float4*)(yr + c);
+      const float4 d = *(const float4*)(s_dp + c);
+      da += (v.x * d.x + v.y * d.y) + (v.z * d.z + v.w * d.w);
+      *(float4*)(dy + (size_t)n * dim + c) = make_float4(a * d.x, a * d.y, a * d.z, a * d.w);
+    }
+    da = wave_sum(da) + (d_attn ? d_attn[n] : 0.f);
+    const float ds = a * (da - cc) + (d_raw ? d_raw[n] : 0.f);
+    dbc += ds;
+    for (int c = lane * 4; c < hid; c += 256) {
+      const float4 w = *(const float4*)(wc + c);
+      float4 ha = *(const float4*)(hid_a + (size_t)n * hid + c);
+      float4 g = make_float4(ds * w.x, ds * w.y, ds * w.z, ds * w.w);          // d (h_a h_b) (or d h_a)
+      float4 h = ha;
+      if (hid_b) {
+        const float4 hb = *(const float4*)(hid_b + (size_t)n * hid + c);
+        *(float4*)(dhid_b + (size_t)n * hid + c) = make_float4(g.x * ha.x, g.y * ha.y, g.z * ha.z, g.w * ha.w);
+        h = make_float4(ha.x * hb.x, ha.y * hb.y, ha.z * hb.z, ha.w * hb.w);
+        g = make_float4(g.x * hb.x, g.y * hb.y, g.z * hb.z, g.w * hb.w);
+      }
+      *(float4*)(dhid_a + (size_t)n * hid + c) = g;
+      float4 acc = *(float4*)(myacc + c);
+      acc.x += ds * h.x; acc.y += ds * h.y; acc.z += ds * h.z; acc.w += ds * h.w;
+      *(float4*)(myacc + c) = acc;
+    }
+  }
+  if (lane == 0) myacc[hid] = dbc;
+  __syncthreads();
+  float* out = part + (size_t)blockIdx.x * (hid + 4);
+  for (int c = tid; c < hid + 1; c += 256)
+    out[c] = (s_acc[c] + s_acc[(hid + 4) + c]) + (s_acc[2 * (hid + 4) + c] + s_acc[3 * (hid + 4) + c]);
+}
+
 }  // namespace
+
+// d wc [hid] and d bc [1] come out as dwcb [hid + 4] (d bc at [hid]); part: ceil(N / 32) * (hid + 4) floats
+hipError_t launch_pool_backward(const float* y, const float* hid_a, const float* hid_b, const float* wc, const float* attn,
+                                const float* pooled, const float* d_pooled, const float* d_attn, const float* d_raw,
+                                const float* c_ext, float* dy, float* dhid_a, float* dhid_b, float* dwcb, float* part, int N,
+                                int dim, int hid, hipStream_t st) {
+  const int nb = (N + POOL_BWD_ROWS - 1) / POOL_BWD_ROWS;
+  const size_t lds = ((size_t)dim + 4 * (hid + 4)) * sizeof(float);
+  pool_backward_kernel<<<dim3(nb), dim3(256), lds, st>>>(y, hid_a, hid_b, wc, attn, pooled, d_pooled, d_attn, d_raw, c_ext, dy,
+                                                         dhid_a, dhid_b, part, N, dim, hid);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return launch_reduce_partials(part, dwcb, nb, (size_t)hid + 4, st);
+}
+size_t pool_backward_part_floats(int N, int hid) { return (size_t)((N + POOL_BWD_ROWS - 1) / POOL_BWD_ROWS) * (hid + 4); }
 
 hipError_t launch_pool_partial(const float* y, const float* hid_a, const float* hid_b, const float* wc,
                                const float* bc, float* a_raw, float* part, int N, int dim, int hid,

@@ -536,7 +536,11 @@ __global__ __launch_bounds__(256) void region_attn_generic_kernel(const float* _
 // MFMAs, which permutes the reduction identically on both sides; V: one key row element per lane), so the kernel is one
 // memory round trip + 128 MFMAs: 6.4 us against 7.2 for the K/V-ring kernel on these 24 small problems.
 // grid (heads, regions), 4 waves; q already scaled by the projection's epilogue.
-__global__ __launch_bounds__(256) void region_attn64_kernel(const float* __restrict__ qkv, float* __restrict__ o, int dim) {
+// Register budget (round 4): with every fragment requested up front the kernel held 164 VGPRs, more than the 144 a SIMD has
+// left beside two waves of another bag's fused R-MSA kernel -- its blocks then WAITED for a fused block to retire and took the
+// CU slot of that kernel's next block (measured beside the fused kernel: 12.4 us of its time per launch, twice this kernel's
+// own 6.1 us).  Now the second half of V is requested behind S^T (into the registers K leaves): <= 128 VGPRs.
+__global__ __launch_bounds__(256, 4) void region_attn64_kernel(const float* __restrict__ qkv, float* __restrict__ o, int dim) {
   const int LDQ = 3 * dim;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int head = blockIdx.x, reg = blockIdx.y;
@@ -550,12 +554,12 @@ __global__ __launch_bounds__(256) void region_attn64_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) kf[kt][i] = *(const float4*)(base + (size_t)(16 * kt + r) * LDQ + dim + 16 * i + 4 * g);
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
+  for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) vf[kt][j][dt] = base[(size_t)(16 * kt + 4 * g + j) * LDQ + 2 * dim + 16 * dt + r];
-  __builtin_amdgcn_sched_barrier(0);                      // every load is issued before the first MFMA waits
+  __builtin_amdgcn_sched_barrier(0);                      // these loads are issued before the first MFMA waits
   // S^T = K q^T: st[kt][j] = score(query 16 wave + r, key 16 kt + 4 g + j)
   f32x4 st[4];
 #pragma unroll
@@ -569,6 +573,14 @@ __global__ __launch_bounds__(256) void region_attn64_kernel(const float* __restr
       st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][i].w, qf[i].w, st[kt], 0, 0, 0);
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kt = 2; kt < 4; ++kt)                          // second half of V: in flight under the softmax
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vf[kt][j][dt] = base[(size_t)(16 * kt + 4 * g + j) * LDQ + 2 * dim + 16 * dt + r];
+  __builtin_amdgcn_sched_barrier(0);
   float mx = NEG_BIG;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)

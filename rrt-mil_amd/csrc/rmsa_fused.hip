@@ -30,13 +30,8 @@ namespace {
 
 #define RRT_STORE_O(ptr, val) (*(ptr) = (val))   // (non-temporal stores measured: no gain)
 
-#ifndef RRT_FUSED_STAGES
-#define RRT_FUSED_STAGES 2
-#endif
 constexpr int BK = 32;
 constexpr int HD = 64;
-template <int N>
-__device__ __forceinline__ void wait_vm_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 constexpr int BN = 3 * HD;          // q | k | v columns of one head
 constexpr float NEG_BIG = -3.0e38f;
 constexpr float LOG2E = 1.4426950408889634f;
@@ -89,9 +84,8 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
   constexpr int NA = BM / 8, NB = BN / 8;          // DMA wave-instructions per A / B stage
   constexpr int LA = (NA + 3) / 4, LB = NB / 4;    // per loader wave (four of them)
   constexpr int NT = 3;                            // 16-column tiles per compute wave (4 x 48 = 192)
+  constexpr int LDS_MAIN = (2 * STAGE > 3 * TILE ? 2 * STAGE : 3 * TILE) * 4;   // bytes: staging ring / Q, K, V tiles
   constexpr bool PIPE = PREC == PREC_F32 && MT <= 11;   // software-pipelined projection loop (phase 1)
-  constexpr int NS = (PIPE && MT <= 9) ? RRT_FUSED_STAGES : 2;   // stages of the LDS-DMA ring
-  constexpr int LDS_MAIN = (NS * STAGE > 3 * TILE ? NS * STAGE : 3 * TILE) * 4;   // bytes: staging ring / Q, K, V tiles
   constexpr bool SPLIT_LAST = MT == 9;             // nine tiles on eight waves: the ninth is shared out (phase 4)
   constexpr int RUN = (BM * 16 + 511) / 512;       // query rows per stencil thread: 5 for BM = 144
   constexpr int TAP_OFF = 12 + RUN - 1;            // tap t lives at taps[t + TAP_OFF]; taps[12..] is 16-byte aligned
@@ -181,28 +175,10 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
       wait_vm0();
       __syncthreads();                              // publishes K tile 0
       if (nk > 1) stage(1, lds_b + STAGE * 4);
-      if constexpr (NS == 3) {
-        // three stages: stage kt + 2 stays in flight across barrier B_kt (its DMA instructions are the youngest of this
-        // wave: wait until at most that many are outstanding), buffer kt % 3 is refilled with stage kt + 3 behind it
-        if (nk > 2) stage(2, lds_b + 2 * STAGE * 4);
-        constexpr int NFULL = NA - 4 * (LA - 1);    // loader waves lw < NFULL issue LA A-pieces per stage, the others LA - 1
-        int bi = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-          if (kt + 2 < nk) {
-            if (lw < NFULL) wait_vm_le<LA + LB>(); else wait_vm_le<LA - 1 + LB>();
-          } else {
-            wait_vm0();
-          }
-          __syncthreads();                          // B_kt
-          if (kt + 3 < nk) stage(kt + 3, lds_b + bi * STAGE * 4);
-          bi = bi == 2 ? 0 : bi + 1;
-        }
-      } else {
       for (int kt = 0; kt < nk; ++kt) {
         wait_vm0();                                 // K tile kt + 1 has landed
         __syncthreads();                            // B_kt
         if (kt + 2 < nk) stage(kt + 2, lds_b + (kt & 1) * STAGE * 4);
-      }
       }
     } else {
       for (int kt = 0; kt < nk; ++kt) {
@@ -305,10 +281,8 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
       second_head(lds);
       __syncthreads();                                            // B_0
       RRT_TRACE_MARK();                                           // [3] B_0
-      int bi = 0;
       for (int kt = 1; kt < nk; ++kt) {
-        bi = bi == NS - 1 ? 0 : bi + 1;
-        const float* As = lds + bi * STAGE;         // stage kt lives in buffer kt % NS
+        const float* As = lds + (kt & 1) * STAGE;
         __builtin_amdgcn_sched_barrier(0);
         second_tail(As, true);                                    // rest of k tile kt - 1
         first_half(As, true);
@@ -784,7 +758,7 @@ template <int MT, int PREC>
 hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w, float* O,
                      int n_regions, int P, int D, int heads, int epeg_k, float* stash, hipStream_t st) {
   constexpr int BM = 16 * MT;
-  constexpr size_t STG = (size_t)((PREC == PREC_F32 && MT <= 9) ? RRT_FUSED_STAGES : 2) * (BM + BN) * BK * 4, QKV = (size_t)3 * BM * HD * 4;
+  constexpr size_t STG = (size_t)2 * (BM + BN) * BK * 4, QKV = (size_t)3 * BM * HD * 4;
   // staging ring / Q, K, V; tap table (512 B) + bias (768 B); partials of the shared-out tile (MT = 9)
   // staging ring / Q, K, V; tap table (512 B) + bias (768 B); shared-out tile (MT = 9): (max, sum) pairs + one partial O
   constexpr size_t LDS = (STG > QKV ? STG : QKV) + 1280 + (MT == 9 ? MT * 32 * 4 + 16 * HD * 4 : 0);

@@ -551,6 +551,30 @@ class RRTEncoder(nn.Module):
             _lib.check(rc, "rrt_encoder_forward_f32")
         return y
 
+    def forward_batch(self, x3d):
+        """(B, N, D) -> (B, N, D) with the reference's batch semantics (CR-MSA's inner attention over the representatives
+        of ALL bags of the batch, modules/rmsa.py:316-322).  Inference; one library call on the current stream."""
+        lib = _lib.load()
+        if not x3d.is_cuda:
+            raise _lib.RRTHipError("rrt_mil_amd.RRTEncoder runs on MI355X only; there is no CPU fallback")
+        x3d = x3d.float().contiguous()
+        b, n, d = x3d.shape
+        if d != self.final_dim:
+            raise ValueError(f"expected feature dim {self.final_dim}, got {d}")
+        desc = self._desc
+        desc.compute = self._compute_mode()
+        need = C.c_size_t()
+        _lib.check(lib.rrt_encoder_batch_workspace_size(C.byref(desc), b, n, C.byref(need)), "rrt_encoder_batch_workspace_size")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=x3d.device)
+        y = torch.empty_like(x3d)
+        w = self._weights()
+        with torch.cuda.device(x3d.device):
+            desc.weights16_valid = 0
+            rc = lib.rrt_encoder_forward_batch_f32(C.byref(desc), C.byref(w), x3d.data_ptr(), y.data_ptr(), b, n,
+                                                   ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x3d.device).cuda_stream)
+        _lib.check(rc, "rrt_encoder_forward_batch_f32")
+        return y
+
     def _stochastic(self):
         return self.training and (self.drop_out > 0 or any(l.drop_path_p > 0 for l in self._trans_layers()))
 
@@ -726,11 +750,15 @@ class RRTEncoder(nn.Module):
             shape_len = 4
         batch, num_patches, ch = x.shape
         if batch != 1:
-            # the reference mixes the bags of a batch inside CR-MSA (regions of all bags share one
-            # attention sequence, modules/rmsa.py:316-322); every reference trainer uses batch_size=1
-            raise NotImplementedError("batch > 1: pass bags one at a time (reference semantics at B>1 "
-                                      "couple the bags inside CR-MSA)")
-        y = (self.forward_bag_train(x[0]) if train else self.forward_bag(x[0])).unsqueeze(0)
+            # the reference couples the bags of a batch inside CR-MSA (the regions of all bags share one attention
+            # sequence, modules/rmsa.py:316-322): reproduced by rrt_encoder_forward_batch_f32 (inference); every reference
+            # trainer uses batch_size = 1, and independent bags belong in forward_bags()
+            if train or self._stochastic():
+                raise NotImplementedError("batch > 1 with an autograd graph or dropout: the HIP backward covers one bag "
+                                          "per call (every reference trainer uses batch_size=1)")
+            y = self.forward_batch(x)
+        else:
+            y = (self.forward_bag_train(x[0]) if train else self.forward_bag(x[0])).unsqueeze(0)
         if shape_len == 2:
             y = y.squeeze(0)
         elif shape_len == 4:

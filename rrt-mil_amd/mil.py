@@ -84,6 +84,86 @@ def lib_linear(lin, x, compute):
     return y.reshape(*x.shape[:-1], lin.out_features)
 
 
+class _AttnPool(torch.autograd.Function):
+    """The pooling of DAttention behind its first Linear + activation (modules/datten.py:28-38, :69-83) as ONE library
+    call each way: scores s_n = c_w . h_n + c_b (h = hid_a, or hid_a * hid_b when gated), attn = softmax over the bag,
+    pooled = sum_n attn_n y_n  (rrt_attn_pool_f32: the online-softmax chunk kernels of the inference path), and the
+    adjoint (rrt_attn_pool_backward_f32: dy, d hid_a, d hid_b, d c_w, d c_b in one pass over y).  Returns
+    (pooled [dim], attn [N] normalised, a_raw [N] scores); gradients flowing into the returned attention / raw scores
+    are honoured."""
+
+    @staticmethod
+    def forward(ctx, y2d, hid_a, hid_b, c_w, c_b):
+        lib = _lib.load()
+        y2d, hid_a = y2d.float().contiguous(), hid_a.float().contiguous()
+        hid_b = hid_b.float().contiguous() if hid_b is not None else None
+        n, d = y2d.shape
+        hdim = hid_a.shape[1]
+        dev = y2d.device
+        pooled = torch.empty(d, dtype=torch.float32, device=dev)
+        attn = torch.empty(n, dtype=torch.float32, device=dev)
+        a_raw = torch.empty(n, dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        _lib.check(lib.rrt_attn_pool_workspace_size(n, d, hdim, C.byref(need)), "rrt_attn_pool_workspace_size")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        cw = c_w.reshape(-1).contiguous()
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.rrt_attn_pool_f32(y2d.data_ptr(), hid_a.data_ptr(), hid_b.data_ptr() if hid_b is not None else None,
+                                             cw.data_ptr(), c_b.data_ptr() if c_b is not None else None, pooled.data_ptr(),
+                                             attn.data_ptr(), a_raw.data_ptr(), n, d, hdim, ws.data_ptr(), ws.numel(), st),
+                       "rrt_attn_pool_f32")
+        ctx.save_for_backward(y2d, hid_a, hid_b, cw, attn, pooled)
+        ctx.has_bias, ctx.cw_shape = c_b is not None, c_w.shape
+        ctx.set_materialize_grads(False)
+        return pooled, attn, a_raw
+
+    @staticmethod
+    def backward(ctx, d_pooled, d_attn, d_raw):
+        lib = _lib.load()
+        y2d, hid_a, hid_b, cw, attn, pooled = ctx.saved_tensors
+        n, d = y2d.shape
+        hdim = hid_a.shape[1]
+        dev = y2d.device
+        d_pooled = (torch.zeros(d, dtype=torch.float32, device=dev) if d_pooled is None else d_pooled.float().contiguous())
+        c_ext = None
+        if d_attn is not None:
+            d_attn = d_attn.float().contiguous()
+            c_ext = (attn * d_attn).sum().reshape(1)           # sum_n attn_n d_attn_n (the softmax adjoint's constant)
+        if d_raw is not None:
+            d_raw = d_raw.float().contiguous()
+        dy = torch.empty_like(y2d)
+        dha = torch.empty_like(hid_a)
+        dhb = torch.empty_like(hid_b) if hid_b is not None else None
+        dwcb = torch.empty(hdim + 4, dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        _lib.check(lib.rrt_attn_pool_workspace_size(n, d, hdim, C.byref(need)), "rrt_attn_pool_workspace_size")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.rrt_attn_pool_backward_f32(y2d.data_ptr(), hid_a.data_ptr(), p(hid_b), cw.data_ptr(), attn.data_ptr(),
+                                                      pooled.data_ptr(), d_pooled.data_ptr(), p(d_attn), p(d_raw), p(c_ext),
+                                                      dy.data_ptr(), dha.data_ptr(), p(dhb), dwcb.data_ptr(), n, d, hdim,
+                                                      ws.data_ptr(), ws.numel(), st), "rrt_attn_pool_backward_f32")
+        dcw = dwcb[:hdim].reshape(ctx.cw_shape)
+        dcb = dwcb[hdim:hdim + 1].clone() if ctx.has_bias else None
+        return dy, dha, dhb, dcw, dcb
+
+
+def lib_attn_pool(x, hid_a, hid_b, lin_c):
+    """(1, N, D) bag x and its hidden rows (1, N, H) through the HIP pooling when it applies (one bag, a plain final
+    nn.Linear(H, 1), H % 4 == 0, D % 32 == 0, fp32); None otherwise (the caller keeps the torch ops)."""
+    ok = (type(lin_c) is nn.Linear and lin_c.out_features == 1 and not lin_c._forward_hooks and not lin_c._forward_pre_hooks
+          and x.is_cuda and x.dim() == 3 and x.size(0) == 1 and x.dtype == torch.float32 and x.size(1) > 0
+          and lin_c.weight.device == x.device and lin_c.weight.dtype == torch.float32
+          and hid_a.shape[-1] % 4 == 0 and x.shape[-1] % 32 == 0 and x.size(1) <= 1000000)
+    if not ok:
+        return None
+    pooled, attn, a_raw = _AttnPool.apply(x[0], hid_a[0], hid_b[0] if hid_b is not None else None, lin_c.weight, lin_c.bias)
+    return pooled.unsqueeze(0), attn.unsqueeze(0), a_raw.unsqueeze(0)
+
+
 class Attention(nn.Module):
     """modules/datten.py:5-38."""
 
@@ -304,11 +384,15 @@ class RRTMIL(nn.Module):
                 t = m(t)
             return t
         if self.pool_fn.gated:
-            s = att.attention_c(seq(att.attention_a, x).mul(seq(att.attention_b, x)))
+            ha, hb, lin_c = seq(att.attention_a, x), seq(att.attention_b, x), att.attention_c
         else:
             mods = list(att.attention)
-            s = mods[-1](seq(mods[:-1], x))
-        s = s.transpose(-1, -2)                           # K x N
+            ha, hb, lin_c = seq(mods[:-1], x), None, mods[-1]
+        out = lib_attn_pool(x, ha, hb, lin_c)          # scores, softmax over the bag and the weighted sum: HIP, both ways
+        if out is not None:
+            pooled, a, a_raw = out
+            return pooled, (a_raw if no_norm else a)
+        s = lin_c(ha.mul(hb) if hb is not None else ha).transpose(-1, -2)   # K x N (batched / odd widths: torch ops)
         a_raw = s.clone()
         a = F.softmax(s, dim=-1)
         pooled = torch.matmul(a, x).squeeze(1)

@@ -276,7 +276,7 @@ def test_crmsa_region_kernel_matches_logits_plus_combine(L, k):
 
 
 # ------------------------------------------------------------------ whole path
-SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G7", "G8", "G11", "G13", "G15", "G16")) and "mlp" not in n]
+SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G7", "G8", "G11", "G13", "G15", "G16", "G20")) and "mlp" not in n]
 # crmsa_mlp needs dim % 128 == 0 on the HIP path (hidden = dim/4 is a GEMM K): D=64 golden is out of range
 
 
@@ -319,6 +319,41 @@ def test_crmsa_mlp_small_dim():
     _cmp(y, O.forward_f64(x, st, cfg), 5e-5, "G6_d64_n700_mlp vs f64 oracle")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", golden_names("G20"))
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_encoder_batch_gt_1_matches_reference(name, mode):
+    """(B, N, D) input with B = 2 / 3 (modules/rrt.py:165-202): the reference couples the bags of a batch inside CR-MSA
+    (its inner attention runs over the representatives of all bags, rmsa.py:316-322).  rrt_encoder_forward_batch_f32
+    against the reference's own outputs (G20, tools/make_golden_batch.py); bf16: the autocast-class bound."""
+    from hip_util import encoder_from_state, dev
+    from rrt_mil_amd import synth as sy
+    g = load_golden(name)
+    cfg, N, B = g["cfg"], int(g["n"]), int(g["b"])
+    st = sy.encoder_state(**{k: v for k, v in cfg.items() if k in _STATE_KEYS})
+    x = np.stack([sy.bag(N, 512, tag=f"batch/b{b}") for b in range(B)])
+    enc = encoder_from_state(st, cfg)
+    if mode == "bf16":
+        enc.compute_dtype = torch.bfloat16
+    xd = dev(x)
+    y = enc(xd)
+    torch.cuda.synchronize()
+    assert y.shape == xd.shape
+    got = y.cpu().numpy().astype(np.float64)
+    err = np.abs(got[:, g["rows"]] - g["y_rows"]).max()
+    assert np.isfinite(got).all() and err <= (2e-4 if mode == "f32" else 6e-2), err
+    if mode == "f32":
+        for b in range(B):
+            s_ = np.array([got[b].sum(), np.abs(got[b]).sum()])
+            assert np.allclose(s_, g["y_sums"][b][:2], rtol=1e-5, atol=N_ATOL(N))
+        # the coupling is real: bag 0 alone gives something else, by what the reference recorded
+        y0 = enc(xd[:1])
+        torch.cuda.synchronize()
+        assert abs(float((y0[0] - y[0]).abs().max()) - float(g["coupling"])) <= 2e-4
+        # a batch of one is the single-bag path
+        assert torch.equal(enc(xd[1:2])[0], enc(xd[1]))
+
+
 @pytest.mark.parametrize("name", ["G7_d512_n2000_mlp", "G7_d128_n700_mlp"])
 def test_crmsa_mlp(name):
     """MLP phi (crmsa_mlp=True, NSCLC-PLIP config): vs the reference golden and the f64 oracle."""
@@ -346,10 +381,17 @@ def test_input_ranks_and_purity():
     assert torch.equal(x, x_keep)
     assert torch.equal(y2, y3[0])
     assert torch.equal(y4.reshape(1, 64, 400).transpose(1, 2)[0], y2)
-    with pytest.raises(NotImplementedError):
-        enc(torch.stack([x, x]))
+    # batch > 1 (round 4): the reference's semantics -- a (2, C, H, W) input comes back (2, C, H, W), and the two bags are
+    # coupled inside CR-MSA (test_encoder_batch_gt_1_matches_reference holds the values to the reference's)
+    yb = enc(torch.stack([x, x]))
+    yb4 = enc(torch.stack([x, x]).transpose(1, 2).reshape(2, 64, 20, 20).contiguous())
+    torch.cuda.synchronize()
+    assert yb.shape == (2, 400, 64) and yb4.shape == (2, 64, 20, 20) and torch.isfinite(yb).all()
+    assert torch.equal(yb4.reshape(2, 64, 400).transpose(1, 2), yb)
     with pytest.raises(NotImplementedError):
         enc.train()(x)
+    with pytest.raises(NotImplementedError):
+        enc.train()(torch.stack([x, x]))                 # a graph / dropout at B > 1: not covered by the HIP backward
 
 
 def test_repeatable_and_workspace_poison():
@@ -576,6 +618,43 @@ def test_rrtmil_readme_configs(name):
     torch.cuda.synchronize()
     _cmp(logits.cpu().numpy(), g["logits"], 1e-4, name + " logits")
     _cmp(attn.cpu().numpy(), g["attn"], 1e-6, name + " attention")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,gated,bias,act,no_norm", [(3000, False, False, "relu", False), (9000, False, True, "gelu", False),
+                                                      (1000, True, False, "tanh", False), (777, True, True, "relu", True),
+                                                      (50, False, False, "tanh", True), (4097, False, True, "none", False)])
+def test_attn_pool_forward_backward(N, gated, bias, act, no_norm):
+    """DAttention's scores -> softmax over the bag -> weighted sum (modules/datten.py:28-38, :69-83) as one HIP call each way
+    (rrt_attn_pool_f32 / rrt_attn_pool_backward_f32 behind mil._AttnPool): pooled, attention and every gradient -- x, both
+    hidden Linears, the score Linear and its bias, including the gradient that flows through the RETURNED attention row --
+    against the same module evaluated by torch in float64."""
+    import copy
+    from rrt_mil_amd.mil import RRTMIL
+    torch.manual_seed(7)
+    mil = RRTMIL(input_dim=64, n_classes=2, da_act=act, da_gated=gated, da_bias=bias, dropout=0.0).to("cuda:0").train()
+    ref = copy.deepcopy(mil.pool_fn).double()
+    x = torch.from_numpy(synth.normal(f"pool/x{N}", (1, N, 512))).to("cuda:0").requires_grad_(True)
+    x64 = x.detach().double().requires_grad_(True)
+    r1 = torch.from_numpy(synth.normal("pool/r1", (1, 512))).to("cuda:0")
+    r2 = torch.from_numpy(synth.normal(f"pool/r2{N}", (1, N))).to("cuda:0")
+    pooled, a = mil._pool(x, no_norm)
+    p64, a64 = ref(x64, return_attn=True, no_norm=no_norm)
+    assert pooled.shape == p64.shape and a.shape == a64.shape
+    assert float((pooled.double() - p64).abs().max()) <= 2e-5 and float((a.double() - a64).abs().max()) <= 2e-5 * max(1.0, float(a64.abs().max()))
+    ((pooled * r1).sum() + (a * r2).sum()).backward()
+    ((p64 * r1.double()).sum() + (a64 * r2.double()).sum()).backward()
+    torch.cuda.synchronize()
+
+    def close(g, g64, what):
+        scale = float(g64.abs().max()) + 1e-30
+        err = float((g.double() - g64).abs().max())
+        assert err <= 2e-4 * scale + 1e-7, (what, err, scale)
+    close(x.grad, x64.grad, "dx")
+    for (name, p), (_, p64_) in zip(mil.pool_fn.named_parameters(), ref.named_parameters()):
+        assert (p.grad is None) == (p64_.grad is None), name
+        if p.grad is not None:
+            close(p.grad, p64_.grad, name)
 
 
 def test_rrtmil_fails_loudly():

@@ -7,7 +7,7 @@ import pytest
 from conftest import golden_names, load_golden, synth_case
 from oracle import rrt_oracle as O
 
-SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G8", "G11", "G13", "G15", "G16"))   # G8/G11/G13 = RRTMIL goldens; G15 / G16: below
+SMALL = [n for n in golden_names("G") if not n.startswith(("G0", "G8", "G11", "G13", "G15", "G16", "G20"))   # G8/G11/G13 = RRTMIL goldens; G15 / G16 / G20: below
          and int(load_golden(n)["n"]) <= 4096]
 LARGE = ["G3_d512_n9000", "G18_d512_n13000", "G19_d512_n5600_k21_c5", "G5_d512_n9000_c1_sc", "G17_epeg_attn2d_d512_n9000", "G17_epeg_valuebf_d512_n9000",
          "G17_epeg_valueaf_d512_n9000"]
@@ -184,3 +184,29 @@ def test_round_lowp():
     t = torch.from_numpy(a.astype(np.float32))
     assert np.array_equal(O.round_lowp(a, "bf16"), t.to(torch.bfloat16).double().numpy())
     assert np.array_equal(O.round_lowp(a, "f16"), t.to(torch.float16).double().numpy())
+
+
+def batch_case(g):
+    """(x [B, N, D], state, cfg) of a G20 golden: bag b = synth.bag(N, D, tag=f"batch/b{b}")."""
+    from rrt_mil_amd import synth
+    from conftest import STATE_KEYS
+    cfg, N, B = g["cfg"], int(g["n"]), int(g["b"])
+    st = synth.encoder_state(**{k: v for k, v in cfg.items() if k in STATE_KEYS})
+    x = np.stack([synth.bag(N, cfg.get("mlp_dim", 512), tag=f"batch/b{b}") for b in range(B)])
+    return x, st, cfg
+
+
+@pytest.mark.parametrize("name", golden_names("G20"))
+def test_eager_port_matches_reference_at_batch_gt_1(name):
+    """(B, N, D) input, B = 2 / 3: the reference's CR-MSA runs its inner attention over the regions of ALL bags
+    (rmsa.py:296-322) -- bag 0 of a batch differs from bag 0 alone by `coupling` (recorded from the reference)."""
+    g = load_golden(name)
+    x, st, cfg = batch_case(g)
+    y = O.forward_eager(x, st, cfg).numpy()
+    assert y.shape == x.shape
+    assert np.abs(y[:, g["rows"]] - g["y_rows"]).max() <= 2e-6
+    for b in range(x.shape[0]):
+        s = np.array([y[b].astype(np.float64).sum(), np.abs(y[b].astype(np.float64)).sum()])
+        assert np.allclose(s, g["y_sums"][b][:2], rtol=1e-6, atol=1e-2)
+    y0 = O.forward_eager(x[0], st, cfg).numpy()
+    assert abs(float(np.abs(y[0] - y0).max()) - float(g["coupling"])) <= 1e-5 and float(g["coupling"]) > 1e-4
