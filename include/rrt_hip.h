@@ -383,8 +383,11 @@ int rrt_linear_act_f32(const float *A, const float *B, const float *bias, float 
  * Bags are independent units, and one bag's forward is a dependent chain of ~10 kernels that leaves
  * launch ramps, tails and store phases idle; the executor keeps `n_streams` bags in flight on its own HIP
  * streams (one workspace each, owned by the executor) so those gaps are filled by another bag's kernels.
- * rrt_executor_forward is ordered on the caller's `stream` like any other call here (fork: the internal
- * streams wait for `stream`; join: `stream` waits for them); it never synchronises the host unless a
+ * rrt_executor_forward is ordered on the caller's `stream` like any other call here; the caller's stream carries the
+ * first share of the bags itself and the executor's streams 1 .. n_streams-1 the others (fork: they wait for `stream`;
+ * join: `stream` waits for them BEHIND its own bags -- a caller stream that only sits on the join's barrier packets is one
+ * more active hardware queue, and four bag queues plus that one lose 13 % on MI355X's four pipes); a one-stream executor is
+ * plain launches on `stream`; it never synchronises the host unless a
  * workspace has to grow.  One executor per host thread and device.  Set GPU_MAX_HW_QUEUES >= 8 in the
  * process environment so every stream gets its own hardware queue. */
 typedef struct rrt_executor rrt_executor;
@@ -395,6 +398,12 @@ typedef struct rrt_bag {
 } rrt_bag;
 int rrt_executor_create(const rrt_encoder_desc *desc, int32_t n_streams, int64_t max_tokens,
                         rrt_executor **out);
+/* The same on streams the CALLER owns (n_streams distinct hipStream_t; they are used, never destroyed): a host framework
+ * hands over streams of its own pool -- rrt_mil_amd passes torch.cuda.Stream handles -- so that the process keeps ONE set of
+ * streams however many executors it makes (HIP maps streams to hardware queues in creation order; streams created and
+ * destroyed by executors of different widths end up sharing queues). */
+int rrt_executor_create_on_streams(const rrt_encoder_desc *desc, int32_t n_streams, void *const *streams,
+                                   int64_t max_tokens, rrt_executor **out);
 int rrt_executor_forward(rrt_executor *ex, const rrt_encoder_weights *w, const rrt_bag *bags,
                          int32_t n_bags, void *stream);
 int rrt_executor_destroy(rrt_executor *ex);

@@ -139,6 +139,8 @@ SIGNATURES = {
     "rrt_attn_pool_backward_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                                                  C.c_void_p]),
     "rrt_executor_create": (C.c_int, [C.POINTER(EncoderDesc), C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "rrt_executor_create_on_streams": (C.c_int, [C.POINTER(EncoderDesc), C.c_int32, C.POINTER(C.c_void_p), C.c_int64,
+                                                 C.POINTER(C.c_void_p)]),
     "rrt_executor_forward": (C.c_int, [C.c_void_p, C.POINTER(EncoderWeights), C.POINTER(Bag), C.c_int32,
                                        C.c_void_p]),
     "rrt_executor_destroy": (C.c_int, [C.c_void_p]),

@@ -1244,17 +1244,19 @@ struct rrt_executor {
   // per workspace: (weights.version, compute) of the 16-bit weight images it holds (0 = none)
   uint64_t w16_version[RRT_EXEC_MAX_STREAMS];
   int w16_compute[RRT_EXEC_MAX_STREAMS];
+  bool own_streams;      // false: the streams are the caller's (rrt_executor_create_on_streams), never destroyed here
 };
 
 extern "C" {
 
 int rrt_executor_destroy(rrt_executor* ex) {
   if (!ex) return RRT_OK;
+  (void)hipDeviceSynchronize();       // slot 0's workspace is used on the callers' streams
   for (int s = 0; s < ex->n_streams; ++s) {
     if (ex->streams[s]) (void)hipStreamSynchronize(ex->streams[s]);
     if (ex->ws[s]) (void)hipFree(ex->ws[s]);
     if (ex->join[s]) (void)hipEventDestroy(ex->join[s]);
-    if (ex->streams[s]) (void)hipStreamDestroy(ex->streams[s]);
+    if (ex->streams[s] && ex->own_streams) (void)hipStreamDestroy(ex->streams[s]);
   }
   if (ex->fork) (void)hipEventDestroy(ex->fork);
   if (ex->gate.done) (void)hipEventDestroy(ex->gate.done);
@@ -1262,7 +1264,8 @@ int rrt_executor_destroy(rrt_executor* ex) {
   return RRT_OK;
 }
 
-int rrt_executor_create(const rrt_encoder_desc* desc, int32_t n_streams, int64_t max_tokens, rrt_executor** out) {
+static int executor_create(const rrt_encoder_desc* desc, int32_t n_streams, int64_t max_tokens, void* const* user_streams,
+                           rrt_executor** out) {
   if (!desc || !out || max_tokens <= 0) return RRT_E_INVALID;
   if (n_streams < 1 || n_streams > RRT_EXEC_MAX_STREAMS) return unsupported("executor: n_streams must be in [1,8]");
   size_t need = 0;
@@ -1272,24 +1275,23 @@ int rrt_executor_create(const rrt_encoder_desc* desc, int32_t n_streams, int64_t
   memset(ex, 0, sizeof(*ex));
   ex->desc = *desc;
   ex->n_streams = n_streams;
+  ex->own_streams = user_streams == nullptr;
   hipError_t e = hipGetDevice(&ex->device);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->gate.done, hipEventDisableTiming);
   for (int s = 0; s < n_streams && e == hipSuccess; ++s) {
-    static const char* smode = rrt_tune_env("RRT_EXEC_STREAMS");     // tuning build: how the executor's streams are made
-    if (smode && smode[0] == 'p') {                                   // "prio": priorities spread over the device's range
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      const int span = lo - hi + 1;
-      e = hipStreamCreateWithPriority(&ex->streams[s], hipStreamNonBlocking, hi + (span > 0 ? s % span : 0));
-    } else if (smode && smode[0] == 'h') {                            // "hi": all at the highest priority
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      e = hipStreamCreateWithPriority(&ex->streams[s], hipStreamNonBlocking, hi);
-    } else if (smode && smode[0] == 'd') {                            // "default": blocking streams
-      e = hipStreamCreate(&ex->streams[s]);
+    if (user_streams) {
+      ex->streams[s] = (hipStream_t)user_streams[s];
     } else {
-      e = hipStreamCreateWithFlags(&ex->streams[s], hipStreamNonBlocking);
+      static const char* smode = rrt_tune_env("RRT_EXEC_STREAMS");     // tuning build: how the executor's streams are made
+      if (smode && smode[0] == 'p') {                                   // "prio": priorities spread over the device's range
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const int span = lo - hi + 1;
+        e = hipStreamCreateWithPriority(&ex->streams[s], hipStreamNonBlocking, hi + (span > 0 ? s % span : 0));
+      } else {
+        e = hipStreamCreateWithFlags(&ex->streams[s], hipStreamNonBlocking);
+      }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->join[s], hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&ex->ws[s], need);
@@ -1301,6 +1303,19 @@ int rrt_executor_create(const rrt_encoder_desc* desc, int32_t n_streams, int64_t
   }
   *out = ex;
   return RRT_OK;
+}
+
+int rrt_executor_create(const rrt_encoder_desc* desc, int32_t n_streams, int64_t max_tokens, rrt_executor** out) {
+  return executor_create(desc, n_streams, max_tokens, nullptr, out);
+}
+
+int rrt_executor_create_on_streams(const rrt_encoder_desc* desc, int32_t n_streams, void* const* streams, int64_t max_tokens,
+                                   rrt_executor** out) {
+  if (!streams) return RRT_E_INVALID;
+  for (int s = 0; s < n_streams && s < RRT_EXEC_MAX_STREAMS; ++s)
+    for (int t = 0; t < s; ++t)
+      if (streams[s] == streams[t]) return RRT_E_INVALID;      // the bags in flight need distinct streams
+  return executor_create(desc, n_streams, max_tokens, streams, out);
 }
 
 int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const rrt_bag* bags, int32_t n_bags,
@@ -1326,8 +1341,21 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
     order[j + 1] = v;
   }
   hipStream_t caller = (hipStream_t)stream;
-  hipError_t e = hipEventRecord(ex->fork, caller);
-  for (int s = 0; s < S && e == hipSuccess; ++s) e = hipStreamWaitEvent(ex->streams[s], ex->fork, 0);
+  // Slot 0 runs on the CALLER's stream, slots 1 .. S-1 on the executor's.  Round 4: with all S slots on own streams the
+  // caller's stream sat through the whole call with S barrier packets (the join) at its head -- a (S+1)-th active hardware
+  // queue next to the S that carry bags.  At S = 4 that is five queues on four pipes: 4.3-4.45 k slides/s where the same
+  // launches on four queues give 5.07-5.10 k (tools/bench_bags.py with the join compiled out; the five-stream bench line
+  // shows the same loss).  Now the join's waits sit BEHIND the caller stream's own share of the bags, the fork only
+  // concerns the other slots, and a one-stream executor is plain launches on the caller's stream.
+  hipStream_t sts[RRT_EXEC_MAX_STREAMS];
+  sts[0] = caller;
+  for (int s = 1; s < S; ++s) sts[s] = ex->streams[s];
+  hipError_t e = hipSuccess;
+  static const bool no_fork = rrt_tune_env("RRT_EXEC_NOFORK") != nullptr;      // (bisecting, tuning build only)
+  if (S > 1 && !no_fork) {
+    e = hipEventRecord(ex->fork, caller);
+    for (int s = 1; s < S && e == hipSuccess; ++s) e = hipStreamWaitEvent(sts[s], ex->fork, 0);
+  }
   int rc = (int)e;
   int64_t load[RRT_EXEC_MAX_STREAMS] = {0};
   // phase gate (the R-MSA cores of the bags in flight take turns): opt-in, RRT_GATE=1.  It paid +1.5 % at two bags in
@@ -1335,6 +1363,10 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
   // mix, bf16: 7.72 k vs 7.49 k slides/s; fp32: 3.74 k vs 3.68 k)
   static const bool gate_on = rrt_tune_env("RRT_GATE") != nullptr;
   const bool gated = S == 2 && gate_on;
+  // tuning build: RRT_EXEC_STAGGER=1 -> only the FIRST bag of every stream goes through the gate, so that the streams of a
+  // call start one R-MSA core apart instead of in lockstep (the fork releases them together)
+  static const bool stagger = rrt_tune_env("RRT_EXEC_STAGGER") != nullptr;
+  if (stagger) ex->gate.armed = false;
   for (int k = 0; k < n_bags && rc == RRT_OK; ++k) {
     const rrt_bag& b = bags[order[k]];
     int s = 0;
@@ -1345,7 +1377,7 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
     rc = rrt_encoder_workspace_size(&ex->desc, b.n_tokens, &need);
     if (rc) break;
     if (need > ex->ws_bytes[s]) {            // grow: the only host synchronisation in this call
-      e = hipStreamSynchronize(ex->streams[s]);
+      e = hipStreamSynchronize(sts[s]);
       if (e == hipSuccess) e = hipFree(ex->ws[s]);
       ex->ws[s] = nullptr;
       ex->ws_bytes[s] = 0;
@@ -1357,14 +1389,15 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
     rrt_encoder_desc d = ex->desc;
     d.solo = S == 1;
     d.weights16_valid = w->version != 0 && ex->w16_version[s] == w->version && ex->w16_compute[s] == d.compute;
-    rc = encoder_forward(&d, w, b.x, b.y, b.n_tokens, ex->ws[s], ex->ws_bytes[s], ex->streams[s], nullptr,
-                         gated ? &ex->gate : nullptr);
+    rc = encoder_forward(&d, w, b.x, b.y, b.n_tokens, ex->ws[s], ex->ws_bytes[s], sts[s], nullptr,
+                         (gated || (stagger && k < S)) ? &ex->gate : nullptr);
     ex->w16_version[s] = rc == RRT_OK ? w->version : 0;
     ex->w16_compute[s] = d.compute;
   }
   // join even after an error so the caller's stream stays ordered after whatever was enqueued
-  for (int s = 0; s < S; ++s) {
-    hipError_t j = hipEventRecord(ex->join[s], ex->streams[s]);
+  static const bool no_join = rrt_tune_env("RRT_EXEC_NOJOIN") != nullptr;      // (bisecting, tuning build only)
+  for (int s = 1; s < S && !no_join; ++s) {
+    hipError_t j = hipEventRecord(ex->join[s], sts[s]);
     if (j == hipSuccess) j = hipStreamWaitEvent(caller, ex->join[s], 0);
     if (rc == RRT_OK && j != hipSuccess) rc = (int)j;
   }

@@ -11,6 +11,7 @@ through a torch.autograd.Function over rrt_encoder_forward_train_f32 /
 rrt_encoder_backward_f32 (train() adds proj dropout and stochastic depth, eval() does not).
 There is no PyTorch/CPU fallback: CPU tensors and configurations outside the HIP path raise.
 """
+import os
 import warnings
 import contextlib
 import ctypes as C
@@ -254,6 +255,8 @@ def _warn_hw_queues(streams):
 
 
 _NULL_CTX = contextlib.nullcontext()
+_SIDE_STREAM = {}         # device -> the stream an executor call runs on when the caller sits on the default stream
+_BAG_STREAMS = {}          # device -> [torch.cuda.Stream]: the streams every executor of this process runs its bags on
 
 
 class RRTEncoder(nn.Module):
@@ -638,8 +641,20 @@ class RRTEncoder(nn.Module):
         lib = _lib.load()
         h = C.c_void_p()
         with torch.cuda.device(device):
-            _lib.check(lib.rrt_executor_create(C.byref(self._desc), n_streams, max_tokens, C.byref(h)),
-                       "rrt_executor_create")
+            if os.environ.get("RRT_EXEC_OWN_STREAMS") == "1":        # (experiments: streams created by the library)
+                _lib.check(lib.rrt_executor_create(C.byref(self._desc), n_streams, max_tokens, C.byref(h)),
+                           "rrt_executor_create")
+            else:
+                # the process's ONE set of bag streams (torch's stream pool), whatever executors come and go
+                pool = _BAG_STREAMS.setdefault(device, [])
+                off = int(os.environ.get("RRT_EXEC_POOL_OFFSET", "0"))        # (experiments)
+                while len(pool) < n_streams + off:
+                    pool.append(torch.cuda.Stream(device))
+                # slot 0 of an executor call runs on the caller's stream: slots 1 .. n-1 take the FIRST streams of the list
+                hs = [pool[off + n_streams - 1].cuda_stream] + [st.cuda_stream for st in pool[off:off + n_streams - 1]]
+                arr = (C.c_void_p * n_streams)(*hs)
+                _lib.check(lib.rrt_executor_create_on_streams(C.byref(self._desc), n_streams, arr, max_tokens, C.byref(h)),
+                           "rrt_executor_create_on_streams")
         self._ex, self._ex_key, self._ex_desc = h, key, _lib.EncoderDesc.from_buffer_copy(self._desc)
         return h
 
@@ -656,7 +671,7 @@ class RRTEncoder(nn.Module):
             pass
 
     @torch.no_grad()
-    def forward_bags(self, bags, streams=2, outs=None):
+    def forward_bags(self, bags, streams=4, outs=None):
         """A batch of independent bags (each (N_i, D) or (1, N_i, D), any mix of sizes) -> list of outputs of
         the same shapes.  What the reference does with ``for bag in loader: model(bag)`` (main.py:466-467),
         with ``streams`` bags in flight on the library's own HIP streams (rrt_executor_forward); ordered on
@@ -689,7 +704,24 @@ class RRTEncoder(nn.Module):
             arr[i].x, arr[i].y, arr[i].n_tokens = x.data_ptr(), y.data_ptr(), x.size(0)
         w = self._weights()
         with torch.cuda.device(dev):
-            rc = lib.rrt_executor_forward(ex, C.byref(w), arr, len(xs), torch.cuda.current_stream(dev).cuda_stream)
+            cur = torch.cuda.current_stream(dev)
+            if not (cur.cuda_stream == 0 and int(streams) >= 4):
+                # the call is ordered on the caller's stream, which carries the first share of the bags itself
+                rc = lib.rrt_executor_forward(ex, C.byref(w), arr, len(xs), cur.cuda_stream)
+            else:
+                # Four bags in flight and the caller on the process's DEFAULT stream (handle 0).  Bags on that stream next
+                # to three others run at 4.5 k slides/s instead of 5.1 k (measured, tools/bench_bags.py: with hundreds of
+                # launches queued the legacy default stream behaves like one queue more), and a default stream that merely
+                # WAITS for the bag streams (event wait) is a fifth active queue with the same cost (4.2-4.5 k).  So the
+                # call runs on a side stream, ordered behind the default stream's earlier work, and the HOST waits for it:
+                # nothing is parked on the default stream (4.8 k at 16 bags per call, 4.95 k at 64, 5.03 k at 256).  Callers
+                # that want the call asynchronous run it under their own `with torch.cuda.stream(s):` (5.07-5.09 k).
+                side = _SIDE_STREAM.get(dev)
+                if side is None:
+                    side = _SIDE_STREAM[dev] = torch.cuda.Stream(dev)
+                side.wait_stream(cur)
+                rc = lib.rrt_executor_forward(ex, C.byref(w), arr, len(xs), side.cuda_stream)
+                side.synchronize()
         _lib.check(rc, "rrt_executor_forward")
         # xs / ys are touched on the executor's streams, but the call joins the current stream before it
         # returns, so the caching allocator's stream-ordered reuse of these buffers stays correct

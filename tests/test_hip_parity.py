@@ -649,7 +649,8 @@ def test_attn_pool_forward_backward(N, gated, bias, act, no_norm):
     def close(g, g64, what):
         scale = float(g64.abs().max()) + 1e-30
         err = float((g.double() - g64).abs().max())
-        assert err <= 2e-4 * scale + 1e-7, (what, err, scale)
+        # (2e-6 absolute: the hidden Linear's bias shifts every score by one constant, its gradient is exactly 0)
+        assert err <= 2e-4 * scale + 2e-6, (what, err, scale)
     close(x.grad, x64.grad, "dx")
     for (name, p), (_, p64_) in zip(mil.pool_fn.named_parameters(), ref.named_parameters()):
         assert (p.grad is None) == (p64_.grad is None), name

@@ -38,6 +38,8 @@ def measure(kind, nb, streams):
         k = int(os.environ["BAGS_ALIAS_OUTS"])
         outs = [outs[i % k] if bags[i].shape == bags[i % k].shape else outs[i] for i in range(len(bags))]
     reps = max(3, 600 // len(bags))               # >= ~150 ms of GPU work
+    if os.environ.get("BAGS_CALLER_STREAM"):      # (experiment: the caller's stream is not the process's default stream)
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
     for _ in range(max(1, 100 // len(bags))):     # warm: executor creation, clocks
         enc.forward_bags(bags, streams=streams, outs=outs)
     torch.cuda.synchronize()

@@ -3,10 +3,10 @@
 # + PMC passes (separate --pmc runs with --kernel-trace only, each under its own timeout) -> profiles-ready files.
 # Run on the GPU box from the repo root:
 #     tools/profile_round.sh <tag>        -> gpurun_out/<tag>_*.{txt,json} and gpurun_out/<tag>_traffic.json
-# Order: the PMC passes first (they produce <tag>_traffic.json, which bench.py reads as profiles/r03_traffic.json when it
+# Order: the PMC passes first (they produce <tag>_traffic.json, which bench.py reads as profiles/r04_traffic.json when it
 # is copied there BEFORE the bench lines are taken -- the script does that copy on the box so one call gives a consistent set).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -24,7 +24,20 @@ for spec in "c1_f32:--config 1 --dtype f32" "c1_bf16:--config 1 --dtype bf16" "c
     python $R/tools/pmc_to_traffic.py $key /tmp/pmc_${key}_FETCH_SIZE/p_results.db /tmp/pmc_${key}_WRITE_SIZE/p_results.db $OUT/${TAG}_traffic.json "bench.py $args --streams 1 --steps 5 --warmup 2"
   fi
 done
-cp $OUT/${TAG}_traffic.json $R/profiles/r03_traffic.json 2>/dev/null
+cp $OUT/${TAG}_traffic.json $R/profiles/r04_traffic.json 2>/dev/null
+# the dominant kernel's duration in a rocprofv3 kernel trace of the DEFAULT command (bench.py reads it back as roofline.rocprof)
+rm -f $OUT/${TAG}_rocprof_dominant.json
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o a -- python $R/bench.py $X > /tmp/a.log 2>&1
+python $R/tools/rocprof_summary.py /tmp/prof_a/a_results.db > $OUT/${TAG}_bench_default_4streams.kernel_stats.txt
+python $R/tools/rocprof_timeline.py /tmp/prof_a/a_results.db 100 0.45 < /dev/null | cut -c1-250 > $OUT/${TAG}_timeline_4streams.txt
+python $R/tools/rocprof_union.py c1_f32_s4 /tmp/prof_a/a_results.db $OUT/${TAG}_rocprof_dominant.json 17213423616 157.3
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a2 -o a -- python $R/bench.py --streams 2 $X > /tmp/a.log 2>&1
+python $R/tools/rocprof_summary.py /tmp/prof_a2/a_results.db > $OUT/${TAG}_bench_2streams.kernel_stats.txt
+python $R/tools/rocprof_union.py c1_f32_s2 /tmp/prof_a2/a_results.db $OUT/${TAG}_rocprof_dominant.json 17213423616 157.3
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a3 -o a -- python $R/bench.py --dtype bf16 $X > /tmp/a.log 2>&1
+python $R/tools/rocprof_summary.py /tmp/prof_a3/a_results.db > $OUT/${TAG}_bench_bf16_3streams.kernel_stats.txt
+python $R/tools/rocprof_union.py c1_bf16_s3 /tmp/prof_a3/a_results.db $OUT/${TAG}_rocprof_dominant.json 17213423616 2500
+cp $OUT/${TAG}_rocprof_dominant.json $R/profiles/r04_rocprof_dominant.json 2>/dev/null
 for dt in f32 bf16; do
   for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     rm -rf /tmp/pmc_x
@@ -41,11 +54,15 @@ for c in 2 3 4; do timeout 300 python $R/bench.py --config $c --no-cpu-baseline 
 timeout 300 python $R/bench.py --dtype bf16 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_config1_bf16.bench.json 2>/dev/null
 timeout 300 python $R/bench.py --dtype f32x3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_config1_f32x3.bench.json 2>/dev/null
 timeout 300 python $R/bench.py --streams 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_1stream.bench.json 2>/dev/null
-timeout 300 python $R/bench.py --streams 4 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_4streams.bench.json 2>/dev/null
-timeout 300 python $R/bench.py --dtype bf16 --streams 3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_config1_bf16_3streams.bench.json 2>/dev/null
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o a -- python $R/bench.py $X > /tmp/a.log 2>&1
-python $R/tools/rocprof_summary.py /tmp/prof_a/a_results.db > $OUT/${TAG}_bench_default_2streams.kernel_stats.txt
-python $R/tools/rocprof_timeline.py /tmp/prof_a/a_results.db 48 < /dev/null | cut -c1-130 > $OUT/${TAG}_timeline_2streams.txt
+timeout 300 python $R/bench.py --streams 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_2streams.bench.json 2>/dev/null
+: > $OUT/${TAG}_streams_sweep.txt
+for S in 1 2 3 4 5 6 8; do
+  timeout 200 python $R/bench.py --streams $S $X 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fp32 N=9000 streams=$S', r['value'], 'slides/s', r['ms_per_step'], 'ms/step', (r.get('value_spread') or {}).get('values'))" >> $OUT/${TAG}_streams_sweep.txt
+done
+for S in 2 3 4 5; do
+  timeout 200 python $R/bench.py --dtype bf16 --streams $S $X 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16 N=9000 streams=$S', r['value'], 'slides/s', r['ms_per_step'], 'ms/step', (r.get('value_spread') or {}).get('values'))" >> $OUT/${TAG}_streams_sweep.txt
+done
+timeout 400 python $R/tools/corun_matrix.py 40 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_corun_matrix.txt
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b -- python $R/bench.py --streams 1 $X > /tmp/b.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_b/b_results.db > $OUT/${TAG}_bench_1stream.kernel_stats.txt
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_c -o c -- python $R/bench.py --dtype bf16 --streams 1 $X > /tmp/c.log 2>&1
