@@ -192,7 +192,7 @@ hipError_t launch_ln_partition_split(const float* x, const float* gamma, const f
   dim3 grid((g.Np + 3) / 4), block(256);
 #define RRT_LNPS(NV)                                                                                          \
   do {                                                                                                      \
-    if (dim == NV * 256) ln_partition_split_kernel<NV, true><<<grid, block, 0, st>>>(x, gamma, beta, (char*)u, dim, g);  \
+    if (RRT_ALLOW_FULL && dim == NV * 256) ln_partition_split_kernel<NV, true><<<grid, block, 0, st>>>(x, gamma, beta, (char*)u, dim, g);  \
     else ln_partition_split_kernel<NV, false><<<grid, block, 0, st>>>(x, gamma, beta, (char*)u, dim, g);                 \
   } while (0)
   if (dim <= 256) RRT_LNPS(1);
@@ -223,7 +223,7 @@ hipError_t launch_ln_partition16(const float* x, const float* gamma, const float
   dim3 grid((g.Np + 3) / 4), block(256);
 #define RRT_LNP16(NV)                                                                               \
   do {                                                                                              \
-    if (dim == NV * 256) {                                                                          \
+    if (RRT_ALLOW_FULL && dim == NV * 256) {                                                                          \
       if (prec == 1) ln_partition16_kernel<NV, 1, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);  \
       else ln_partition16_kernel<NV, 2, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);           \
     } else {                                                                                        \

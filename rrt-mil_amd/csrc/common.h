@@ -59,28 +59,46 @@ __device__ __forceinline__ bool rrt_drop_keep(unsigned seed, unsigned long long 
   return h >= thresh;
 }
 
+// Reproducer switches (tools/repro_guarded_ln.py; ablation builds only):
+//   -DRRT_FORCE_GUARDED     the LayerNorm-type kernels keep their lane-predicated (column-guarded) form at every width
+//   -DRRT_PERMLANE_NOPS=n   n extra wait states in front of every v_permlane16/32_swap of the reduction helpers
+#ifdef RRT_FORCE_GUARDED
+constexpr bool RRT_ALLOW_FULL = false;
+#else
+constexpr bool RRT_ALLOW_FULL = true;
+#endif
+#ifdef RRT_PERMLANE_NOPS
+#define RRT_PERMLANE_PAD(a, b) asm volatile("s_nop %2" : "+v"(a), "+v"(b) : "n"(RRT_PERMLANE_NOPS - 1))
+#else
+#define RRT_PERMLANE_PAD(a, b)
+#endif
+
 // ---- lane ^ 16 / lane ^ 32 reductions on the VALU ------------------------------------------------
 // gfx950 v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two registers.  __shfl_xor lowers to
 // ds_bpermute_b32, which queues in the LDS pipe behind every wave's fragment reads (traced in the attention phases: a
 // softmax with six dependent bpermutes took 3.5 K cycles next to ~1.5 K of VALU work).
 static __device__ __forceinline__ float max_xor16(float v) {
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  unsigned a = __float_as_uint(v), b = a;
+  RRT_PERMLANE_PAD(a, b);
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 static __device__ __forceinline__ float max_xor32(float v) {
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  unsigned a = __float_as_uint(v), b = a;
+  RRT_PERMLANE_PAD(a, b);
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 static __device__ __forceinline__ float sum_xor16(float v) {
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  unsigned a = __float_as_uint(v), b = a;
+  RRT_PERMLANE_PAD(a, b);
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 static __device__ __forceinline__ float sum_xor32(float v) {
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  unsigned a = __float_as_uint(v), b = a;
+  RRT_PERMLANE_PAD(a, b);
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 

@@ -930,7 +930,7 @@ hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
   dim3 grid((L + 4 * RW_DISPATCH - 1) / (4 * RW_DISPATCH)), block(256);
 #define RRT_DISPATCH(NV)                                                                                         \
   do {                                                                                                           \
-    if (dim == NV * 256)                                                                                         \
+    if (RRT_ALLOW_FULL && dim == NV * 256)                                                                                         \
       crmsa_dispatch_ln_kernel<NV, CRMSA, true><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g);  \
     else                                                                                                         \
       crmsa_dispatch_ln_kernel<NV, CRMSA, false><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
@@ -957,7 +957,7 @@ hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float*
   const size_t lds = (size_t)dim * k * sizeof(float);
 #define RRT_LOGITS(NV) \
   do {                                                                                                      \
-    if (dim == NV * 256) crmsa_logits_kernel<NV, true><<<grid, block, lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, dim, k, g8);  \
+    if (RRT_ALLOW_FULL && dim == NV * 256) crmsa_logits_kernel<NV, true><<<grid, block, lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, dim, k, g8);  \
     else crmsa_logits_kernel<NV, false><<<grid, block, lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, dim, k, g8);               \
   } while (0)
   if (dim <= 256) RRT_LOGITS(1);

@@ -68,7 +68,7 @@ hipError_t launch_ln_partition(const float* x, const float* gamma, const float* 
   dim3 grid((g.Np + 3) / 4), block(256);
 #define RRT_LNP(NV)                                                                              \
   do {                                                                                         \
-    if (dim == NV * 256) ln_partition_kernel<NV, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);  \
+    if (RRT_ALLOW_FULL && dim == NV * 256) ln_partition_kernel<NV, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);  \
     else ln_partition_kernel<NV, false><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);                 \
   } while (0)
   if (dim <= 256) RRT_LNP(1);

@@ -5,6 +5,7 @@ Tolerances: BASELINE.json asks for <= 1e-3 max-abs (fp32) on the encoder output.
 The kernels compute in exact fp32 (f32 MFMA), so the tests hold them to 2e-4 end to
 end and ~1e-5 relative per stage; see DESIGN.md for the error budget.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -674,7 +675,7 @@ def test_rrtmil_fails_loudly():
 
 
 # ------------------------------------------------------------------ batch-of-bags executor
-@pytest.mark.parametrize("streams", [1, 2, 3])
+@pytest.mark.parametrize("streams", [1, 2, 3, 4])
 def test_forward_bags_mixed_sizes(streams):
     """BASELINE configs[4] shape of work: a batch of independent bags of mixed N through the executor
     (several bags in flight on the library's streams) == the same bags one at a time, bit for bit."""
@@ -702,6 +703,31 @@ def test_forward_bags_mixed_sizes(streams):
     for i in range(3):
         assert torch.equal(small[i], ref[i])
     assert enc.forward_bags([]) == []
+
+
+@pytest.mark.parametrize("streams", [2, 4])
+def test_forward_bags_is_ordered_on_the_callers_stream(streams):
+    """Round 4: slot 0 of an executor call runs on the CALLER's stream and the executor's other slots on streams handed over by
+    the host framework (rrt_executor_create_on_streams).  The call must still behave like one op of the caller's stream:
+    inputs produced on that stream just before the call are seen, outputs consumed on it right after are complete -- on a
+    side stream (asynchronous) and on the default stream (four bags in flight: side stream + host wait) alike."""
+    from hip_util import dev, encoder_from_state
+    cfg = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)
+    enc = encoder_from_state(synth.encoder_state(**cfg), cfg)
+    enc.solo = False
+    base = [dev(synth.bag(n, 512, tag=f"ord/{i}")) for i, n in enumerate([4096, 3000, 5000, 2500, 4096, 700])]
+    ref = [enc((b * 2.0 - 1.0).unsqueeze(0)).squeeze(0).clone() for b in base]
+    torch.cuda.synchronize()
+    for ctx in (torch.cuda.stream(torch.cuda.Stream()), contextlib.nullcontext()):
+        with ctx:
+            for rep in range(3):
+                bags = [b * 2.0 - 1.0 for b in base]                 # produced on the caller's stream, no sync
+                outs = enc.forward_bags(bags, streams=streams)
+                sums = torch.stack([o.double().sum() for o in outs])  # consumed on the caller's stream, no sync
+            torch.cuda.current_stream().synchronize()
+        for o, r in zip(outs, ref):
+            assert torch.equal(o, r)
+        assert torch.allclose(sums, torch.stack([r.double().sum() for r in ref]), rtol=0, atol=1e-9)
 
 
 @pytest.mark.parametrize("dt", [None, torch.bfloat16])
