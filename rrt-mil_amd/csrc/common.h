@@ -108,6 +108,9 @@ static __device__ __forceinline__ float sum_xor32(float v) {
 #define RRT_DPP_ROR(x, n) \
   __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0x120 + (n), 0xF, 0xF, false))
 __device__ __forceinline__ float rrt_readlane(float v, int l) {
+#ifdef RRT_READLANE_NOPS      // reproducer switch: extra wait states between the producer of v and v_readlane
+  asm volatile("s_nop %1" : "+v"(v) : "n"(RRT_READLANE_NOPS - 1));
+#endif
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 __device__ __forceinline__ float wave_sum(float v) {

@@ -27,40 +27,51 @@ enc = enc.to("cuda:0")
 lib = _lib.load()
 enc._desc.compute = mode
 w = enc._weights()
-x = torch.from_numpy(synth.bag(n, 512, tag="repro/x")).to("cuda:0")
-need = C.c_size_t()
-_lib.check(lib.rrt_encoder_workspace_size(C.byref(enc._desc), n, C.byref(need)), "ws")
+ns = [n, int(os.environ.get("REPRO_N2", "9000"))]                 # stream 0: small bags, stream 1: big ones -> the kernels drift
+xs = [torch.from_numpy(synth.bag(m, 512, tag=f"repro/x{m}")).to("cuda:0") for m in ns]
 streams = [torch.cuda.Stream() for _ in range(2)]
-ws = [torch.zeros(need.value, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
-ys = [torch.zeros_like(x) for _ in range(2)]
+wss = []
+for m in ns:
+    need = C.c_size_t()
+    _lib.check(lib.rrt_encoder_workspace_size(C.byref(enc._desc), m, C.byref(need)), "ws")
+    wss.append(torch.zeros(need.value, dtype=torch.uint8, device="cuda:0"))
+reps = [8, 3]                                                       # forwards per stream and round (about equal time)
+ys = [[torch.zeros_like(xs[i]) for _ in range(reps[i])] for i in range(2)]
 
 
-def run(i):
-    _lib.check(lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), x.data_ptr(), ys[i].data_ptr(), n, ws[i].data_ptr(),
-                                           ws[i].numel(), streams[i].cuda_stream), "forward")
+def run(i, j):
+    _lib.check(lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), xs[i].data_ptr(), ys[i][j].data_ptr(), ns[i],
+                                           wss[i].data_ptr(), wss[i].numel(), streams[i].cuda_stream), "forward")
 
 
 torch.cuda.synchronize()
-run(0)
-torch.cuda.synchronize()
-ref = ys[0].clone()
-solo_bad = 0
-for _ in range(20):
-    run(0)
+refs = []
+for i in range(2):
+    run(i, 0)
     torch.cuda.synchronize()
-    solo_bad += int(not torch.equal(ys[0], ref))
-bad, shown = 0, 0
+    refs.append(ys[i][0].clone())
+solo_bad = 0
+for _ in range(10):
+    for i in range(2):
+        run(i, 0)
+        torch.cuda.synchronize()
+        solo_bad += int(not torch.equal(ys[i][0], refs[i]))
+bad, total, shown = 0, 0, 0
 for r in range(runs):
-    run(0)
-    run(1)
+    for j in range(max(reps)):
+        for i in range(2):
+            if j < reps[i]:
+                run(i, j)
     torch.cuda.synchronize()
     for i in range(2):
-        if not torch.equal(ys[i], ref):
-            bad += 1
-            if shown < 4:
-                rows = torch.nonzero((ys[i] != ref).any(dim=1)).flatten()
-                d = (ys[i] - ref).abs().max().item()
-                print(f"  run {r} stream {i}: {rows.numel()} rows differ (first {rows[:6].tolist()}), max |diff| {d:.3e}")
-                shown += 1
+        for j in range(reps[i]):
+            total += 1
+            if not torch.equal(ys[i][j], refs[i]):
+                bad += 1
+                if shown < 6:
+                    rows = torch.nonzero((ys[i][j] != refs[i]).any(dim=1)).flatten()
+                    d = (ys[i][j] - refs[i]).abs().max().item()
+                    print(f"  round {r} stream {i} forward {j}: {rows.numel()} rows differ (first {rows[:6].tolist()}), max |diff| {d:.3e}")
+                    shown += 1
 print(f"lib={os.path.basename(os.environ.get('RRT_HIP_LIB', 'librrt_hip.so'))} mode={os.environ.get('REPRO_MODE', 'f32x3')} "
-      f"region4_off={bool(os.environ.get('RRT_NO_CRMSA_REGION4'))}: solo {solo_bad}/20 differ, concurrent {bad}/{2 * runs} differ")
+      f"region4_off={bool(os.environ.get('RRT_NO_CRMSA_REGION4'))} N={ns}: solo {solo_bad}/20 differ, concurrent {bad}/{total} differ")
