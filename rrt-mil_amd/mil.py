@@ -291,6 +291,52 @@ class RRTMIL(nn.Module):
         w.pred_w, w.pred_b = p(self.predictor.weight), p(self.predictor.bias)
         return w
 
+    @torch.no_grad()
+    def forward_bags(self, bags, streams=4, return_attn=False, no_norm=False):
+        """A batch of independent slides (each (N_i, input_dim) or (1, N_i, input_dim), any mix of sizes) -> list of logits
+        [(n_classes,) or (1, n_classes)] (and attention rows with return_attn): the reference's validation loop
+        ``for bag in loader: model(bag)`` (main.py:466-467) with ``streams`` slides in flight -- each slide is one
+        rrt_mil_forward_f32 call with its own workspace on one of the process's bag streams (the same list
+        RRTEncoder.forward_bags uses; at most four: the chip schedules four hardware queues).  Ordered like one op of the
+        caller's stream: the bag streams wait for it, and the host waits for them before the call returns."""
+        if not bags:
+            return []
+        if self.training and (isinstance(self.dp, nn.Dropout) or self.online_encoder._stochastic()):
+            return [self(b if b.dim() == 3 else b.unsqueeze(0), return_attn=return_attn, no_norm=no_norm) for b in bags]
+        from .encoder import _BAG_STREAMS
+        dev = bags[0].device
+        if not bags[0].is_cuda:
+            raise _lib.RRTHipError("rrt_mil_amd.RRTMIL runs on MI355X only; there is no CPU fallback")
+        S = max(1, min(int(streams), 4, len(bags)))
+        pool = _BAG_STREAMS.setdefault(dev, [])
+        while len(pool) < S:
+            pool.append(torch.cuda.Stream(dev))
+        slots = self.__dict__.setdefault("_slots", {})
+        cur = torch.cuda.current_stream(dev)
+        order = sorted(range(len(bags)), key=lambda i: -bags[i].shape[-2])        # big slides first, least loaded stream
+        load, outs = [0] * S, [None] * len(bags)
+        for st in pool[:S]:
+            st.wait_stream(cur)
+        ws_was, key_was = self._ws, self.__dict__.get("_w16_key")
+        try:
+            for i in order:
+                s_ = min(range(S), key=lambda t: load[t])
+                load[s_] += bags[i].shape[-2]
+                b = bags[i]
+                x2 = b[0] if b.dim() == 3 else b
+                self._ws, self.__dict__["_w16_key"] = slots.get((dev, s_), (None, None))
+                with torch.cuda.stream(pool[s_]):
+                    o = self.forward_bag(x2, return_attn=return_attn, no_norm=no_norm)
+                slots[(dev, s_)] = (self._ws, self.__dict__.get("_w16_key"))
+                if b.dim() == 3:
+                    o = tuple(t.unsqueeze(0) for t in o) if return_attn else o.unsqueeze(0)
+                outs[i] = o
+        finally:
+            self._ws, self.__dict__["_w16_key"] = ws_was, key_was
+            for st in pool[:S]:
+                st.synchronize()      # host wait: nothing is parked on the caller's stream (INTEGRATION.md section 4)
+        return outs
+
     def forward_bag(self, x2d, return_attn=False, no_norm=False):
         """One bag: x2d (N, input_dim) fp32 device tensor -> logits (n_classes,) [, attention (N,)]."""
         lib = _lib.load()

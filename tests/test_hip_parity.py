@@ -659,6 +659,28 @@ def test_attn_pool_forward_backward(N, gated, bias, act, no_norm):
             close(p.grad, p64_.grad, name)
 
 
+@pytest.mark.parametrize("dt", [None, torch.bfloat16])
+def test_rrtmil_forward_bags(dt):
+    """RRTMIL.forward_bags: a list of slides of mixed sizes, four in flight on the process's bag streams, each one
+    rrt_mil_forward_f32 call with its own workspace == the same slides one at a time, bit for bit (logits and attention)."""
+    from rrt_mil_amd.mil import RRTMIL
+    torch.manual_seed(3)
+    mil = RRTMIL(input_dim=256, n_classes=3, da_gated=True, dropout=0.25).to("cuda:0").eval()
+    if dt is not None:
+        mil.online_encoder.compute_dtype = dt
+    sizes = [3000, 700, 5000, 1, 4096, 2200, 3000]
+    bags = [torch.from_numpy(synth.bag(n, 256, tag=f"milbags/{i}", nonneg=True)).to("cuda:0") for i, n in enumerate(sizes)]
+    with torch.no_grad():
+        ref = [mil(b.unsqueeze(0), return_attn=True) for b in bags]
+        outs = mil.forward_bags(bags, streams=4, return_attn=True)
+        outs3 = mil.forward_bags([b.unsqueeze(0) for b in bags], streams=2)
+        again = mil.forward_bags(bags, streams=4, return_attn=True)          # cached 16-bit weight images per stream slot
+    torch.cuda.synchronize()
+    for (lg, at), (rl, ra), l3, (lg2, _) in zip(outs, ref, outs3, again):
+        assert torch.equal(lg, rl[0]) and torch.equal(at, ra[0]) and torch.equal(l3, rl) and torch.equal(lg2, rl[0])
+    assert mil.forward_bags([]) == []
+
+
 def test_rrtmil_fails_loudly():
     from rrt_mil_amd import RRTMIL
     mil = RRTMIL(input_dim=64, n_classes=2).eval()
