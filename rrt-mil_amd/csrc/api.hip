@@ -681,12 +681,15 @@ namespace {
 struct BatchWs {
   Workspace one;          // the single-bag workspace (R-MSA layers, FFN / MLP-phi temporaries), reused bag after bag
   float *x1, *mean_rstd, *logits, *wdisp, *rep, *rep_qkv, *rep_o, *rep2;
-  size_t bytes;
+  size_t one_bytes, bytes;
 };
 BatchWs carve_batch(const rrt_encoder_desc& d, int64_t B, int64_t N, const rrt_grid& g, const rrt_grid& g8, char* base) {
   BatchWs w{};
+  // (the single-bag carve is sized by its QUERY form: with ffn = 1 the query counts xa / xb twice -- a null pointer does not
+  //  tell it they are taken -- so the queried size, which encoder_forward checks against, exceeds what the real carve uses)
+  w.one_bytes = carve(d, N, g, g8, nullptr).bytes;
   w.one = carve(d, N, g, g8, base);
-  size_t off = align_up(w.one.bytes, 256);
+  size_t off = align_up(w.one_bytes, 256);
   auto take = [&](size_t nfloat) {
     float* p = base ? (float*)(base + off) : nullptr;
     off = align_up(off + nfloat * sizeof(float), 256);
@@ -754,7 +757,7 @@ int rrt_encoder_forward_batch_f32(const rrt_encoder_desc* desc_in, const rrt_enc
   } while (0)
   // ---- positional encoder + R-MSA layers, bag by bag -> x1 [B, N, D]
   for (int64_t b = 0; b < B; ++b) {
-    rc = encoder_forward(&dloc, w, x + (size_t)b * N * D, y + (size_t)b * N * D, N, workspace, bw.one.bytes, stream, nullptr,
+    rc = encoder_forward(&dloc, w, x + (size_t)b * N * D, y + (size_t)b * N * D, N, workspace, bw.one_bytes, stream, nullptr,
                          nullptr, bw.x1 + (size_t)b * N * D);
     if (rc) return rc;
     dloc.weights16_valid = 1;   // same workspace, same weights, same mode: the images of bag 0 stand

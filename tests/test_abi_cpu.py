@@ -128,6 +128,36 @@ def test_weight_fingerprint_covers_every_parameter(n_layers):
     assert enc._weights().crmsa.qkv_w == enc.cr_msa.attn.attn.qkv.weight.data_ptr()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(ffn=True), dict(ffn=True, crmsa_mlp=True), dict(n_layers=1), dict(n_layers=3),
+                                dict(pos="ppeg", pos_pos=-1), dict(cr_msa=False), dict(epeg_2d=True), dict(epeg_type="value_bf")])
+def test_workspace_queries_cover_what_the_forwards_check(kw):
+    """The size a workspace query returns is the size the forward checks its workspace against -- for the single-bag entry
+    point and the batch one (round 4: with ffn = 1 the batch carve handed the inner forward the REAL size of the single-bag
+    carve, which is smaller than the queried one it checks).  No GPU here: a call that passes validation fails at its first
+    launch with a HIP error (> 0); a sizing bug shows up as RRT_E_WORKSPACE (-3) before anything is launched."""
+    lib = _lib.load()
+    enc = RRTEncoder(mlp_dim=512, **kw)
+    d, w = enc._desc, enc._weights()
+    n = 700
+    x, y = torch.zeros(2, n, 512), torch.zeros(2, n, 512)
+    for mode in (_lib.COMPUTE_F32, _lib.COMPUTE_BF16, _lib.COMPUTE_F32X3):
+        d.compute = mode
+        need = C.c_size_t()
+        assert lib.rrt_encoder_workspace_size(C.byref(d), n, C.byref(need)) == 0
+        buf = (C.c_char * need.value)()
+        rc = lib.rrt_encoder_forward_f32(C.byref(d), C.byref(w), x.data_ptr(), y.data_ptr(), n, C.addressof(buf), need.value, None)
+        assert rc > 0 or rc == 0, (mode, rc)
+        assert lib.rrt_encoder_forward_f32(C.byref(d), C.byref(w), x.data_ptr(), y.data_ptr(), n, C.addressof(buf),
+                                           need.value - 1, None) == -3
+        assert lib.rrt_encoder_batch_workspace_size(C.byref(d), 2, n, C.byref(need)) == 0
+        buf = (C.c_char * need.value)()
+        rc = lib.rrt_encoder_forward_batch_f32(C.byref(d), C.byref(w), x.data_ptr(), y.data_ptr(), 2, n, C.addressof(buf),
+                                               need.value, None)
+        assert rc > 0 or rc == 0, (mode, rc)
+        assert lib.rrt_encoder_forward_batch_f32(C.byref(d), C.byref(w), x.data_ptr(), y.data_ptr(), 2, n, C.addressof(buf),
+                                                 need.value - 1, None) == -3
+
+
 def test_need_init_matches_reference_rule():
     enc = RRTEncoder(mlp_dim=64, need_init=True)
     assert float(enc.layers[0].attn.attn.qkv.bias.abs().max()) == 0.0

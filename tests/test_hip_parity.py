@@ -395,6 +395,26 @@ def test_input_ranks_and_purity():
         enc.train()(torch.stack([x, x]))                 # a graph / dropout at B > 1: not covered by the HIP backward
 
 
+@pytest.mark.parametrize("extra", [dict(ffn=True), dict(ffn=True, ffn_act="relu", all_shortcut=True), dict(n_layers=3),
+                                   dict(pos="ppeg", pos_pos=-1), dict(pos="peg", pos_pos=-1, n_layers=1), dict(cr_msa=False),
+                                   dict(epeg=False, crmsa_k=8), dict(region_num=4, crmsa_k=2)])
+def test_encoder_batch_gt_1_variants_match_oracle(extra):
+    """The batch entry point on the constructor variants the G20 fixtures do not cover (FFN after every layer, three layers,
+    PEG / PPEG in front, no CR-MSA, no EPEG, other region counts) against the oracle's eager port on the same (3, N, D)
+    input -- the port is pinned to the reference at B > 1 by the G20 fixtures (tests/test_oracle_golden.py)."""
+    from hip_util import encoder_from_state, dev
+    cfg = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)
+    cfg.update(extra)
+    st = synth.encoder_state(**{k: v for k, v in cfg.items() if k in _STATE_KEYS})
+    B, N = 3, 1100
+    x = np.stack([synth.bag(N, 512, tag=f"batchv/b{b}") for b in range(B)])
+    ref = O.forward_eager(x, st, cfg).numpy()
+    enc = encoder_from_state(st, cfg)
+    y = enc(dev(x))
+    torch.cuda.synchronize()
+    _cmp(y.cpu().numpy(), ref, 2e-4, f"batch {extra}")
+
+
 def test_repeatable_and_workspace_poison():
     """Bit-identical across calls, also after the cached workspace is filled with NaNs
     (no read-before-write of scratch)."""
