@@ -18,9 +18,9 @@ quoted on; the N = 1 line of that config is what the driver records):
   4  TCGA-NSCLC mix: 64 bags, N ~ randint(3000, 15001) (seed 2021), epeg_k=21 crmsa_k=5; the batch is split over
      the ranks by cost (sharding.assign_bags, longest-processing-time first) and each rank runs its share through
      the batch-of-bags executor; a step = one pass over the whole batch ("scaling": "strong")
-In configs 0-3 a step = `--streams` (default 4 in fp32, 3 in bf16) independent bags per GPU, each an ordinary forward on its own HIP
-stream with its own workspace (bags are independent units), and every rank owns its own bags
-("scaling": "weak").  No data-path collective anywhere: RCCL carries the barrier and a MAX of the elapsed time.
+In configs 0-3 a step = one batch of `--streams` (default 4 in fp32, 3 in bf16) x `--bags-per-stream` (default 4) independent
+bags per GPU: `--streams` bags in flight, each an ordinary forward on its own HIP stream with its own workspace (bags are
+independent units), and every rank owns its own bags ("scaling": "weak").  No data-path collective anywhere: RCCL carries the barrier and a MAX of the elapsed time.
 
 Besides the contract fields the JSON line carries
   roofline     -- the dominant kernel (the fused R-MSA kernel): algorithmic FLOPs per launch / its average
@@ -127,7 +127,8 @@ CONFIGS = {
     1: dict(kind="encoder", n=9000, dtype="f32", enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8),
             label="BASELINE configs[1]: RRTEncoder(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8).eval() forward, "
                   "`streams_per_gpu` device-resident bags N=9000 D=512 in flight per GPU (one per HIP stream, each an ordinary "
-                  "forward with its own workspace) = one step; fp32, closed-form weights"),
+                  "forward with its own workspace), `bags_per_stream_per_step` of them back to back on every stream = one step; "
+                  "fp32, closed-form weights"),
     2: dict(kind="mil", n=9000, dtype="bf16", input_dim=1024, streams=4,
             enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=1, region_num=8, all_shortcut=True),
             label="BASELINE configs[2]: C16-R50 RRTMIL(input_dim=1024, epeg_k=15, crmsa_k=1, all_shortcut=True).eval() "
@@ -300,7 +301,11 @@ class EncoderWorkload:
         self.compute = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f16": _lib.COMPUTE_F16,
                         "f32x3": _lib.COMPUTE_F32X3}[self.dtype]
         self.S = S = max(1, args.streams)
-        self.units_global = world * S
+        # a step = one batch of synthetic bags = S bags in flight x R bags per stream (R back to back on every stream): the
+        # timed region is bracketed by device syncs, so its first bags start in lockstep and its last ones drain alone --
+        # with R = 1 a 20-step region (80 bags) read 2 % under a 200-step one; with R = 4 the same 20 steps are 320 bags
+        self.R = R = max(1, getattr(args, "bags_per_stream", 0) or 4)
+        self.units_global = world * S * R
         self.scaling = "weak"
         self.lib = _lib.load()
         self.hev = HipEvents()
@@ -347,9 +352,9 @@ class EncoderWorkload:
         # region, every stream (an event pair costs the stream two marker packets: measured ~5 us per forward, 2 % of an
         # fp32 bag and 10 % of a bf16 one -- so the window is 6 steps, not the whole region).  Consecutive steps, all
         # streams: the launches' intervals can then be merged into the time during which the kernel was running at all.
-        self.ev_win = min(6, args.steps)
+        self.ev_win = min(max(1, 6 // R), args.steps)
         self.ev_w0 = (args.steps - self.ev_win) // 2
-        self.ev_pairs = [(self.hev.create(), self.hev.create()) for _ in range(self.ev_win * S)]
+        self.ev_pairs = [(self.hev.create(), self.hev.create()) for _ in range(self.ev_win * S * R)]
         self.ev_arr = (C.c_void_p * _lib.EV_COUNT)()
         # optional phase gate (RRT_BENCH_GATE=1): the bags' MFMA-bound R-MSA cores take turns instead of time-slicing.
         # Off by default since round 2: with the denser kernels free-running streams are faster at every S
@@ -369,8 +374,8 @@ class EncoderWorkload:
 
     def step(self, i, timed):
         lib, _lib = self.lib, self._lib
-        for s_ in range(self.S):
-            x = self.bags[(i * self.S + s_) % len(self.bags)]
+        for r_, s_ in ((r_, s_) for r_ in range(self.R) for s_ in range(self.S)):
+            x = self.bags[((i * self.R + r_) * self.S + s_) % len(self.bags)]
             if self.mil is not None:
                 mode = self.mdesc.enc.compute     # (as RRTMIL.forward_bag: the 16-bit weight images stay in the workspace)
                 self.mdesc.enc.weights16_valid = int(mode != _lib.COMPUTE_F32 and self._w16_mode[s_] == mode)
@@ -381,7 +386,7 @@ class EncoderWorkload:
                 _lib.check(rc, "rrt_mil_forward_f32")
                 continue
             # mark the dominant kernel: [after LN+partition, after the fused R-MSA core]
-            evs = (self._mark(*self.ev_pairs[(i - self.ev_w0) * self.S + s_])
+            evs = (self._mark(*self.ev_pairs[((i - self.ev_w0) * self.R + r_) * self.S + s_])
                    if (timed and self.ev_w0 <= i < self.ev_w0 + self.ev_win) else None)
             # reduced-precision modes: this stream's workspace keeps the 16-bit weight images of the (unchanged)
             # weights from its first call on, as rrt_mil_amd.RRTEncoder does between forwards (weights16_valid)
@@ -558,7 +563,7 @@ class EncoderWorkload:
                                "launches": len(iv), "bags_in_flight": self.S,
                                "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
                                "rocprof": rp,
-                               "note": f"{len(iv)} launches = {self.ev_win} consecutive steps x {self.S} stream(s) in the middle of "
+                               "note": f"{len(iv)} launches = {self.ev_win} consecutive step(s) x {self.R} bags x {self.S} stream(s) in the middle of "
                                        "the timed region, one HIP event pair per launch (recorded by librrt_hip on the launch "
                                        "stream).  avg_launch_ms = the UNION of the launches' [start, end] intervals / launches: "
                                        "with several bags in flight launches of different streams overlap and time-slice the "
@@ -711,6 +716,8 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("RRT_BENCH_STREAMS", "0")),
                     help="bags in flight per GPU (one HIP stream + workspace each); a step = this many bags.  Default: 4 for "
                          "fp32 arithmetic, 3 for bf16 / fp16 (measured optima, see the comment in main())")
+    ap.add_argument("--bags-per-stream", type=int, default=0,
+                    help="forwards per stream and step (configs 0-3; default 4): a step = streams x this many bags")
     ap.add_argument("--stub-cpu", action="store_true", help="rank logic only: CPU stand-in workload over gloo (tests)")
     args = ap.parse_args()
 
@@ -799,7 +806,8 @@ def main():
                                   "use": "barrier + MAX all-reduce of the elapsed time only (no data-path collective)"},
                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                   "baseline_config_index": args.config, "dim": DIM, "bags_per_step": wl.units_global,
-                  "streams_per_gpu": getattr(wl, "S", None), "untimed_ramp_steps": ramp,
+                  "streams_per_gpu": getattr(wl, "S", None), "bags_per_stream_per_step": getattr(wl, "R", None),
+                  "untimed_ramp_steps": ramp,
                   "parallelism": f"bag-parallel x{world} (no data-path collective)"}
         if cfg["n"]:
             config["n_tokens"] = cfg["n"]
@@ -931,7 +939,7 @@ def config_record(c):
     feeder's copy stream, the executor's own) no longer gives a new workload the queues a fresh process gets (measured:
     configs[4] 7.8 k slides/s in-process vs 14.5 k in its own process)."""
     import subprocess
-    steps = {0: 200, 2: 80, 3: 40, 4: 12}[c]
+    steps = {0: 100, 2: 30, 3: 12, 4: 12}[c]        # (configs 0-3: a step = streams x 4 bags)
     t0 = time.perf_counter()
     cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--steps", str(steps), "--warmup", "5",
            "--no-extras", "--no-cpu-baseline"]
@@ -973,7 +981,7 @@ def extras(wl, dev):
     for i in range(40):
         wl.step(i, False)
     torch.cuda.synchronize()
-    out["amp_bf16"] = {"value": round(S * 40 / (time.perf_counter() - ta), 2), "unit": "slides/s", "n_gpus": 1,
+    out["amp_bf16"] = {"value": round(wl.units_global * 40 / (time.perf_counter() - ta), 2), "unit": "slides/s", "n_gpus": 1,
                        "note": "rank 0 only, 40 steps after the timed region; RRT_COMPUTE_BF16 (bf16 operands on the "
                                "matrix cores, fp32 accumulate; `--config 3` / `--dtype bf16` give the full record)"}
     # fp32 EMULATED on the bf16 matrix cores for the two big projections (RRT_COMPUTE_F32X3; ~1e-6 from the exact path)
@@ -998,7 +1006,7 @@ def extras(wl, dev):
     wl.enc._desc.compute = _lib.COMPUTE_F32
     wl.step(39, False)
     torch.cuda.synchronize()
-    out["f32x3"] = {"value": round(S * 40 / tb, 2), "unit": "slides/s", "n_gpus": 1,
+    out["f32x3"] = {"value": round(wl.units_global * 40 / tb, 2), "unit": "slides/s", "n_gpus": 1,
                     "max_abs_vs_exact_f32": float((y_x3 - wl.outs[0]).abs().max()),
                     "note": "rank 0 only, 40 steps after the timed region; RRT_COMPUTE_F32X3: qkv / proj GEMMs of the R-MSA "
                             "layers as three bf16 MFMAs per product on (hi, lo) bf16 operand pairs, fp32 accumulate; attention, "

@@ -1031,6 +1031,16 @@ hipError_t launch_linear16(const void* A, const void* B, float* C, int M, int N,
   RRT_CASE16(6, 1);
   RRT_CASE16(4, 1);
   RRT_CASE16(2, 1);
+#ifdef RRT_TUNING        // wide tiles for the round-4 sweep (fewer bytes through the CU's memory pipe per output)
+  RRT_CASE16(5, 4);
+  RRT_CASE16(4, 4);
+  RRT_CASE16(6, 4);
+  RRT_CASE16(8, 4);
+  RRT_CASE16(3, 4);
+  RRT_CASE16(5, 2);
+  RRT_CASE16(6, 2);
+  RRT_CASE16(4, 2);
+#endif
 #undef RRT_CASE16
 #undef RRT_MODES16
   return hipErrorInvalidValue;

@@ -42,9 +42,12 @@ for L in [int(a) for a in sys.argv[1:]] or [3000, 4096, 5000, 6000, 7000, 9000, 
                                                     C.byref(g), 1, st))
     libc.unsetenv(ENV)
     res = [("default", timeit(f))]
-    for mt, nt in ((9, 1), (8, 1), (6, 1), (4, 1), (9, 2), (8, 2)):
-        for cap in (512, 768, 1024):
-            if nt == 2 and cap > 512:
+    shapes = ((9, 1), (8, 1), (6, 1), (4, 1), (9, 2), (8, 2))
+    if os.environ.get("SWEEP_WIDE"):          # round 4: 256-column tiles (tuning build instantiations)
+        shapes = ((6, 1), (9, 2), (8, 2), (6, 2), (5, 2), (4, 2), (8, 4), (6, 4), (5, 4), (4, 4), (3, 4))
+    for mt, nt in shapes:
+        for cap in (256, 512, 768, 1024):
+            if (nt >= 2 and cap > 512) or (nt == 1 and cap == 256):
                 continue
             libc.setenv(ENV, f"{mt},{nt},{cap}".encode(), 1)
             try:
