@@ -1091,6 +1091,9 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
   RRT_CASE(6, 1);
   RRT_CASE(4, 1);
   RRT_CASE(2, 1);
+#ifdef RRT_TUNING        // round 4: 16-row tiles for the representatives' GEMMs (more, lighter blocks), RRT_LINEAR_CFG=1,1,1024
+  RRT_CASE(1, 1);
+#endif
 #undef RRT_CASE
 #undef RRT_MODES
   return hipErrorInvalidValue;
