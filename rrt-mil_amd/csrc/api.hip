@@ -1315,7 +1315,8 @@ int rrt_executor_create(const rrt_encoder_desc* desc, int32_t n_streams, int64_t
 int rrt_executor_create_on_streams(const rrt_encoder_desc* desc, int32_t n_streams, void* const* streams, int64_t max_tokens,
                                    rrt_executor** out) {
   if (!streams) return RRT_E_INVALID;
-  for (int s = 0; s < n_streams && s < RRT_EXEC_MAX_STREAMS; ++s)
+  if (n_streams < 1 || n_streams > RRT_EXEC_MAX_STREAMS) return unsupported("executor: n_streams must be in [1,8]");
+  for (int s = 0; s < n_streams; ++s)
     for (int t = 0; t < s; ++t)
       if (streams[s] == streams[t]) return RRT_E_INVALID;      // the bags in flight need distinct streams
   return executor_create(desc, n_streams, max_tokens, streams, out);

@@ -158,6 +158,23 @@ def test_workspace_queries_cover_what_the_forwards_check(kw):
                                                  need.value - 1, None) == -3
 
 
+def test_executor_argument_checks_need_no_gpu():
+    """rrt_executor_create_on_streams refuses duplicate / missing stream handles and widths outside [1, 8] before touching
+    the device; the batch entry points refuse empty batches (host-side validation only)."""
+    lib = _lib.load()
+    enc = RRTEncoder(mlp_dim=512)
+    h = C.c_void_p()
+    dup = (C.c_void_p * 2)(0x1000, 0x1000)
+    assert lib.rrt_executor_create_on_streams(C.byref(enc._desc), 2, dup, 9000, C.byref(h)) == -1
+    assert lib.rrt_executor_create_on_streams(C.byref(enc._desc), 2, None, 9000, C.byref(h)) == -1
+    ok = (C.c_void_p * 2)(0x1000, 0x2000)
+    assert lib.rrt_executor_create_on_streams(C.byref(enc._desc), 9, ok, 9000, C.byref(h)) == -2
+    assert lib.rrt_executor_create_on_streams(C.byref(enc._desc), 2, ok, 0, C.byref(h)) == -1
+    need = C.c_size_t()
+    assert lib.rrt_encoder_batch_workspace_size(C.byref(enc._desc), 0, 100, C.byref(need)) == -1
+    assert lib.rrt_encoder_forward_batch_f32(C.byref(enc._desc), C.byref(enc._weights()), 1, 2, 0, 100, None, 0, None) == -1
+
+
 def test_need_init_matches_reference_rule():
     enc = RRTEncoder(mlp_dim=64, need_init=True)
     assert float(enc.layers[0].attn.attn.qkv.bias.abs().max()) == 0.0
