@@ -318,6 +318,20 @@ class RRTEncoder(nn.Module):
         if need_init:
             self.apply(initialize_weights)
 
+    # per-process state that must not travel with copy.deepcopy / pickle / torch.save(module): raw pointers (the cached ctypes
+    # weight struct, the executor handle), device workspaces and the caches keyed on them
+    _TRANSIENT = ("_w_struct", "_plist", "_w_fp", "_w16_key", "_ws", "_ws_need", "_ex", "_ex_key", "_ex_desc")
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in self._TRANSIENT:
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self.__dict__.setdefault("_ws", None)
+
     # ------------------------------------------------------------------ C-ABI plumbing
     @staticmethod
     def _ptr(t):

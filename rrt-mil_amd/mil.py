@@ -259,6 +259,16 @@ class RRTMIL(nn.Module):
         self._da_act = da_act
         self._ws = None
 
+    def __getstate__(self):          # device workspaces and their validity keys stay with the process (deepcopy / pickle)
+        st = dict(self.__dict__)
+        for k in ("_ws", "_slots", "_w16_key"):
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self.__dict__.setdefault("_ws", None)
+
     # ------------------------------------------------------------------ the one-call HIP path
     def _mil_desc(self, input_dim):
         enc = self.online_encoder

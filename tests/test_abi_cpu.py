@@ -175,6 +175,31 @@ def test_executor_argument_checks_need_no_gpu():
     assert lib.rrt_encoder_forward_batch_f32(C.byref(enc._desc), C.byref(enc._weights()), 1, 2, 0, 100, None, 0, None) == -1
 
 
+def test_modules_deepcopy_and_pickle_with_warm_caches():
+    """copy.deepcopy (EMA / teacher copies), pickle and torch.save of the whole module keep working after the C-ABI caches
+    are warm (round 4 cached the ctypes pointer struct in the module: ctypes objects with pointers cannot be pickled) -- the
+    copy owns its own parameters and builds its own struct."""
+    import copy
+    import io
+    import pickle
+    from rrt_mil_amd import RRTMIL
+    enc = RRTEncoder(mlp_dim=64)
+    w = enc._weights()
+    e2 = copy.deepcopy(enc)
+    w2 = e2._weights()
+    assert w2 is not w and w2.norm_w == e2.norm.weight.data_ptr() != w.norm_w
+    e3 = pickle.loads(pickle.dumps(enc))
+    assert torch.equal(e3.norm.weight, enc.norm.weight) and e3._weights().norm_w == e3.norm.weight.data_ptr()
+    buf = io.BytesIO()
+    torch.save(enc, buf)
+    mil = RRTMIL(input_dim=64, n_classes=2)
+    mil.online_encoder._weights()
+    m2 = copy.deepcopy(mil)
+    assert m2.online_encoder._weights().norm_w == m2.online_encoder.norm.weight.data_ptr()
+    sd = {k: v.clone() for k, v in mil.state_dict().items()}
+    m2.load_state_dict(sd, strict=True)
+
+
 def test_need_init_matches_reference_rule():
     enc = RRTEncoder(mlp_dim=64, need_init=True)
     assert float(enc.layers[0].attn.attn.qkv.bias.abs().max()) == 0.0
