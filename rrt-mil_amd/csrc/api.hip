@@ -1248,6 +1248,9 @@ struct rrt_executor {
   uint64_t w16_version[RRT_EXEC_MAX_STREAMS];
   int w16_compute[RRT_EXEC_MAX_STREAMS];
   bool own_streams;      // false: the streams are the caller's (rrt_executor_create_on_streams), never destroyed here
+  // slot 0 (its workspace) runs on whatever stream the CALLER passes: two calls from different streams must not overlap there
+  hipEvent_t done0;
+  bool has_done0;
 };
 
 extern "C" {
@@ -1262,6 +1265,7 @@ int rrt_executor_destroy(rrt_executor* ex) {
     if (ex->streams[s] && ex->own_streams) (void)hipStreamDestroy(ex->streams[s]);
   }
   if (ex->fork) (void)hipEventDestroy(ex->fork);
+  if (ex->done0) (void)hipEventDestroy(ex->done0);
   if (ex->gate.done) (void)hipEventDestroy(ex->gate.done);
   delete ex;
   return RRT_OK;
@@ -1282,6 +1286,7 @@ static int executor_create(const rrt_encoder_desc* desc, int32_t n_streams, int6
   hipError_t e = hipGetDevice(&ex->device);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->gate.done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->done0, hipEventDisableTiming);
   for (int s = 0; s < n_streams && e == hipSuccess; ++s) {
     if (user_streams) {
       ex->streams[s] = (hipStream_t)user_streams[s];
@@ -1355,6 +1360,11 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
   sts[0] = caller;
   for (int s = 1; s < S; ++s) sts[s] = ex->streams[s];
   hipError_t e = hipSuccess;
+  // (the previous call may have come from ANOTHER stream: its slot-0 work, on that stream, owns workspace 0 until it is done)
+  if (ex->has_done0) {
+    e = hipStreamWaitEvent(caller, ex->done0, 0);
+    if (e != hipSuccess) return (int)e;
+  }
   static const bool no_fork = rrt_tune_env("RRT_EXEC_NOFORK") != nullptr;      // (bisecting, tuning build only)
   if (S > 1 && !no_fork) {
     e = hipEventRecord(ex->fork, caller);
@@ -1405,6 +1415,7 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
     if (j == hipSuccess) j = hipStreamWaitEvent(caller, ex->join[s], 0);
     if (rc == RRT_OK && j != hipSuccess) rc = (int)j;
   }
+  if (hipEventRecord(ex->done0, caller) == hipSuccess) ex->has_done0 = true;
   if (order != order_buf) delete[] order;
   return rc;
 }

@@ -770,6 +770,21 @@ def test_forward_bags_is_ordered_on_the_callers_stream(streams):
         for o, r in zip(outs, ref):
             assert torch.equal(o, r)
         assert torch.allclose(sums, torch.stack([r.double().sum() for r in ref]), rtol=0, atol=1e-9)
+    # two calls from two DIFFERENT caller streams back to back, no sync in between: slot 0 (its workspace) moves from one
+    # caller's stream to the other's and must not be shared while the first call is still running
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    inputs = [b * 2.0 - 1.0 for b in base]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        with torch.cuda.stream(sa):
+            oa = enc.forward_bags(inputs, streams=streams)
+        with torch.cuda.stream(sb):
+            ob = enc.forward_bags(list(reversed(inputs)), streams=streams)
+    torch.cuda.synchronize()
+    for o, r in zip(oa, ref):
+        assert torch.equal(o, r)
+    for o, r in zip(ob, reversed(ref)):
+        assert torch.equal(o, r)
 
 
 @pytest.mark.parametrize("dt", [None, torch.bfloat16])
