@@ -35,7 +35,9 @@ scr = torch.zeros(256 + 64 * 8 * 3 * 520 * 4 + 4096, dtype=torch.uint8, device=d
 Wp = t(D, D) / 22; bp = torch.zeros(D, device=dev); xo = torch.empty(N, D, device=dev)
 rqkv = torch.empty(k * R, 3 * D, device=dev); ro = torch.empty(k * R, D, device=dev); rep2 = t(k * R, D)
 ub = torch.empty(Np, D, device=dev); y = torch.empty(N, D, device=dev)
-sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+# CORUN_PRIO="a,b": stream priorities (lower = more urgent; e.g. "-1,0": the launch under test outranks its co-runner)
+_pr = [int(v) for v in os.environ.get("CORUN_PRIO", "0,0").split(",")]
+sa, sb = torch.cuda.Stream(priority=_pr[0]), torch.cuda.Stream(priority=_pr[1])
 ck = _lib.check
 
 
