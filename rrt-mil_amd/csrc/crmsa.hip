@@ -796,7 +796,11 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   RRT_TRACE_MARK();                                 // [10] dispatch weights written
 }
 
-template <int NV, bool CRMSA, bool FULL>   // FULL: dim == NV * 256, no lane predication (see ln_partition.hip)
+// KB > 0 (round 4): the dispatch weights and the representatives' rows of the first KB representatives are requested UP FRONT,
+// together with the token row, and gamma / beta with them -- the loop over n issued one dependent L2 round trip per
+// representative behind the row's HBM round trip (and a fourth one for gamma / beta behind the statistics): 8.7 us for the
+// bytes LayerNorm + partition moves in 5.9.  Representatives n >= k are fetched clamped and weighted 0.  KB = 0: the loop.
+template <int NV, bool CRMSA, bool FULL, int KB = 0>   // FULL: dim == NV * 256, no lane predication (see ln_partition.hip)
 __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
     const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ wdisp,
     const float* __restrict__ rep2, const float* __restrict__ gamma,
@@ -821,7 +825,48 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
       }
     }
   }
-  if (CRMSA) {
+  float4 gm_pre[NV], bt_pre[NV];
+  if constexpr (KB > 0) {
+    if (gamma != nullptr) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        gm_pre[v] = (FULL || c < dim) ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt_pre[v] = (FULL || c < dim) ? *(const float4*)(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  if (CRMSA && KB > 0) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int t = t0 + i < L ? t0 + i : L - 1;
+      const int slot = token_to_slot(t, g);
+      const int reg = fdiv(slot, g.P, g.inv_P);
+      const float* wd = wdisp + (size_t)slot * k;
+      float w[KB > 0 ? KB : 1];
+      float4 q[KB > 0 ? KB : 1][NV];
+#pragma unroll
+      for (int n = 0; n < KB; ++n) {
+        const int nn = n < k ? n : k - 1;                  // in bounds; its weight is zeroed below
+        w[n] = wd[nn];
+        const float* rp = rep2 + ((size_t)nn * R + reg) * dim;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int c = (v * 64 + lane) * 4;
+          q[n][v] = (FULL || c < dim) ? *(const float4*)(rp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);                 // every request is out before the first use waits
+#pragma unroll
+      for (int n = 0; n < KB; ++n) {
+        const float wn = n < k ? w[n] : 0.f;               // branch-free; same summation order as the loop form
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          r[i][v].x += wn * q[n][v].x; r[i][v].y += wn * q[n][v].y; r[i][v].z += wn * q[n][v].z; r[i][v].w += wn * q[n][v].w;
+        }
+      }
+    }
+  } else if (CRMSA) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int t = t0 + i < L ? t0 + i : L - 1;
@@ -882,7 +927,9 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
     if (FULL || c < dim) {
-      const float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
+      float4 gm, bt;
+      if constexpr (KB > 0) { gm = gm_pre[v]; bt = bt_pre[v]; }
+      else { gm = *(const float4*)(gamma + c); bt = *(const float4*)(beta + c); }
 #pragma unroll
       for (int i = 0; i < RW; ++i)
         if (t0 + i < L) {
@@ -930,9 +977,14 @@ hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
   dim3 grid((L + 4 * RW_DISPATCH - 1) / (4 * RW_DISPATCH)), block(256);
 #define RRT_DISPATCH(NV)                                                                                         \
   do {                                                                                                           \
-    if (RRT_ALLOW_FULL && dim == NV * 256)                                                                                         \
-      crmsa_dispatch_ln_kernel<NV, CRMSA, true><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g);  \
-    else                                                                                                         \
+    if (RRT_ALLOW_FULL && dim == NV * 256) {                                                                     \
+      if (NV <= 2 && CRMSA && k <= 3)                                                                            \
+        crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 3 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
+      else if (NV <= 2 && CRMSA)                                                                                 \
+        crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 8 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
+      else                                                                                                       \
+        crmsa_dispatch_ln_kernel<NV, CRMSA, true><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g);  \
+    } else                                                                                                       \
       crmsa_dispatch_ln_kernel<NV, CRMSA, false><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
   } while (0)
   if (dim <= 256) RRT_DISPATCH(1);
