@@ -748,7 +748,7 @@ def main():
 
     cfg = CONFIGS[args.config]
     if args.streams <= 0:
-        # fp32: measured on MI355X (round 4, profiles/r04_streams_sweep.txt): 2 -> 4.84 k, 3 -> 4.90 k, 4 -> 5.10 k, 5 -> 4.78 k,
+        # fp32: measured on MI355X (round 4, profiles/r04_final_streams_sweep.txt): 2 -> 4.84 k, 3 -> 4.90 k, 4 -> 5.10 k, 5 -> 4.78 k,
         # 6 -> 4.85 k, 8 -> 5.07 k slides/s.  Kernels of different bags do not overlap on this chip in any way that saves
         # time (tools/corun_matrix.py: a kernel beside the fused R-MSA launch costs that launch the kernel's own solo
         # duration) -- what more bags in flight buy is the latency-bound CR-MSA chains of DIFFERENT bags running next to
