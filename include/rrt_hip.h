@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 22
+#define RRT_ABI_VERSION 23
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -239,6 +239,18 @@ int rrt_region_attention_f32(const float *qkv, const float *pe_w, float *o,
 int rrt_rmsa_fused_f32(const float *u, const float *qkv_w, const float *qkv_b, const float *pe_w,
                        float *o, int32_t n_regions, int32_t P, int32_t dim, int32_t heads,
                        int32_t epeg_k, int32_t compute, void *stream);
+
+/* The same kernel with the out-projection as a later phase of the SAME launch (fp32 exact): rrt_rmsa_fused_f32 followed by
+ * rrt_linear_unpartition_residual_f32 in one launch, bit-identical to that pair --
+ * out[t] = resid[t] + (o . proj_w^T + proj_b)[slot(t)] (rmsa.py:100-131, :41-54, :227-228; rrt.py:125).
+ * u [H*H, dim] region-major (rrt_ln_partition_f32 on g); o_scratch: H*H*dim floats (the attention output, device scratch);
+ * counters: regions_side^2 int32 of device scratch (zeroed by the call).  Needs heads * regions >= 2 x the CU count
+ * (block b of the launch runs (region, head) item b and then the 64-column projection slab b - CUs of a region whose
+ * items finished a whole item earlier), otherwise RRT_E_UNSUPPORTED; rrt_encoder_forward_f32 chooses by itself. */
+int rrt_rmsa_fused_proj_f32(const float *u, const float *qkv_w, const float *qkv_b, const float *pe_w,
+                            const float *proj_w, const float *proj_b, const float *resid, float *out,
+                            float *o_scratch, int32_t *counters, int32_t dim, int32_t heads, int32_t epeg_k,
+                            const rrt_grid *g, void *stream);
 
 /* 16-bit operand stages of the reduced-precision modes (compute = RRT_COMPUTE_BF16 / F16 selects the element type;
  * uint16_t* = raw bf16 / fp16 bits, round-to-nearest-even):

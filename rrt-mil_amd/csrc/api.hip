@@ -34,6 +34,7 @@ struct Workspace {
   uint16_t *rep16, *repo16;   // 16-bit representatives [k * 64, D] and their attention output (the fused 16-bit inner MSA)
   float* cr_part;    // crmsa_region4_kernel: partial records of the region quarters
   int* cr_cnt;       // ... and the 64 arrival counters (zeroed by an R-MSA GEMM of the same forward)
+  int* proj_cnt;     // rmsa_fused_kernel<.., PROJ>: one arrival counter per region (zeroed by the layer's LayerNorm + partition)
   size_t bytes;
 };
 
@@ -60,6 +61,7 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     w.qkv = take(Np * 3 * D);
     w.xa = take((size_t)N * D);
     if (d.n_rmsa_layers > 1 || d.ffn) w.xb = take((size_t)N * D);
+    w.proj_cnt = (int*)take((size_t)g.regions_side * g.regions_side);
     if (d.epeg && d.epeg_type != RRT_EPEG_ATTN) w.pe_out = take(Np * D);
     if (d.epeg && d.epeg_2d && d.epeg_type == RRT_EPEG_ATTN) {
       const size_t sm = attn_scoremap_scratch_floats(g.regions_side * g.regions_side, g.s * g.s, d.n_heads, d.epeg_k, 1);
@@ -445,7 +447,13 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       }
       continue;
     }
-    RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, ws.uo, D, gd, st));
+    // the exact fp32 path of bags that fill the chip twice over: fused R-MSA kernel with the out-projection as a
+    // later phase of the same launch (rmsa_fused.hip, PROJ); its arrival counters are zeroed by LayerNorm + partition
+    const bool merged = !epeg_variant && desc->compute == RRT_COMPUTE_F32 && ws.proj_cnt != nullptr &&
+                        rmsa_fused_supported_rows(gd.Np, D) &&
+                        rmsa_fused_proj_supported(gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, desc->compute);
+    RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, ws.uo, D, gd, st, merged ? ws.proj_cnt : nullptr,
+                                merged ? gd.rs * gd.rs : 0));
     if (epeg_variant) {
       if (!lw.pe_w) return RRT_E_INVALID;
       const int nreg = gd.rs * gd.rs;
@@ -490,6 +498,29 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     rrt_phase_gate* const gt = (gate && fused && gd.P > 112) ? gate : nullptr;
     if (gt && gt->armed) RRT_TRY(hipStreamWaitEvent(st, gt->done, 0));
     if (li == 0) RRT_MARK(RRT_EV_LN_PARTITION);    // after the gate: the mark brackets the kernel, not the wait
+    if (fused && merged) {
+      // ... and the out-projection + un-partition + residual as a later phase of the same launch's blocks (fp32,
+      // bags of >= two rounds of (region, head) items): one launch per R-MSA layer
+      FusedProj pj{};
+      pj.Wp = lw.proj_w;
+      pj.bias = lw.proj_b;
+      pj.resid = xin;
+      pj.out = xout;
+      pj.cnt = ws.proj_cnt;
+      pj.zero64 = ws.cr_cnt;
+      pj.g = gd;
+      RRT_TRY(launch_rmsa_fused(ws.uo, lw.qkv_w, lw.qkv_b, desc->epeg ? lw.pe_w : nullptr, ws.qkv,
+                                gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, desc->compute, st, nullptr, &pj));
+      if (gt) { RRT_TRY(hipEventRecord(gt->done, st)); gt->armed = true; }
+      if (li == 0) { RRT_MARK(RRT_EV_QKV); RRT_MARK(RRT_EV_ATTN); RRT_MARK(RRT_EV_PROJ); }
+      xin = xout;
+      if (desc->ffn) {
+        rc = ffn_block(lw, xout, fout);
+        if (rc) return rc;
+        xin = fout;
+      }
+      continue;
+    }
     if (fused) {
       // qkv projection + EPEG + attention in one kernel per (region, head): qkv never reaches HBM.
       // O goes to the qkv workspace (first Np*D floats), u stays in uo.
@@ -878,6 +909,30 @@ int rrt_rmsa_fused_f32(const float* u, const float* qkv_w, const float* qkv_b, c
     return unsupported("rmsa_fused: needs head dim 64, 48 < P <= 208, epeg_k <= 63 (use linear + region_attention)");
   return (int)launch_rmsa_fused(u, qkv_w, qkv_b, pe_w, o, n_regions, P, dim, heads, ek, compute,
                                 (hipStream_t)stream);
+}
+
+int rrt_rmsa_fused_proj_f32(const float* u, const float* qkv_w, const float* qkv_b, const float* pe_w,
+                            const float* proj_w, const float* proj_b, const float* resid, float* out, float* o_scratch,
+                            int32_t* counters, int32_t dim, int32_t heads, int32_t epeg_k, const rrt_grid* g,
+                            void* stream) {
+  if (!u || !qkv_w || !proj_w || !resid || !out || !o_scratch || !counters || !g || dim <= 0 || heads <= 0 || out == resid)
+    return RRT_E_INVALID;
+  const GridDev gd = to_dev(*g);
+  const int ek = pe_w ? epeg_k : 0, R = gd.rs * gd.rs;
+  if (!rmsa_fused_proj_supported(R, gd.P, dim, heads, ek, RRT_COMPUTE_F32) || !rmsa_fused_supported_rows(gd.Np, dim))
+    return unsupported("rmsa_fused_proj: needs what rmsa_fused needs (head dim 64, 48 < P <= 208, epeg_k <= 63) and at "
+                       "least two rounds of (region, head) items (heads * regions >= 2 x the CU count)");
+  hipError_t e = hipMemsetAsync(counters, 0, (size_t)R * sizeof(int32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  FusedProj pj{};
+  pj.Wp = proj_w;
+  pj.bias = proj_b;
+  pj.resid = resid;
+  pj.out = out;
+  pj.cnt = counters;
+  pj.g = gd;
+  return (int)launch_rmsa_fused(u, qkv_w, qkv_b, pe_w, o_scratch, R, gd.P, dim, heads, ek, RRT_COMPUTE_F32,
+                                (hipStream_t)stream, nullptr, &pj);
 }
 
 // ---- 16-bit operand stages of the reduced-precision modes (cast16.hip, linear_f32.hip IN16, rmsa_fused16.hip)

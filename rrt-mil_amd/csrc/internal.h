@@ -30,8 +30,9 @@ struct OncePerDevice {
   }
 };
 
+// zero / n_zero: side job of block 0 -- n_zero ints set to 0 (arrival counters of a later kernel of the same forward)
 hipError_t launch_ln_partition(const float* x, const float* gamma, const float* beta, float* u,
-                               int dim, const GridDev& g, hipStream_t st);
+                               int dim, const GridDev& g, hipStream_t st, int* zero = nullptr, int n_zero = 0);
 
 struct LinearEpilogue {
   int prec;              // MFMA operand precision: 0 f32 (exact), 1 bf16, 2 f16 (fp32 accumulate)
@@ -96,9 +97,26 @@ hipError_t launch_region_attention(const float* qkv, const float* pe_w, float* o
 // fused qkv projection + EPEG + attention per (region, head) (rmsa_fused.hip); P in (112,144], head dim 64
 bool rmsa_fused_supported(int P, int D, int heads, int epeg_k);
 bool rmsa_fused_supported_rows(long n_rows, int D);
+// The out-projection as a later phase of the SAME launch (fp32, inference): block b < heads * n_regions runs the
+// (region, head) item b; block b >= lag also runs the projection slab b - lag -- 64 output columns of one region,
+// C = O_r . Wp[64 c .., :]^T + bias, region_reverse + un-pad + residual (rmsa.py:131, :41-54, :227-228; rrt.py:125) --
+// once that region's `heads` items have arrived at cnt[region].  cnt [n_regions] must be zero at launch.
+struct FusedProj {
+  const float* Wp;       // [D, D]
+  const float* bias;     // [D] or null
+  const float* resid;    // [L, D] token order
+  float* out;            // [L, D]
+  int* cnt;              // [n_regions] arrival counters (zero at launch)
+  int* zero64;           // side job of block 0 (LinearEpilogue.zero64), may be null
+  int lag;               // blocks between an item and the slab of the same index (multiple of 8, >= 8 * heads)
+  int n_items;           // heads * n_regions
+  GridDev g;
+};
+bool rmsa_fused_proj_supported(int n_regions, int P, int D, int heads, int epeg_k, int prec);
 hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w,
                              float* O, int n_regions, int P, int D, int heads, int epeg_k, int prec,
-                             hipStream_t st, float* stash = nullptr);   // stash: [rows, 3 D] q | k | v for the backward
+                             hipStream_t st, float* stash = nullptr,    // stash: [rows, 3 D] q | k | v for the backward
+                             const FusedProj* proj = nullptr);           // lag / n_items are filled by the launcher
 
 // EPEG ablations (epeg_variants.hip): 2-D 'attn' EPEG over the score map; value EPEG over v's token image
 size_t attn_scoremap_lds(int P, int k);

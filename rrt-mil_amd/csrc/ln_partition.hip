@@ -14,7 +14,10 @@ template <int NV, bool FULL>   // float4 per lane: supports dim <= NV*256
 __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
-                                                           float* __restrict__ u, int dim, GridDev g) {
+                                                           float* __restrict__ u, int dim, GridDev g,
+                                                           int* __restrict__ zero, int n_zero) {
+  if (zero != nullptr && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n_zero; i += 256) zero[i] = 0;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);   // padded-grid token index
   if (t >= g.Np) return;
@@ -64,12 +67,12 @@ __global__ __launch_bounds__(256) void ln_partition_kernel(const float* __restri
 }
 
 hipError_t launch_ln_partition(const float* x, const float* gamma, const float* beta, float* u,
-                               int dim, const GridDev& g, hipStream_t st) {
+                               int dim, const GridDev& g, hipStream_t st, int* zero, int n_zero) {
   dim3 grid((g.Np + 3) / 4), block(256);
 #define RRT_LNP(NV)                                                                              \
   do {                                                                                         \
-    if (RRT_ALLOW_FULL && dim == NV * 256) ln_partition_kernel<NV, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);  \
-    else ln_partition_kernel<NV, false><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);                 \
+    if (RRT_ALLOW_FULL && dim == NV * 256) ln_partition_kernel<NV, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g, zero, n_zero);  \
+    else ln_partition_kernel<NV, false><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g, zero, n_zero);                 \
   } while (0)
   if (dim <= 256) RRT_LNP(1);
   else if (dim <= 512) RRT_LNP(2);

@@ -28,8 +28,6 @@
 
 namespace {
 
-#define RRT_STORE_O(ptr, val) (*(ptr) = (val))   // (non-temporal stores measured: no gain)
-
 constexpr int BK = 32;
 constexpr int HD = 64;
 constexpr int BN = 3 * HD;          // q | k | v columns of one head
@@ -37,6 +35,22 @@ constexpr float NEG_BIG = -3.0e38f;
 constexpr float LOG2E = 1.4426950408889634f;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool WT>
+__device__ __forceinline__ void store_o(f32x2* p, f32x2 v) {
+  if constexpr (WT) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  else *p = v;
+}
+#define RRT_STORE_O(ptr, val) store_o<PROJ>((ptr), (val))   // (non-temporal stores measured: no gain)
+
+// O leaves the block through an ordinary store -- or, when the out-projection runs as a later phase of OTHER blocks of
+// the same launch (PROJ, below), through a write-through one (sc0 sc1: the line reaches memory, not just this XCD's L2;
+// the eight XCDs' L2s are not coherent with each other inside a launch -- crmsa.hip's hand-over note)
+template <bool WT>
+__device__ __forceinline__ void store_o(f32x4* p, f32x4 v) {
+  if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  else *p = v;
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
@@ -70,14 +84,249 @@ struct Frag8<PREC_F16> {
   }
 };
 
-template <int MT, int PREC>
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate): n <= 31 here
+__device__ __forceinline__ void wait_vmcnt(const int n) {
+#define RRT_VMC(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
+  switch (n) {
+    RRT_VMC(1) RRT_VMC(2) RRT_VMC(3) RRT_VMC(4) RRT_VMC(5) RRT_VMC(6) RRT_VMC(7) RRT_VMC(8) RRT_VMC(9) RRT_VMC(10)
+    RRT_VMC(11) RRT_VMC(12) RRT_VMC(13) RRT_VMC(14) RRT_VMC(15) RRT_VMC(16) RRT_VMC(17) RRT_VMC(18) RRT_VMC(19) RRT_VMC(20)
+    RRT_VMC(21) RRT_VMC(22) RRT_VMC(23) RRT_VMC(24) RRT_VMC(25) RRT_VMC(26) RRT_VMC(27) RRT_VMC(28) RRT_VMC(29) RRT_VMC(30)
+    RRT_VMC(31)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef RRT_VMC
+}
+
+// block -> (region, head) for n_items = n_regions * heads blocks (see the kernel's comment on the XCD-aware order)
+__device__ __forceinline__ void map_item(const int b, const int n_items, const int heads, int& reg, int& head) {
+  const int n_regions = n_items / heads;
+  const int full = (n_regions >> 3) * 8 * heads;            // blocks of complete 8-region groups
+  if (b < full) {
+    const int xcd = b & 7, idx = b >> 3;
+    const int grp = idx / heads;                             // group of 8 regions, one per XCD
+    reg = grp * 8 + xcd;
+    head = idx - grp * heads;
+  } else {                                                   // ragged tail: plain order (bijective)
+    const int rem = b - full;
+    reg = (n_regions >> 3) * 8 + rem / heads;
+    head = rem % heads;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PROJ phase: one 64-column slab of one region's out-projection, by the whole block (after its own item, if any).
+//     Y[P x 64] = O_r[P x D] . Wp[64 c .. 64 c + 63, :]^T + b ;  out[token(slot)] = resid[token(slot)] + Y[slot]
+// (proj nn.Linear, region_reverse, un-pad, residual: modules/rmsa.py:131, :41-54, :227-228; rrt.py:125).
+// Why here and not as the next launch: as a kernel of its own the projection's blocks move in lockstep -- every block of
+// the chip waits for its first (cold) DMA round trip at the same moment and later bursts its un-partition epilogue at
+// the same moment: 45 us for 31 us of MFMA.  As a phase of the fused launch's blocks the
+// slabs drift apart, O_r is an item old (in this XCD's L2) and the launch ramp is paid once.
+// Machinery: the projection loop's -- four loader waves feed a two-stage LDS-DMA ring of 128-byte rows (XOR-swizzled
+// by the source address), four compute waves (one 16-column tile each, all MT row tiles) run v_mfma_f32_16x16x4_f32
+// with the operand roles swapped; both halves' fragments are double-buffered in registers, the tile barrier sits
+// between the halves (stage kt is in registers everywhere -> its buffer is free for stage kt + 2).  The K-sum order
+// per accumulator (k tile, half, component) is linear_ws_kernel's: the result is bit-identical to the separate launch.
+#ifdef RRT_TRACE
+#define RRT_SLAB_TRACE_ARG , WaveTrace& _tr
+#define RRT_SLAB_TRACE_PASS , _tr
+#else
+#define RRT_SLAB_TRACE_ARG
+#define RRT_SLAB_TRACE_PASS
+#endif
+template <int MT>
+__device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const float* __restrict__ O, const int n_rows,
+                                          const int P, const int D, const int heads_rt, const FusedProj& pj,
+                                          char* smem RRT_SLAB_TRACE_ARG) {
+  constexpr int BM = 16 * MT;
+  constexpr int SST = (BM + HD) * BK;              // floats per stage: A tile (BM rows) + B tile (64 rows of Wp)
+  constexpr int NA = BM / 8, NB = HD / 8;          // 1 KiB DMA pieces per stage
+  constexpr int LA = (NA + 3) / 4, LB = NB / 4;
+  constexpr bool PREF = MT <= 9;                   // residual rows requested under the K loop (registers allow it)
+  constexpr int LDS_MAIN_F = (2 * (BM + BN) * BK > 3 * BM * HD ? 2 * (BM + BN) * BK : 3 * BM * HD);   // the kernel's LDS, floats
+  constexpr int NS = LDS_MAIN_F / SST >= 4 ? 4 : LDS_MAIN_F / SST;     // ring stages that fit it (MT = 6, 7: three)
+  static_assert(NS >= 3 && NS * SST <= LDS_MAIN_F, "slab ring");
+  const int b = (int)blockIdx.x;
+  if (b < pj.lag) return;
+  const int sidx = b - pj.lag;                     // < n_items by the grid size
+  int reg, col;
+  map_item(sidx, pj.n_items, heads_rt, reg, col);
+  float* lds = (float*)smem;
+  const unsigned lds_b = lds_addr_of(lds);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int row0 = reg * P;
+  const int nk = D / BK;
+  RRT_TRACE_MARK();                                 // slab [1] entry
+  // the region's `heads` items have arrived (their O rows are in memory): blocks with lower indices, dispatched earlier
+  if (tid == 0)
+    while (__hip_atomic_load(pj.cnt + reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < heads_rt) __builtin_amdgcn_s_sleep(8);
+  __syncthreads();
+  RRT_TRACE_MARK();                                 // slab [2] region complete
+  if (wave >= 4) {
+    const int lw = wave - 4;
+    unsigned aoff[LA], boff[LB];
+#pragma unroll
+    for (int qi = 0; qi < LA; ++qi) {
+      const int S = (qi * 4 + lw) * 64 + lane;
+      const int row = S >> 3, p = S & 7;
+      int gr = row0 + row;
+      gr = gr < n_rows ? gr : n_rows - 1;            // rows past the last region: re-read (never used)
+      aoff[qi] = (unsigned)gr * (unsigned)D * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int qi = 0; qi < LB; ++qi) {
+      const int S = (qi * 4 + lw) * 64 + lane;
+      const int row = S >> 3, p = S & 7;             // row in [0, 64): output column 64 col + row
+      boff[qi] = (unsigned)(col * HD + row) * (unsigned)D * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
+    }
+    auto stage = [&](int kt, unsigned buf) {
+#pragma unroll
+      for (int qi = 0; qi < LA; ++qi)
+        if (qi * 4 + lw < NA) dma16s(O + kt * BK, aoff[qi], buf + (qi * 4 + lw) * 1024);
+#pragma unroll
+      for (int qi = 0; qi < LB; ++qi) dma16s(pj.Wp + kt * BK, boff[qi], buf + BM * BK * 4 + (qi * 4 + lw) * 1024);
+    };
+    // NS-stage ring: a slab's K tile is 72 MFMAs per wave (2.3 K cycles) -- less than a DMA round trip, and the block
+    // is alone on its CU -- so the stages of the next NS - 1 K tiles are always in flight (with two stages every K tile
+    // waited for its operands: the slab took as long as the separate launch's tile).  Barrier B_j = "stage j is in
+    // registers everywhere, stage j + 1 has landed": stage j + NS goes into buffer j % NS right behind it.
+    const int mine = (NA - lw + 3) / 4 + LB;        // DMA pieces this wave issues per stage (vmcnt counts them)
+    // Issuing a stage takes a wave ~1.1 K cycles (6 or 7 pieces that block it ~160 cycles each), so the ring is filled
+    // as the loop goes: stages 0 and 1, K tile 0 published, stage 2, and behind barrier B_kt stage kt + 3 -- into buffer
+    // (kt + 3) % NS, which B_kt (NS = 3) or B_kt-1 (NS = 4) freed.  Before B_kt the wave waits for stage kt + 1 with
+    // stage kt + 2 still in flight (vmcnt counts this wave's own pieces).
+    stage(0, lds_b);
+    if (nk > 1) stage(1, lds_b + SST * 4);
+    RRT_TRACE_MARK();                               // loader slab [3] first stages issued
+    wait_vmcnt(nk > 1 ? mine : 0);
+    RRT_TRACE_MARK();                               // loader slab [4] K tile 0 landed
+    __syncthreads();                                // publishes K tile 0
+    if (nk > 2) stage(2, lds_b + 2 * SST * 4);
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_vmcnt(kt + 2 < nk ? mine : 0);           // K tile kt + 1 has landed
+      if (kt == 0 || kt == 7 || kt == 14) RRT_TRACE_MARK();   // loader slab [5,6,7] K tile 1 / 8 / 15 landed
+      __syncthreads();                              // B_kt
+      if (kt + 3 < nk) stage(kt + 3, lds_b + ((kt + 3) % NS) * SST * 4);
+    }
+    return;
+  }
+  // ------------------------------------------------------------------ compute waves: column tile `wave`
+  const int ncol = col * HD + wave * 16 + 4 * lg;   // this lane's four output columns
+  // un-partition map of this lane's MT rows (region_reverse, rmsa.py:41-54: the region is known, one division per row);
+  // computed where it is used (twice) rather than held in MT registers across the K loop
+  const int tbase = [&] {
+    const int ri = fdiv(reg, pj.g.rs, pj.g.inv_rs), rj = reg - ri * pj.g.rs;
+    return ri * pj.g.s * pj.g.H + rj * pj.g.s;
+  }();
+  auto token_of = [&](const int i) {
+    const int m = i * 16 + lr;
+    const int pi = fdiv(m, pj.g.s, pj.g.inv_s), pjj = m - pi * pj.g.s;
+    const int t = tbase + pi * pj.g.H + pjj;
+    return (m < P && t < pj.g.L) ? t : -1;          // rows past the region / pad slots: nothing to write
+  };
+  float4 rq[PREF ? MT : 1];
+  const float4 bias = pj.bias ? *(const float4*)(pj.bias + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 af[2][MT], bfr[2];
+  auto frags = [&](const float* As, const int kk, float4 (&a)[MT], float4& bb) {
+    {
+      const int row = wave * 16 + lr;
+      bb = *(const float4*)(As + BM * BK + row * BK + (((4 * kk + lg) ^ ((row >> 1) & 7)) << 2));
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = i * 16 + lr;
+      a[i] = *(const float4*)(As + row * BK + (((4 * kk + lg) ^ ((row >> 1) & 7)) << 2));
+    }
+  };
+  // one half K tile: 4 MT MFMAs on the fragments (a, bb) while the OTHER set's MT + 1 fragment reads (na, nb from
+  // nAs / nkk; nAs == nullptr: none) are issued between them -- one read behind every third MFMA (a wave issues in
+  // order: ten reads in a row drain the matrix pipe, ~150 cycles per half), the last one six or more MFMAs before the
+  // half ends, so that the lgkmcnt(0) of the barrier behind a first half does not wait
+  auto half = [&](const float4 (&a)[MT], const float4& bb, const bool load, const float* nAs, const int nkk,
+                  float4 (&na)[MT], float4& nb) {
+    if (load) frags(nAs, nkk, na, nb);
+#pragma unroll
+    for (int comp = 0; comp < 4; ++comp) {
+      const float bv = comp == 0 ? bb.x : comp == 1 ? bb.y : comp == 2 ? bb.z : bb.w;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float av = comp == 0 ? a[i].x : comp == 1 ? a[i].y : comp == 2 ? a[i].z : a[i].w;
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i], 0, 0, 0);
+      }
+    }
+    if (load) {
+#pragma unroll
+      for (int r = 0; r < MT + 1; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // three MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 3 * (MT + 1), 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // (barriers of the compute side: LDS reads retired + s_barrier, nothing to do with vmcnt)
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  RRT_TRACE_MARK();                                 // slab [3] ready for K tile 0
+  lds_barrier();                                    // K tile 0 published
+  RRT_TRACE_MARK();                                 // slab [4] K tile 0 published
+  frags(lds, 0, af[0], bfr[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    half(af[0], bfr[0], true, lds + (kt % NS) * SST, 1, af[1], bfr[1]);   // first half; the second half's fragments under it
+    lds_barrier();                                  // B_kt: stage kt is in registers everywhere, stage kt + 1 published
+    if (kt == 0 || kt == 7 || kt == 14) RRT_TRACE_MARK();   // slab [5,6,7] B_0, B_7, B_14
+    half(af[1], bfr[1], true, lds + ((kt + 1) % NS) * SST, 0, af[0], bfr[0]);
+  }
+  half(af[0], bfr[0], true, lds + ((nk - 1) % NS) * SST, 1, af[1], bfr[1]);
+  lds_barrier();                                    // (the loader side counts one barrier per K tile)
+  if constexpr (PREF) {
+    // the residual rows, requested under the last half K tile (into the registers the first fragment set leaves: held
+    // from the start of the slab they cost the kernel 8 VGPRs over what the item phases need).  Unconditional (rows that
+    // are not written re-read token 0): loads under per-row branches left the compiler's wait-count bookkeeping with
+    // "anything may be outstanding" at every store of the epilogue -- s_waitcnt vmcnt(0) in front of each
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int t = token_of(i);
+      rq[i] = *(const float4*)(pj.resid + (size_t)(t < 0 ? 0 : t) * D + ncol);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  half(af[1], bfr[1], false, nullptr, 0, af[0], bfr[0]);
+  RRT_TRACE_MARK();                                 // slab [8] last MFMA issued
+  // epilogue: + bias, un-partition, + residual (plain stores: the next launch reads them)
+  if constexpr (PREF) {
+    // every residual row is "consumed" here, in front of the first store: the compiler's waits for them are then
+    // counted against loads only (long landed) -- placed at each row's use they count the stores issued in between as
+    // well (vmcnt(9 - i) in front of store i: the last stores went out one at a time)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(rq[i].x), "+v"(rq[i].y), "+v"(rq[i].z), "+v"(rq[i].w));
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int t = token_of(i);
+    float4 q;
+    if constexpr (PREF) q = rq[i];
+    else q = *(const float4*)(pj.resid + (size_t)(t < 0 ? 0 : t) * D + ncol);
+    const float4 v = make_float4(acc[i][0] + bias.x + q.x, acc[i][1] + bias.y + q.y, acc[i][2] + bias.z + q.z, acc[i][3] + bias.w + q.w);
+    if (t >= 0) *(float4*)(pj.out + (size_t)t * D + ncol) = v;
+  }
+  RRT_TRACE_MARK();                                 // slab [9] stores issued
+}
+
+template <int MT, int PREC, bool PROJ>
 __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restrict__ U,
                                                             const float* __restrict__ Wqkv,
                                                             const float* __restrict__ bqkv,
                                                             const float* __restrict__ pe_w,
                                                             float* __restrict__ O, int n_rows, int P,
                                                             int D, int heads_rt, int epeg_k, float q_scale,
-                                                            float* __restrict__ stash) {
+                                                            float* __restrict__ stash, FusedProj pj) {
+  static_assert(!PROJ || PREC == PREC_F32, "the projection phase is fp32 only");
   constexpr int BM = 16 * MT;
   constexpr int STAGE = (BM + BN) * BK;            // floats per pipeline stage
   constexpr int TILE = BM * HD;                    // floats of one Q / K / V tile
@@ -105,24 +354,22 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
   // only): the 8 head-blocks of a region are given consecutive slots of ONE XCD, so the region's
   // U panel (P x D fp32 = 295 KB) is fetched from HBM once and served to the other 7 heads from
   // that XCD's L2 (the naive head-fastest order put the 8 heads on 8 different XCDs: 8x the reads).
-  int head, reg;
-  {
-    const int b = blockIdx.x;
-    const int n_regions = gridDim.x / heads_rt;
-    const int full = (n_regions >> 3) * 8 * heads_rt;       // blocks of complete 8-region groups
-    if (b < full) {
-      const int xcd = b & 7, idx = b >> 3;
-      const int grp = idx / heads_rt;                        // group of 8 regions, one per XCD
-      reg = grp * 8 + xcd;
-      head = idx - grp * heads_rt;
-    } else {                                                 // ragged tail: plain order (bijective)
-      const int rem = b - full;
-      reg = (n_regions >> 3) * 8 + rem / heads_rt;
-      head = rem % heads_rt;
-    }
+  const int n_items = PROJ ? pj.n_items : (int)gridDim.x;
+  auto item_of = [&](const int b, int& reg_, int& head_) { map_item(b, n_items, heads_rt, reg_, head_); };
+  // PROJ: block b runs item b (b < n_items) and then the projection slab b - lag (b >= lag): the slab's region finished
+  // its items a whole item (~150 K cycles) earlier, on blocks with lower indices -- dispatched before this one, so the
+  // wait below is on work that is already running or done (no deadlock), and in practice never spins.  lag % 8 == 0
+  // keeps slab (r, c) on the XCD whose L2 holds O_r.
+  const bool has_item = !PROJ || (int)blockIdx.x < n_items;
+  int head = 0, reg = 0;
+  if (has_item) item_of(blockIdx.x, reg, head);
+  if constexpr (PROJ) {
+    if (pj.zero64 != nullptr && blockIdx.x == 0 && threadIdx.x < 64) pj.zero64[threadIdx.x] = 0;
   }
   const int row0 = reg * P;                        // first token row of this region
   const int nk = D / BK;
+  RRT_TRACE_INIT(blockIdx.x * 8 + wave);
+  if (has_item) {
   // EPEG taps as the stencil wants them -- log2(e) * (w[t] + [t == k/2]), zero outside [0, k) -- in a 128-entry LDS
   // table behind the tiles (index t + TAP_OFF).  (Fetching w[t] from global inside the stencil loop put one
   // dependent vector load on every source row: the trace showed 9.2K cycles for a phase with ~2K cycles of work.)
@@ -138,7 +385,6 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
     if (t == (epeg_k >> 1)) wt += 1.0f;
     taps[tid] = wt * LOG2E;
   }
-  RRT_TRACE_INIT(blockIdx.x * 8 + wave);
   RRT_TRACE_MARK();                                 // [1] entry
 
   // ================================================================== phase 1: projection
@@ -752,24 +998,65 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
     RRT_TRACE_MARK();                               // tile: O stored
   }
   }
+  // ---------------------------------------------------------------- PROJ: this item has arrived
+  if constexpr (PROJ) {
+    wait_vm0();                                     // this thread's write-through stores of O are in memory ...
+    __syncthreads();                                // ... and everybody's; the tiles in LDS are dead
+    RRT_TRACE_MARK();                               // item: O in memory
+    if (tid == 0) __hip_atomic_fetch_add(pj.cnt + reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  }   // has_item
+  if constexpr (PROJ) proj_slab<MT>(U, O, n_rows, P, D, heads_rt, pj, smem RRT_SLAB_TRACE_PASS);
+}
+
+// Blocks between an item and the slab of the same index: one block per CU runs at a time (LDS), so a lag of one
+// "round" (the CU count, a multiple of 8 so that a slab stays on its region's XCD) puts a slab a whole item behind the
+// items it waits for.  Never more than the items themselves (the launch is n_items + lag blocks).
+int proj_lag(int n_items) {
+  static int cus[64] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  d &= 63;
+  if (cus[d] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    cus[d] = n;
+  }
+  int lag = cus[d] & ~7;
+  if (lag > n_items) lag = n_items & ~7;
+  return lag;
 }
 
 template <int MT, int PREC>
 hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w, float* O,
-                     int n_regions, int P, int D, int heads, int epeg_k, float* stash, hipStream_t st) {
+                     int n_regions, int P, int D, int heads, int epeg_k, float* stash, hipStream_t st,
+                     const FusedProj* proj) {
   constexpr int BM = 16 * MT;
   constexpr size_t STG = (size_t)2 * (BM + BN) * BK * 4, QKV = (size_t)3 * BM * HD * 4;
-  // staging ring / Q, K, V; tap table (512 B) + bias (768 B); partials of the shared-out tile (MT = 9)
   // staging ring / Q, K, V; tap table (512 B) + bias (768 B); shared-out tile (MT = 9): (max, sum) pairs + one partial O
   constexpr size_t LDS = (STG > QKV ? STG : QKV) + 1280 + (MT == 9 ? MT * 32 * 4 + 16 * HD * 4 : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = rmsa_fused_kernel<MT, PREC>;
+  const float q_scale = 1.0f / sqrtf((float)HD);
+  if constexpr (PREC == PREC_F32) {
+    if (proj != nullptr) {
+      auto kern = rmsa_fused_kernel<MT, PREC_F32, true>;
+      static OncePerDevice once;
+      if (once.first())
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+      FusedProj pj = *proj;
+      pj.n_items = heads * n_regions;
+      pj.lag = proj_lag(pj.n_items);
+      kern<<<dim3(pj.n_items + pj.lag), dim3(512), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D, heads,
+                                                              pe_w ? epeg_k : 0, q_scale, nullptr, pj);
+      return hipGetLastError();
+    }
+  }
+  auto kern = rmsa_fused_kernel<MT, PREC, false>;
   static OncePerDevice once;
   if (once.first())
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-  const float q_scale = 1.0f / sqrtf((float)HD);
   kern<<<dim3(heads * n_regions), dim3(512), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D, heads,
-                                                      pe_w ? epeg_k : 0, q_scale, stash);
+                                                      pe_w ? epeg_k : 0, q_scale, stash, FusedProj{});
   return hipGetLastError();
 }
 
@@ -792,14 +1079,27 @@ bool rmsa_fused_supported_rows(long n_rows, int D) {   // 32-bit DMA byte offset
   return n_rows * (long)D * 4 < 4000000000L;
 }
 
+// The projection as a phase of the fused launch pays when the launch has at least two rounds of items (a slab then
+// runs a whole item behind the blocks it waits for, and the last round of slabs is as wide as the chip) -- and the wait
+// is deadlock-free when every item a slab waits for has a LOWER block index than the slab's block: a region's items
+// span 8 * heads consecutive indices, lag >= that.  fp32 exact arithmetic only.
+bool rmsa_fused_proj_supported(int n_regions, int P, int D, int heads, int epeg_k, int prec) {
+  static const bool off = rrt_tune_env("RRT_NO_FUSED_PROJ") != nullptr;
+  if (off || prec != PREC_F32 || !rmsa_fused_supported(P, D, heads, epeg_k)) return false;
+  const int n_items = n_regions * heads, lag = proj_lag(n_items);
+  return D % 4 == 0 && n_items >= 2 * lag && lag >= 8 * heads;
+}
+
 hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w,
                              float* O, int n_regions, int P, int D, int heads, int epeg_k, int prec,
-                             hipStream_t st, float* stash) {
+                             hipStream_t st, float* stash, const FusedProj* proj) {
+  if (proj != nullptr && (stash != nullptr || !rmsa_fused_proj_supported(n_regions, P, D, heads, epeg_k, prec)))
+    return hipErrorInvalidValue;
 #define RRT_FUSED(MT_)                                                                              \
   switch (prec) {                                                                                   \
-    case 1: return launch_mt<MT_, PREC_BF16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, stash, st); \
-    case 2: return launch_mt<MT_, PREC_F16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, stash, st);  \
-    default: return launch_mt<MT_, PREC_F32>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, stash, st); \
+    case 1: return launch_mt<MT_, PREC_BF16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, stash, st, proj); \
+    case 2: return launch_mt<MT_, PREC_F16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, stash, st, proj);  \
+    default: return launch_mt<MT_, PREC_F32>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, stash, st, proj); \
   }
   if (P > 176) { RRT_FUSED(13) }
   if (P > 144) { RRT_FUSED(11) }

@@ -961,6 +961,68 @@ def test_rmsa_fused_unsupported_shapes_report():
         assert rc == -2 and b"rmsa_fused" in lib.rrt_strerror(rc)
 
 
+# every row-tile count of the kernel (MT = 4 ... 13) at region_num = 8 (64 regions = 512 items = two rounds of the chip),
+# a real bag with pad slots, region_num = 16 (256 regions), the ragged-tail block order (region_num = 9: 81 regions)
+@pytest.mark.parametrize("L,rn,D,heads,ek", [(9000, 8, 512, 8, 15), (3000, 8, 512, 8, 15), (4096, 8, 512, 8, 21),
+                                             (5000, 8, 512, 8, 15), (6200, 8, 512, 8, 15), (7000, 8, 512, 8, 0),
+                                             (8000, 8, 512, 8, 15), (10500, 8, 512, 8, 15), (12000, 8, 512, 8, 15),
+                                             (30000, 16, 512, 8, 15), (9000, 9, 512, 8, 15)])
+def test_rmsa_fused_proj(L, rn, D, heads, ek):
+    """R-MSA core + out-projection + un-partition + residual in ONE launch (rmsa_fused_kernel<.., PROJ>: block b runs
+    (region, head) item b, then the projection slab of a region whose items arrived a round earlier) against the
+    two-launch pair it replaces -- bit for bit -- and against the float64 restatement of rmsa.py:100-131 / :41-54."""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    g = _lib.region_grid(L, rn)
+    Np, R, P = g.H * g.H, g.regions_side ** 2, g.s * g.s
+    u = synth.normal(f"fp/u{Np}", (Np, D))
+    W = synth.uniform(f"fp/w{D}", (3 * D, D), -1, 1) / np.sqrt(D)
+    b = synth.uniform(f"fp/b{D}", (3 * D,), -0.3, 0.3)
+    pe = synth.uniform("fp/pe", (heads, max(ek, 1)), -1, 1) / np.sqrt(max(ek, 1))
+    Wp = synth.uniform(f"fp/wp{D}", (D, D), -1, 1) / np.sqrt(D)
+    bp = synth.uniform(f"fp/bp{D}", (D,), -0.5, 0.5)
+    res = synth.normal(f"fp/r{L}", (L, D))
+    d_u, d_W, d_b, d_pe, d_Wp, d_bp, d_res = dev(u), dev(W), dev(b), dev(pe), dev(Wp), dev(bp), dev(res)
+    o1 = torch.full((Np, D), float("nan"), device=DEV)
+    out1 = torch.full((L, D), float("nan"), device=DEV)
+    _lib.check(lib.rrt_rmsa_fused_f32(p(d_u), p(d_W), p(d_b), p(d_pe) if ek else None, p(o1), R, P, D, heads, ek, 0,
+                                      stream()), "rmsa_fused")
+    _lib.check(lib.rrt_linear_unpartition_residual_f32(p(o1), p(d_Wp), p(d_bp), p(d_res), p(out1), D, D, C.byref(g), 0,
+                                                       stream()), "unpart")
+    o2 = torch.full((Np, D), float("nan"), device=DEV)
+    out2 = torch.full((L, D), float("nan"), device=DEV)
+    cnt = torch.full((R,), 12345, device=DEV, dtype=torch.int32)
+    for _ in range(3):                                   # repeated launches on the same scratch (stale O rows, used counters)
+        _lib.check(lib.rrt_rmsa_fused_proj_f32(p(d_u), p(d_W), p(d_b), p(d_pe) if ek else None, p(d_Wp), p(d_bp), p(d_res),
+                                               p(out2), p(o2), p(cnt), D, heads, ek, C.byref(g), stream()), "rmsa_fused_proj")
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2), "attention output differs from the two-launch path"
+    assert torch.equal(out1, out2), "projection differs from the two-launch path"
+    if L <= 9000:
+        qkv = u.astype(np.float64) @ W.astype(np.float64).T + b
+        qkv[:, :D] *= (D // heads) ** -0.5
+        o_ref = _attn_ref(qkv, pe, R, P, D, heads, ek)
+        Z = o_ref @ Wp.astype(np.float64).T + bp
+        z = np.empty((Np, D))
+        z[O.partition_index(g.H, g.s)] = Z
+        _cmp(out2.cpu().numpy(), res + z[:L], 1e-4, f"rmsa_fused_proj L{L} rn{rn}")
+
+
+def test_rmsa_fused_proj_unsupported_shapes_report():
+    """fewer than two rounds of items (region_num = 4: 16 regions) and regions outside the fused kernel's range stay with
+    the two launches"""
+    from hip_util import p, stream, DEV
+    lib = _lib.load()
+    t = torch.zeros(16000, 512, device=DEV)
+    t2 = torch.zeros(16000, 512, device=DEV)
+    cnt = torch.zeros(1024, device=DEV, dtype=torch.int32)
+    for L, rn in ((2000, 4), (15000, 8), (600, 8)):
+        g = _lib.region_grid(L, rn)
+        rc = lib.rrt_rmsa_fused_proj_f32(p(t), p(t), None, None, p(t), None, p(t), p(t2), p(t), p(cnt), 512, 8, 0,
+                                         C.byref(g), stream())
+        assert rc == -2 and b"rmsa_fused_proj" in lib.rrt_strerror(rc), (L, rn, rc)
+
+
 def test_bag_feeder_matches_direct_copy(tmp_path):
     """Row f3: pinned double-buffered H2D feed -- same bags, same order, same results as bag.to(device);
     accepts tensors and .pt paths (dataloader.py:181)."""
