@@ -174,11 +174,20 @@ def flops_total(n, enc_cfg):
             + 6 * g8.Np * D * k + 8 * k * 64 * D * D + 4 * k * 64 * 64 * D)
 
 
-def fused_flops(n, enc_cfg):
-    """The fused R-MSA kernel's share: qkv projection [Np, D] x [3D, D]^T + Q K^T + A V per (region, head)."""
+def fused_flops(n, enc_cfg, with_proj=False):
+    """The fused R-MSA kernel's share: qkv projection [Np, D] x [3D, D]^T + Q K^T + A V per (region, head) -- and, where
+    the out-projection runs as a later phase of the same launch (rrt_encoder_plan: RRT_PLAN_FUSED_PROJ), [Np, D] x [D, D]^T."""
     from rrt_mil_amd.geometry import region_grid
     g = region_grid(n, enc_cfg["region_num"])
-    return 2.0 * g.Np * (3 * DIM) * DIM + 4.0 * g.Np * g.P * DIM, g
+    return 2.0 * g.Np * (3 * DIM) * DIM + 4.0 * g.Np * g.P * DIM + (2.0 * g.Np * DIM * DIM if with_proj else 0.0), g
+
+
+def plan_flags(enc, n):
+    """rrt_encoder_plan of an RRTEncoder's current descriptor for a bag of n tokens"""
+    from rrt_mil_amd import _lib
+    fl = C.c_int32(0)
+    _lib.check(_lib.load().rrt_encoder_plan(C.byref(enc._desc), n, C.byref(fl)), "rrt_encoder_plan")
+    return fl.value
 
 
 class HipEvents:
@@ -486,15 +495,22 @@ class EncoderWorkload:
         mpeak = PEAK_TFLOPS["bf16" if lowp else "f32"]
         es = 2 if lowp else 4                                   # bytes of a u / O element in HBM
         sc = 1 if self.enc_cfg.get("all_shortcut") else 0
-        f_fused, _ = fused_flops(self.n, self.enc_cfg)
+        merged = bool(plan_flags(self.enc, self.n) & self._lib.PLAN_FUSED_PROJ)
+        f_fused, _ = fused_flops(self.n, self.enc_cfg, with_proj=merged)
         tab = traffic_table(args.config, self.dtype)
         fused_pat = RMSA_CORE_KERNELS
+        if merged:      # one launch: the two event marks behind it are a marker gap, counted with the launch
+            stages["fused_rmsa"] += stages.pop("out_projection")
         spec = [
             ("ln_partition", "LayerNorm + zero-pad + region partition (rrt.py:121, rmsa.py:199-200,28-39)", "hbm",
              N * D * 4 + g.Np * D * es, ("ln_partition",)),
-            ("fused_rmsa", "qkv projection + EPEG + softmax(QK^T)V per (region, head) (rmsa.py:100-122)", "mfma", f_fused, fused_pat),
+            ("fused_rmsa", "qkv projection + EPEG + softmax(QK^T)V per (region, head) (rmsa.py:100-122)"
+             + (" + proj Linear + region_reverse + un-pad + residual as a later phase of the same launch (rmsa.py:131,41-54; "
+                "rrt.py:125)" if merged else ""), "mfma", f_fused, fused_pat),
+        ] + ([] if merged else [
             ("out_projection", "proj Linear + region_reverse + un-pad + residual (rmsa.py:131,41-54; rrt.py:125)", "mfma",
              2.0 * g.Np * D * D, ("linear_ws_kernel<6, 1, 1", "linear_ws_kernel<8, 1, 1", "linear_ws_kernel<9, 1, 1")),
+        ]) + [
             ("crmsa_combine", "LN2 + logits + region softmax / min-max + combine (rmsa.py:303-316): x1 read once", "hbm",
              N * D * 4, ("crmsa_region4", "crmsa_logits", "crmsa_combine")),
             ("crmsa_inner", "MSA over the 64 k representatives: qkv, 64 x 64 attention, proj (rmsa.py:322)", "mfma",
@@ -528,7 +544,8 @@ class EncoderWorkload:
         if rank != 0:
             return {}
         rec = {}
-        flops, g = fused_flops(self.n, self.enc_cfg)
+        merged = bool(plan_flags(self.enc, self.n) & self._lib.PLAN_FUSED_PROJ)
+        flops, g = fused_flops(self.n, self.enc_cfg, with_proj=merged)
         peak = PEAK_TFLOPS["bf16" if self.dtype in ("bf16", "f16") else "f32"]
         if self.dtype == "f32x3":
             # projection: 3 bf16 MFMAs per product; attention: fp32 MFMA.  The roofline of THIS arithmetic is the sum of
@@ -538,7 +555,10 @@ class EncoderWorkload:
         iso_ms = self.isolated_fused_ms()
         tr = traffic_of(traffic_table(args.config, self.dtype), RMSA_CORE_KERNELS)
         kernel = (f"rmsa_fused_kernel (R-MSA per (region, head): qkv projection {g.P}x192x512 + EPEG + softmax(QK^T)V "
-                  f"from LDS; {2.0 * g.Np * 1536 * DIM / 1e9:.2f} + {4.0 * g.Np * g.P * DIM / 1e9:.2f} GFLOP), {self.dtype} operands"
+                  f"from LDS; {2.0 * g.Np * 1536 * DIM / 1e9:.2f} + {4.0 * g.Np * g.P * DIM / 1e9:.2f} GFLOP"
+                  + (f"; then, as a later phase of the same launch's blocks, the out-projection {g.P}x64x512 slab of a region "
+                     f"that finished a round earlier + un-partition + residual: {2.0 * g.Np * DIM * DIM / 1e9:.2f} GFLOP" if merged else "")
+                  + f"), {self.dtype} operands"
                   + (" (projection: fp32 emulated by 3 bf16 MFMAs per product; attention: fp32 MFMA; peak = FLOPs over "
                      "3 x projection / 2.5 PFLOP/s + attention / 157.3 TFLOP/s)" if self.dtype == "f32x3" else ""))
         if self.mil is None:

@@ -155,6 +155,14 @@ int rrt_region_grid(int64_t L, int32_t region_num, int32_t region_size,
 /* host-only: bytes of workspace rrt_encoder_forward_f32 needs for a bag of n_tokens */
 int rrt_encoder_workspace_size(const rrt_encoder_desc *desc, int64_t n_tokens, size_t *bytes);
 
+/* host-only: which kernels rrt_encoder_forward_f32 takes for the R-MSA layers of a bag of n_tokens (for measurement:
+ * bench.py attributes FLOPs to launches with it).  *flags = RRT_PLAN_* bits. */
+#define RRT_PLAN_FUSED      1   /* qkv projection + EPEG + attention in one kernel per (region, head) (fp32 data) */
+#define RRT_PLAN_FUSED_PROJ 2   /* ... with the out-projection + un-partition + residual as a later phase of the same launch */
+#define RRT_PLAN_FUSED16    4   /* the 16-bit fused kernels (bf16 / fp16 modes) */
+#define RRT_PLAN_FUSED_X3   8   /* the split-bf16 fused kernel (RRT_COMPUTE_F32X3) */
+int rrt_encoder_plan(const rrt_encoder_desc *desc, int64_t n_tokens, int32_t *flags);
+
 /* Whole path: RRTEncoder.forward, modules/rrt.py:165-202 (eval mode, one bag).
  * x [n_tokens, dim] -> y [n_tokens, dim]; x is not modified; y may not alias x. */
 int rrt_encoder_forward_f32(const rrt_encoder_desc *desc, const rrt_encoder_weights *w,

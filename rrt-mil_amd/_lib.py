@@ -82,6 +82,7 @@ SIGNATURES = {
     "rrt_strerror": (C.c_char_p, [C.c_int]),
     "rrt_region_grid": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.POINTER(Grid)]),
     "rrt_encoder_workspace_size": (C.c_int, [C.POINTER(EncoderDesc), C.c_int64, C.POINTER(C.c_size_t)]),
+    "rrt_encoder_plan": (C.c_int, [C.POINTER(EncoderDesc), C.c_int64, C.POINTER(C.c_int32)]),
     "rrt_encoder_forward_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p,
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rrt_encoder_forward_events_f32": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p,
@@ -170,6 +171,7 @@ COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32X3 = 0, 1, 2, 3
 POS_NONE, POS_PEG, POS_PPEG = 0, 1, 2
 EPEG_ATTN, EPEG_VALUE_BF, EPEG_VALUE_AF = 0, 1, 2
 
+PLAN_FUSED, PLAN_FUSED_PROJ, PLAN_FUSED16, PLAN_FUSED_X3 = 1, 2, 4, 8     # rrt_encoder_plan flags
 # stage-boundary event slots of rrt_encoder_forward_events_f32 (enum in include/rrt_hip.h)
 EV_START, EV_LN_PARTITION, EV_QKV, EV_ATTN, EV_PROJ, EV_CR_COMBINE, EV_CR_INNER, EV_END, EV_COUNT = range(9)
 

@@ -223,6 +223,39 @@ int rrt_encoder_workspace_size(const rrt_encoder_desc* desc, int64_t n_tokens, s
   return RRT_OK;
 }
 
+// Mirrors the kernel choice of encoder_forward's R-MSA layer loop (same predicates, same order); measurement only.
+int rrt_encoder_plan(const rrt_encoder_desc* desc, int64_t n_tokens, int32_t* flags) {
+  if (!flags) return RRT_E_INVALID;
+  *flags = 0;
+  int rc = check_desc(desc, n_tokens);
+  if (rc) return rc;
+  if (desc->n_rmsa_layers <= 0) return RRT_OK;
+  rrt_grid g{};
+  rc = rrt_region_grid(n_tokens, desc->region_num, desc->region_size, desc->min_region_num, desc->min_region_ratio, &g);
+  if (rc) return rc;
+  const GridDev gd = to_dev(g);
+  const int D = desc->dim, ek = desc->epeg ? desc->epeg_k : 0;
+  const bool want_x3 = desc->compute == RRT_COMPUTE_F32X3;
+  const int compute = want_x3 ? RRT_COMPUTE_F32 : desc->compute;
+  const bool epeg_variant = desc->epeg && (desc->epeg_2d || desc->epeg_type != RRT_EPEG_ATTN);
+  if (epeg_variant) return RRT_OK;
+  const bool rows_ok = rmsa_fused_supported_rows(gd.Np, D);
+  if (compute != RRT_COMPUTE_F32 && D % 64 == 0 && rmsa_fused16_supported(gd.P, D, desc->n_heads, ek) && rows_ok) {
+    *flags = RRT_PLAN_FUSED16;
+    return RRT_OK;
+  }
+  if (want_x3 && D % 256 == 0 && rmsa_fused_x3_supported(gd.P, D, desc->n_heads, ek) && rows_ok) {
+    *flags = RRT_PLAN_FUSED_X3;
+    return RRT_OK;
+  }
+  if (rmsa_fused_supported(gd.P, D, desc->n_heads, ek) && rows_ok) {
+    *flags = RRT_PLAN_FUSED;
+    if (compute == RRT_COMPUTE_F32 && rmsa_fused_proj_supported(gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, compute))
+      *flags |= RRT_PLAN_FUSED_PROJ;
+  }
+  return RRT_OK;
+}
+
 // Serialises the MFMA-bound R-MSA core (fused kernel, or qkv linear + attention) of forwards that run
 // concurrently on different streams: two of them co-running just time-slice the matrix pipes (each takes
 // twice as long), while one of them next to another bag's memory- and latency-bound kernels overlaps well.

@@ -133,6 +133,9 @@ __device__ __forceinline__ void map_item(const int b, const int n_items, const i
 #define RRT_SLAB_TRACE_ARG
 #define RRT_SLAB_TRACE_PASS
 #endif
+#ifndef RRT_PROJ_RQE
+#define RRT_PROJ_RQE 16
+#endif
 template <int MT>
 __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const float* __restrict__ O, const int n_rows,
                                           const int P, const int D, const int heads_rt, const FusedProj& pj,
@@ -226,6 +229,14 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
     const int t = tbase + pi * pj.g.H + pjj;
     return (m < P && t < pj.g.L) ? t : -1;          // rows past the region / pad slots: nothing to write
   };
+  // element offset of each row's four columns in resid / out, -1 = not written; MT registers held across the K loop
+  // (recomputed at both uses the index arithmetic was ~2 K cycles of the slab's VALU time)
+  int toff[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int t = token_of(i);
+    toff[i] = t < 0 ? -1 : t * D + ncol;
+  }
   float4 rq[PREF ? MT : 1];
   const float4 bias = pj.bias ? *(const float4*)(pj.bias + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
   f32x4 acc[MT];
@@ -247,6 +258,7 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
   // nAs / nkk; nAs == nullptr: none) are issued between them -- one read behind every third MFMA (a wave issues in
   // order: ten reads in a row drain the matrix pipe, ~150 cycles per half), the last one six or more MFMAs before the
   // half ends, so that the lgkmcnt(0) of the barrier behind a first half does not wait
+  constexpr int RQE_ = PREF ? (RRT_PROJ_RQE < MT ? RRT_PROJ_RQE : MT) : 0;
   auto half = [&](const float4 (&a)[MT], const float4& bb, const bool load, const float* nAs, const int nkk,
                   float4 (&na)[MT], float4& nb) {
     if (load) frags(nAs, nkk, na, nb);
@@ -266,6 +278,13 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 3 * (MT + 1), 0);
+    } else if (PREF) {                                       // the last half: the residual rows' requests between its MFMAs
+#pragma unroll
+      for (int r = 0; r < MT - RQE_; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // three MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one global load
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 3 * (MT - RQE_), 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -282,19 +301,22 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
     if (kt == 0 || kt == 7 || kt == 14) RRT_TRACE_MARK();   // slab [5,6,7] B_0, B_7, B_14
     half(af[1], bfr[1], true, lds + ((kt + 1) % NS) * SST, 0, af[0], bfr[0]);
   }
+  // The residual rows are requested under the last K tile: the first RQE of them in front of its first half (both
+  // fragment sets are live there: as many as the register file of the item phases leaves room for), the rest in
+  // front of its second half, into the registers the first fragment set leaves.  (Held from the start of the slab they
+  // cost the kernel 8 VGPRs over what the item phases need -- and a co-resident kernel of another bag its place.)
+  // Unconditional (rows that are not written re-read row 0): loads under per-row branches left the compiler's
+  // wait-count bookkeeping with "anything may be outstanding" at every store of the epilogue.
+  constexpr int RQE = PREF ? (RRT_PROJ_RQE < MT ? RRT_PROJ_RQE : MT) : 0;
+  if constexpr (PREF) {
+#pragma unroll
+    for (int i = 0; i < RQE; ++i) rq[i] = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
+  }
   half(af[0], bfr[0], true, lds + ((nk - 1) % NS) * SST, 1, af[1], bfr[1]);
   lds_barrier();                                    // (the loader side counts one barrier per K tile)
   if constexpr (PREF) {
-    // the residual rows, requested under the last half K tile (into the registers the first fragment set leaves: held
-    // from the start of the slab they cost the kernel 8 VGPRs over what the item phases need).  Unconditional (rows that
-    // are not written re-read token 0): loads under per-row branches left the compiler's wait-count bookkeeping with
-    // "anything may be outstanding" at every store of the epilogue -- s_waitcnt vmcnt(0) in front of each
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int t = token_of(i);
-      rq[i] = *(const float4*)(pj.resid + (size_t)(t < 0 ? 0 : t) * D + ncol);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = RQE; i < MT; ++i) rq[i] = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
   }
   half(af[1], bfr[1], false, nullptr, 0, af[0], bfr[0]);
   RRT_TRACE_MARK();                                 // slab [8] last MFMA issued
@@ -308,12 +330,11 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int t = token_of(i);
     float4 q;
     if constexpr (PREF) q = rq[i];
-    else q = *(const float4*)(pj.resid + (size_t)(t < 0 ? 0 : t) * D + ncol);
+    else q = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
     const float4 v = make_float4(acc[i][0] + bias.x + q.x, acc[i][1] + bias.y + q.y, acc[i][2] + bias.z + q.z, acc[i][3] + bias.w + q.w);
-    if (t >= 0) *(float4*)(pj.out + (size_t)t * D + ncol) = v;
+    if (toff[i] >= 0) *(float4*)(pj.out + toff[i]) = v;
   }
   RRT_TRACE_MARK();                                 // slab [9] stores issued
 }
