@@ -133,8 +133,8 @@ __device__ __forceinline__ void map_item(const int b, const int n_items, const i
 #define RRT_SLAB_TRACE_ARG
 #define RRT_SLAB_TRACE_PASS
 #endif
-#ifndef RRT_PROJ_RQE
-#define RRT_PROJ_RQE 16
+#ifndef RRT_PROJ_RQA
+#define RRT_PROJ_RQA 6
 #endif
 template <int MT>
 __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const float* __restrict__ O, const int n_rows,
@@ -258,7 +258,6 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
   // nAs / nkk; nAs == nullptr: none) are issued between them -- one read behind every third MFMA (a wave issues in
   // order: ten reads in a row drain the matrix pipe, ~150 cycles per half), the last one six or more MFMAs before the
   // half ends, so that the lgkmcnt(0) of the barrier behind a first half does not wait
-  constexpr int RQE_ = PREF ? (RRT_PROJ_RQE < MT ? RRT_PROJ_RQE : MT) : 0;
   auto half = [&](const float4 (&a)[MT], const float4& bb, const bool load, const float* nAs, const int nkk,
                   float4 (&na)[MT], float4& nb) {
     if (load) frags(nAs, nkk, na, nb);
@@ -278,13 +277,6 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 3 * (MT + 1), 0);
-    } else if (PREF) {                                       // the last half: the residual rows' requests between its MFMAs
-#pragma unroll
-      for (int r = 0; r < MT - RQE_; ++r) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // three MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one global load
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 3 * (MT - RQE_), 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -295,29 +287,31 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
   RRT_TRACE_MARK();                                 // slab [4] K tile 0 published
   frags(lds, 0, af[0], bfr[0]);
   __builtin_amdgcn_sched_barrier(0);
-  for (int kt = 0; kt + 1 < nk; ++kt) {
+  auto tile = [&](const int kt) {                   // K tile kt < nk - 1: both halves, the next tile's first fragments
     half(af[0], bfr[0], true, lds + (kt % NS) * SST, 1, af[1], bfr[1]);   // first half; the second half's fragments under it
     lds_barrier();                                  // B_kt: stage kt is in registers everywhere, stage kt + 1 published
     if (kt == 0 || kt == 7 || kt == 14) RRT_TRACE_MARK();   // slab [5,6,7] B_0, B_7, B_14
     half(af[1], bfr[1], true, lds + ((kt + 1) % NS) * SST, 0, af[0], bfr[0]);
-  }
-  // The residual rows are requested under the last K tile: the first RQE of them in front of its first half (both
-  // fragment sets are live there: as many as the register file of the item phases leaves room for), the rest in
-  // front of its second half, into the registers the first fragment set leaves.  (Held from the start of the slab they
-  // cost the kernel 8 VGPRs over what the item phases need -- and a co-resident kernel of another bag its place.)
+  };
+  // The residual rows are requested under the last two K tiles (a request takes 3-4 K cycles to come back on a busy
+  // chip, a K tile 2.5 K): the first RQA of them in front of the second-last tile, the rest in front of the last one --
+  // as early as the register file of the item phases leaves room for (held from the start of the slab they cost the
+  // kernel 8 VGPRs over what the item phases need -- and a co-resident kernel of another bag its place).
   // Unconditional (rows that are not written re-read row 0): loads under per-row branches left the compiler's
   // wait-count bookkeeping with "anything may be outstanding" at every store of the epilogue.
-  constexpr int RQE = PREF ? (RRT_PROJ_RQE < MT ? RRT_PROJ_RQE : MT) : 0;
+  constexpr int RQA = PREF ? (RRT_PROJ_RQA < MT ? RRT_PROJ_RQA : MT) : 0;
+  for (int kt = 0; kt + 2 < nk; ++kt) tile(kt);
   if constexpr (PREF) {
 #pragma unroll
-    for (int i = 0; i < RQE; ++i) rq[i] = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
+    for (int i = 0; i < RQA; ++i) rq[i] = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
+  }
+  if (nk >= 2) tile(nk - 2);
+  if constexpr (PREF) {
+#pragma unroll
+    for (int i = RQA; i < MT; ++i) rq[i] = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
   }
   half(af[0], bfr[0], true, lds + ((nk - 1) % NS) * SST, 1, af[1], bfr[1]);
   lds_barrier();                                    // (the loader side counts one barrier per K tile)
-  if constexpr (PREF) {
-#pragma unroll
-    for (int i = RQE; i < MT; ++i) rq[i] = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
-  }
   half(af[1], bfr[1], false, nullptr, 0, af[0], bfr[0]);
   RRT_TRACE_MARK();                                 // slab [8] last MFMA issued
   // epilogue: + bias, un-partition, + residual (plain stores: the next launch reads them)
