@@ -30,10 +30,10 @@ rm -f $OUT/${TAG}_rocprof_dominant.json
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o a -- python $R/bench.py $X > /tmp/a.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_a/a_results.db > $OUT/${TAG}_bench_default_4streams.kernel_stats.txt
 python $R/tools/rocprof_timeline.py /tmp/prof_a/a_results.db 100 0.45 < /dev/null | cut -c1-250 > $OUT/${TAG}_timeline_4streams.txt
-python $R/tools/rocprof_union.py c1_f32_s4 /tmp/prof_a/a_results.db $OUT/${TAG}_rocprof_dominant.json 17213423616 157.3
+python $R/tools/rocprof_union.py c1_f32_s4 /tmp/prof_a/a_results.db $OUT/${TAG}_rocprof_dominant.json 22045261824 157.3
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a2 -o a -- python $R/bench.py --streams 2 $X > /tmp/a.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_a2/a_results.db > $OUT/${TAG}_bench_2streams.kernel_stats.txt
-python $R/tools/rocprof_union.py c1_f32_s2 /tmp/prof_a2/a_results.db $OUT/${TAG}_rocprof_dominant.json 17213423616 157.3
+python $R/tools/rocprof_union.py c1_f32_s2 /tmp/prof_a2/a_results.db $OUT/${TAG}_rocprof_dominant.json 22045261824 157.3
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a3 -o a -- python $R/bench.py --dtype bf16 $X > /tmp/a.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_a3/a_results.db > $OUT/${TAG}_bench_bf16_3streams.kernel_stats.txt
 python $R/tools/rocprof_union.py c1_bf16_s3 /tmp/prof_a3/a_results.db $OUT/${TAG}_rocprof_dominant.json 17213423616 2500
@@ -73,6 +73,7 @@ timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o e -- python $R/be
 python $R/tools/rocprof_summary.py /tmp/prof_e/e_results.db > $OUT/${TAG}_bench_config4_bf16_1stream.kernel_stats.txt
 if [ -f $R/tools/_abl/librrt_trace.so ]; then
   RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_fused.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_fused_f32_wave_timeline.txt
+  RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_fused_proj.py 9000 8 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_fused_proj_f32_wave_timeline.txt
   RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_linear.py proj 9000 8 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_out_projection_f32_wave_timeline.txt
   RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_pair16.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_pair16_wave_timeline.txt
 fi
