@@ -252,7 +252,7 @@ int rrt_rmsa_fused_f32(const float *u, const float *qkv_w, const float *qkv_b, c
  * rrt_linear_unpartition_residual_f32 in one launch, bit-identical to that pair --
  * out[t] = resid[t] + (o . proj_w^T + proj_b)[slot(t)] (rmsa.py:100-131, :41-54, :227-228; rrt.py:125).
  * u [H*H, dim] region-major (rrt_ln_partition_f32 on g); o_scratch: H*H*dim floats (the attention output, device scratch);
- * counters: regions_side^2 int32 of device scratch (zeroed by the call).  Needs heads * regions >= 2 x the CU count
+ * counters: regions_side^2 int32 of device scratch (zeroed by the call).  Needs regions of > 64 tokens and heads * regions >= 2 x the CU count
  * (block b of the launch runs (region, head) item b and then the 64-column projection slab b - CUs of a region whose
  * items finished a whole item earlier), otherwise RRT_E_UNSUPPORTED; rrt_encoder_forward_f32 chooses by itself. */
 int rrt_rmsa_fused_proj_f32(const float *u, const float *qkv_w, const float *qkv_b, const float *pe_w,

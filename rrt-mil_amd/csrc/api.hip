@@ -953,7 +953,7 @@ int rrt_rmsa_fused_proj_f32(const float* u, const float* qkv_w, const float* qkv
   const GridDev gd = to_dev(*g);
   const int ek = pe_w ? epeg_k : 0, R = gd.rs * gd.rs;
   if (!rmsa_fused_proj_supported(R, gd.P, dim, heads, ek, RRT_COMPUTE_F32) || !rmsa_fused_supported_rows(gd.Np, dim))
-    return unsupported("rmsa_fused_proj: needs what rmsa_fused needs (head dim 64, 48 < P <= 208, epeg_k <= 63) and at "
+    return unsupported("rmsa_fused_proj: needs what rmsa_fused needs (head dim 64, 64 < P <= 208, epeg_k <= 63) and at "
                        "least two rounds of (region, head) items (heads * regions >= 2 x the CU count)");
   hipError_t e = hipMemsetAsync(counters, 0, (size_t)R * sizeof(int32_t), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;

@@ -1102,7 +1102,10 @@ bool rmsa_fused_proj_supported(int n_regions, int P, int D, int heads, int epeg_
   static const bool off = rrt_tune_env("RRT_NO_FUSED_PROJ") != nullptr;
   if (off || prec != PREC_F32 || !rmsa_fused_supported(P, D, heads, epeg_k)) return false;
   const int n_items = n_regions * heads, lag = proj_lag(n_items);
-  return D % 4 == 0 && n_items >= 2 * lag && lag >= 8 * heads;
+  // regions of <= 64 tokens (MT = 4: bags of <= ~4.1 k tokens at region_num = 8) keep the two launches: their items are
+  // short (the slab is a third of a block's life, not a quarter) and the separate projection's small tiles fill the chip
+  // well -- measured 0.125 vs 0.122 ms per bag (profiles/r04_final_sweep_n_merged_vs_pair.txt); from 81 tokens on the phase wins
+  return D % 4 == 0 && P > 64 && n_items >= 2 * lag && lag >= 8 * heads;
 }
 
 hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w,

@@ -60,6 +60,30 @@ def test_workspace_and_errors(lib):
     assert lib.rrt_encoder_forward_f32(C.byref(enc._desc), None, None, None, 10, None, 0, None) == -1
 
 
+def test_encoder_plan_flags(lib):
+    """rrt_encoder_plan mirrors the forward's kernel choice for the R-MSA layers (host-only; without a GPU the launcher
+    assumes 256 CUs): the fused kernel on regions of 49-208 tokens, the out-projection as a phase of its launch from 81
+    tokens on when the bag has two rounds of (region, head) items, the 16-bit / split kernels in their modes."""
+    enc = RRTEncoder()
+    fl = C.c_int32(-1)
+
+    def plan(n, compute=_lib.COMPUTE_F32, e=enc):
+        e._desc.compute = compute
+        assert lib.rrt_encoder_plan(C.byref(e._desc), n, C.byref(fl)) == 0
+        e._desc.compute = _lib.COMPUTE_F32
+        return fl.value
+    both = _lib.PLAN_FUSED | _lib.PLAN_FUSED_PROJ
+    assert plan(9000) == both and plan(5000) == both and plan(12000) == both
+    assert plan(3000) == _lib.PLAN_FUSED and plan(4096) == _lib.PLAN_FUSED     # regions of <= 64 tokens: two launches
+    assert plan(15000) == 0 and plan(600) == 0                                  # regions outside the fused kernel's range
+    assert plan(9000, _lib.COMPUTE_BF16) == _lib.PLAN_FUSED16
+    assert plan(9000, _lib.COMPUTE_F32X3) == _lib.PLAN_FUSED_X3
+    assert plan(12000, _lib.COMPUTE_F32X3) == both                             # x3 covers P <= 144: exact kernels beyond
+    assert plan(2000, e=RRTEncoder(region_num=4)) == _lib.PLAN_FUSED           # 16 regions: one round of items
+    assert plan(30000, e=RRTEncoder(region_num=16)) == both
+    assert lib.rrt_encoder_plan(C.byref(enc._desc), 9000, None) == -1
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_lib.RRTHipError):
         _lib.load(str(tmp_path / "nope.so"))

@@ -961,10 +961,9 @@ def test_rmsa_fused_unsupported_shapes_report():
         assert rc == -2 and b"rmsa_fused" in lib.rrt_strerror(rc)
 
 
-# every row-tile count of the kernel (MT = 4 ... 13) at region_num = 8 (64 regions = 512 items = two rounds of the chip),
+# every row-tile count the rule takes (MT = 6 ... 13) at region_num = 8 (64 regions = 512 items = two rounds of the chip),
 # a real bag with pad slots, region_num = 16 (256 regions), the ragged-tail block order (region_num = 9: 81 regions)
-@pytest.mark.parametrize("L,rn,D,heads,ek", [(9000, 8, 512, 8, 15), (3000, 8, 512, 8, 15), (4096, 8, 512, 8, 21),
-                                             (5000, 8, 512, 8, 15), (6200, 8, 512, 8, 15), (7000, 8, 512, 8, 0),
+@pytest.mark.parametrize("L,rn,D,heads,ek", [(9000, 8, 512, 8, 15), (5000, 8, 512, 8, 21), (6200, 8, 512, 8, 15), (7000, 8, 512, 8, 0),
                                              (8000, 8, 512, 8, 15), (10500, 8, 512, 8, 15), (12000, 8, 512, 8, 15),
                                              (30000, 16, 512, 8, 15), (9000, 9, 512, 8, 15)])
 def test_rmsa_fused_proj(L, rn, D, heads, ek):
@@ -1009,14 +1008,14 @@ def test_rmsa_fused_proj(L, rn, D, heads, ek):
 
 
 def test_rmsa_fused_proj_unsupported_shapes_report():
-    """fewer than two rounds of items (region_num = 4: 16 regions) and regions outside the fused kernel's range stay with
+    """fewer than two rounds of items (region_num = 4: 16 regions) and regions outside the merged launch's range stay with
     the two launches"""
     from hip_util import p, stream, DEV
     lib = _lib.load()
     t = torch.zeros(16000, 512, device=DEV)
     t2 = torch.zeros(16000, 512, device=DEV)
     cnt = torch.zeros(1024, device=DEV, dtype=torch.int32)
-    for L, rn in ((2000, 4), (15000, 8), (600, 8)):
+    for L, rn in ((2000, 4), (15000, 8), (600, 8), (3000, 8), (4096, 8)):   # (regions of <= 64 tokens: the rule keeps two launches)
         g = _lib.region_grid(L, rn)
         rc = lib.rrt_rmsa_fused_proj_f32(p(t), p(t), None, None, p(t), None, p(t), p(t2), p(t), p(cnt), 512, 8, 0,
                                          C.byref(g), stream())
