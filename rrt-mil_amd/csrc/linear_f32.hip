@@ -104,12 +104,28 @@ __device__ __forceinline__ float activate(float v, int act) {
   }
 }
 
+template <int MT, int NT>
+__device__ __forceinline__ void store_unpart_batched(const f32x4 (&acc)[MT][NT], const float (&bias)[NT][4],
+                                                     float* __restrict__ C, int M, int N, int m0, int n0, int wave,
+                                                     int lr, int lg, const LinearEpilogue& ep);
+
 template <int MT, int NT, int MODE>
 __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT][NT], float* __restrict__ C, int M, int N,
                                            int m0, int n0, int wave, int lr, int lg,
                                            const LinearEpilogue& ep RRT_EPI_TRACE_ARG) {
   constexpr bool UNPART = MODE == MODE_UNPART || MODE == MODE_UNPART_DROP, ACT = MODE == MODE_ACT, DROP = MODE >= MODE_UNPART_DROP;
   const bool vec = (N & 3) == 0;
+  if constexpr (MODE == MODE_UNPART) {
+    if (N % (64 * NT) == 0 && ep.q_cols == 0) {            // the straight-line form (see store_unpart_batched)
+      float bz[NT][4];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bz[j][r] = ep.bias ? ep.bias[n0 + wave * (16 * NT) + j * 16 + 4 * lg + r] : 0.f;
+      store_unpart_batched<MT, NT>(acc, bz, C, M, N, m0, n0, wave, lr, lg, ep);
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int nb = n0 + wave * (16 * NT) + j * 16 + 4 * lg;      // first of this lane's 4 columns
@@ -208,6 +224,58 @@ __device__ __forceinline__ void store_slice(const f32x4 (&acc)[MT][NT], const fl
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (nb + r < N) dst[r] = v[r] + (UNPART ? ep.resid[row * N + nb + r] : 0.f);
+    }
+  }
+}
+
+// Un-partition + residual epilogue of a whole tile in straight-line code: every row's slot -> token map first, then ALL
+// residual rows requested (unconditionally: rows that are not written re-read row 0), then the stores.  store_slice's
+// form -- per row: map, branch, load, add, store -- left the compiler's wait-count bookkeeping with s_waitcnt vmcnt(0)
+// in front of every load and every store (seen in the ISA: the per-row branches merge "anything may be outstanding"),
+// i.e. one memory round trip per 16-row slice, MT of them in a row, with every block of the chip in the same phase: the
+// "store-bound epilogue" the round-3 traces show (17 K cycles for a 96 x 64 tile).  Needs full 16-byte columns inside N and
+// no column scale (q_cols == 0); rows in chunks of CH so that the residual values fit 32 registers.
+template <int MT, int NT>
+__device__ __forceinline__ void store_unpart_batched(const f32x4 (&acc)[MT][NT], const float (&bias)[NT][4],
+                                                     float* __restrict__ C, int M, int N, int m0, int n0, int wave,
+                                                     int lr, int lg, const LinearEpilogue& ep) {
+  constexpr int CH = NT >= 8 ? 1 : 8 / NT;
+  const int ncol = n0 + wave * (16 * NT) + 4 * lg;
+#pragma unroll
+  for (int i0 = 0; i0 < MT; i0 += CH) {
+    long off[CH];
+    float4 rq[CH][NT];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (i0 + c < MT) {
+        const int m = m0 + (i0 + c) * 16 + lr;
+        int t = -1;
+        if (m < M) {
+          t = slot_to_token(m, ep.g);
+          if (t >= ep.g.L) t = -1;               // pad slot: nothing to write
+        }
+        off[c] = t < 0 ? -1L : (long)t * N + ncol;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rq[c][j] = *(const float4*)(ep.resid + (off[c] < 0 ? (long)ncol : off[c]) + j * 16);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (i0 + c < MT) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(rq[c][j].x), "+v"(rq[c][j].y), "+v"(rq[c][j].z), "+v"(rq[c][j].w));
+      }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (i0 + c < MT) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const f32x4 a = acc[i0 + c][j];
+          const float4 q = rq[c][j];
+          const float4 v = make_float4(a[0] + bias[j][0] + q.x, a[1] + bias[j][1] + q.y, a[2] + bias[j][2] + q.z, a[3] + bias[j][3] + q.w);
+          if (off[c] >= 0) *(float4*)(C + off[c] + j * 16) = v;
+        }
+      }
     }
   }
 }
@@ -658,7 +726,8 @@ __global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void
     for (int kt = 0; kt < nk; ++kt, ++it) kstep(kt);
     if constexpr (!DEFER) {
       RRT_TRACE_MARK();                               // compute: last MFMA of the tile issued
-      store_all_slices<MT, NT, MODE>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep);
+      if (MODE == MODE_UNPART && pref_ok) store_unpart_batched<MT, NT>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep);
+      else store_all_slices<MT, NT, MODE>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep);
       RRT_TRACE_MARK();
     }
     if constexpr (DEFER) {
@@ -691,7 +760,10 @@ __global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void
   }
   // the block's last tile has no successor to hide behind
   if constexpr (DEFER)
-    if (have_prev) store_all_slices<MT, NT, MODE>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
+    if (have_prev) {
+      if (MODE == MODE_UNPART && pref_ok) store_unpart_batched<MT, NT>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
+      else store_all_slices<MT, NT, MODE>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
+    }
 }
 
 
