@@ -601,7 +601,11 @@ __global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto kstep = [&](int kt) {
-      __syncthreads();
+      // compute side of the tile barrier: this wave's LDS reads of the previous K tile retired + s_barrier.  Not
+      // __syncthreads(): that also drains vmcnt -- the bias row, the deferred epilogue's residual request and its stores
+      // of the previous slice -- i.e. a memory round trip on the critical path of every K iteration (the loader waves
+      // keep theirs: vmcnt(0) is how they know the DMA has landed)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (kt == 0 || kt == 1 || kt == 8 || kt == 9) RRT_TRACE_MARK();   // compute: barrier kt passed
       const float* As = lds + (it & 1) * STAGE;
       const float* Bs = As + BM * BK;
