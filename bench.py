@@ -359,9 +359,10 @@ class EncoderWorkload:
         self.w = self.enc._weights()
         # one event pair per launch of the dominant kernel over a WINDOW of consecutive steps in the middle of the timed
         # region, every stream (an event pair costs the stream two marker packets: measured ~5 us per forward, 2 % of an
-        # fp32 bag and 10 % of a bf16 one -- so the window is 6 steps, not the whole region).  Consecutive steps, all
+        # fp32 bag and 10 % of a bf16 one -- so the window is 12 bags per stream, not the whole region; one step of 16 launches
+        # read anywhere between 0.27 and 0.35 ms run to run).  Consecutive steps, all
         # streams: the launches' intervals can then be merged into the time during which the kernel was running at all.
-        self.ev_win = min(max(1, 6 // R), args.steps)
+        self.ev_win = min(max(1, 12 // R), args.steps)
         self.ev_w0 = (args.steps - self.ev_win) // 2
         self.ev_pairs = [(self.hev.create(), self.hev.create()) for _ in range(self.ev_win * S * R)]
         self.ev_arr = (C.c_void_p * _lib.EV_COUNT)()
