@@ -61,6 +61,23 @@ __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restri
   __syncthreads();
   // persistent: phi is staged once per block, then the block grid-strides over groups of 4*RW rows
   const int ngroups = (g.Np + 4 * RW - 1) / (4 * RW);
+  // the NEXT group's rows are requested before this group's are worked on (round 4: a trip was one exposed memory round
+  // trip per RW rows -- 3.5 TB/s on bags whose regions take this kernel); rows past the bag re-read row 0 (unconditional
+  // loads keep the request order straight-line) and are zeroed after they land
+  float4 nxt[RW][NV];
+  auto request = [&](const int grp_) {
+    const int tt0 = (grp_ * 4 + wave) * RW;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int t = tt0 + i;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        nxt[i][v] = *(const float4*)(x1 + (size_t)(t < g.L ? t : 0) * dim + ((FULL || c < dim) ? c : 0));
+      }
+    }
+  };
+  if ((int)blockIdx.x < ngroups) request(blockIdx.x);
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
   const int t0 = (grp * 4 + wave) * RW;
   float4 r[RW][NV];
@@ -72,10 +89,14 @@ __global__ __launch_bounds__(256) void crmsa_logits_kernel(const float* __restri
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      r[i][v] = (t < g.L && (FULL || c < dim)) ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      sum[i] += (r[i][v].x + r[i][v].y) + (r[i][v].z + r[i][v].w);
+      r[i][v] = (t < g.L && (FULL || c < dim)) ? nxt[i][v] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  if (grp + (int)gridDim.x < ngroups) request(grp + gridDim.x);
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) sum[i] += (r[i][v].x + r[i][v].y) + (r[i][v].z + r[i][v].w);
   const float inv_d = 1.0f / (float)dim;
   float mean[RW], sq[RW], rstd[RW];
 #pragma unroll
@@ -244,26 +265,29 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
 #pragma unroll
   for (int n = 0; n < KMAX; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < dim) {
-    for (int p0 = rg; p0 < g.P; p0 += 64) {        // 4 independent rows per trip
-      float4 xv[4];
-      int pp[4];
+    // 8 independent rows per trip, requested unconditionally (rows that do not count re-read row 0 and meet weight 0):
+    // four conditional loads per trip were four branches, a wait for everything in flight behind each (3.1 TB/s)
+    constexpr int TR = 8;
+    for (int p0 = rg; p0 < g.P; p0 += 16 * TR) {
+      float4 xv[TR];
+      int pp[TR];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < TR; ++u) {
         pp[u] = p0 + 16 * u;
         const int t = pp[u] < g.P ? tok[pp[u]] : -1;
-        xv[u] = t >= 0 ? *(const float4*)(x1 + (size_t)t * dim + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[u] = *(const float4*)(x1 + (size_t)(t >= 0 ? t : 0) * dim + col);
         if (t < 0) pp[u] = -1;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (pp[u] >= 0) {
+      for (int u = 0; u < TR; ++u) {
 #pragma unroll
-          for (int n = 0; n < KMAX; ++n)
-            if (n < k) {
-              const float w = Wc[pp[u] * KMAX + n];
-              acc[n].x += w * xv[u].x; acc[n].y += w * xv[u].y; acc[n].z += w * xv[u].z; acc[n].w += w * xv[u].w;
-            }
-        }
+        for (int n = 0; n < KMAX; ++n)
+          if (n < k) {
+            const float w = pp[u] >= 0 ? Wc[pp[u] * KMAX + n] : 0.f;
+            const float4 x = pp[u] >= 0 ? xv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[n].x += w * x.x; acc[n].y += w * x.y; acc[n].z += w * x.z; acc[n].w += w * x.w;
+          }
+      }
     }
   }
 #pragma unroll
