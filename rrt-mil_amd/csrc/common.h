@@ -175,6 +175,12 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+// Block barrier for hand-overs through LDS only: this wave's LDS accesses retired + s_barrier.  __syncthreads() is a
+// workgroup-scope release / acquire fence as well -- it waits for every global access the wave has in flight (vmcnt(0)):
+// row loads that are only needed later, write-through stores whose acknowledgement only the arrival counter needs (round 4:
+// a memory round trip per barrier in linear_ws_kernel's K loop and in crmsa_region4_kernel's middle phases).
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define LN_EPS 1e-5f
 
 // ---- optional in-kernel timeline tracing (tools/build_ablation.sh trace -DRRT_TRACE) ------------

@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
     const int d = idx / k, n = idx - d * k;
     phi_t[n * DIM + d] = phi[idx];
   }
-  __syncthreads();
+  lds_sync();
   RRT_TRACE_MARK();                                 // [2] rows requested, phi in LDS
   const float inv_d = 1.0f / (float)DIM;
 #pragma unroll
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
     }
   }
   RRT_TRACE_MARK();                                 // [3] LayerNorm statistics + logits of this wave's rows
-  __syncthreads();
+  lds_sync();
   const int nrow = min(PQ, g.P - q * PQ);           // rows of this quarter (>= 1: P >= 4 is checked by the launcher)
   // wave n < k owns representative n: local max / min / sum of exp over the quarter's rows, the combine coefficients
   // c * rstd of every row, and the two LayerNorm-fold sums (Identity 3) -- five wave reductions on k waves, one barrier
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
       s_c0[n][0] = c0; s_c1[n][0] = c1;
     }
   }
-  __syncthreads();
+  lds_sync();
   RRT_TRACE_MARK();                                 // [4] local softmax statistics + coefficients
   float4 acc[KM][2];
 #pragma unroll
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
 #pragma unroll
   for (int n0 = 0; n0 < KM; n0 += KC) {
     if (n0 >= k) break;
-    if (n0 > 0) __syncthreads();                    // the previous chunk's reads of s_part are done
+    if (n0 > 0) lds_sync();                    // the previous chunk's reads of s_part are done
     if (wave >= HW) {
 #pragma unroll
       for (int n = n0; n < n0 + KC && n < KM; ++n)
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
           s_part[((wave - HW) * KC + n - n0) * 128 + 64 + lane] = acc[n][1];
         }
     }
-    __syncthreads();
+    lds_sync();
     if (wave < HW) {
 #pragma unroll
       for (int n = n0; n < n0 + KC && n < KM; ++n)
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
           s_part[(wave * KC + n - n0) * 128 + 64 + lane] = b;
         }
     }
-    __syncthreads();
+    lds_sync();
     const int kc = min(KC, k - n0);
     for (int idx = tid; idx < kc * 128; idx += 64 * NW) {
       const int n = idx >> 7, c = idx & 127;
