@@ -1526,6 +1526,60 @@ def test_concurrent_forwards_are_bit_reproducible(mode, dim):
     assert bad == 0, f"{bad} of {total} concurrent forwards differ from the solo run"
 
 
+@pytest.mark.gpu
+def test_concurrent_merged_launches_are_bit_reproducible():
+    """The fp32 path of bags whose out-projection runs as a phase of the fused launch (regions of more than 64 tokens:
+    rmsa_fused_kernel<.., PROJ>, blocks waiting for EARLIER blocks' attention output through workspace counters and reading
+    it back through L2): four forwards in flight on four streams -- two bag sizes, so that the launches drift across
+    each other and across the other bags' tails -- give, run after run, exactly the bits of a forward that had the chip to
+    itself, and the plan says that these sizes take the merged launch."""
+    import ctypes as C
+    from hip_util import encoder_from_state, dev
+    g = load_golden("G3_d512_n9000")
+    x, st, cfg = synth_case(g)
+    lib = _lib.load()
+    enc = encoder_from_state(st, cfg)
+    enc._desc.compute = _lib.COMPUTE_F32
+    w = enc._weights()
+    ns, reps = [9000, 6200, 9000, 7000], [3, 4, 3, 4]
+    fl = C.c_int32(0)
+    for m in set(ns):
+        _lib.check(lib.rrt_encoder_plan(C.byref(enc._desc), m, C.byref(fl)), "plan")
+        assert fl.value & _lib.PLAN_FUSED_PROJ, m
+    xs = [dev(x[:m] * (1.0 + 0.01 * i)).contiguous() for i, m in enumerate(ns)]
+    streams = [torch.cuda.Stream() for _ in ns]
+    ws = []
+    for m in ns:
+        need = C.c_size_t()
+        _lib.check(lib.rrt_encoder_workspace_size(C.byref(enc._desc), m, C.byref(need)), "workspace size")
+        ws.append(torch.zeros(need.value, dtype=torch.uint8, device="cuda:0"))
+    ys = [[torch.zeros_like(xs[i]) for _ in range(reps[i])] for i in range(len(ns))]
+
+    def run(i, j):
+        _lib.check(lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), xs[i].data_ptr(), ys[i][j].data_ptr(), ns[i],
+                                               ws[i].data_ptr(), ws[i].numel(), streams[i].cuda_stream), "forward")
+    torch.cuda.synchronize()
+    refs = []
+    for i in range(len(ns)):
+        run(i, 0)
+        torch.cuda.synchronize()
+        refs.append(ys[i][0].clone())
+        assert torch.isfinite(refs[i]).all()
+    bad = total = 0
+    for _ in range(10):
+        for j in range(max(reps)):
+            for i in range(len(ns)):
+                if j < reps[i]:
+                    run(i, j)
+        torch.cuda.synchronize()
+        for i in range(len(ns)):
+            for j in range(reps[i]):
+                total += 1
+                bad += int(not torch.equal(ys[i][j], refs[i]))
+                ys[i][j].fill_(float("nan"))
+    assert bad == 0, f"{bad} of {total} concurrent forwards differ from the solo run"
+
+
 # ------------------------------------------------------------------ RRT_COMPUTE_F32X3: fp32 emulated on the bf16 matrix cores
 def _split_image(a):
     """numpy restatement of cast16.hip's split image: per 32 elements [32 bf16 hi | 32 bf16 lo] as uint16 bits"""

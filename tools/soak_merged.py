@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Soak of the merged R-MSA + out-projection launch: S streams x many forwards of mixed bag sizes, every output compared
+bit for bit with the solo result of its (stream, size).   python tools/soak_merged.py [rounds] [streams]"""
+import ctypes as C
+import os
+import sys
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rrt_mil_amd import RRTEncoder, _lib, synth  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+dev = torch.device("cuda:0")
+cfg = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)
+enc = RRTEncoder(**cfg).eval()
+enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.encoder_state(**cfg).items()}, strict=True)
+enc = enc.to(dev)
+lib = _lib.load()
+w = enc._weights()
+sizes = [9000, 6200, 7000, 12000, 5000, 10500, 8000, 9000][:max(S, 1)]
+big = torch.from_numpy(synth.bag(12000, 512, tag="soak")).to(dev)
+xs = [(big[:m] * (1.0 + 0.003 * i)).contiguous() for i, m in enumerate(sizes)]
+streams = [torch.cuda.Stream() for _ in sizes]
+wss, refs, ys = [], [], []
+for i, m in enumerate(sizes):
+    need = C.c_size_t()
+    _lib.check(lib.rrt_encoder_workspace_size(C.byref(enc._desc), m, C.byref(need)), "ws")
+    wss.append(torch.empty(need.value, dtype=torch.uint8, device=dev))
+    ys.append([torch.empty_like(xs[i]) for _ in range(4)])
+
+
+def run(i, j):
+    _lib.check(lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), xs[i].data_ptr(), ys[i][j].data_ptr(), sizes[i],
+                                           wss[i].data_ptr(), wss[i].numel(), streams[i].cuda_stream), "forward")
+
+
+for i in range(len(sizes)):
+    run(i, 0)
+    torch.cuda.synchronize()
+    refs.append(ys[i][0].clone())
+bad = total = 0
+for r in range(rounds):
+    for j in range(4):
+        for i in range(len(sizes)):
+            run(i, j)
+    torch.cuda.synchronize()
+    for i in range(len(sizes)):
+        for j in range(4):
+            total += 1
+            bad += int(not torch.equal(ys[i][j], refs[i]))
+            ys[i][j].fill_(float("nan"))
+print(f"soak: {total} forwards on {len(sizes)} streams (sizes {sizes}), {bad} differ from the solo result")
+sys.exit(1 if bad else 0)
