@@ -1039,6 +1039,10 @@ int proj_lag(int n_items) {
   }
   int lag = cus[d] & ~7;
   if (lag > n_items) lag = n_items & ~7;
+  // tuning build: RRT_PROJ_LAG=n (e.g. 250: every slab then runs on ANOTHER XCD than the items it reads -- the test that the
+  // hand-over does not depend on the placement heuristic)
+  static const char* force = rrt_tune_env("RRT_PROJ_LAG");
+  if (force != nullptr && atoi(force) > 0) lag = atoi(force);
   return lag;
 }
 

@@ -22,7 +22,10 @@ lib = _lib.load()
 w = enc._weights()
 sizes = [9000, 6200, 7000, 12000, 5000, 10500, 8000, 9000][:max(S, 1)]
 big = torch.from_numpy(synth.bag(12000, 512, tag="soak")).to(dev)
-xs = [(big[:m] * (1.0 + 0.003 * i)).contiguous() for i, m in enumerate(sizes)]
+# two inputs per stream, alternating between rounds: a slab that read the PREVIOUS forward's attention output (a stale
+# cache line) would not reproduce the solo result of the current one
+xs2 = [[(big[:m] * (1.0 + 0.003 * i)).contiguous(), (big[:m].flip(0) * (0.9 - 0.002 * i)).contiguous()] for i, m in enumerate(sizes)]
+xs = [p[0] for p in xs2]
 streams = [torch.cuda.Stream() for _ in sizes]
 wss, refs, ys = [], [], []
 for i, m in enumerate(sizes):
@@ -32,25 +35,29 @@ for i, m in enumerate(sizes):
     ys.append([torch.empty_like(xs[i]) for _ in range(4)])
 
 
-def run(i, j):
-    _lib.check(lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), xs[i].data_ptr(), ys[i][j].data_ptr(), sizes[i],
+def run(i, j, v=0):
+    _lib.check(lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), xs2[i][v].data_ptr(), ys[i][j].data_ptr(), sizes[i],
                                            wss[i].data_ptr(), wss[i].numel(), streams[i].cuda_stream), "forward")
 
 
 for i in range(len(sizes)):
-    run(i, 0)
-    torch.cuda.synchronize()
-    refs.append(ys[i][0].clone())
+    pair = []
+    for v in range(2):
+        run(i, 0, v)
+        torch.cuda.synchronize()
+        pair.append(ys[i][0].clone())
+    assert not torch.equal(pair[0], pair[1])
+    refs.append(pair)
 bad = total = 0
 for r in range(rounds):
     for j in range(4):
         for i in range(len(sizes)):
-            run(i, j)
+            run(i, j, (r + j) & 1)
     torch.cuda.synchronize()
     for i in range(len(sizes)):
         for j in range(4):
             total += 1
-            bad += int(not torch.equal(ys[i][j], refs[i]))
+            bad += int(not torch.equal(ys[i][j], refs[i][(r + j) & 1]))
             ys[i][j].fill_(float("nan"))
 print(f"soak: {total} forwards on {len(sizes)} streams (sizes {sizes}), {bad} differ from the solo result")
 sys.exit(1 if bad else 0)
