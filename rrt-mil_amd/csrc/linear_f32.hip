@@ -33,6 +33,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "internal.h"
 
 namespace {
@@ -464,7 +466,8 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
 // NLW: loader waves (2 for the MFMA-bound fp32 forms; 4 for 16-bit operands, whose K loop is bound by how many LDS-DMA
 // pieces the CU keeps in flight -- tools/ubench/dma_rows.hip: 14 B/clk/CU with four issuing waves, 21 with eight)
 template <int MT, int NT, int MODE, int PREC, bool IN16 = false, bool DEFER = true, int NLW = 2>
-__global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void* __restrict__ Av,
+__global__ __launch_bounds__(64 * (4 + NLW), 2)
+void linear_ws_kernel(const void* __restrict__ Av,
                                                            const void* __restrict__ Bv,
                                                            float* __restrict__ C, int M, int N, int K,
                                                            int tiles_n, int ntiles, LinearEpilogue ep) {
@@ -575,7 +578,270 @@ __global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void
   // deferred un-partition epilogue: the next slice's residual row, requested a K iteration ahead (full 16-byte columns
   // only; q_scale does not apply to this epilogue)
   const bool pref_ok = MODE == MODE_UNPART && N % (64 * NT) == 0 && ep.q_cols == 0;
+  // Every other instantiation (plain / activation / dropout epilogues, the non-deferred form) keeps the round-3 code below
+  // verbatim: restructuring the tile loop for all of them moved the plain deferred GEMM <8, 1> from 128 to 130 VGPRs and
+  // cost the N = 15000 qkv projection 5 % (measured, same box).
+  if constexpr (MODE == MODE_UNPART && DEFER) {
+  // Branch-free form (round 4): the residual rows come through buffer loads and the slices leave through buffer stores of
+  // `out` / `resid` as raw buffers of L * N floats -- a row that is not written (pad slot, no previous tile, slices used up)
+  // has the byte offset OOB, which the hardware answers with zeros / drops.  With per-row branches the compiler waited
+  // vmcnt(0) in front of every deferred store (one in-order counter for loads and stores; a branch merges to "anything may
+  // be outstanding"): the residual request of the next slice AND the store of the previous one on the critical path of
+  // every K iteration.  Here the next slice's request is issued BEFORE this slice's store, so the wait for a residual row
+  // counts the NT stores and NT requests behind it instead of draining them.
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned out_bytes = pref_ok ? (unsigned)((size_t)ep.g.L * N * 4) : 0u;
+  __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)out_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)ep.resid, 0, (int)out_bytes, 0x00020000);
   float4 rq[NT];
+  unsigned roff = OOB;
+  auto slice_off = [&](int mbase, int nbase, bool valid) -> unsigned {
+    const int m = mbase + lr;
+    const int t = slot_to_token(m < M ? m : 0, ep.g);
+    const bool ok = valid && m < M && t < ep.g.L;
+    return ok ? (unsigned)(((size_t)t * N + nbase + wave * (16 * NT) + 4 * lg) * 4) : OOB;
+  };
+  auto resid_request = [&](unsigned off, float4 (&dst)[NT]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      dst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off + 64u * j, 0, 0));
+  };
+  // the tile loop in two instantiations: PF = the branch-free un-partition epilogue applies (decided once per launch, so
+  // that neither form's memory operations sit in the other's loop and blur its wait counts)
+  float4 rq2[NT];
+  auto tiles = [&](auto pfc) {
+  constexpr bool PF = decltype(pfc)::value;
+  for (int tile = first; tile < ntiles; tile += G) {
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    float cbias[NT][4];
+    load_bias(n0, cbias);                 // lands under the K loop
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto kstep = [&](int kt, auto parity) {        // parity: which of the two residual-row buffers holds THIS slice's row
+      constexpr bool PAR = decltype(parity)::value;
+      // compute side of the tile barrier: this wave's LDS reads of the previous K tile retired + s_barrier.  Not
+      // __syncthreads(): that also drains vmcnt -- the bias row, the deferred epilogue's residual request and its stores
+      // of the previous slice -- i.e. a memory round trip on the critical path of every K iteration (the loader waves
+      // keep theirs: vmcnt(0) is how they know the DMA has landed)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kt == 0 || kt == 1 || kt == 8 || kt == 9) RRT_TRACE_MARK();   // compute: barrier kt passed
+      const float* As = lds + (it & 1) * STAGE;
+      const float* Bs = As + BM * BK;
+      if constexpr (PREC == PREC_F32) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          float4 af[MT], bf[NT];
+          const int cslot = 4 * kk + lg;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            int row = wave * (16 * NT) + j * 16 + lr;
+            bf[j] = *(const float4*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            int row = i * 16 + lr;
+            af[i] = *(const float4*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+#pragma unroll
+          for (int comp = 0; comp < 4; ++comp)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                const float a = comp == 0 ? af[i].x : comp == 1 ? af[i].y : comp == 2 ? af[i].z : af[i].w;
+                const float b = comp == 0 ? bf[j].x : comp == 1 ? bf[j].y : comp == 2 ? bf[j].z : bf[j].w;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
+              }
+        }
+      } else if constexpr (PREC == PREC_SPLIT) {
+        // fp32 emulated on the bf16 matrix cores: a = ah + al, b = bh + bl (bf16 each), a.b ~ ah.bh + ah.bl + al.bh
+        // (the dropped al.bl term is 2^-16 of the product).  A tile row = [32 hi | 32 lo]: slots 0..3 / 4..7.
+        bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wave * (16 * NT) + j * 16 + lr, f = (row >> 1) & 7;
+          bh[j] = *(const bf16x8*)(Bs + row * BK + ((lg ^ f) << 2));
+          bl[j] = *(const bf16x8*)(Bs + row * BK + (((4 + lg) ^ f) << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = i * 16 + lr, f = (row >> 1) & 7;
+          ah[i] = *(const bf16x8*)(As + row * BK + ((lg ^ f) << 2));
+          al[i] = *(const bf16x8*)(As + row * BK + (((4 + lg) ^ f) << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+          }
+      } else if constexpr (IN16) {
+        using F = Frag8<PREC>;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          typename F::type a8[MT], b8[NT];
+          const int cslot = 4 * kk + lg;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int row = wave * (16 * NT) + j * 16 + lr;
+            b8[j] = *(const typename F::type*)(Bs + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int row = i * 16 + lr;
+            a8[i] = *(const typename F::type*)(As + row * BK + ((cslot ^ ((row >> 1) & 7)) << 2));
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(b8[j], a8[i], acc[i][j]);
+        }
+      } else {
+        using F = Frag8<PREC>;
+        typename F::type a8[MT], b8[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wave * (16 * NT) + j * 16 + lr, f = (row >> 1) & 7;
+          b8[j] = F::pack(*(const float4*)(Bs + row * BK + (((2 * lg) ^ f) << 2)),
+                          *(const float4*)(Bs + row * BK + (((2 * lg + 1) ^ f) << 2)));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = i * 16 + lr, f = (row >> 1) & 7;
+          a8[i] = F::pack(*(const float4*)(As + row * BK + (((2 * lg) ^ f) << 2)),
+                          *(const float4*)(As + row * BK + (((2 * lg + 1) ^ f) << 2)));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(b8[j], a8[i], acc[i][j]);
+      }
+      // one 16-row slice of the PREVIOUS tile per K iteration (behind this iteration's MFMAs)
+      // (static register indexing: always slice 0, then rotate the remaining slices down)
+      if constexpr (DEFER) {
+        // (fp32: K / 32 iterations for MT slices -- the iterations behind the last slice skip the block: their requests
+        // and stores would all be out of range, issued for nothing; an fp32 K iteration is thousands of cycles of MFMA and
+        // does not notice the uniform branch's conservative wait.  16-bit operands: K / 64 = 8 iterations, no branch.)
+        if constexpr (PF) {
+        if (IN16 || kt <= MT) {
+          // (no `have_prev && kt < MT` branch: the offsets carry it; no copy of the requested row either: the two row
+          // buffers swap roles from one K iteration to the next -- a copy would wait for the request on the spot)
+          float4 (&rqc)[NT] = PAR ? rq2 : rq;
+          float4 (&rqnx)[NT] = PAR ? rq : rq2;
+          const unsigned offn = slice_off(pm0 + (kt + 1) * 16, pn0, have_prev && kt + 1 < MT);
+          resid_request(offn, rqnx);                // the next slice's residual row first ...
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {            // ... then this slice (its row was requested a K iteration ago)
+            const float4 q = rqc[j];
+            // (the bias went into `prev` at the hand-over: four registers that this form does not hold across the K loop --
+            // at MT = 8 the difference between two blocks per CU and one)
+            const float4 v = make_float4(prev[0][j][0] + q.x, prev[0][j][1] + q.y, prev[0][j][2] + q.z, prev[0][j][3] + q.w);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, roff + 64u * j, 0, 0);
+          }
+          roff = offn;
+#pragma unroll
+          for (int i = 0; i + 1 < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) prev[i][j] = prev[i + 1][j];
+        }
+        } else if (have_prev && kt < MT) {
+          store_slice<MT, NT, MODE, 0>(prev, pbias, C, M, N, pm0 + kt * 16, pn0, wave, lr, lg, ep);
+#pragma unroll
+          for (int i = 0; i + 1 < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) prev[i][j] = prev[i + 1][j];
+        }
+      }
+        };
+    if constexpr (!PF) {
+      for (int kt = 0; kt < nk; ++kt, ++it) kstep(kt, std::false_type{});
+    } else {
+      int kt = 0;
+      for (; kt + 1 < nk; kt += 2) {
+        kstep(kt, std::false_type{});
+        ++it;
+        kstep(kt + 1, std::true_type{});
+        ++it;
+      }
+      if (kt < nk) {                                  // odd K tile count: one copy (and its wait) per tile
+        kstep(kt, std::false_type{});
+        ++it;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rq[j] = rq2[j];
+      }
+    }
+    if constexpr (!DEFER) {
+      RRT_TRACE_MARK();                               // compute: last MFMA of the tile issued
+      if (MODE == MODE_UNPART && pref_ok) store_unpart_batched<MT, NT>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep);
+      else store_all_slices<MT, NT, MODE>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep);
+      RRT_TRACE_MARK();
+    }
+    if constexpr (DEFER) {
+    if (have_prev)                        // K shorter than MT iterations: flush what is left
+      for (int i = nk; i < MT; ++i) {
+        store_slice<MT, NT, MODE, 0>(prev, pbias, C, M, N, pm0 + i * 16, pn0, wave, lr, lg, ep);
+#pragma unroll
+        for (int q = 0; q + 1 < MT; ++q)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) prev[q][j] = prev[q + 1][j];
+      }
+
+    RRT_TRACE_MARK();                                 // compute: last MFMA of the tile issued
+    // hand the tile over to the deferred epilogue (stores are fire-and-forget: nothing in this
+    // wave ever waits on vmcnt for them)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        prev[i][j] = acc[i][j];
+        if constexpr (PF) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) prev[i][j][r] += cbias[j][r];
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pbias[j][r] = PF ? 0.f : cbias[j][r];
+    pm0 = m0;
+    pn0 = n0;
+    have_prev = true;
+    if constexpr (PF) {                                                 // slice 0 of the tile just handed over
+      roff = slice_off(pm0, pn0, true);
+      resid_request(roff, rq);
+    }
+    RRT_TRACE_MARK();
+    }
+  }
+  // the block's last tile has no successor to hide behind
+  if constexpr (DEFER)
+    if (have_prev) {
+      if (PF) store_unpart_batched<MT, NT>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
+      else store_all_slices<MT, NT, MODE>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
+    }
+  };
+  if constexpr (MODE == MODE_UNPART && DEFER) {     // (the non-deferred form has no K-loop epilogue: one instantiation)
+    // (the buffer form addresses `out` / `resid` with 32-bit byte offsets)
+    // (fp32 144 x 128 tiles: the form does not fit 256 VGPRs -- 17 spilled -- and keeps the per-slice one)
+    if constexpr (IN16 || MT * NT <= 16) {
+      if (pref_ok && (size_t)ep.g.L * N * 4 <= 0xFFFFF000u) tiles(std::true_type{});
+      else tiles(std::false_type{});
+    } else {
+      tiles(std::false_type{});
+    }
+  } else {
+    tiles(std::false_type{});
+  }
+  } else {
+  float4 orq[NT];
   long rrow = -1;
   auto resid_prefetch = [&](int mbase, int nbase) {
     const int m = mbase + lr;
@@ -586,7 +852,7 @@ __global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void
     }
     if (rrow >= 0) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) rq[j] = *(const float4*)(ep.resid + (size_t)rrow * N + nbase + wave * (16 * NT) + j * 16 + 4 * lg);
+      for (int j = 0; j < NT; ++j) orq[j] = *(const float4*)(ep.resid + (size_t)rrow * N + nbase + wave * (16 * NT) + j * 16 + 4 * lg);
     }
   };
   for (int tile = first; tile < ntiles; tile += G) {
@@ -711,7 +977,7 @@ __global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void
 #pragma unroll
               for (int j = 0; j < NT; ++j) {
                 const int nb = pn0 + wave * (16 * NT) + j * 16 + 4 * lg;
-                const float4 q = rq[j];
+                const float4 q = orq[j];
                 *(float4*)(C + (size_t)rrow * N + nb) = make_float4(prev[0][j][0] + pbias[j][0] + q.x, prev[0][j][1] + pbias[j][1] + q.y,
                                                                     prev[0][j][2] + pbias[j][2] + q.z, prev[0][j][3] + pbias[j][3] + q.w);
               }
@@ -768,8 +1034,8 @@ __global__ __launch_bounds__(64 * (4 + NLW), 2) void linear_ws_kernel(const void
       if (MODE == MODE_UNPART && pref_ok) store_unpart_batched<MT, NT>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
       else store_all_slices<MT, NT, MODE>(prev, pbias, C, M, N, pm0, pn0, wave, lr, lg, ep);
     }
+  }
 }
-
 
 // ---------------------------------------------------------------------------------------
 // Small-M GEMMs (the 64 k representatives of CR-MSA: M = 192..512 rows): split K INSIDE the block.
