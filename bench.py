@@ -362,7 +362,7 @@ class EncoderWorkload:
         # fp32 bag and 10 % of a bf16 one -- so the window is 12 bags per stream, not the whole region; one step of 16 launches
         # read anywhere between 0.27 and 0.35 ms run to run).  Consecutive steps, all
         # streams: the launches' intervals can then be merged into the time during which the kernel was running at all.
-        self.ev_win = min(max(1, 12 // R), args.steps)
+        self.ev_win = min(max(1, (12 if args.steps >= 100 else 4) // R), args.steps)   # (the driver's 20-step run: one step)
         self.ev_w0 = (args.steps - self.ev_win) // 2
         self.ev_pairs = [(self.hev.create(), self.hev.create()) for _ in range(self.ev_win * S * R)]
         self.ev_arr = (C.c_void_p * _lib.EV_COUNT)()
