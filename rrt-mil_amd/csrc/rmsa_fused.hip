@@ -21,6 +21,11 @@
 // LDS: max(2 x 43 KB staging, Q/K/V 3 x 36.9 KB) = 108 KiB (Q~ overwrites Q) -> one block per CU, with
 // 52 KiB left for a co-resident kernel of another bag; 512 blocks at N = 9000 = 2 per CU.
 // Requires head dim 64 and P <= 16*MT <= 208 (MT = 13: 3 x 52 KB tiles = 156 KiB of the 160 KiB LDS).
+//
+// PROJ (round 4; fp32, inference, bags of >= two rounds of (region, head) items): the same launch also runs the layer's
+// out-projection + region_reverse + un-pad + residual (modules/rmsa.py:131, :41-54, :227-228; rrt.py:125) -- block b does
+// item b and then the 64-column projection slab b - lag of a region whose items finished a round earlier (proj_slab below;
+// DESIGN.md section 3, "K2+K3+K4 in one launch").  Bit-identical to this kernel followed by linear_ws_kernel<.., UNPART>.
 #include <stdio.h>
 #include <stdlib.h>
 
