@@ -28,7 +28,10 @@ Besides the contract fields the JSON line carries
                   the timed region (config 2: in an untimed pass of the same encoder; the one-call classifier
                   entry takes no event array; config 4: summed over the rank's bags in an untimed pass);
                   `traffic` = HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes of THIS config,
-                  read from profiles/r03_traffic.json (tools/pmc_to_traffic.py; never a typed-in constant);
+                  read from the newest profiles/rNN_traffic.json (tools/pmc_to_traffic.py; never a typed-in constant);
+                  `frac` follows from the HIP-event UNION of the launches' intervals (several bags in flight: launches of
+                  different streams overlap) when that is consistent with the line's own ms_per_step, and is never above
+                  what ms_per_step allows; `frac_lower_bound` = FLOPs of the step's launches / ms_per_step / peak;
   roofline_kernels -- every stage of one bag's forward (LN + partition, fused R-MSA, out-projection, CR-MSA logits +
                   combine, the representatives' MSA, dispatch + LayerNorm) with ITS bound: MFMA TFLOP/s for the matrix
                   kernels, HBM GB/s over the stage's algorithmic bytes for the streaming ones; stage boundaries from the
@@ -65,10 +68,17 @@ if ROOT not in sys.path:
 DIM = 512
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (f32 in / bf16 in)
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")   # tools/pmc_to_traffic.py, from the PMC passes
-ROCPROF_FILE = os.path.join(ROOT, "profiles", "r04_rocprof_dominant.json")   # tools/rocprof_union.py, from --kernel-trace runs
-if not os.path.exists(TRAFFIC_FILE):
-    TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+def _newest(stem):
+    """profiles/rNN_<stem> of the latest round that has one (the files are written by tools/, never typed in)"""
+    for rnd in ("r05", "r04", "r03"):
+        f = os.path.join(ROOT, "profiles", f"{rnd}_{stem}")
+        if os.path.exists(f):
+            return f
+    return os.path.join(ROOT, "profiles", f"r05_{stem}")
+
+
+TRAFFIC_FILE = _newest("traffic.json")             # tools/pmc_to_traffic.py, from the PMC passes
+ROCPROF_FILE = _newest("rocprof_dominant.json")    # tools/rocprof_union.py, from --kernel-trace runs
 
 
 def rocprof_record(config, dtype, streams):
@@ -362,7 +372,7 @@ class EncoderWorkload:
         # fp32 bag and 10 % of a bf16 one -- so the window is 12 bags per stream, not the whole region; one step of 16 launches
         # read anywhere between 0.27 and 0.35 ms run to run).  Consecutive steps, all
         # streams: the launches' intervals can then be merged into the time during which the kernel was running at all.
-        self.ev_win = min(max(1, (12 if args.steps >= 100 else 4) // R), args.steps)   # (the driver's 20-step run: one step)
+        self.ev_win = min(max(2, (12 if args.steps >= 100 else 4) // R), args.steps)   # (the driver's 20-step run: two steps)
         self.ev_w0 = (args.steps - self.ev_win) // 2
         self.ev_pairs = [(self.hev.create(), self.hev.create()) for _ in range(self.ev_win * S * R)]
         self.ev_arr = (C.c_void_p * _lib.EV_COUNT)()
@@ -534,7 +544,7 @@ class EncoderWorkload:
         note = ("one bag in flight, stage boundaries = the library's event marks (7 markers per instrumented forward, every "
                 f"fourth forward, median of 12); the same loop without markers takes {plain_ms:.4f} ms per bag, the marked "
                 f"stages add up to {sum(stages.values()):.4f} ms -- the difference is what the marker packets cost; "
-                "`traffic` = HBM-side bytes per forward of the stage's kernels (profiles/r03_traffic.json)")
+                f"`traffic` = HBM-side bytes per forward of the stage's kernels ({os.path.relpath(TRAFFIC_FILE, ROOT)})")
         return out, note, plain_ms
 
     def finish(self, args, world, rank, elapsed):
@@ -575,24 +585,41 @@ class EncoderWorkload:
                 else:
                     cur_e = max(cur_e, e_)
             busy += cur_e - cur_s
-            ms = busy / len(iv)            # time the kernel was running at all, per launch
-            ach = flops / (ms * 1e-3) / 1e12
+            busy_ms = busy / len(iv)       # time the kernel was running at all, per launch
+            # What the line itself allows: the step's S x R launches cannot have been running for longer than the step
+            # took.  The instrumented steps carry two marker packets per forward and run slower than the steps around them
+            # (round 4: one 16-launch step read 0.27-0.35 ms run to run) -- when the union figure contradicts ms_per_step it
+            # is not evidence, and the line falls back to the bound that follows from ms_per_step alone.
+            ms_per_step = elapsed / args.steps * 1e3
+            per_step = self.S * self.R
+            lb_ach = flops * per_step / (ms_per_step * 1e-3) / 1e12
+            consistent = busy_ms * per_step <= ms_per_step * 1.03
+            ach = flops / (busy_ms * 1e-3) / 1e12 if consistent else lb_ach
             rp = rocprof_record(args.config, self.dtype, self.S)
             rec["roofline"] = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak,
-                               "unit": "TFLOP/s", "frac": round(ach / peak, 4), "flops_per_launch": flops,
-                               "avg_launch_ms": round(ms, 5), "raw_interval_ms": round(raw_ms, 5),
-                               "launches": len(iv), "bags_in_flight": self.S,
+                               "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                               "frac_source": "hip_event_union" if consistent else "lower_bound_from_ms_per_step",
+                               "frac_lower_bound": round(lb_ach / peak, 4),
+                               "frac_event_union": round(flops / (busy_ms * 1e-3) / 1e12 / peak, 4),
+                               "flops_per_launch": flops,
+                               "avg_launch_ms": round(raw_ms, 5), "busy_ms_per_launch": round(busy_ms, 5),
+                               "launches": len(iv), "launches_per_step": per_step, "bags_in_flight": self.S,
                                "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
                                "rocprof": rp,
                                "note": f"{len(iv)} launches = {self.ev_win} consecutive step(s) x {self.R} bags x {self.S} stream(s) in the middle of "
                                        "the timed region, one HIP event pair per launch (recorded by librrt_hip on the launch "
-                                       "stream).  avg_launch_ms = the UNION of the launches' [start, end] intervals / launches: "
-                                       "with several bags in flight launches of different streams overlap and time-slice the "
-                                       "matrix cores, so the mean raw interval (raw_interval_ms) counts the same wall time "
-                                       "several times; the union is the time during which this kernel was running at all "
-                                       "(it still contains whatever the other bags' kernels took from it: the kernel's own "
-                                       "number is roofline_isolated).  `rocprof` = the same two numbers from the committed "
-                                       "rocprofv3 --kernel-trace table of this command (tools/rocprof_union.py)"}
+                                       "stream).  avg_launch_ms = mean [start, end] interval of a launch (what rocprofv3's average "
+                                       "duration of the kernel says; with several bags in flight the launches of different streams "
+                                       "overlap and time-slice the matrix cores, so it counts the same wall time several times).  "
+                                       "busy_ms_per_launch = the UNION of the launches' intervals / launches: the time during which "
+                                       "this kernel was running at all (it still contains whatever the other bags' kernels took "
+                                       "from it; the kernel alone is roofline_isolated).  achieved = flops_per_launch / "
+                                       "busy_ms_per_launch when busy_ms_per_launch x launches_per_step <= 1.03 ms_per_step (the "
+                                       "marker packets slow the instrumented steps), otherwise the bound that needs no events: "
+                                       "frac_lower_bound = flops_per_launch x launches_per_step / ms_per_step / peak.  `rocprof` = "
+                                       "mean duration and union per launch from the committed rocprofv3 --kernel-trace table of "
+                                       "this command (tools/rocprof_union.py).  Rounds 1-3 printed the mean interval of 1-2 bags in "
+                                       "flight as avg_launch_ms and round 4 the union under that name: compare `frac`, not the field"}
         ach = flops / (iso_ms * 1e-3) / 1e12
         iso = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                "frac": round(ach / peak, 4), "flops_per_launch": flops, "avg_launch_ms": round(iso_ms, 5),

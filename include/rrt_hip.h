@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 23
+#define RRT_ABI_VERSION 24
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -30,7 +30,8 @@ enum {
   RRT_OK = 0,
   RRT_E_INVALID = -1,       /* null pointer / non-positive size */
   RRT_E_UNSUPPORTED = -2,   /* configuration outside the HIP path (see rrt_strerror) */
-  RRT_E_WORKSPACE = -3      /* workspace too small */
+  RRT_E_WORKSPACE = -3,     /* workspace too small */
+  RRT_E_HANDOVER = -4       /* an earlier merged R-MSA launch gave up its in-launch hand-over wait (rrt_device_error) */
 };
 
 /* Arithmetic of the nn.Linear layers (qkv / proj of R-MSA and CR-MSA, MLP phi).  F32 is exact
@@ -259,6 +260,25 @@ int rrt_rmsa_fused_proj_f32(const float *u, const float *qkv_w, const float *qkv
                             const float *proj_w, const float *proj_b, const float *resid, float *out,
                             float *o_scratch, int32_t *counters, int32_t dim, int32_t heads, int32_t epeg_k,
                             const rrt_grid *g, void *stream);
+/* The in-launch hand-over of that kernel and what it assumes.  A projection slab (block b >= lag) spins on its region's
+ * arrival counter until the region's `heads` items -- blocks with LOWER indices -- have stored their O rows.  Forward
+ * progress rests on the GPU dispatching the workgroups of one launch in index order (so an awaited item is running or
+ * done when its slab starts): observed on every gfx9 part, relied on here, but NOT an architectural guarantee.  The wait
+ * is therefore bounded (2^22 sleeps of ~0.2 us, about a second): a slab that gives up writes nothing and raises the
+ * process's hand-over error word (pinned host memory, no device sync needed to read it).  From then on
+ * rrt_encoder_forward_* / rrt_mil_forward_f32 / rrt_executor_forward / rrt_rmsa_fused_proj_f32 return RRT_E_HANDOVER
+ * without launching anything, until the caller has looked at it:
+ *   rrt_device_error(clear): 0, or 1 + the region whose slab gave up; clear != 0 resets the word (after the caller has
+ *   synchronised the device and discarded the outputs of the forwards in flight).  This word is the library's only state. */
+int rrt_device_error(int32_t clear);
+/* Test hook for that path (tests/test_hip_parity.py): rrt_rmsa_fused_proj_f32 with a caller-chosen lag (0: the rule;
+ * otherwise 8 * heads <= lag <= heads * regions; a lag that is not a multiple of 8 puts every slab on ANOTHER XCD than
+ * the items it reads -- the hand-over must not depend on the placement heuristic), spin limit (0: 2^22) and
+ * `wait_extra` arrivals more than a region ever gets (> 0: every slab times out -- exercises the error path). */
+int rrt_debug_rmsa_fused_proj_f32(const float *u, const float *qkv_w, const float *qkv_b, const float *pe_w,
+                                  const float *proj_w, const float *proj_b, const float *resid, float *out,
+                                  float *o_scratch, int32_t *counters, int32_t dim, int32_t heads, int32_t epeg_k,
+                                  const rrt_grid *g, int32_t lag, int32_t spin_limit, int32_t wait_extra, void *stream);
 
 /* 16-bit operand stages of the reduced-precision modes (compute = RRT_COMPUTE_BF16 / F16 selects the element type;
  * uint16_t* = raw bf16 / fp16 bits, round-to-nearest-even):
@@ -407,7 +427,9 @@ int rrt_linear_act_f32(const float *A, const float *B, const float *bias, float 
  * first share of the bags itself and the executor's streams 1 .. n_streams-1 the others (fork: they wait for `stream`;
  * join: `stream` waits for them BEHIND its own bags -- a caller stream that only sits on the join's barrier packets is one
  * more active hardware queue, and four bag queues plus that one lose 13 % on MI355X's four pipes); a one-stream executor is
- * plain launches on `stream`; it never synchronises the host unless a
+ * plain launches on `stream`, and so is a call of fewer than 8 bags on any executor (a call uses one stream per four
+ * bags, at most n_streams: forking for 2-4 bags costs more than it hides -- the kernels and bits are those of the
+ * executor's configured width either way); it never synchronises the host unless a
  * workspace has to grow.  One executor per host thread and device.  Set GPU_MAX_HW_QUEUES >= 8 in the
  * process environment so every stream gets its own hardware queue. */
 typedef struct rrt_executor rrt_executor;

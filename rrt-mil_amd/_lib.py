@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _f32p = C.POINTER(C.c_float)
 
@@ -107,6 +107,8 @@ SIGNATURES = {
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "rrt_rmsa_fused_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
     "rrt_rmsa_fused_proj_f32": (C.c_int, [C.c_void_p] * 10 + [C.c_int32] * 3 + [C.c_void_p] * 2),
+    "rrt_device_error": (C.c_int, [C.c_int32]),
+    "rrt_debug_rmsa_fused_proj_f32": (C.c_int, [C.c_void_p] * 10 + [C.c_int32] * 3 + [C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p]),
     "rrt_cast16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "rrt_ln_partition16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                      C.POINTER(Grid), C.c_int32, C.c_void_p]),

@@ -20,16 +20,32 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
          "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall", "-Wno-unused-function"]
 
 
-def _digest():
+def _hdr_digest():
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for f in SOURCES + HEADERS:
+    for f in HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
+    return h
+
+
+def _src_digest(src):
+    """digest of one translation unit: flags + every header + the source (headers are few: no dependency scan)"""
+    h = _hdr_digest()
+    with open(os.path.join(CSRC, src), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in SOURCES:
+        h.update(_src_digest(f).encode())
     return h.hexdigest()
 
 
 def build(force=False, verbose=False):
-    """Compile if sources changed; returns the library path."""
+    """Compile what changed (force: everything); returns the library path.  Each object carries the digest of its
+    source + headers + flags in a side file (csrc/<name>.o.stamp), the library the digest of all of them."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP):
@@ -42,17 +58,30 @@ def build(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        sd = _src_digest(src)
+        if not force and os.path.exists(obj) and os.path.exists(obj + ".stamp"):
+            with open(obj + ".stamp") as fh:
+                if fh.read().strip() == sd:
+                    continue
         cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, p in procs:
+        if os.path.exists(obj + ".stamp"):
+            os.remove(obj + ".stamp")
+        procs.append((src, obj, sd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = []
+    for src, obj, sd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+            failed.append(f"hipcc failed on {src}:\n{out.decode()}")
+            continue
+        with open(obj + ".stamp", "w") as fh:
+            fh.write(sd)
         if verbose and out:
             print(out.decode())
+    if failed:
+        raise RuntimeError("\n".join(failed))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     subprocess.run(cmd, check=True)
     with open(STAMP, "w") as fh:

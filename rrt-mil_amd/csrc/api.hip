@@ -173,6 +173,8 @@ const char* rrt_strerror(int code) {
     case RRT_E_INVALID: return "invalid argument (null pointer or non-positive size)";
     case RRT_E_UNSUPPORTED: return g_detail[0] ? g_detail : "unsupported configuration";
     case RRT_E_WORKSPACE: return "workspace too small (see rrt_encoder_workspace_size)";
+    case RRT_E_HANDOVER: return "an earlier merged R-MSA launch gave up its in-launch hand-over wait; outputs in flight are invalid "
+                                "(synchronise, then rrt_device_error(1) to clear)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }
@@ -302,6 +304,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
   if (!desc_in || !w || !x || !y || x == y) return RRT_E_INVALID;
   int rc = check_desc(desc_in, n_tokens);
   if (rc) return rc;
+  if (handover_err_peek(false)) return RRT_E_HANDOVER;    // (a host read of pinned memory; rrt_hip.h, rrt_device_error)
   // RRT_COMPUTE_F32X3 concerns the R-MSA layers' two big projections (below); every other GEMM of the call is exact fp32
   rrt_encoder_desc dloc = *desc_in;
   const bool want_x3 = dloc.compute == RRT_COMPUTE_F32X3;
@@ -944,12 +947,24 @@ int rrt_rmsa_fused_f32(const float* u, const float* qkv_w, const float* qkv_b, c
                                 (hipStream_t)stream);
 }
 
+int rrt_device_error(int32_t clear) { return handover_err_peek(clear != 0); }
+
 int rrt_rmsa_fused_proj_f32(const float* u, const float* qkv_w, const float* qkv_b, const float* pe_w,
                             const float* proj_w, const float* proj_b, const float* resid, float* out, float* o_scratch,
                             int32_t* counters, int32_t dim, int32_t heads, int32_t epeg_k, const rrt_grid* g,
                             void* stream) {
-  if (!u || !qkv_w || !proj_w || !resid || !out || !o_scratch || !counters || !g || dim <= 0 || heads <= 0 || out == resid)
+  return rrt_debug_rmsa_fused_proj_f32(u, qkv_w, qkv_b, pe_w, proj_w, proj_b, resid, out, o_scratch, counters, dim, heads,
+                                       epeg_k, g, 0, 0, 0, stream);
+}
+
+int rrt_debug_rmsa_fused_proj_f32(const float* u, const float* qkv_w, const float* qkv_b, const float* pe_w,
+                                  const float* proj_w, const float* proj_b, const float* resid, float* out, float* o_scratch,
+                                  int32_t* counters, int32_t dim, int32_t heads, int32_t epeg_k, const rrt_grid* g,
+                                  int32_t lag, int32_t spin_limit, int32_t wait_extra, void* stream) {
+  if (!u || !qkv_w || !proj_w || !resid || !out || !o_scratch || !counters || !g || dim <= 0 || heads <= 0 || out == resid ||
+      lag < 0 || spin_limit < 0 || wait_extra < 0)
     return RRT_E_INVALID;
+  if (handover_err_peek(false)) return RRT_E_HANDOVER;
   const GridDev gd = to_dev(*g);
   const int ek = pe_w ? epeg_k : 0, R = gd.rs * gd.rs;
   if (!rmsa_fused_proj_supported(R, gd.P, dim, heads, ek, RRT_COMPUTE_F32) || !rmsa_fused_supported_rows(gd.Np, dim))
@@ -964,6 +979,10 @@ int rrt_rmsa_fused_proj_f32(const float* u, const float* qkv_w, const float* qkv
   pj.out = out;
   pj.cnt = counters;
   pj.g = gd;
+  pj.lag = lag;
+  pj.spin_limit = spin_limit;
+  pj.wait_for = wait_extra > 0 ? heads + wait_extra : 0;
+  if (lag > 0 && (lag < 8 * heads || lag > heads * R)) return unsupported("rmsa_fused_proj: lag must be in [8 * heads, heads * regions]");
   return (int)launch_rmsa_fused(u, qkv_w, qkv_b, pe_w, o_scratch, R, gd.P, dim, heads, ek, RRT_COMPUTE_F32,
                                 (hipStream_t)stream, nullptr, &pj);
 }
@@ -1428,7 +1447,14 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
   }
   // longest-processing-time-first onto the least loaded stream (cost ~ tokens); submission order within
   // a stream follows that order, so the big bags start first and the small ones fill the tail
-  const int S = ex->n_streams < n_bags ? ex->n_streams : n_bags;
+  // Slots used by THIS call: one per four bags.  A fork / join costs every extra stream ~10 us of event waits and releases
+  // the streams in lockstep, which pays off only when each stream then carries a few bags: with 2-4 bags per call four
+  // streams were SLOWER than one (round 4, profiles/r04_final_bench_bags.txt: 4026-4368 vs 4480 slides/s), from 16 bags per
+  // call on they win (4936-5062).  A call of < 8 bags is therefore plain launches on the caller's stream.  The kernels (and
+  // bits) stay those of the executor's configured width: solo = (n_streams == 1) below does not depend on the call.
+  int S = n_bags / 4;
+  if (S < 1) S = 1;
+  if (S > ex->n_streams) S = ex->n_streams;
   int order_buf[256];
   int* order = n_bags <= 256 ? order_buf : new int[n_bags];
   for (int i = 0; i < n_bags; ++i) order[i] = i;
@@ -1489,7 +1515,7 @@ int rrt_executor_forward(rrt_executor* ex, const rrt_encoder_weights* w, const r
       ex->w16_version[s] = 0;
     }
     rrt_encoder_desc d = ex->desc;
-    d.solo = S == 1;
+    d.solo = ex->n_streams == 1;
     d.weights16_valid = w->version != 0 && ex->w16_version[s] == w->version && ex->w16_compute[s] == d.compute;
     rc = encoder_forward(&d, w, b.x, b.y, b.n_tokens, ex->ws[s], ex->ws_bytes[s], sts[s], nullptr,
                          (gated || (stagger && k < S)) ? &ex->gate : nullptr);

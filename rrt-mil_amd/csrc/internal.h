@@ -108,10 +108,19 @@ struct FusedProj {
   float* out;            // [L, D]
   int* cnt;              // [n_regions] arrival counters (zero at launch)
   int* zero64;           // side job of block 0 (LinearEpilogue.zero64), may be null
-  int lag;               // blocks between an item and the slab of the same index (multiple of 8, >= 8 * heads)
+  int lag;               // blocks between an item and the slab of the same index (multiple of 8, >= 8 * heads); 0: the launcher's rule
   int n_items;           // heads * n_regions
   GridDev g;
+  // the bounded hand-over wait (proj_slab): a slab waits until cnt[region] >= wait_for (0: heads) for at most spin_limit
+  // sleeps of ~0.2 us (0: 2^22); a slab that gives up stores 1 + region to *err (system scope; may be null) and writes nothing
+  int* err;
+  int spin_limit;
+  int wait_for;
 };
+// The process's hand-over error word (pinned, device-mapped host memory; created on first use): device pointer for the
+// kernels, and the host's view of it -- 0, or 1 + the region whose projection slab gave up waiting (rrt_device_error)
+int* handover_err_device();
+int handover_err_peek(bool clear);
 bool rmsa_fused_proj_supported(int n_regions, int P, int D, int heads, int epeg_k, int prec);
 hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqkv, const float* pe_w,
                              float* O, int n_regions, int P, int D, int heads, int epeg_k, int prec,

@@ -28,6 +28,8 @@
 // DESIGN.md section 3, "K2+K3+K4 in one launch").  Bit-identical to this kernel followed by linear_ws_kernel<.., UNPART>.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <mutex>
 
 #include "internal.h"
 
@@ -167,10 +169,24 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
   const int row0 = reg * P;
   const int nk = D / BK;
   RRT_TRACE_MARK();                                 // slab [1] entry
-  // the region's `heads` items have arrived (their O rows are in memory): blocks with lower indices, dispatched earlier
-  if (tid == 0)
-    while (__hip_atomic_load(pj.cnt + reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < heads_rt) __builtin_amdgcn_s_sleep(8);
+  // the region's `heads` items have arrived (their O rows are in memory): blocks with lower indices, dispatched earlier.
+  // The wait rests on in-order workgroup dispatch (an item this slab waits for has a lower block index, so it is running
+  // or done) -- an assumption about the dispatcher, not an architectural guarantee.  It is therefore BOUNDED: after
+  // pj.spin_limit sleeps of ~0.2 us (product: 2^22, about a second -- five orders of magnitude over an item) the block
+  // gives up, raises the process's hand-over error word (pinned host memory: the next C-ABI call that could launch this
+  // kernel returns RRT_E_HANDOVER instead of queueing behind a wedged GPU) and leaves WITHOUT writing its slab.
+  int* const s_abort = (int*)(smem + LDS_MAIN_F * 4 + 1272);      // (behind the tap / bias tables, unused by the slab)
+  if (tid == 0) {
+    int spins = 0, bad = 0;
+    while (__hip_atomic_load(pj.cnt + reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pj.wait_for) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > pj.spin_limit) { bad = 1; break; }
+    }
+    if (bad && pj.err != nullptr) __hip_atomic_store(pj.err, 1 + reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    *s_abort = bad;
+  }
   __syncthreads();
+  if (*s_abort) return;                             // (block-uniform)
   RRT_TRACE_MARK();                                 // slab [2] region complete
   if (wave >= 4) {
     const int lw = wave - 4;
@@ -179,8 +195,11 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
     for (int qi = 0; qi < LA; ++qi) {
       const int S = (qi * 4 + lw) * 64 + lane;
       const int row = S >> 3, p = S & 7;
-      int gr = row0 + row;
-      gr = gr < n_rows ? gr : n_rows - 1;            // rows past the last region: re-read (never used)
+      // rows past the region (P < BM) re-read the region's LAST row (their accumulators are never stored): the slab has
+      // waited for cnt[reg] only, so it must not touch O rows of region reg + 1 -- those may not be written yet, and a
+      // line fetched early would sit stale in this XCD's L2 when that region's own slab (ragged tails: any XCD) reads it
+      int gr = row < P ? row0 + row : row0 + P - 1;
+      gr = gr < n_rows ? gr : n_rows - 1;
       aoff[qi] = (unsigned)gr * (unsigned)D * 4u + (unsigned)((p ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
@@ -1069,7 +1088,10 @@ hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
       FusedProj pj = *proj;
       pj.n_items = heads * n_regions;
-      pj.lag = proj_lag(pj.n_items);
+      if (pj.lag <= 0) pj.lag = proj_lag(pj.n_items);
+      if (pj.wait_for <= 0) pj.wait_for = heads;
+      if (pj.spin_limit <= 0) pj.spin_limit = 1 << 22;
+      if (pj.err == nullptr) pj.err = handover_err_device();
       kern<<<dim3(pj.n_items + pj.lag), dim3(512), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D, heads,
                                                               pe_w ? epeg_k : 0, q_scale, nullptr, pj);
       return hipGetLastError();
@@ -1089,6 +1111,41 @@ hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const
 #ifdef RRT_TRACE
 RRT_TRACE_DEFINE_READER(rrt_debug_trace_fused)
 #endif
+
+// ---- hand-over error word: 64 bytes of pinned host memory mapped into the device's address space, one per process.
+// A slab that gives up its bounded wait stores into it with system scope; the host reads it without any device sync.
+namespace {
+int* g_err_host = nullptr;
+int* g_err_dev = nullptr;
+bool g_err_tried = false;
+void handover_err_init() {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (g_err_tried) return;
+  void* h = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && h != nullptr) {
+    memset(h, 0, 64);
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d != nullptr) {
+      g_err_host = (int*)h;
+      g_err_dev = (int*)d;
+    }
+  } else {
+    (void)hipGetLastError();     // no pinned memory: the wait stays bounded, the error is just not reported
+  }
+  g_err_tried = true;
+}
+}  // namespace
+int* handover_err_device() {
+  if (!g_err_tried) handover_err_init();
+  return g_err_dev;
+}
+int handover_err_peek(bool clear) {
+  if (g_err_host == nullptr) return 0;
+  const int v = __atomic_load_n(g_err_host, __ATOMIC_RELAXED);
+  if (clear && v != 0) __atomic_store_n(g_err_host, 0, __ATOMIC_RELAXED);
+  return v;
+}
 
 bool rmsa_fused_supported(int P, int D, int heads, int epeg_k) {
   static const bool off = rrt_tune_env("RRT_NO_FUSED") != nullptr;
@@ -1122,6 +1179,9 @@ hipError_t launch_rmsa_fused(const float* U, const float* Wqkv, const float* bqk
                              hipStream_t st, float* stash, const FusedProj* proj) {
   if (proj != nullptr && (stash != nullptr || !rmsa_fused_proj_supported(n_regions, P, D, heads, epeg_k, prec)))
     return hipErrorInvalidValue;
+  // a caller-chosen lag (rrt_debug_rmsa_fused_proj_f32: slabs on other XCDs than their items) keeps the deadlock-freedom
+  // rule -- every item a slab waits for has a lower block index -- and the "never more blocks than two per item" bound
+  if (proj != nullptr && proj->lag > 0 && (proj->lag < 8 * heads || proj->lag > n_regions * heads)) return hipErrorInvalidValue;
 #define RRT_FUSED(MT_)                                                                              \
   switch (prec) {                                                                                   \
     case 1: return launch_mt<MT_, PREC_BF16>(U, Wqkv, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, stash, st, proj); \

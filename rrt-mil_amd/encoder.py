@@ -719,7 +719,8 @@ class RRTEncoder(nn.Module):
         w = self._weights()
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
-            if not (cur.cuda_stream == 0 and int(streams) >= 4):
+            in_flight = max(1, min(int(streams), len(xs) // 4))      # the executor's rule: one stream per four bags of the call
+            if not (cur.cuda_stream == 0 and in_flight >= 4):
                 # the call is ordered on the caller's stream, which carries the first share of the bags itself
                 rc = lib.rrt_executor_forward(ex, C.byref(w), arr, len(xs), cur.cuda_stream)
             else:

@@ -1022,6 +1022,127 @@ def test_rmsa_fused_proj_unsupported_shapes_report():
         assert rc == -2 and b"rmsa_fused_proj" in lib.rrt_strerror(rc), (L, rn, rc)
 
 
+def _fused_proj_case(L, rn, D=512, heads=8, ek=15, tag="fp2"):
+    """inputs of one merged launch + the two-launch pair's result for them (device tensors)"""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    g = _lib.region_grid(L, rn)
+    Np, R, P = g.H * g.H, g.regions_side ** 2, g.s * g.s
+    t = {"g": g, "Np": Np, "R": R, "P": P}
+    t["u"] = dev(synth.normal(f"{tag}/u{Np}", (Np, D)))
+    t["W"] = dev(synth.uniform(f"{tag}/w{D}", (3 * D, D), -1, 1) / np.sqrt(D))
+    t["b"] = dev(synth.uniform(f"{tag}/b{D}", (3 * D,), -0.3, 0.3))
+    t["pe"] = dev(synth.uniform(f"{tag}/pe", (heads, ek), -1, 1) / np.sqrt(ek))
+    t["Wp"] = dev(synth.uniform(f"{tag}/wp{D}", (D, D), -1, 1) / np.sqrt(D))
+    t["bp"] = dev(synth.uniform(f"{tag}/bp{D}", (D,), -0.5, 0.5))
+    t["res"] = dev(synth.normal(f"{tag}/r{L}", (L, D)))
+    o1 = torch.full((Np, D), float("nan"), device=DEV)
+    out1 = torch.full((L, D), float("nan"), device=DEV)
+    _lib.check(lib.rrt_rmsa_fused_f32(p(t["u"]), p(t["W"]), p(t["b"]), p(t["pe"]), p(o1), R, P, D, heads, ek, 0, stream()), "rmsa_fused")
+    _lib.check(lib.rrt_linear_unpartition_residual_f32(p(o1), p(t["Wp"]), p(t["bp"]), p(t["res"]), p(out1), D, D, C.byref(g), 0,
+                                                       stream()), "unpart")
+    torch.cuda.synchronize()
+    t["o_ref"], t["out_ref"] = o1, out1
+    return t
+
+
+@pytest.mark.parametrize("L,rn", [(9000, 9), (8200, 10), (9000, 8)])
+def test_rmsa_fused_proj_ragged_tail_fresh_inputs(L, rn):
+    """Advisor (round 4, medium): with P < 16 MT a slab's loader used to over-read the first rows of region r + 1 -- whose
+    counter it has not waited on -- into its XCD's L2; on ragged tails (81 / 100 regions: the tail regions' slabs run on
+    every XCD) a later slab could then hit the stale lines.  Re-launching with IDENTICAL inputs cannot see that (stale ==
+    fresh), so here the inputs CHANGE between launches on the same scratch: every launch must reproduce the two-launch
+    pair of ITS inputs bit for bit."""
+    from hip_util import p, stream, DEV
+    lib = _lib.load()
+    D, heads, ek = 512, 8, 15
+    cases = [_fused_proj_case(L, rn, tag=f"rag{i}") for i in range(3)]
+    g, Np, R = cases[0]["g"], cases[0]["Np"], cases[0]["R"]
+    o2 = torch.full((Np, D), float("nan"), device=DEV)
+    cnt = torch.full((R,), 777, device=DEV, dtype=torch.int32)
+    outs = [torch.full((L, D), float("nan"), device=DEV) for _ in range(12)]
+    for i in range(12):                                  # back to back, no host sync in between
+        t = cases[i % 3]
+        _lib.check(lib.rrt_rmsa_fused_proj_f32(p(t["u"]), p(t["W"]), p(t["b"]), p(t["pe"]), p(t["Wp"]), p(t["bp"]), p(t["res"]),
+                                               p(outs[i]), p(o2), p(cnt), D, heads, ek, C.byref(g), stream()), "rmsa_fused_proj")
+    torch.cuda.synchronize()
+    for i in range(12):
+        assert torch.equal(outs[i], cases[i % 3]["out_ref"]), f"launch {i}: projection differs from the two-launch pair of its inputs"
+    assert lib.rrt_device_error(0) == 0
+
+
+@pytest.mark.parametrize("lag", [250, 64, 504])
+def test_rmsa_fused_proj_off_xcd_slabs_beside_a_cu_hog(lag):
+    """The hand-over must not depend on where the dispatcher puts a block: with a lag that is not a multiple of 8 every
+    slab runs on ANOTHER XCD than the items whose O rows it reads (write-through stores + first-touch loads), and a
+    kernel on a second stream that occupies the CUs delays and reorders when the launch's blocks start.  Same bits as the
+    two-launch pair, no hand-over error."""
+    from hip_util import p, stream, DEV
+    lib = _lib.load()
+    L, rn, D, heads, ek = 9000, 8, 512, 8, 15
+    t = _fused_proj_case(L, rn, tag="hog")
+    g, Np, R = t["g"], t["Np"], t["R"]
+    o2 = torch.full((Np, D), float("nan"), device=DEV)
+    cnt = torch.zeros((R,), device=DEV, dtype=torch.int32)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    big = torch.randn(64 * 1024 * 1024, device=DEV)
+    outs = [torch.full((L, D), float("nan"), device=DEV) for _ in range(8)]
+    torch.cuda.synchronize()
+    for i in range(8):
+        with torch.cuda.stream(side):                    # the hog: matrix products and streaming kernels of another "tenant"
+            for _ in range(3):
+                a = (a @ a).clamp_(-1, 1)
+                big.mul_(1.0001)
+        _lib.check(lib.rrt_debug_rmsa_fused_proj_f32(p(t["u"]), p(t["W"]), p(t["b"]), p(t["pe"]), p(t["Wp"]), p(t["bp"]),
+                                                     p(t["res"]), p(outs[i]), p(o2), p(cnt), D, heads, ek, C.byref(g), lag, 0, 0,
+                                                     stream()), "rmsa_fused_proj (debug)")
+    torch.cuda.synchronize()
+    for i in range(8):
+        assert torch.equal(outs[i], t["out_ref"]), f"lag {lag}, launch {i}: differs from the two-launch pair"
+    assert lib.rrt_device_error(0) == 0
+    # lags outside [8 * heads, heads * regions] are refused (a slab would wait for an item with a HIGHER block index)
+    for bad in (8, 63, 513):
+        rc = lib.rrt_debug_rmsa_fused_proj_f32(p(t["u"]), p(t["W"]), p(t["b"]), p(t["pe"]), p(t["Wp"]), p(t["bp"]), p(t["res"]),
+                                               p(outs[0]), p(o2), p(cnt), D, heads, ek, C.byref(g), bad, 0, 0, stream())
+        assert rc == -2, (bad, rc)
+
+
+def test_rmsa_fused_proj_bounded_wait_reports_and_recovers():
+    """A slab whose region never 'arrives' (wait_extra = 1: one arrival more than a region gets) gives up after the spin
+    limit instead of hanging the GPU, writes nothing, and raises the process's hand-over error word: every entry point that
+    could launch the kernel then returns RRT_E_HANDOVER until rrt_device_error(1) has cleared it -- after which the same
+    call works and is bit-identical again."""
+    from hip_util import encoder_from_state, p, stream, DEV
+    lib = _lib.load()
+    L, rn, D, heads, ek = 9000, 8, 512, 8, 15
+    t = _fused_proj_case(L, rn, tag="bw")
+    g, Np, R = t["g"], t["Np"], t["R"]
+    o2 = torch.full((Np, D), float("nan"), device=DEV)
+    cnt = torch.zeros((R,), device=DEV, dtype=torch.int32)
+    out = torch.full((L, D), 123.0, device=DEV)
+    args = (p(t["u"]), p(t["W"]), p(t["b"]), p(t["pe"]), p(t["Wp"]), p(t["bp"]), p(t["res"]), p(out), p(o2), p(cnt), D, heads, ek,
+            C.byref(g))
+    assert lib.rrt_device_error(1) == 0
+    _lib.check(lib.rrt_debug_rmsa_fused_proj_f32(*args, 0, 2000, 1, stream()), "rmsa_fused_proj (starved)")
+    torch.cuda.synchronize()                              # returns: the wait is bounded
+    assert torch.equal(o2, t["o_ref"]), "the items themselves ran"
+    assert bool((out == 123.0).all()), "a slab that gave up must not write"
+    code = lib.rrt_device_error(0)
+    assert 1 <= code <= R, code
+    assert lib.rrt_rmsa_fused_proj_f32(*args, stream()) == -4
+    assert b"hand-over" in lib.rrt_strerror(-4)
+    enc = encoder_from_state(synth.encoder_state(), dict(mlp_dim=512))
+    x = torch.from_numpy(synth.bag(L, D, tag="bw/x")).to(DEV)
+    with pytest.raises(_lib.RRTHipError, match="hand-over"):
+        enc(x.unsqueeze(0))
+    assert lib.rrt_device_error(1) == code and lib.rrt_device_error(0) == 0
+    _lib.check(lib.rrt_rmsa_fused_proj_f32(*args, stream()), "rmsa_fused_proj after the clear")
+    torch.cuda.synchronize()
+    assert torch.equal(out, t["out_ref"])
+    assert torch.isfinite(enc(x.unsqueeze(0))).all()
+
+
 def test_bag_feeder_matches_direct_copy(tmp_path):
     """Row f3: pinned double-buffered H2D feed -- same bags, same order, same results as bag.to(device);
     accepts tensors and .pt paths (dataloader.py:181)."""
