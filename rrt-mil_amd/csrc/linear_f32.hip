@@ -590,6 +590,9 @@ void linear_ws_kernel(const void* __restrict__ Av,
   // every K iteration.  Here the next slice's request is issued BEFORE this slice's store, so the wait for a residual row
   // counts the NT stores and NT requests behind it instead of draining them.
   constexpr unsigned OOB = 0xFFFFFF00u;
+  // the sentinel + the last slice's column offset + one 16-byte access must not wrap into the buffer (NT <= 4 today; a wider
+  // instantiation has to fold 64 j into the instruction's soffset instead)
+  static_assert(64u * (NT - 1) + 16u <= 0x100u, "OOB sentinel would wrap to an in-range offset");
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const unsigned out_bytes = pref_ok ? (unsigned)((size_t)ep.g.L * N * 4) : 0u;
   __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)out_bytes, 0x00020000);

@@ -247,6 +247,9 @@ def _warn_hw_queues(streams):
         q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
     except ValueError:
         q = 4
+    from . import HW_QUEUES
+    if HW_QUEUES == "late":            # HIP was initialised before the package could set the variable: the default holds
+        q = 4
     if q < 2 * streams + 4:
         _HWQ_WARNED = True
         warnings.warn(f"rrt_mil_amd: {streams} bags in flight but GPU_MAX_HW_QUEUES={q} (HIP default 4): the executor's "

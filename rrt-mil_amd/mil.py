@@ -308,7 +308,9 @@ class RRTMIL(nn.Module):
         ``for bag in loader: model(bag)`` (main.py:466-467) with ``streams`` slides in flight -- each slide is one
         rrt_mil_forward_f32 call with its own workspace on one of the process's bag streams (the same list
         RRTEncoder.forward_bags uses; at most four: the chip schedules four hardware queues).  Ordered like one op of the
-        caller's stream: the bag streams wait for it, and the host waits for them before the call returns."""
+        caller's stream: the bag streams wait for it, and the host waits for them before the call returns (the call BLOCKS
+        the host; it swaps the module's workspace per stream slot while it runs, so one call at a time per module: not
+        re-entrant, not thread-safe)."""
         if not bags:
             return []
         if self.training and (isinstance(self.dp, nn.Dropout) or self.online_encoder._stochastic()):
@@ -338,6 +340,11 @@ class RRTMIL(nn.Module):
                 with torch.cuda.stream(pool[s_]):
                     o = self.forward_bag(x2, return_attn=return_attn, no_norm=no_norm)
                 slots[(dev, s_)] = (self._ws, self.__dict__.get("_w16_key"))
+                # the outputs were allocated under the bag stream (the caching allocator ties a block to the stream it was
+                # taken on) and are consumed on the caller's: tell the allocator, so that a freed logits / attention row
+                # is not handed out again on the bag stream while the caller's stream still reads it
+                for t_ in (o if return_attn else (o,)):
+                    t_.record_stream(cur)
                 if b.dim() == 3:
                     o = tuple(t.unsqueeze(0) for t in o) if return_attn else o.unsqueeze(0)
                 outs[i] = o

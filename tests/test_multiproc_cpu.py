@@ -106,3 +106,43 @@ def test_bench_single_rank_and_weak_scaling_record():
     assert rec1["n_gpus"] == 1 and rec1["scaling"] == "weak" and rec1["config"]["n_tokens"] == 30000
     rec2 = _run_bench("--gpus", "2", "--stub-cpu", "--steps", "2", "--warmup", "0", "--config", "3")
     assert rec2["n_gpus"] == 2 and rec2["config"]["bags_per_step"] == 2 * rec1["config"]["bags_per_step"]
+
+
+def test_bench_world8_configs_3_and_4_stub():
+    """The driver's 8-GPU SCALE command shape, on CPU: `python bench.py --gpus 8 --config c` with no torch.distributed
+    environment.  Eight ranks over gloo (the stand-in for RCCL), one JSON line with n_gpus == 8; configs[3] = every rank its
+    own N=30000 bags ("weak"), configs[4] = the 64-bag mix LPT-split eight ways with <= 5 % cost imbalance ("strong").  The
+    only collectives in the rank program are a barrier and one MAX all-reduce of the elapsed time -- both exist in RCCL."""
+    from rrt_mil_amd import sharding
+    rec = _run_bench("--gpus", "8", "--stub-cpu", "--steps", "2", "--warmup", "1", "--config", "4")
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "strong" and rec["data"] == "stub"
+    assert rec["config"]["bags_per_step"] == 64 and rec["config"]["collectives"]["world"] == 8
+    assert rec["config"]["collectives"]["backend"] == "gloo"
+    assert "barrier + MAX all-reduce" in rec["config"]["collectives"]["use"]
+    sizes = [int(v) for v in np.random.RandomState(2021).randint(3000, 15001, size=64)]
+    kw = dict(region_num=8, epeg_k=21, crmsa_k=5)
+    a = sharding.assign_bags(sizes, 8, **kw)
+    assert sorted(i for r in a for i in r) == list(range(64))
+    loads = [sum(sharding.bag_cost(sizes[i], **kw) for i in r) for r in a]
+    assert max(loads) / (sum(loads) / 8) <= 1.05, "LPT imbalance of the configs[4] mix over 8 ranks"
+    assert rec["config"]["bags_this_rank"] == len(a[0])
+    assert abs(rec["value"] - 64 * 2 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 1e-3
+    rec3 = _run_bench("--gpus", "8", "--stub-cpu", "--steps", "2", "--warmup", "0", "--config", "3")
+    assert rec3["n_gpus"] == 8 and rec3["scaling"] == "weak" and rec3["config"]["n_tokens"] == 30000
+    one = _run_bench("--stub-cpu", "--steps", "2", "--warmup", "0", "--config", "3")
+    assert rec3["config"]["bags_per_step"] == 8 * one["config"]["bags_per_step"]
+    # configs[3] on 8 ranks as the BASELINE words it (8 bags, one per GPU): exactly one each, imbalance 1.0
+    assert sharding.assign_bags([30000] * 8, 8, region_num=16) == [[i] for i in range(8)]
+
+
+def test_rank_program_uses_only_rccl_shaped_collectives():
+    """No data-path collective: the only torch.distributed calls in bench.py and the package are init / barrier /
+    all_reduce / get_backend / get_world_size / destroy -- all of which RCCL implements (no gloo-only object collectives, no
+    send / recv of activations)."""
+    import re
+    allowed = {"init_process_group", "barrier", "all_reduce", "get_backend", "get_world_size", "destroy_process_group",
+               "is_available", "is_initialized", "ReduceOp", "get_rank"}
+    for rel in ("bench.py", os.path.join("rrt-mil_amd", "sharding.py")):
+        src = open(os.path.join(ROOT, rel)).read()
+        used = set(re.findall(r"\bdist\.([A-Za-z_]+)", src))
+        assert used <= allowed, (rel, sorted(used - allowed))

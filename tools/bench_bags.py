@@ -12,7 +12,14 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HWQ=unset: leave GPU_MAX_HW_QUEUES to the package (rrt_mil_amd sets 16 at import when HIP is not up yet); HWQ=<n>: force n;
+# HWQ=torch_first: `import torch` + a CUDA call BEFORE the package is imported (the "late" case: HIP's default 4 holds)
+_hwq = os.environ.get("HWQ", "unset")
+if _hwq == "torch_first":
+    import torch as _t
+    _t.zeros(1, device="cuda:0")
+elif _hwq != "unset":
+    os.environ["GPU_MAX_HW_QUEUES"] = _hwq
 
 
 def measure(kind, nb, streams):
@@ -65,8 +72,13 @@ if __name__ == "__main__":
         measure("uniform", int(sys.argv[2]), int(sys.argv[3]))
     elif len(sys.argv) > 1 and sys.argv[1] == "mix":
         measure("mix", 64, int(sys.argv[2]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "hwq":
+        # what a user gets at 64 bags / call, S = 4, depending on who set GPU_MAX_HW_QUEUES (the child inherits HWQ)
+        for mode in ("unset", "4", "16", "torch_first"):
+            os.environ["HWQ"] = mode
+            print(f"HWQ={mode:12s} uniform N=9000, 64 bags/call, S=4: {spawn('uniform', 64, 4)[0]} slides/s", flush=True)
     else:
-        for nb in (2, 4, 16, 64):
+        for nb in (2, 4, 8, 16, 64):
             print(f"uniform N=9000, {nb:3d} bags/call:", "  ".join(f"S={s}: {spawn('uniform', nb, s)[0]:>5s}/s" for s in (1, 2, 3, 4)),
                   flush=True)
         for s in (1, 2, 3, 4):
