@@ -162,6 +162,8 @@ int rrt_encoder_workspace_size(const rrt_encoder_desc *desc, int64_t n_tokens, s
 #define RRT_PLAN_FUSED_PROJ 2   /* ... with the out-projection + un-partition + residual as a later phase of the same launch */
 #define RRT_PLAN_FUSED16    4   /* the 16-bit fused kernels (bf16 / fp16 modes) */
 #define RRT_PLAN_FUSED_X3   8   /* the split-bf16 fused kernel (RRT_COMPUTE_F32X3) */
+#define RRT_PLAN_CRMSA_PARTS 16 /* the last layer's merged launch also leaves CR-MSA's row records (LayerNorm 2 statistics +
+                                   logit dot products); CR-MSA's first pass is rrt_crmsa_combine_parts_f32 */
 int rrt_encoder_plan(const rrt_encoder_desc *desc, int64_t n_tokens, int32_t *flags);
 
 /* Whole path: RRTEncoder.forward, modules/rrt.py:165-202 (eval mode, one bag).
@@ -260,6 +262,24 @@ int rrt_rmsa_fused_proj_f32(const float *u, const float *qkv_w, const float *qkv
                             const float *proj_w, const float *proj_b, const float *resid, float *out,
                             float *o_scratch, int32_t *counters, int32_t dim, int32_t heads, int32_t epeg_k,
                             const rrt_grid *g, void *stream);
+/* ... and CR-MSA's first pass as a by-product (what rrt_encoder_forward_f32 does for the LAST R-MSA layer when a plain-phi
+ * CR-MSA follows it directly): out = x1 is CR-MSA's input, and the slabs hold its tiles in registers -- per (token t,
+ * 64-column slab c) they also store the record  part[(t * dim / 64 + c) * S ..] = (mean, M2, d_0 .. d_k-1), S = 2 + k rounded
+ * up to a multiple of 4:  mean and
+ * centred sum of squares of x1[t, 64 c .. 64 c + 63], d_n = sum_j x1[t, j] ln2_gamma[j] phi[j, n] over those columns
+ * (LayerNorm 2 = cr_msa.norm, phi [dim, k] = cr_msa.attn.phi; modules/rmsa.py:303-307, rrt.py:121).  part: n_tokens * dim / 64 *
+ * S floats of device scratch (dim <= 512).  rrt_crmsa_combine_parts_f32 turns them and ONE pass over x1 into CR-MSA's combine:
+ * logits / region softmax / min-max / dispatch weights wdisp [H8*H8, k] (region-major) and the representatives
+ * rep [k, 64, dim] (rmsa.py:307-316) -- the job of rrt_crmsa_logits_f32 + rrt_crmsa_combine_f32, without re-reading x1 for
+ * LayerNorm and without any hand-over between blocks.  g8 = rrt_region_grid(n_tokens, 8, ...). */
+int rrt_rmsa_fused_proj_stats_f32(const float *u, const float *qkv_w, const float *qkv_b, const float *pe_w,
+                                  const float *proj_w, const float *proj_b, const float *resid, float *out,
+                                  float *o_scratch, int32_t *counters, const float *ln2_gamma, const float *phi,
+                                  int32_t crmsa_k, float *part, int32_t dim, int32_t heads, int32_t epeg_k,
+                                  const rrt_grid *g, void *stream);
+int rrt_crmsa_combine_parts_f32(const float *x1, const float *part, const float *gamma, const float *beta,
+                                const float *phi, float *wdisp, float *rep, int64_t n_tokens, int32_t dim, int32_t k,
+                                const rrt_grid *g8, void *stream);
 /* The in-launch hand-over of that kernel and what it assumes.  A projection slab (block b >= lag) spins on its region's
  * arrival counter until the region's `heads` items -- blocks with LOWER indices -- have stored their O rows.  Forward
  * progress rests on the GPU dispatching the workgroups of one launch in index order (so an awaited item is running or
@@ -294,6 +314,13 @@ int rrt_ln_partition16(const float *x, const float *gamma, const float *beta, ui
                        int32_t dim, const rrt_grid *g, int32_t compute, void *stream);
 int rrt_linear16_f32(const uint16_t *A, const uint16_t *B, const float *bias, const float *resid, float *C,
                      int64_t M, int32_t N, int32_t K, const rrt_grid *g, int32_t compute, void *stream);
+/* rrt_linear16_f32's un-partition + residual epilogue with CR-MSA's row records as a by-product (see
+ * rrt_rmsa_fused_proj_stats_f32: same records, same reader rrt_crmsa_combine_parts_f32): what rrt_encoder_forward_f32 does
+ * for the LAST R-MSA layer in the BF16 / F16 modes when a plain-phi CR-MSA follows it directly and the product's 64-column
+ * tiles are all resident at once (bags of up to ~13.7 k tokens at N = K = 512); otherwise RRT_E_UNSUPPORTED. */
+int rrt_linear16_stats_f32(const uint16_t *A, const uint16_t *B, const float *bias, const float *resid, float *C,
+                           const float *ln2_gamma, const float *phi, int32_t crmsa_k, float *part, int64_t M,
+                           int32_t N, int32_t K, const rrt_grid *g, int32_t compute, void *stream);
 int rrt_rmsa_fused16(const uint16_t *u, const uint16_t *qkv_w, const float *qkv_b, const float *pe_w,
                      uint16_t *o, int32_t n_regions, int32_t P, int32_t dim, int32_t heads, int32_t epeg_k,
                      int32_t compute, void *stream);

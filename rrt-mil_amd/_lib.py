@@ -108,12 +108,16 @@ SIGNATURES = {
     "rrt_rmsa_fused_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
     "rrt_rmsa_fused_proj_f32": (C.c_int, [C.c_void_p] * 10 + [C.c_int32] * 3 + [C.c_void_p] * 2),
     "rrt_device_error": (C.c_int, [C.c_int32]),
+    "rrt_rmsa_fused_proj_stats_f32": (C.c_int, [C.c_void_p] * 12 + [C.c_int32, C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p] * 2),
+    "rrt_crmsa_combine_parts_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_void_p]),
     "rrt_debug_rmsa_fused_proj_f32": (C.c_int, [C.c_void_p] * 10 + [C.c_int32] * 3 + [C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p]),
     "rrt_cast16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "rrt_ln_partition16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                      C.POINTER(Grid), C.c_int32, C.c_void_p]),
     "rrt_linear16_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_int32,
                                                       C.c_void_p]),
+    "rrt_linear16_stats_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid),
+                                                       C.c_int32, C.c_void_p]),
     "rrt_rmsa_fused16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
     "rrt_cast_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rrt_ln_partition_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
@@ -173,7 +177,7 @@ COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32X3 = 0, 1, 2, 3
 POS_NONE, POS_PEG, POS_PPEG = 0, 1, 2
 EPEG_ATTN, EPEG_VALUE_BF, EPEG_VALUE_AF = 0, 1, 2
 
-PLAN_FUSED, PLAN_FUSED_PROJ, PLAN_FUSED16, PLAN_FUSED_X3 = 1, 2, 4, 8     # rrt_encoder_plan flags
+PLAN_FUSED, PLAN_FUSED_PROJ, PLAN_FUSED16, PLAN_FUSED_X3, PLAN_CRMSA_PARTS = 1, 2, 4, 8, 16     # rrt_encoder_plan flags
 # stage-boundary event slots of rrt_encoder_forward_events_f32 (enum in include/rrt_hip.h)
 EV_START, EV_LN_PARTITION, EV_QKV, EV_ATTN, EV_PROJ, EV_CR_COMBINE, EV_CR_INNER, EV_END, EV_COUNT = range(9)
 

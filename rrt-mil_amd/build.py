@@ -20,6 +20,23 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
          "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall", "-Wno-unused-function"]
 
 
+# The streaming (non-MFMA) kernels are compiled WITHOUT packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).
+# Round 5 found what the round-2 "lanes 48..63" mis-sums were: compiler-formed packed fp32 operations (seen: the low lane of a
+# v_pk_fma_f32 whose op_sel takes the HIGH dword of a source pair) return run-to-run different values when the wave shares
+# its SIMD with bf16-MFMA waves of ANOTHER bag's kernel -- crmsa_combine_parts_kernel's representative n = 1, components x / z,
+# bf16 mode only, two bags in flight only; never alone, never next to fp32-MFMA kernels (tools/experiments/dbg_abi2.py;
+# DESIGN.md).  With the feature off for the translation unit the same forwards are bit-identical.  These kernels are bound
+# by memory latency, not VALU issue: the cost is below measurement noise.  (The flag reaches the host compilation too, which
+# says "not a recognized feature for this target" and ignores it: filtered from the build output.)
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FILE_FLAGS = {f: NO_PACKED_FP32 for f in ("crmsa.hip", "ln_partition.hip", "mil_pool.hip", "crmsa_bwd.hip", "ln_bwd.hip",
+                                           "cast16.hip", "peg.hip")}
+
+
+def flags_for(src):
+    return FLAGS + FILE_FLAGS.get(src, [])
+
+
 def _hdr_digest():
     h = hashlib.sha256(" ".join(FLAGS).encode())
     for f in HEADERS:
@@ -31,6 +48,7 @@ def _hdr_digest():
 def _src_digest(src):
     """digest of one translation unit: flags + every header + the source (headers are few: no dependency scan)"""
     h = _hdr_digest()
+    h.update(" ".join(FILE_FLAGS.get(src, [])).encode())
     with open(os.path.join(CSRC, src), "rb") as fh:
         h.update(fh.read())
     return h.hexdigest()
@@ -64,7 +82,7 @@ def build(force=False, verbose=False):
             with open(obj + ".stamp") as fh:
                 if fh.read().strip() == sd:
                     continue
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *flags_for(src), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         if os.path.exists(obj + ".stamp"):
@@ -79,7 +97,7 @@ def build(force=False, verbose=False):
         with open(obj + ".stamp", "w") as fh:
             fh.write(sd)
         if verbose and out:
-            print(out.decode())
+            print("\n".join(l for l in out.decode().splitlines() if "not a recognized feature for this target" not in l))
     if failed:
         raise RuntimeError("\n".join(failed))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]

@@ -35,6 +35,7 @@ struct Workspace {
   float* cr_part;    // crmsa_region4_kernel: partial records of the region quarters
   int* cr_cnt;       // ... and the 64 arrival counters (zeroed by an R-MSA GEMM of the same forward)
   int* proj_cnt;     // rmsa_fused_kernel<.., PROJ>: one arrival counter per region (zeroed by the layer's LayerNorm + partition)
+  float* cr_pstat;   // row records of the last R-MSA layer's projection slabs [N][D / 64][2 + k] (crmsa_combine_parts_kernel)
   size_t bytes;
 };
 
@@ -88,6 +89,7 @@ Workspace carve(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
     if (d.n_rmsa_layers > 0) {
       w.cr_part = take(crmsa_region4_scratch_floats(to_dev(g8), d.crmsa_k));
       w.cr_cnt = (int*)take(64);
+      if (D % 64 == 0) w.cr_pstat = take(crmsa_parts_floats(N, (int)D, d.crmsa_k));
     }
     if (d.crmsa_mlp) {
       w.v8 = take(Np8 * D);
@@ -252,8 +254,13 @@ int rrt_encoder_plan(const rrt_encoder_desc* desc, int64_t n_tokens, int32_t* fl
   }
   if (rmsa_fused_supported(gd.P, D, desc->n_heads, ek) && rows_ok) {
     *flags = RRT_PLAN_FUSED;
-    if (compute == RRT_COMPUTE_F32 && rmsa_fused_proj_supported(gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, compute))
+    if (compute == RRT_COMPUTE_F32 && rmsa_fused_proj_supported(gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, compute)) {
       *flags |= RRT_PLAN_FUSED_PROJ;
+      rrt_grid g8{};
+      if (rrt_region_grid(n_tokens, 8, 0, 0, 0.f, &g8) == RRT_OK && desc->cr_msa && !desc->crmsa_mlp && !desc->ffn && D % 64 == 0 &&
+          crmsa_combine_parts_supported(D, desc->crmsa_k, to_dev(g8)))
+        *flags |= RRT_PLAN_CRMSA_PARTS;
+    }
   }
   return RRT_OK;
 }
@@ -296,6 +303,13 @@ static int ffn_apply(const rrt_encoder_desc* desc, const rrt_attn_weights& lw, c
   e2.resid = xi;
   e2.g = gid;
   return (int)launch_linear(ws.ffn_hid, lw.fc2_w, xo, (int)N, D, desc->ffn_hidden, e2, st);
+}
+
+// CR-MSA's first pass as a by-product of the last R-MSA layer's projection slabs: that layer's output must BE CR-MSA's
+// input (no FFN behind the attention, not the batch entry point's per-bag stop), phi a plain parameter, 64-column slabs
+static bool crmsa_parts_wanted(const rrt_encoder_desc& d, const Workspace& ws, const GridDev& g8, bool stops_before_crmsa) {
+  return d.cr_msa && !d.crmsa_mlp && !d.ffn && !stops_before_crmsa && ws.cr_pstat != nullptr &&
+         crmsa_combine_parts_supported(d.dim, d.crmsa_k, g8);
 }
 
 static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_weights* w, const float* x,
@@ -412,6 +426,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     }
     if (!desc->weights16_valid) RRT_TRY(launch_cast_split(jobs, st));
   }
+  bool parts_done = false;      // the last R-MSA layer left CR-MSA's row records in ws.cr_pstat
   // ---- R-MSA TransLayers: x = x + unpart(InnerAttention(part(pad(LN(x)))))  (rrt.py:117-125)
   for (int li = 0; li < desc->n_rmsa_layers; ++li) {
     if (li == 1 && desc->pos && desc->pos_pos == 0) {
@@ -447,6 +462,18 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       ep.resid = xin;
       ep.g = gd;
       ep.zero64 = ws.cr_cnt;
+      // the LAST R-MSA layer feeding CR-MSA directly: the un-partition epilogue also leaves LayerNorm 2's statistics and
+      // the logits' dot products of every row (x1 is in its registers) -- CR-MSA's first pass shrinks to the combine
+      if (li == desc->n_rmsa_layers - 1 && crmsa_parts_wanted(*desc, ws, to_dev(g8), rmsa_out != nullptr) &&
+          linear16_parts_supported(gd.Np, D, D)) {
+        if (!w->crmsa.norm_w || !w->crmsa.norm_b || !w->phi) return RRT_E_INVALID;
+        ep.part = ws.cr_pstat;
+        ep.ln_g = w->crmsa.norm_w;
+        ep.phi = w->phi;
+        ep.k = desc->crmsa_k;
+        static const bool ignore = rrt_tune_env("RRT_DBG_PARTS_IGNORE") != nullptr;   // (bisecting: records written, not used)
+        parts_done = !ignore;
+      }
       RRT_TRY(launch_linear16(o16, wq16 + (size_t)3 * D * D, xout, gd.Np, D, D, ep, st));
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;
@@ -488,6 +515,10 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     const bool merged = !epeg_variant && desc->compute == RRT_COMPUTE_F32 && ws.proj_cnt != nullptr &&
                         rmsa_fused_supported_rows(gd.Np, D) &&
                         rmsa_fused_proj_supported(gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, desc->compute);
+    const bool parts = merged && li == desc->n_rmsa_layers - 1 && !epeg_variant &&
+                       rmsa_fused_supported(gd.P, D, desc->n_heads, ek) &&
+                       crmsa_parts_wanted(*desc, ws, to_dev(g8), rmsa_out != nullptr);
+    if (parts && (!w->crmsa.norm_w || !w->crmsa.norm_b || !w->phi)) return RRT_E_INVALID;
     RRT_TRY(launch_ln_partition(xin, lw.norm_w, lw.norm_b, ws.uo, D, gd, st, merged ? ws.proj_cnt : nullptr,
                                 merged ? gd.rs * gd.rs : 0));
     if (epeg_variant) {
@@ -545,6 +576,15 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       pj.cnt = ws.proj_cnt;
       pj.zero64 = ws.cr_cnt;
       pj.g = gd;
+      // the LAST R-MSA layer feeding CR-MSA directly: its slabs also leave LayerNorm 2's statistics and the logits' dot
+      // products of every row (x1 is in their registers), and CR-MSA's first pass shrinks to the combine
+      if (parts) {
+        pj.part = ws.cr_pstat;
+        pj.ln_g = w->crmsa.norm_w;
+        pj.phi = w->phi;
+        pj.k = desc->crmsa_k;
+        parts_done = true;
+      }
       RRT_TRY(launch_rmsa_fused(ws.uo, lw.qkv_w, lw.qkv_b, desc->epeg ? lw.pe_w : nullptr, ws.qkv,
                                 gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, desc->compute, st, nullptr, &pj));
       if (gt) { RRT_TRY(hipEventRecord(gt->done, st)); gt->armed = true; }
@@ -637,6 +677,12 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     RRT_TRY(launch_crmsa_mlp_logits(ws.hid, w->phi2_w, ws.logits, gd8.Np, D / 4, k, st));
     RRT_TRY(launch_crmsa_combine(ws.v8, nullptr, nullptr, nullptr, ws.logits, ws.wdisp, ws.rep, inner16 ? ws.rep16 : nullptr,
                                  desc->compute, D, k, gd8, st));
+    rep16_done = inner16;
+  } else if (parts_done) {
+    // LayerNorm 2's statistics and the logits' dot products came out of the projection slabs: one pass over x1, 64 x D / 64
+    // independent blocks (crmsa_combine_parts_kernel)
+    RRT_TRY(launch_crmsa_combine_parts(xin, ws.cr_pstat, cw.norm_w, cw.norm_b, w->phi, ws.wdisp, ws.rep,
+                                       inner16 ? ws.rep16 : nullptr, desc->compute, D, k, gd8, st));
     rep16_done = inner16;
   } else if (ws.cr_cnt && desc->n_rmsa_layers > 0 && crmsa_region4_supported(D, k, gd8) && gd8.P <= 144) {
     // logits + combine in one pass over x1: four blocks per region, the last to arrive merges (crmsa_region4_kernel).
@@ -957,10 +1003,46 @@ int rrt_rmsa_fused_proj_f32(const float* u, const float* qkv_w, const float* qkv
                                        epeg_k, g, 0, 0, 0, stream);
 }
 
+}  // extern "C"
+// the merged launch of one layer through the stage entry points (tests): optional test knobs, optional CR-MSA row records
+static int fused_proj_stage(const float* u, const float* qkv_w, const float* qkv_b, const float* pe_w,
+                            const float* proj_w, const float* proj_b, const float* resid, float* out, float* o_scratch,
+                            int32_t* counters, int32_t dim, int32_t heads, int32_t epeg_k, const rrt_grid* g,
+                            int32_t lag, int32_t spin_limit, int32_t wait_extra, const float* ln2_gamma, const float* phi,
+                            int32_t crmsa_k, float* part, void* stream);
+extern "C" {
 int rrt_debug_rmsa_fused_proj_f32(const float* u, const float* qkv_w, const float* qkv_b, const float* pe_w,
                                   const float* proj_w, const float* proj_b, const float* resid, float* out, float* o_scratch,
                                   int32_t* counters, int32_t dim, int32_t heads, int32_t epeg_k, const rrt_grid* g,
                                   int32_t lag, int32_t spin_limit, int32_t wait_extra, void* stream) {
+  return fused_proj_stage(u, qkv_w, qkv_b, pe_w, proj_w, proj_b, resid, out, o_scratch, counters, dim, heads, epeg_k, g, lag,
+                          spin_limit, wait_extra, nullptr, nullptr, 0, nullptr, stream);
+}
+
+int rrt_rmsa_fused_proj_stats_f32(const float* u, const float* qkv_w, const float* qkv_b, const float* pe_w,
+                                  const float* proj_w, const float* proj_b, const float* resid, float* out, float* o_scratch,
+                                  int32_t* counters, const float* ln2_gamma, const float* phi, int32_t crmsa_k, float* part,
+                                  int32_t dim, int32_t heads, int32_t epeg_k, const rrt_grid* g, void* stream) {
+  if (!ln2_gamma || !phi || !part || crmsa_k < 1 || crmsa_k > RRT_MAX_CRMSA_K) return RRT_E_INVALID;
+  return fused_proj_stage(u, qkv_w, qkv_b, pe_w, proj_w, proj_b, resid, out, o_scratch, counters, dim, heads, epeg_k, g, 0, 0, 0,
+                          ln2_gamma, phi, crmsa_k, part, stream);
+}
+
+int rrt_crmsa_combine_parts_f32(const float* x1, const float* part, const float* gamma, const float* beta, const float* phi,
+                                float* wdisp, float* rep, int64_t n_tokens, int32_t dim, int32_t k, const rrt_grid* g8,
+                                void* stream) {
+  if (!x1 || !part || !gamma || !beta || !phi || !wdisp || !rep || !g8 || n_tokens <= 0 || g8->L != n_tokens) return RRT_E_INVALID;
+  const GridDev gd = to_dev(*g8);
+  if (!crmsa_combine_parts_supported(dim, k, gd)) return unsupported("crmsa_combine_parts: dim % 64 == 0, dim <= 512, 1 <= k <= 8");
+  return (int)launch_crmsa_combine_parts(x1, part, gamma, beta, phi, wdisp, rep, nullptr, 0, dim, k, gd, (hipStream_t)stream);
+}
+}  // extern "C"
+
+static int fused_proj_stage(const float* u, const float* qkv_w, const float* qkv_b, const float* pe_w,
+                            const float* proj_w, const float* proj_b, const float* resid, float* out, float* o_scratch,
+                            int32_t* counters, int32_t dim, int32_t heads, int32_t epeg_k, const rrt_grid* g,
+                            int32_t lag, int32_t spin_limit, int32_t wait_extra, const float* ln2_gamma, const float* phi,
+                            int32_t crmsa_k, float* part, void* stream) {
   if (!u || !qkv_w || !proj_w || !resid || !out || !o_scratch || !counters || !g || dim <= 0 || heads <= 0 || out == resid ||
       lag < 0 || spin_limit < 0 || wait_extra < 0)
     return RRT_E_INVALID;
@@ -982,10 +1064,15 @@ int rrt_debug_rmsa_fused_proj_f32(const float* u, const float* qkv_w, const floa
   pj.lag = lag;
   pj.spin_limit = spin_limit;
   pj.wait_for = wait_extra > 0 ? heads + wait_extra : 0;
+  pj.part = part;
+  pj.ln_g = ln2_gamma;
+  pj.phi = phi;
+  pj.k = crmsa_k;
   if (lag > 0 && (lag < 8 * heads || lag > heads * R)) return unsupported("rmsa_fused_proj: lag must be in [8 * heads, heads * regions]");
   return (int)launch_rmsa_fused(u, qkv_w, qkv_b, pe_w, o_scratch, R, gd.P, dim, heads, ek, RRT_COMPUTE_F32,
                                 (hipStream_t)stream, nullptr, &pj);
 }
+extern "C" {
 
 // ---- 16-bit operand stages of the reduced-precision modes (cast16.hip, linear_f32.hip IN16, rmsa_fused16.hip)
 int rrt_cast16(const float* src, uint16_t* dst, int64_t n, int32_t compute, void* stream) {
@@ -1017,6 +1104,30 @@ int rrt_linear16_f32(const uint16_t* A, const uint16_t* B, const float* bias, co
     ep.g = to_dev(*g);
     if (M != ep.g.Np) return RRT_E_INVALID;
   }
+  return (int)launch_linear16(A, B, C, (int)M, N, K, ep, (hipStream_t)stream);
+}
+
+int rrt_linear16_stats_f32(const uint16_t* A, const uint16_t* B, const float* bias, const float* resid, float* C,
+                           const float* ln2_gamma, const float* phi, int32_t crmsa_k, float* part, int64_t M, int32_t N,
+                           int32_t K, const rrt_grid* g, int32_t compute, void* stream) {
+  if (!A || !B || !C || !resid || !g || !ln2_gamma || !phi || !part || M <= 0 || N <= 0 || K <= 0 || crmsa_k < 1 ||
+      crmsa_k > RRT_MAX_CRMSA_K)
+    return RRT_E_INVALID;
+  if (K % 64) return unsupported("linear16: K must be a multiple of 64");
+  if (compute != RRT_COMPUTE_BF16 && compute != RRT_COMPUTE_F16) return unsupported("compute must be BF16 or F16");
+  LinearEpilogue ep{};
+  ep.prec = compute;
+  ep.bias = bias;
+  ep.resid = resid;
+  ep.g = to_dev(*g);
+  if (M != ep.g.Np) return RRT_E_INVALID;
+  if (!linear16_parts_supported((int)M, N, K))
+    return unsupported("linear16_stats: needs N % 64 == 0, N <= 512 and a product whose 64-column tiles are all resident at once "
+                       "(bags of up to ~13.7 k tokens at N = K = 512)");
+  ep.part = part;
+  ep.ln_g = ln2_gamma;
+  ep.phi = phi;
+  ep.k = crmsa_k;
   return (int)launch_linear16(A, B, C, (int)M, N, K, ep, (hipStream_t)stream);
 }
 

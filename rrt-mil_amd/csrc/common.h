@@ -102,6 +102,23 @@ static __device__ __forceinline__ float sum_xor32(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// the two values of a lane pair (lane, lane ^ 16) / (lane, lane ^ 32): a = the even row's (lower half's), b = the odd
+// row's (upper half's) -- the same (a, b) in both lanes, so symmetric formulas give both lanes the same bits
+static __device__ __forceinline__ void pair_xor16(float v, float& a, float& b) {
+  unsigned x = __float_as_uint(v), y = x;
+  RRT_PERMLANE_PAD(x, y);
+  const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+static __device__ __forceinline__ void pair_xor32(float v, float& a, float& b) {
+  unsigned x = __float_as_uint(v), y = x;
+  RRT_PERMLANE_PAD(x, y);
+  const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
 // Wave-wide reductions without LDS traffic: __shfl_xor lowers to ds_bpermute_b32 (an LDS-pipe round
 // trip per step, 6 dependent steps per reduction); here 4 DPP row rotations reduce each 16-lane row
 // in the VALU and 4 v_readlane + scalar-operand adds combine the rows.  Result is wave-uniform.

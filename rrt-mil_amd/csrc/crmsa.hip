@@ -320,6 +320,261 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
   }
 }
 
+// ---- combine from the projection slabs' row records (round 5) --------------------------------------------------------
+// The last R-MSA layer's out-projection leaves, per (token, 64-column slab), the record (mean_64, M2_64, d_0 .. d_k-1),
+// d_n = sum_c x1[c] gamma[c] phi[c, n] over the slab's columns (rmsa_fused.hip, proj_slab) -- LayerNorm 2's statistics and
+// the logits' dot products taken from the x1 tiles while they were still in registers.  What is left of
+// modules/rmsa.py:303-316 is ONE pass over x1 with no LayerNorm arithmetic in it and no hand-over between blocks:
+//   block = (region, 64-column slab), as crmsa_combine_kernel.  Every block of a region re-derives the region's logits
+//   from the records (P x D/64 x 8 floats, served by the L2: 37 KB at P = 144) -- Chan-merge of the slabs' (mean, M2),
+//   logit_n = rstd (sum d_n - mean G_n) + B_n, G_n = sum_c gamma_c phi_cn, B_n = sum_c beta_c phi_cn (2 k numbers, by the
+//   block's fourth wave while the other three merge their rows' records) -- then wave n does everything of representative
+//   n (max, min, sum of exp, the combine coefficients c * rstd and the LayerNorm-fold sums c0, c1), and the block contracts
+//   ITS 64 columns of the region's rows, whose loads were requested before any of that (they do not depend on it).
+//   Slab 0 also writes the dispatch weights.
+// 8 x the statistics work of one block per region, which is nothing (P x ~60 flops), instead of the write-through hand-over
+// of crmsa_region4_kernel's quarters (14.6 us at N = 9000 for one 18 MB read: a chain of ten latencies).
+// KM (4 / 8): representatives the instantiation carries (k <= KM; the table and phi-products of n >= k are zero) -- with a
+// run-time k every per-n loop was a chain of scalar branches: 3.8 K instructions, 13 us (traced: 23 K cycles per wave).
+template <int TR, int KM>   // x1 rows in flight per thread (16 row groups x 16 column lanes per block); representatives
+__global__ __launch_bounds__(256) void crmsa_combine_parts_kernel(const float* __restrict__ x1, const float* __restrict__ part,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ phi, float* __restrict__ wdisp,
+                                                                  float* __restrict__ rep, uint16_t* __restrict__ rep16,
+                                                                  int prec16, int dim, int k, int n_slabs, GridDev g) {
+  constexpr int MAXS = 8;                           // slabs whose records a thread keeps in flight at once (dim <= 512: all)
+  constexpr int NL = KM / 4;                        // float4s of a row's logits / coefficients
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* s_lg = (float4*)smem;                     // [P][NL] logits, then the combine coefficients c * rstd in place
+  float2* s_mr = (float2*)(s_lg + (size_t)g.P * NL);   // [P] mean, rstd (rstd = 0: pad token)
+  float4* s_part = (float4*)(s_mr + ((g.P + 1) & ~1));  // [16 row groups][KM + 1][16 col lanes]
+  __shared__ float s_stat[KM][5];                   // max, min, 1 / sum exp, c0, c1
+  const int reg = blockIdx.x, slab = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R = g.Rt, nf = (2 + k + 3) >> 2;        // float4s per record
+  const int ri = fdiv(reg, g.rs, g.inv_rs), rj = reg - ri * g.rs;
+  RRT_TRACE_INIT((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave);
+  RRT_TRACE_MARK();                                 // [1] entry
+  auto token_of = [&](const int p) {
+    const int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
+    const int t = (ri * g.s + pi) * g.H + rj * g.s + pj;
+    return (p < g.P && t < g.L) ? t : -1;
+  };
+  // ---- every load of the kernel is requested up front, in the order it is consumed (the vector memory counter is in
+  // order): this thread's row records, the G / B table, the contraction's rows, the affine of the last stage
+  const int t_mine = token_of(tid);                 // row `tid` of the region (regions of > 256 rows: the loop below)
+  constexpr int NFM = KM <= 2 ? 1 : KM <= 6 ? 2 : 3;
+  float4 rc[MAXS][NFM];
+  {
+    const float4* r = (const float4*)(part + (size_t)(t_mine < 0 ? 0 : t_mine) * n_slabs * (4 * nf));
+#pragma unroll
+    for (int c = 0; c < MAXS; ++c)
+#pragma unroll
+      for (int f = 0; f < NFM; ++f) rc[c][f] = r[(c < n_slabs ? c : 0) * nf + (f < nf ? f : 0)];
+  }
+  // G_n = sum_c gamma_c phi_cn, B_n = sum_c beta_c phi_cn: wave 3's job (regions of <= 192 rows leave it idle in the row
+  // pass; larger ones pay ~200 cycles).  Its loads go out with everybody's, the sums meet the rows' statistics at the barrier
+  __shared__ float s_gb[2 * KM];
+  float ag[KM], ab[KM];
+  if (wave == 3) {
+#pragma unroll
+    for (int n = 0; n < KM; ++n) ag[n] = ab[n] = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+      const float gm = gamma[c], bt = beta[c];
+#pragma unroll
+      for (int n = 0; n < KM; ++n) {
+        const float ph = n < k ? phi[(size_t)c * k + n] : 0.f;
+        ag[n] += gm * ph;
+        ab[n] += bt * ph;
+      }
+    }
+  }
+  const int cl = tid & 15, rg = tid >> 4;
+  const int col = slab * 64 + cl * 4;
+  float4 xv[TR];
+  int pp[TR];
+#pragma unroll
+  for (int u = 0; u < TR; ++u) {
+    const int p = rg + 16 * u;
+    const int t = token_of(p);
+    pp[u] = t < 0 ? -1 : p;
+    xv[u] = *(const float4*)(x1 + (size_t)(t < 0 ? 0 : t) * dim + col);
+  }
+  const float4 fgm = *(const float4*)(gamma + col), fbt = *(const float4*)(beta + col);   // (the last stage: threads < 16 KM)
+  RRT_TRACE_MARK();                                 // [2] every load requested
+  // ---- the row's statistics from its records (Chan et al., equal counts: slabs of 64 columns); its logits once G, B are there
+  const float inv_d = 1.0f / (float)dim;
+  auto row_stats = [&](const float4 (&q)[MAXS][NFM], const int t, float& mean, float& rstd, float (&dn)[KM]) {
+    float m = q[0][0].x, m2 = q[0][0].y;
+    auto dval = [&](const int c, const int n) {       // d_n of slab c: float 2 + n of the record
+      const int e = 2 + n;
+      const float4 v = q[c][(e >> 2) < NFM ? (e >> 2) : 0];
+      return (e & 3) == 0 ? v.x : (e & 3) == 1 ? v.y : (e & 3) == 2 ? v.z : v.w;
+    };
+#pragma unroll
+    for (int n = 0; n < KM; ++n) dn[n] = dval(0, n);
+#pragma unroll
+    for (int c = 1; c < MAXS; ++c)
+      if (c < n_slabs) {
+        const float mb = q[c][0].x, qb = q[c][0].y;
+        const float dl = mb - m, w = 1.0f / (float)(c + 1);        // (compile-time reciprocal)
+        m += dl * w;
+        m2 += qb + dl * dl * (64.0f * (float)c * w);
+#pragma unroll
+        for (int n = 0; n < KM; ++n) dn[n] += dval(c, n);
+      }
+    mean = t >= 0 ? m : 0.f;
+    rstd = t >= 0 ? 1.0f / sqrtf(m2 * inv_d + LN_EPS) : 0.f;
+  };
+  auto put_row = [&](const int p, const int t, const float mean, const float rstd, const float (&dn)[KM]) {
+    float lg[KM];
+#pragma unroll
+    for (int n = 0; n < KM; ++n) lg[n] = t >= 0 ? rstd * (dn[n] - mean * s_gb[n]) + s_gb[KM + n] : 0.f;   // pad tokens: zero logits
+#pragma unroll
+    for (int f = 0; f < NL; ++f) s_lg[p * NL + f] = make_float4(lg[4 * f], lg[4 * f + 1], lg[4 * f + 2], lg[4 * f + 3]);
+    s_mr[p] = make_float2(mean, rstd);
+  };
+  float mean_mine = 0.f, rstd_mine = 0.f, dn_mine[KM];
+  if (wave == 3) {
+#pragma unroll
+    for (int n = 0; n < KM; ++n) {
+      const float a_ = wave_sum(ag[n]), b_ = wave_sum(ab[n]);
+      if (lane == 0) { s_gb[n] = a_; s_gb[KM + n] = b_; }
+    }
+  }
+  if (tid < g.P) row_stats(rc, t_mine, mean_mine, rstd_mine, dn_mine);
+  lds_sync();                                         // G, B published
+  if (tid < g.P) put_row(tid, t_mine, mean_mine, rstd_mine, dn_mine);
+  for (int p = tid + 256; p < g.P; p += 256) {        // regions of more than 256 rows (bags of > 16 k tokens)
+    const int t = token_of(p);
+    const float4* r = (const float4*)(part + (size_t)(t < 0 ? 0 : t) * n_slabs * (4 * nf));
+    float4 q[MAXS][NFM];
+#pragma unroll
+    for (int c = 0; c < MAXS; ++c)
+#pragma unroll
+      for (int f = 0; f < NFM; ++f) q[c][f] = r[(c < n_slabs ? c : 0) * nf + (f < nf ? f : 0)];
+    float mean, rstd, dn[KM];
+    row_stats(q, t, mean, rstd, dn);
+    put_row(p, t, mean, rstd, dn);
+  }
+  RRT_TRACE_MARK();                                 // [3] logits in LDS (records landed)
+  lds_sync();
+  RRT_TRACE_MARK();                                 // [4] barrier
+  // ---- wave n owns representative n: max / min / sum of exp over the region, the combine coefficients c * rstd of every
+  // row (in place of its logit: only this wave touches column n) and the two LayerNorm-fold sums (Identity 3)
+  // (slab 0 keeps the logits for the dispatch weights: its coefficients go to a second table behind the partials)
+  const float* lgs = (const float*)s_lg;
+  float* const wtab = slab != 0 ? (float*)s_lg : (float*)(s_part + 16 * (KM + 1) * 16);
+  for (int n = wave; n < KM; n += 4) {
+    if (n >= k) {                                     // (wave-uniform) columns nobody owns: zero weights
+      for (int p = lane; p < g.P; p += 64) wtab[p * KM + n] = 0.f;
+      continue;
+    }
+    float mx = -3.0e38f, mn = 3.0e38f;
+    for (int p = lane; p < g.P; p += 64) {
+      const float v = lgs[p * KM + n];
+      mx = fmaxf(mx, v);
+      mn = fminf(mn, v);
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    float se = 0.f;
+    for (int p = lane; p < g.P; p += 64) se += __expf(lgs[p * KM + n] - mx);
+    se = wave_sum(se);
+    const float inv = 1.0f / se;
+    float c0 = 0.f, c1 = 0.f;
+    for (int p = lane; p < g.P; p += 64) {
+      const float2 mr = s_mr[p];
+      const float c = mr.y != 0.f ? __expf(lgs[p * KM + n] - mx) * inv : 0.f;   // pad rows: in the softmax sum, not in the contraction
+      c0 += c * mr.y * mr.x;
+      c1 += c;
+      wtab[p * KM + n] = c * mr.y;
+    }
+    c0 = wave_sum(c0);
+    c1 = wave_sum(c1);
+    if (lane == 0) { s_stat[n][0] = mx; s_stat[n][1] = mn; s_stat[n][2] = inv; s_stat[n][3] = c0; s_stat[n][4] = c1; }
+  }
+  RRT_TRACE_MARK();                                 // [5] region statistics + coefficients
+  lds_sync();
+  RRT_TRACE_MARK();                                 // [6] barrier
+  // ---- contraction over the region's rows (this block's 64 columns)
+  const float4* wt = (const float4*)wtab;
+  float4 acc[KM];
+#pragma unroll
+  for (int n = 0; n < KM; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p0 = rg;; ) {
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      const int pc = pp[u] >= 0 ? pp[u] : 0;
+      const float4 x = pp[u] >= 0 ? xv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int f = 0; f < NL; ++f) {
+        const float4 w4 = wt[pc * NL + f];
+        acc[4 * f].x += w4.x * x.x; acc[4 * f].y += w4.x * x.y; acc[4 * f].z += w4.x * x.z; acc[4 * f].w += w4.x * x.w;
+        acc[4 * f + 1].x += w4.y * x.x; acc[4 * f + 1].y += w4.y * x.y; acc[4 * f + 1].z += w4.y * x.z; acc[4 * f + 1].w += w4.y * x.w;
+        acc[4 * f + 2].x += w4.z * x.x; acc[4 * f + 2].y += w4.z * x.y; acc[4 * f + 2].z += w4.z * x.z; acc[4 * f + 2].w += w4.z * x.w;
+        acc[4 * f + 3].x += w4.w * x.x; acc[4 * f + 3].y += w4.w * x.y; acc[4 * f + 3].z += w4.w * x.z; acc[4 * f + 3].w += w4.w * x.w;
+      }
+    }
+    p0 += 16 * TR;
+    if (p0 >= g.P) break;
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      const int p = p0 + 16 * u;
+      const int t = token_of(p);
+      pp[u] = t < 0 ? -1 : p;
+      xv[u] = *(const float4*)(x1 + (size_t)(t < 0 ? 0 : t) * dim + col);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < KM; ++n) s_part[(rg * (KM + 1) + n) * 16 + cl] = acc[n];
+  RRT_TRACE_MARK();                                 // [7] contraction (x1 rows landed)
+  lds_sync();
+  RRT_TRACE_MARK();                                 // [8] barrier
+  if (tid < k * 16) {
+    const int n = tid >> 4;                           // (cl = tid & 15: this thread's columns are `col`)
+    float4 a = s_part[n * 16 + cl];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+      const float4 b = s_part[(q * (KM + 1) + n) * 16 + cl];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const float c0 = s_stat[n][3], c1 = s_stat[n][4];
+    float4 out;
+    out.x = fgm.x * (a.x - c0) + fbt.x * c1;
+    out.y = fgm.y * (a.y - c0) + fbt.y * c1;
+    out.z = fgm.z * (a.z - c0) + fbt.z * c1;
+    out.w = fgm.w * (a.w - c0) + fbt.w * c1;
+    *(float4*)(rep + ((size_t)n * R + reg) * dim + col) = out;   // rep [k, R, D]
+    if (rep16) *(uint2*)(rep16 + ((size_t)n * R + reg) * dim + col) = prec16 == 2 ? r4_pack4<2>(out) : r4_pack4<1>(out);
+  }
+  RRT_TRACE_MARK();                                 // [9] representatives stored
+  // dispatch weights of the region's tokens (slab 0): minmax_p(Lg)[n, p] * softmax_n(Lg)[n, p]  (rmsa.py:310-314, :324-325)
+  if (slab == 0) {
+    for (int p = tid; p < g.P; p += 256) {
+      float v[KM], e[KM];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int n = 0; n < KM; ++n) {
+        v[n] = lgs[p * KM + n];
+        if (n < k) mx = fmaxf(mx, v[n]);
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int n = 0; n < KM; ++n) {
+        e[n] = n < k ? __expf(v[n] - mx) : 0.f;
+        se += e[n];
+      }
+      const float inv = 1.0f / se;
+#pragma unroll
+      for (int n = 0; n < KM; ++n)
+        if (n < k)
+          wdisp[((size_t)reg * g.P + p) * k + n] = (v[n] - s_stat[n][1]) / (s_stat[n][0] - s_stat[n][1] + 1e-8f) * (e[n] * inv);
+    }
+    RRT_TRACE_MARK();                               // [10] dispatch weights written
+  }
+}
+
 // ---- logits + combine in ONE pass over x1 (dim = 512, P <= 16 * NR_MAX, k <= 3) -------------------------------------
 // One block of 16 waves per region.  Wave w owns the region's rows w, w + 16, ... (<= NR_MAX = 9 of them, two float4
 // per lane each: 72 registers) and issues every load at once -- one memory round trip for the whole region, and the
@@ -1130,6 +1385,38 @@ hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   kern<<<grid, block, lds, st>>>(x1, gamma, beta, mean_rstd, logits, wdisp, rep, rep16, prec16, dim, k, g8);
+  return hipGetLastError();
+}
+
+// dim % 64 == 0 (the slabs are 64 columns wide), dim <= 512; any k <= 8, any region size whose tables fit the LDS
+static size_t combine_parts_lds(int P, int KM) {
+  // logits / coefficients [P][KM], (mean, rstd) [P], the row groups' partials [16][KM + 1][16] float4 and (slab 0) a
+  // second coefficient table [P][KM]
+  return (size_t)P * KM * 4 * 2 + (size_t)((P + 1) & ~1) * 8 + (size_t)16 * (KM + 1) * 16 * 16;
+}
+bool crmsa_combine_parts_supported(int dim, int k, const GridDev& g8) {
+  static const bool off = rrt_tune_env("RRT_NO_CRMSA_PARTS") != nullptr;
+  return !off && dim % 64 == 0 && dim >= 64 && dim <= 512 && k >= 1 && k <= KMAX && combine_parts_lds(g8.P, k <= 4 ? 4 : 8) <= 150 * 1024;
+}
+size_t crmsa_parts_floats(long n_tokens, int dim, int k) { return (size_t)n_tokens * (dim / 64) * ((2 + k + 3) & ~3); }
+hipError_t launch_crmsa_combine_parts(const float* x1, const float* part, const float* gamma, const float* beta,
+                                      const float* phi, float* wdisp, float* rep, uint16_t* rep16, int prec16, int dim,
+                                      int k, const GridDev& g8, hipStream_t st) {
+  if (!crmsa_combine_parts_supported(dim, k, g8)) return hipErrorInvalidValue;
+  dim3 grid(g8.rs * g8.rs, dim / 64), block(256);
+  constexpr int TR = 9;                               // P = 144: every row of the region in flight at once
+#define RRT_CPARTS(KM_)                                                                                              \
+  do {                                                                                                               \
+    const size_t lds = combine_parts_lds(g8.P, KM_);                                                                 \
+    auto kern = crmsa_combine_parts_kernel<TR, KM_>;                                                                 \
+    static OncePerDevice once;                                                                                       \
+    if (lds > 64 * 1024 && once.first())                                                                             \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);          \
+    kern<<<grid, block, lds, st>>>(x1, part, gamma, beta, phi, wdisp, rep, rep16, prec16, dim, k, dim / 64, g8);     \
+  } while (0)
+  if (k <= 4) RRT_CPARTS(4);
+  else RRT_CPARTS(8);
+#undef RRT_CPARTS
   return hipGetLastError();
 }
 

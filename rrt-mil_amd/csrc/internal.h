@@ -53,7 +53,16 @@ struct LinearEpilogue {
   int* zero64;
   // scheduling hint (rrt_encoder_desc.solo): this GEMM may use whole CUs (small-M GEMMs: split K inside a 16-wave block)
   bool solo;
+  // CR-MSA's first pass as a by-product of the un-partition epilogue (null: off; 16-bit-operand GEMMs whose tiles are
+  // 64 columns wide and all resident at once: linear16_parts_supported) -- the row records of FusedProj.part, same layout
+  float* part;
+  const float* ln_g;     // the CR-MSA TransLayer's LayerNorm weight [N]
+  const float* phi;      // [N, k]
+  int k;
 };
+// whether launch_linear16's un-partition epilogue can leave the row records for these shapes (its tile rule picks
+// 64-column tiles with one tile per block: bags of up to ~13.7 k tokens at N = K = 512)
+bool linear16_parts_supported(int M, int N, int K);
 hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
                          const LinearEpilogue& ep, hipStream_t st);
 
@@ -116,6 +125,14 @@ struct FusedProj {
   int* err;
   int spin_limit;
   int wait_for;
+  // CR-MSA's first pass as a by-product of the slab (null: off): per (token, 64-column slab) the record
+  // (mean, centred sum of squares, d_0 .. d_k-1), d_n = sum_c x1[c] gamma[c] phi[c, n] -- part [L][n_slabs][2 + k], read by
+  // launch_crmsa_combine_parts.  ln_g = the CR-MSA TransLayer's LayerNorm weight [D], phi [D, k]
+  float* part;
+  const float* ln_g;
+  const float* phi;
+  int k;
+  int n_slabs;           // D / 64 (filled by the launcher)
 };
 // The process's hand-over error word (pinned, device-mapped host memory; created on first use): device pointer for the
 // kernels, and the host's view of it -- 0, or 1 + the region whose projection slab gave up waiting (rrt_device_error)
@@ -165,6 +182,13 @@ hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float*
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
                                 const float* mean_rstd, const float* logits, float* wdisp,
                                 float* rep, uint16_t* rep16, int prec16, int dim, int k, const GridDev& g8, hipStream_t st);
+// combine from the row records the last R-MSA layer's projection slabs left (FusedProj.part): x1 read once, no LayerNorm
+// arithmetic, no hand-over between blocks (crmsa.hip, crmsa_combine_parts_kernel)
+bool crmsa_combine_parts_supported(int dim, int k, const GridDev& g8);
+size_t crmsa_parts_floats(long n_tokens, int dim, int k);
+hipError_t launch_crmsa_combine_parts(const float* x1, const float* part, const float* gamma, const float* beta,
+                                      const float* phi, float* wdisp, float* rep, uint16_t* rep16, int prec16, int dim,
+                                      int k, const GridDev& g8, hipStream_t st);
 // mean_rstd == nullptr: x1 is LN(x1) already, region-major [Np8, dim] (crmsa_mlp path)
 hipError_t launch_crmsa_mlp_logits(const float* hid, const float* w2, float* logits, int rows, int hdim,
                                    int k, hipStream_t st);

@@ -44,7 +44,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool WT>
 __device__ __forceinline__ void store_o(f32x2* p, f32x2 v) {
-  if constexpr (WT) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  if constexpr (WT) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");   // (64 bits: no store-data hazard)
   else *p = v;
 }
 #define RRT_STORE_O(ptr, val) store_o<PROJ>((ptr), (val))   // (non-temporal stores measured: no gain)
@@ -54,7 +54,9 @@ __device__ __forceinline__ void store_o(f32x2* p, f32x2 v) {
 // the eight XCDs' L2s are not coherent with each other inside a launch -- crmsa.hip's hand-over note)
 template <bool WT>
 __device__ __forceinline__ void store_o(f32x4* p, f32x4 v) {
-  if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  // (+ the wait states a > 64-bit VMEM store needs before a VALU write may reuse its data registers: the compiler's hazard
+  // recogniser does not see through inline asm -- tools/experiments/inner_msa.hip found that the hard way)
+  if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   else *p = v;
 }
 
@@ -143,7 +145,7 @@ __device__ __forceinline__ void map_item(const int b, const int n_items, const i
 #ifndef RRT_PROJ_RQA
 #define RRT_PROJ_RQA 6
 #endif
-template <int MT>
+template <int MT, int KM>     // KM: CR-MSA representatives the by-product has registers for (0: none; k <= KM)
 __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const float* __restrict__ O, const int n_rows,
                                           const int P, const int D, const int heads_rt, const FusedProj& pj,
                                           char* smem RRT_SLAB_TRACE_ARG) {
@@ -175,7 +177,7 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
   // pj.spin_limit sleeps of ~0.2 us (product: 2^22, about a second -- five orders of magnitude over an item) the block
   // gives up, raises the process's hand-over error word (pinned host memory: the next C-ABI call that could launch this
   // kernel returns RRT_E_HANDOVER instead of queueing behind a wedged GPU) and leaves WITHOUT writing its slab.
-  int* const s_abort = (int*)(smem + LDS_MAIN_F * 4 + 1272);      // (behind the tap / bias tables, unused by the slab)
+  int* const s_abort = (int*)(smem + LDS_MAIN_F * 4 + 2048);      // (behind the tap / bias tables + the slab's gamma * phi table)
   if (tid == 0) {
     int spins = 0, bad = 0;
     while (__hip_atomic_load(pj.cnt + reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pj.wait_for) {
@@ -219,6 +221,15 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
     // is alone on its CU -- so the stages of the next NS - 1 K tiles are always in flight (with two stages every K tile
     // waited for its operands: the slab took as long as the separate launch's tile).  Barrier B_j = "stage j is in
     // registers everywhere, stage j + 1 has landed": stage j + NS goes into buffer j % NS right behind it.
+    if constexpr (KM > 0) {
+      // gamma[c] * phi[c, n] of this slab's 64 columns (zero for n >= k), for the compute waves' epilogue: [KM][64] floats
+      // behind the ring (the tap / bias tables of the item phases, dead now), published by the barriers of the K loop
+      float* const gpl = (float*)(smem + LDS_MAIN_F * 4);
+      for (int e = tid - 256; e < 64 * KM; e += 256) {
+        const int n = e >> 6, c = col * HD + (e & 63);
+        gpl[e] = n < pj.k ? pj.ln_g[c] * pj.phi[(size_t)c * pj.k + n] : 0.f;
+      }
+    }
     const int mine = (NA - lw + 3) / 4 + LB;        // DMA pieces this wave issues per stage (vmcnt counts them)
     // Issuing a stage takes a wave ~1.1 K cycles (6 or 7 pieces that block it ~160 cycles each), so the ring is filled
     // as the loop goes: stages 0 and 1, K tile 0 published, stage 2, and behind barrier B_kt stage kt + 3 -- into buffer
@@ -346,18 +357,97 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
 #pragma unroll
     for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(rq[i].x), "+v"(rq[i].y), "+v"(rq[i].z), "+v"(rq[i].w));
   }
+  if constexpr (KM == 0) {
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    float4 q;
-    if constexpr (PREF) q = rq[i];
-    else q = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
-    const float4 v = make_float4(acc[i][0] + bias.x + q.x, acc[i][1] + bias.y + q.y, acc[i][2] + bias.z + q.z, acc[i][3] + bias.w + q.w);
-    if (toff[i] >= 0) *(float4*)(pj.out + toff[i]) = v;
+    for (int i = 0; i < MT; ++i) {
+      float4 q;
+      if constexpr (PREF) q = rq[i];
+      else q = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
+      const float4 v = make_float4(acc[i][0] + bias.x + q.x, acc[i][1] + bias.y + q.y, acc[i][2] + bias.z + q.z, acc[i][3] + bias.w + q.w);
+      if (toff[i] >= 0) *(float4*)(pj.out + toff[i]) = v;
+    }
+    RRT_TRACE_MARK();                               // slab [9] stores issued
+  } else {
+    // ---- CR-MSA's first pass as a by-product (round 5): this block holds x1[token(m), 64 col .. 64 col + 63] of every row
+    // m of its region in registers -- the rows LayerNorm 2 and the logits <LN2(x1), phi_n> of modules/rmsa.py:303-307 are
+    // about to re-read from memory.  Per row and slab it leaves a record  (mean_64, M2_64, d_0 .. d_k-1):  mean and centred
+    // sum of squares of the row's 64 values here, and d_n = sum_c x1[c] * (gamma[c] phi[c, n]) -- merged over the D / 64
+    // slabs of a row (Chan et al.: exact in real arithmetic, no E[x^2] - E[x]^2 cancellation) they give mean, rstd and
+    //   logit_n = rstd * (sum_slabs d_n - mean * G_n) + B_n ,  G_n = sum_c gamma_c phi_cn ,  B_n = sum_c beta_c phi_cn
+    // (crmsa_combine_parts_kernel, crmsa.hip).  Lane (lr, lg) of column tile `wave` holds 4 values of row 16 i + lr: it
+    // writes (mean_4, M2_4, d_n over its 4 columns) to LDS -- the ring is dead: every fragment of the last K tile was in
+    // registers before the last barrier -- and one thread per row merges the row's 16 four-column parts in column order.
+    // (First form: lane-swap merges over lg in registers, (2 + k) x 2 v_permlane swaps per row with their wait states and
+    // a run-time k: 8.4 K cycles per slab, traced; this form: ~2.5 K.)
+    constexpr int NF = KM <= 2 ? 1 : KM <= 6 ? 2 : 3;   // float4s per part record: (m, q, d_0, d_1) (d_2 .. d_5) (d_6, d_7)
+    float4* const rec = (float4*)lds;                  // [16 parts][BM rows][NF]
+    const float* gpl = (const float*)(smem + LDS_MAIN_F * 4);      // [KM][64] gamma * phi of this slab's columns (loader waves)
+    float4 gp[KM];
+#pragma unroll
+    for (int n = 0; n < KM; ++n) gp[n] = *(const float4*)(gpl + n * 64 + wave * 16 + 4 * lg);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float4 q;
+      if constexpr (PREF) q = rq[i];
+      else q = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
+      const float4 v = make_float4(acc[i][0] + bias.x + q.x, acc[i][1] + bias.y + q.y, acc[i][2] + bias.z + q.z, acc[i][3] + bias.w + q.w);
+      if (toff[i] >= 0) *(float4*)(pj.out + toff[i]) = v;
+      const float m = ((v.x + v.y) + (v.z + v.w)) * 0.25f;
+      const float a = v.x - m, b = v.y - m, c = v.z - m, d = v.w - m;
+      float o[4 * NF];
+      o[0] = m;
+      o[1] = (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+      for (int n = 0; n < 4 * NF - 2; ++n)
+        o[2 + n] = n < KM ? (v.x * gp[n < KM ? n : 0].x + v.y * gp[n < KM ? n : 0].y) + (v.z * gp[n < KM ? n : 0].z + v.w * gp[n < KM ? n : 0].w) : 0.f;
+      float4* const r = rec + ((size_t)(wave * 4 + lg) * BM + i * 16 + lr) * NF;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) r[f] = make_float4(o[4 * f], o[4 * f + 1], o[4 * f + 2], o[4 * f + 3]);
+    }
+    RRT_TRACE_MARK();                               // slab [9] stores issued, part records in LDS
+    lds_barrier();                                  // (the four compute waves: the loader waves have left)
+    const int m_ = tid;                             // compute waves are threads 0 .. 255 >= BM rows
+    if (m_ < P) {
+      const int pi = fdiv(m_, pj.g.s, pj.g.inv_s), pjj = m_ - pi * pj.g.s;
+      const int t = tbase + pi * pj.g.H + pjj;
+      if (t < pj.g.L) {
+        float o[4 * NF];
+        {
+          const float4* r0 = rec + (size_t)m_ * NF;
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const float4 x = r0[f];
+            o[4 * f] = x.x; o[4 * f + 1] = x.y; o[4 * f + 2] = x.z; o[4 * f + 3] = x.w;
+          }
+        }
+#pragma unroll
+        for (int j = 1; j < 16; ++j) {                // Chan et al.: (4 j values) + (4 values), column order
+          const float4* rj = rec + ((size_t)j * BM + m_) * NF;
+          float x[4 * NF];
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const float4 y = rj[f];
+            x[4 * f] = y.x; x[4 * f + 1] = y.y; x[4 * f + 2] = y.z; x[4 * f + 3] = y.w;
+          }
+          const float dl = x[0] - o[0], w = 1.0f / (float)(j + 1);
+          o[0] += dl * w;
+          o[1] += x[1] + dl * dl * (4.0f * (float)j * w);
+#pragma unroll
+          for (int n = 2; n < 4 * NF; ++n) o[n] += x[n];
+        }
+        // the record leaves as float4s (stride: 2 + k rounded up to a multiple of 4 floats; the pad is never read)
+        const int nf = (2 + pj.k + 3) >> 2;
+        float4* dst = (float4*)(pj.part + ((size_t)t * pj.n_slabs + col) * (4 * nf));
+        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+        if constexpr (NF > 1) if (nf > 1) dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+        if constexpr (NF > 2) if (nf > 2) dst[2] = make_float4(o[8], o[9], o[10], o[11]);
+      }
+    }
+    RRT_TRACE_MARK();                               // slab [10] row records stored
   }
-  RRT_TRACE_MARK();                                 // slab [9] stores issued
 }
 
-template <int MT, int PREC, bool PROJ>
+template <int MT, int PREC, bool PROJ, int KM = 0>
 __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restrict__ U,
                                                             const float* __restrict__ Wqkv,
                                                             const float* __restrict__ bqkv,
@@ -1045,7 +1135,7 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
     if (tid == 0) __hip_atomic_fetch_add(pj.cnt + reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   }   // has_item
-  if constexpr (PROJ) proj_slab<MT>(U, O, n_rows, P, D, heads_rt, pj, smem RRT_SLAB_TRACE_PASS);
+  if constexpr (PROJ) proj_slab<MT, KM>(U, O, n_rows, P, D, heads_rt, pj, smem RRT_SLAB_TRACE_PASS);
 }
 
 // Blocks between an item and the slab of the same index: one block per CU runs at a time (LDS), so a lag of one
@@ -1077,23 +1167,39 @@ hipError_t launch_mt(const float* U, const float* Wqkv, const float* bqkv, const
   constexpr int BM = 16 * MT;
   constexpr size_t STG = (size_t)2 * (BM + BN) * BK * 4, QKV = (size_t)3 * BM * HD * 4;
   // staging ring / Q, K, V; tap table (512 B) + bias (768 B); shared-out tile (MT = 9): (max, sum) pairs + one partial O
-  constexpr size_t LDS = (STG > QKV ? STG : QKV) + 1280 + (MT == 9 ? MT * 32 * 4 + 16 * HD * 4 : 0);
+  // (PROJ: the slab's gamma * phi table [8][64] + its abort flag use the first 2052 bytes behind the ring)
+  constexpr size_t LDS = (STG > QKV ? STG : QKV) + (MT == 9 ? 1280 + MT * 32 * 4 + 16 * HD * 4 : 2064);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   const float q_scale = 1.0f / sqrtf((float)HD);
   if constexpr (PREC == PREC_F32) {
     if (proj != nullptr) {
-      auto kern = rmsa_fused_kernel<MT, PREC_F32, true>;
-      static OncePerDevice once;
-      if (once.first())
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
       FusedProj pj = *proj;
       pj.n_items = heads * n_regions;
       if (pj.lag <= 0) pj.lag = proj_lag(pj.n_items);
       if (pj.wait_for <= 0) pj.wait_for = heads;
+      pj.n_slabs = D / HD;
+      if (pj.part != nullptr && (pj.ln_g == nullptr || pj.phi == nullptr || pj.k < 1 || pj.k > RRT_MAX_CRMSA_K))
+        return hipErrorInvalidValue;
       if (pj.spin_limit <= 0) pj.spin_limit = 1 << 22;
       if (pj.err == nullptr) pj.err = handover_err_device();
-      kern<<<dim3(pj.n_items + pj.lag), dim3(512), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D, heads,
-                                                              pe_w ? epeg_k : 0, q_scale, nullptr, pj);
+#define RRT_LAUNCH_PROJ(KM_)                                                                                    \
+  do {                                                                                                           \
+    auto kern = rmsa_fused_kernel<MT, PREC_F32, true, KM_>;                                                      \
+    static OncePerDevice once;                                                                                   \
+    if (once.first())                                                                                            \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);        \
+    kern<<<dim3(pj.n_items + pj.lag), dim3(512), LDS, st>>>(U, Wqkv, bqkv, pe_w, O, n_regions * P, P, D, heads,  \
+                                                            pe_w ? epeg_k : 0, q_scale, nullptr, pj);            \
+  } while (0)
+      if constexpr (MT >= 6) {                       // (the merged launch starts at regions of > 64 tokens)
+        if (pj.part != nullptr && pj.k <= 4) RRT_LAUNCH_PROJ(4);
+        else if (pj.part != nullptr) RRT_LAUNCH_PROJ(8);
+        else RRT_LAUNCH_PROJ(0);
+      } else {
+        if (pj.part != nullptr) return hipErrorInvalidValue;
+        RRT_LAUNCH_PROJ(0);
+      }
+#undef RRT_LAUNCH_PROJ
       return hipGetLastError();
     }
   }

@@ -73,14 +73,17 @@ def test_encoder_plan_flags(lib):
         e._desc.compute = _lib.COMPUTE_F32
         return fl.value
     both = _lib.PLAN_FUSED | _lib.PLAN_FUSED_PROJ
-    assert plan(9000) == both and plan(5000) == both and plan(12000) == both
+    parts = both | _lib.PLAN_CRMSA_PARTS      # round 5: the merged launch of the last layer also leaves CR-MSA's row records
+    assert plan(9000) == parts and plan(5000) == parts and plan(12000) == parts
+    assert plan(9000, e=RRTEncoder(crmsa_mlp=True)) == both and plan(9000, e=RRTEncoder(ffn=True)) == both
+    assert plan(9000, e=RRTEncoder(cr_msa=False)) == both
     assert plan(3000) == _lib.PLAN_FUSED and plan(4096) == _lib.PLAN_FUSED     # regions of <= 64 tokens: two launches
     assert plan(15000) == 0 and plan(600) == 0                                  # regions outside the fused kernel's range
     assert plan(9000, _lib.COMPUTE_BF16) == _lib.PLAN_FUSED16
     assert plan(9000, _lib.COMPUTE_F32X3) == _lib.PLAN_FUSED_X3
-    assert plan(12000, _lib.COMPUTE_F32X3) == both                             # x3 covers P <= 144: exact kernels beyond
+    assert plan(12000, _lib.COMPUTE_F32X3) == parts                            # x3 covers P <= 144: exact kernels beyond
     assert plan(2000, e=RRTEncoder(region_num=4)) == _lib.PLAN_FUSED           # 16 regions: one round of items
-    assert plan(30000, e=RRTEncoder(region_num=16)) == both
+    assert plan(30000, e=RRTEncoder(region_num=16)) == parts
     assert lib.rrt_encoder_plan(C.byref(enc._desc), 9000, None) == -1
 
 

@@ -1143,6 +1143,184 @@ def test_rmsa_fused_proj_bounded_wait_reports_and_recovers():
     assert torch.isfinite(enc(x.unsqueeze(0))).all()
 
 
+@pytest.mark.parametrize("L,rn,k,shift", [(9000, 8, 3, 0.0), (9000, 8, 5, 30.0), (5000, 8, 1, 0.0), (12000, 8, 8, -7.0),
+                                          (30000, 16, 3, 0.0), (9000, 9, 3, 0.0)])
+def test_rmsa_fused_proj_stats_and_combine_parts(L, rn, k, shift):
+    """Round 5: the merged launch of the LAST R-MSA layer also leaves CR-MSA's row records -- per (token, 64-column slab) the
+    mean and centred sum of squares of x1 there and d_n = sum x1 gamma phi_n -- and rrt_crmsa_combine_parts_f32 turns them
+    and one pass over x1 into the dispatch weights and the representatives (rmsa.py:303-316).  (1) x1 is bit-identical to the
+    launch without the by-product; (2) the records against float64 on that x1; (3) wdisp / rep against the float64
+    restatement -- also with every row sitting at |mean| = 30 sigma (shift: the residual stream moved by a constant), where a
+    one-pass E[x^2] - E[x]^2 variance would lose three digits; (4) region_num = 16 / 9: the R-MSA grid is not CR-MSA's 8 x 8
+    grid, the records are per token."""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    D, heads, ek = 512, 8, 15
+    t = _fused_proj_case(L, rn, tag=f"st{k}")
+    g, Np, R = t["g"], t["Np"], t["R"]
+    res = t["res"] + shift
+    gm = dev(1.0 + synth.uniform("st/g", (D,), -0.3, 0.3))
+    bt = dev(synth.uniform("st/b", (D,), -0.2, 0.2))
+    phi = dev(synth.uniform("st/phi", (D, k), -1, 1) * (3.0 / np.sqrt(D)))
+    o2 = torch.full((Np, D), float("nan"), device=DEV)
+    cnt = torch.zeros((R,), device=DEV, dtype=torch.int32)
+    x1_plain = torch.full((L, D), float("nan"), device=DEV)
+    _lib.check(lib.rrt_rmsa_fused_proj_f32(p(t["u"]), p(t["W"]), p(t["b"]), p(t["pe"]), p(t["Wp"]), p(t["bp"]), p(res), p(x1_plain),
+                                           p(o2), p(cnt), D, heads, ek, C.byref(g), stream()), "rmsa_fused_proj")
+    K2, NS = (2 + k + 3) // 4 * 4, D // 64               # record stride: 2 + k floats rounded up to whole float4s
+    x1 = torch.full((L, D), float("nan"), device=DEV)
+    part = torch.full((L, NS, K2), float("nan"), device=DEV)
+    for _ in range(2):
+        _lib.check(lib.rrt_rmsa_fused_proj_stats_f32(p(t["u"]), p(t["W"]), p(t["b"]), p(t["pe"]), p(t["Wp"]), p(t["bp"]), p(res), p(x1),
+                                                     p(o2), p(cnt), p(gm), p(phi), k, p(part), D, heads, ek, C.byref(g), stream()),
+                   "rmsa_fused_proj_stats")
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x1_plain), "the by-product must not change x1"
+    x64 = x1.cpu().numpy().astype(np.float64)
+    xs = x64.reshape(L, NS, 64)
+    got = part.cpu().numpy().astype(np.float64)[..., :2 + k]
+    assert np.isfinite(got).all()
+    m_ref = xs.mean(-1)
+    q_ref = ((xs - m_ref[..., None]) ** 2).sum(-1)
+    gphi = (gm.cpu().numpy().astype(np.float64)[:, None] * phi.cpu().numpy().astype(np.float64)).reshape(NS, 64, k)
+    d_ref = np.einsum("tsc,sck->tsk", xs, gphi)
+    scale = max(1.0, abs(shift))
+    assert np.abs(got[..., 0] - m_ref).max() <= 2e-6 * scale
+    assert (np.abs(got[..., 1] - q_ref) / q_ref).max() <= 2e-5
+    assert np.abs(got[..., 2:] - d_ref).max() <= 2e-5 * scale
+    # combine from the records
+    g8 = _lib.region_grid(L, 8)
+    Np8, R8, P8 = g8.H * g8.H, 64, g8.s * g8.s
+    wd = torch.full((Np8, k), float("nan"), device=DEV)
+    rep = torch.full((k, R8, D), float("nan"), device=DEV)
+    gbs = torch.full((16,), float("nan"), device=DEV)
+    _lib.check(lib.rrt_crmsa_combine_parts_f32(p(x1), p(part), p(gm), p(bt), p(phi), p(wd), p(rep), L, D, k, C.byref(g8), stream()),
+               "crmsa_combine_parts")
+    torch.cuda.synchronize()
+    gm64, bt64, phi64 = (a.cpu().numpy().astype(np.float64) for a in (gm, bt, phi))
+    mu = x64.mean(-1, keepdims=True)
+    v = (x64 - mu) / np.sqrt(((x64 - mu) ** 2).mean(-1, keepdims=True) + 1e-5) * gm64 + bt64
+    perm = O.partition_index(g8.H, g8.s)
+    V = np.concatenate([v, np.zeros((g8.add, D))], 0)[perm].reshape(R8, P8, D)
+    Lg = (V @ phi64).transpose(0, 2, 1)
+    Cw = np.exp(Lg - Lg.max(-1, keepdims=True))
+    Cw /= Cw.sum(-1, keepdims=True)
+    tol = 2e-5 if shift == 0.0 else 2e-4           # (|mean| = 30 sigma: the logits carry ~30 x the rounding of the dot products)
+    _cmp(rep.cpu().numpy(), (Cw @ V).transpose(1, 0, 2), tol, "combine from the records")
+    Dw = np.exp(Lg - Lg.max(1, keepdims=True))
+    Dw /= Dw.sum(1, keepdims=True)
+    mn, mx = Lg.min(-1, keepdims=True), Lg.max(-1, keepdims=True)
+    _cmp(wd.cpu().numpy().reshape(R8, P8, k).transpose(0, 2, 1), (Lg - mn) / (mx - mn + 1e-8) * Dw, tol * 5,
+         "dispatch weights from the records")
+
+
+@pytest.mark.parametrize("L,rn,k,compute", [(9000, 8, 3, 1), (5000, 8, 1, 1), (12000, 8, 5, 2), (3000, 8, 8, 1), (8100, 9, 3, 1)])
+def test_linear16_stats_and_combine_parts(L, rn, k, compute):
+    """The 16-bit out-projection's un-partition epilogue with CR-MSA's row records (BF16 / F16 modes; rrt_linear16_stats_f32):
+    x1 bit-identical to the epilogue without them, the records against float64 on that x1, and the combine from the records
+    against the float64 restatement of rmsa.py:303-316 on that x1."""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    D = 512
+    g = _lib.region_grid(L, rn)
+    Np = g.H * g.H
+    o = synth.normal(f"l16s/o{Np}", (Np, D))
+    Wp = synth.uniform("l16s/wp", (D, D), -1, 1) / np.sqrt(D)
+    bp = synth.uniform("l16s/bp", (D,), -0.5, 0.5)
+    res = synth.normal(f"l16s/r{L}", (L, D))
+    d_o, d_Wp, d_bp, d_res = dev(o), dev(Wp), dev(bp), dev(res)
+    o16 = torch.empty((Np, D), dtype=torch.int16, device=DEV)
+    w16 = torch.empty((D, D), dtype=torch.int16, device=DEV)
+    _lib.check(lib.rrt_cast16(p(d_o), p(o16), Np * D, compute, stream()), "cast o")
+    _lib.check(lib.rrt_cast16(p(d_Wp), p(w16), D * D, compute, stream()), "cast w")
+    gm = dev(1.0 + synth.uniform("l16s/g", (D,), -0.3, 0.3))
+    bt = dev(synth.uniform("l16s/b", (D,), -0.2, 0.2))
+    phi = dev(synth.uniform("l16s/phi", (D, k), -1, 1) * (3.0 / np.sqrt(D)))
+    x1_plain = torch.full((L, D), float("nan"), device=DEV)
+    _lib.check(lib.rrt_linear16_f32(p(o16), p(w16), p(d_bp), p(d_res), p(x1_plain), Np, D, D, C.byref(g), compute, stream()), "linear16")
+    K2, NS = (2 + k + 3) // 4 * 4, D // 64
+    x1 = torch.full((L, D), float("nan"), device=DEV)
+    part = torch.full((L, NS, K2), float("nan"), device=DEV)
+    _lib.check(lib.rrt_linear16_stats_f32(p(o16), p(w16), p(d_bp), p(d_res), p(x1), p(gm), p(phi), k, p(part), Np, D, D, C.byref(g),
+                                          compute, stream()), "linear16_stats")
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x1_plain), "the by-product must not change x1"
+    x64 = x1.cpu().numpy().astype(np.float64)
+    xs = x64.reshape(L, NS, 64)
+    got = part.cpu().numpy().astype(np.float64)[..., :2 + k]
+    assert np.isfinite(got).all()
+    m_ref = xs.mean(-1)
+    q_ref = ((xs - m_ref[..., None]) ** 2).sum(-1)
+    gphi = (gm.cpu().numpy().astype(np.float64)[:, None] * phi.cpu().numpy().astype(np.float64)).reshape(NS, 64, k)
+    assert np.abs(got[..., 0] - m_ref).max() <= 2e-6
+    assert (np.abs(got[..., 1] - q_ref) / q_ref).max() <= 2e-5
+    assert np.abs(got[..., 2:] - np.einsum("tsc,sck->tsk", xs, gphi)).max() <= 2e-5
+    g8 = _lib.region_grid(L, 8)
+    Np8, R8, P8 = g8.H * g8.H, 64, g8.s * g8.s
+    wd = torch.full((Np8, k), float("nan"), device=DEV)
+    rep = torch.full((k, R8, D), float("nan"), device=DEV)
+    _lib.check(lib.rrt_crmsa_combine_parts_f32(p(x1), p(part), p(gm), p(bt), p(phi), p(wd), p(rep), L, D, k, C.byref(g8), stream()),
+               "crmsa_combine_parts")
+    torch.cuda.synchronize()
+    gm64, bt64, phi64 = (a.cpu().numpy().astype(np.float64) for a in (gm, bt, phi))
+    mu = x64.mean(-1, keepdims=True)
+    v = (x64 - mu) / np.sqrt(((x64 - mu) ** 2).mean(-1, keepdims=True) + 1e-5) * gm64 + bt64
+    perm = O.partition_index(g8.H, g8.s)
+    V = np.concatenate([v, np.zeros((g8.add, D))], 0)[perm].reshape(R8, P8, D)
+    Lg = (V @ phi64).transpose(0, 2, 1)
+    Cw = np.exp(Lg - Lg.max(-1, keepdims=True))
+    Cw /= Cw.sum(-1, keepdims=True)
+    _cmp(rep.cpu().numpy(), (Cw @ V).transpose(1, 0, 2), 2e-5, "combine from the records (16-bit projection)")
+    # shapes the by-product does not cover report
+    gbig = _lib.region_grid(20000, 8)
+    assert lib.rrt_linear16_stats_f32(p(o16), p(w16), p(d_bp), p(d_res), p(x1), p(gm), p(phi), k, p(part), gbig.H * gbig.H, D, D,
+                                      C.byref(gbig), compute, stream()) == -2
+
+
+@pytest.mark.parametrize("n_tokens,compute", [(5000, "bf16"), (9000, "bf16"), (9000, "f16"), (5000, "f32")])
+def test_two_bags_in_flight_bit_identical_to_one(n_tokens, compute):
+    """Two bags in flight through rrt_encoder_forward_f32 (two streams, two workspaces, forwards enqueued back to back so
+    that the kernels of the two bags really overlap) == the same bag alone, bit for bit.  Round 5 found the mechanism of
+    the round-2 'lanes 48..63' mis-sums with this loop: compiler-formed packed fp32 instructions (v_pk_fma_f32 with a
+    cross-half op_sel) in a streaming kernel return run-to-run different values when the wave shares its SIMD with
+    bf16-MFMA waves of the OTHER bag's kernels -- one (region, representative, 64 columns) chunk of CR-MSA's representatives
+    in ~1 of 2 forwards, 1e-3 on the output.  The streaming kernels are therefore compiled without packed fp32
+    (rrt-mil_amd/build.py FILE_FLAGS); this test is what failed before."""
+    from hip_util import DEV
+    lib = _lib.load()
+    cfg = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)
+    from hip_util import encoder_from_state
+    enc = encoder_from_state(synth.encoder_state(**cfg), cfg)
+    enc._desc.compute = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f16": _lib.COMPUTE_F16}[compute]
+    enc._desc.solo = 0
+    w = enc._weights()
+    x = torch.from_numpy(synth.bag(n_tokens, 512, tag="inflight")).to(DEV)
+    need = C.c_size_t()
+    _lib.check(lib.rrt_encoder_workspace_size(C.byref(enc._desc), n_tokens, C.byref(need)), "workspace size")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    wss = [torch.zeros(need.value, dtype=torch.uint8, device=DEV) for _ in streams]
+
+    def fwd(si, y, valid):
+        enc._desc.weights16_valid = valid
+        _lib.check(lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), x.data_ptr(), y.data_ptr(), n_tokens,
+                                               wss[si].data_ptr(), wss[si].numel(), streams[si].cuda_stream), "forward")
+    ref = torch.empty_like(x)
+    fwd(0, ref, 0)
+    torch.cuda.synchronize()
+    other = torch.empty_like(x)
+    fwd(1, other, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(ref, other)
+    for trial in range(3):
+        ys = [torch.empty_like(x) for _ in range(12)]
+        for i, y in enumerate(ys):
+            fwd(i % 2, y, 1)
+        torch.cuda.synchronize()
+        bad = [i for i, y in enumerate(ys) if not torch.equal(y, ref)]
+        assert not bad, f"trial {trial}: forwards {bad} of 12 differ from the bag alone (max {max(float((ys[i] - ref).abs().max()) for i in bad):.1e})"
+    enc._desc.weights16_valid = 0
+
+
 def test_bag_feeder_matches_direct_copy(tmp_path):
     """Row f3: pinned double-buffered H2D feed -- same bags, same order, same results as bag.to(device);
     accepts tensors and .pt paths (dataloader.py:181)."""

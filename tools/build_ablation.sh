@@ -1,15 +1,46 @@
 #!/bin/bash
 # tools/build_ablation.sh <name> <extra hipcc flags...>  -> tools/_abl/librrt_<name>.so (git-ignored; ships with gpurun)
+# Incremental: objects are kept under tools/_abl/obj_<name>/ with a stamp of (source + headers + flags); only what changed
+# is recompiled.
 set -e
 name=$1; shift
 cd "$(dirname "$0")/.."
-mkdir -p tools/_abl
-objs=""
-for f in $(python -c "import sys; sys.path.insert(0, 'rrt-mil_amd'); import build; print(' '.join(s[:-4] for s in build.SOURCES))"); do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c rrt-mil_amd/csrc/$f.hip -o tools/_abl/${name}_$f.o &
-  objs="$objs tools/_abl/${name}_$f.o"
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o tools/_abl/librrt_$name.so
-rm -f $objs
-echo tools/_abl/librrt_$name.so
+mkdir -p tools/_abl/obj_$name
+python - "$name" "$@" <<'PY'
+import hashlib, os, subprocess, sys
+sys.path.insert(0, "rrt-mil_amd")
+import build
+name, extra = sys.argv[1], sys.argv[2:]
+flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + extra
+od = f"tools/_abl/obj_{name}"
+hd = hashlib.sha256(" ".join(flags).encode())
+for h in build.HEADERS:
+    hd.update(open(os.path.join(build.CSRC, h), "rb").read())
+procs, objs = [], []
+for src in build.SOURCES:
+    obj = os.path.join(od, src.replace(".hip", ".o"))
+    objs.append(obj)
+    d = hd.copy()
+    d.update(" ".join(build.FILE_FLAGS.get(src, [])).encode())
+    d.update(open(os.path.join(build.CSRC, src), "rb").read())
+    dig = d.hexdigest()
+    st = obj + ".stamp"
+    if os.path.exists(obj) and os.path.exists(st) and open(st).read().strip() == dig:
+        continue
+    if os.path.exists(st):
+        os.remove(st)
+    procs.append((src, st, dig, subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, *build.FILE_FLAGS.get(src, []), "-c", os.path.join(build.CSRC, src), "-o", obj],
+                                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+bad = False
+for src, st, dig, p in procs:
+    out, _ = p.communicate()
+    if p.returncode:
+        print(f"hipcc failed on {src}:\n" + "\n".join(l for l in out.decode().splitlines() if "not a recognized feature" not in l))
+        bad = True
+    else:
+        open(st, "w").write(dig)
+if bad:
+    sys.exit(1)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", f"tools/_abl/librrt_{name}.so"], check=True)
+print(f"tools/_abl/librrt_{name}.so ({len(procs)} recompiled)")
+PY

@@ -19,7 +19,15 @@ Wp = torch.randn(D, D, device="cuda") / D ** 0.5; bp = torch.randn(D, device="cu
 res = torch.randn(N, D, device="cuda"); out = torch.empty(N, D, device="cuda")
 o = torch.empty(Np, D, device="cuda"); cnt = torch.zeros(R, device="cuda", dtype=torch.int32)
 st = torch.cuda.current_stream().cuda_stream
-call = lambda: _lib.check(lib.rrt_rmsa_fused_proj_f32(u.data_ptr(), W.data_ptr(), b.data_ptr(), pe.data_ptr(), Wp.data_ptr(), bp.data_ptr(),
+K = int(os.environ.get("TRACE_STATS_K", "0"))          # > 0: with CR-MSA's row records as a by-product (k representatives)
+gm2 = torch.randn(D, device="cuda"); phi = torch.randn(D, max(K, 1), device="cuda") * 0.1
+part = torch.empty(N * (D // 64) * (2 + max(K, 1)), device="cuda")
+if K > 0:
+    call = lambda: _lib.check(lib.rrt_rmsa_fused_proj_stats_f32(u.data_ptr(), W.data_ptr(), b.data_ptr(), pe.data_ptr(), Wp.data_ptr(),
+                                                                bp.data_ptr(), res.data_ptr(), out.data_ptr(), o.data_ptr(), cnt.data_ptr(),
+                                                                gm2.data_ptr(), phi.data_ptr(), K, part.data_ptr(), D, H, ek, C.byref(g), st))
+else:
+  call = lambda: _lib.check(lib.rrt_rmsa_fused_proj_f32(u.data_ptr(), W.data_ptr(), b.data_ptr(), pe.data_ptr(), Wp.data_ptr(), bp.data_ptr(),
                                                       res.data_ptr(), out.data_ptr(), o.data_ptr(), cnt.data_ptr(), D, H, ek, C.byref(g), st))
 for _ in range(3):
     call()
