@@ -104,7 +104,9 @@ typedef struct rrt_encoder_desc {
   int32_t weights16_valid;
   /* Scheduling hint.  Results are deterministic for a given setting and equal between the two settings up to fp32 summation
    * order: with 1 the representatives' two small GEMMs sum K in four interleaved groups (linear_splitk), so low-order
-   * bits of the output may differ from a solo = 0 forward of the same bag (both within ~1e-6 of the float64 oracle);
+   * bits of the output may differ from a solo = 0 forward of the same bag (both within ~1e-6 of the float64 oracle); with 1 the
+   * last R-MSA layer's merged launch also leaves CR-MSA's LayerNorm statistics / logit products (RRT_PLAN_CRMSA_PARTS), which
+   * are then merged slab-wise instead of summed row-wise (same distance);
    * callers that compare bits across entry points use one setting (RRTEncoder.solo; the executor uses 0 unless it has
    * exactly one stream).  0 (default): other work may share the GPU with this forward (more bags in
    * flight on other streams): every kernel of the latency-bound CR-MSA tail keeps a footprint that fits NEXT TO a block
@@ -263,7 +265,8 @@ int rrt_rmsa_fused_proj_f32(const float *u, const float *qkv_w, const float *qkv
                             float *o_scratch, int32_t *counters, int32_t dim, int32_t heads, int32_t epeg_k,
                             const rrt_grid *g, void *stream);
 /* ... and CR-MSA's first pass as a by-product (what rrt_encoder_forward_f32 does for the LAST R-MSA layer when a plain-phi
- * CR-MSA follows it directly): out = x1 is CR-MSA's input, and the slabs hold its tiles in registers -- per (token t,
+ * CR-MSA with k <= 4 follows it directly and desc.solo != 0 -- it trades ~3 us of the merged launch's matrix-pipe time for
+ * ~6 us of latency-bound CR-MSA front: a gain with one bag in flight, none with four): out = x1 is CR-MSA's input, and the slabs hold its tiles in registers -- per (token t,
  * 64-column slab c) they also store the record  part[(t * dim / 64 + c) * S ..] = (mean, M2, d_0 .. d_k-1), S = 2 + k rounded
  * up to a multiple of 4:  mean and
  * centred sum of squares of x1[t, 64 c .. 64 c + 63], d_n = sum_j x1[t, j] ln2_gamma[j] phi[j, n] over those columns
@@ -314,13 +317,6 @@ int rrt_ln_partition16(const float *x, const float *gamma, const float *beta, ui
                        int32_t dim, const rrt_grid *g, int32_t compute, void *stream);
 int rrt_linear16_f32(const uint16_t *A, const uint16_t *B, const float *bias, const float *resid, float *C,
                      int64_t M, int32_t N, int32_t K, const rrt_grid *g, int32_t compute, void *stream);
-/* rrt_linear16_f32's un-partition + residual epilogue with CR-MSA's row records as a by-product (see
- * rrt_rmsa_fused_proj_stats_f32: same records, same reader rrt_crmsa_combine_parts_f32): what rrt_encoder_forward_f32 does
- * for the LAST R-MSA layer in the BF16 / F16 modes when a plain-phi CR-MSA follows it directly and the product's 64-column
- * tiles are all resident at once (bags of up to ~13.7 k tokens at N = K = 512); otherwise RRT_E_UNSUPPORTED. */
-int rrt_linear16_stats_f32(const uint16_t *A, const uint16_t *B, const float *bias, const float *resid, float *C,
-                           const float *ln2_gamma, const float *phi, int32_t crmsa_k, float *part, int64_t M,
-                           int32_t N, int32_t K, const rrt_grid *g, int32_t compute, void *stream);
 int rrt_rmsa_fused16(const uint16_t *u, const uint16_t *qkv_w, const float *qkv_b, const float *pe_w,
                      uint16_t *o, int32_t n_regions, int32_t P, int32_t dim, int32_t heads, int32_t epeg_k,
                      int32_t compute, void *stream);

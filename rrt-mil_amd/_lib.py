@@ -116,8 +116,6 @@ SIGNATURES = {
                                      C.POINTER(Grid), C.c_int32, C.c_void_p]),
     "rrt_linear16_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_int32,
                                                       C.c_void_p]),
-    "rrt_linear16_stats_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid),
-                                                       C.c_int32, C.c_void_p]),
     "rrt_rmsa_fused16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
     "rrt_cast_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rrt_ln_partition_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,

@@ -257,7 +257,8 @@ int rrt_encoder_plan(const rrt_encoder_desc* desc, int64_t n_tokens, int32_t* fl
     if (compute == RRT_COMPUTE_F32 && rmsa_fused_proj_supported(gd.rs * gd.rs, gd.P, D, desc->n_heads, ek, compute)) {
       *flags |= RRT_PLAN_FUSED_PROJ;
       rrt_grid g8{};
-      if (rrt_region_grid(n_tokens, 8, 0, 0, 0.f, &g8) == RRT_OK && desc->cr_msa && !desc->crmsa_mlp && !desc->ffn && D % 64 == 0 &&
+      if (rrt_region_grid(n_tokens, 8, 0, 0, 0.f, &g8) == RRT_OK && desc->solo != 0 && desc->crmsa_k <= 4 && desc->cr_msa &&
+          !desc->crmsa_mlp && !desc->ffn && D % 64 == 0 &&
           crmsa_combine_parts_supported(D, desc->crmsa_k, to_dev(g8)))
         *flags |= RRT_PLAN_CRMSA_PARTS;
     }
@@ -307,8 +308,12 @@ static int ffn_apply(const rrt_encoder_desc* desc, const rrt_attn_weights& lw, c
 
 // CR-MSA's first pass as a by-product of the last R-MSA layer's projection slabs: that layer's output must BE CR-MSA's
 // input (no FFN behind the attention, not the batch entry point's per-bag stop), phi a plain parameter, 64-column slabs
+// ... and the forward has the GPU to itself (rrt_encoder_desc.solo): the statistics cost the merged launch ~3 us of matrix-pipe
+// time and save ~6 us of the latency-bound CR-MSA front -- one bag in flight 0.2238 -> 0.2218 ms, but with four bags in
+// flight the tail hides behind other bags' tails anyway and the matrix pipe is the scarce thing: 5.26 k against 5.31 k
+// slides/s (round 5, same box); likewise k > 4 representatives (twice the record) stay with the region kernels
 static bool crmsa_parts_wanted(const rrt_encoder_desc& d, const Workspace& ws, const GridDev& g8, bool stops_before_crmsa) {
-  return d.cr_msa && !d.crmsa_mlp && !d.ffn && !stops_before_crmsa && ws.cr_pstat != nullptr &&
+  return d.solo != 0 && d.cr_msa && !d.crmsa_mlp && !d.ffn && d.crmsa_k <= 4 && !stops_before_crmsa && ws.cr_pstat != nullptr &&
          crmsa_combine_parts_supported(d.dim, d.crmsa_k, g8);
 }
 
@@ -462,18 +467,6 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       ep.resid = xin;
       ep.g = gd;
       ep.zero64 = ws.cr_cnt;
-      // the LAST R-MSA layer feeding CR-MSA directly: the un-partition epilogue also leaves LayerNorm 2's statistics and
-      // the logits' dot products of every row (x1 is in its registers) -- CR-MSA's first pass shrinks to the combine
-      if (li == desc->n_rmsa_layers - 1 && crmsa_parts_wanted(*desc, ws, to_dev(g8), rmsa_out != nullptr) &&
-          linear16_parts_supported(gd.Np, D, D)) {
-        if (!w->crmsa.norm_w || !w->crmsa.norm_b || !w->phi) return RRT_E_INVALID;
-        ep.part = ws.cr_pstat;
-        ep.ln_g = w->crmsa.norm_w;
-        ep.phi = w->phi;
-        ep.k = desc->crmsa_k;
-        static const bool ignore = rrt_tune_env("RRT_DBG_PARTS_IGNORE") != nullptr;   // (bisecting: records written, not used)
-        parts_done = !ignore;
-      }
       RRT_TRY(launch_linear16(o16, wq16 + (size_t)3 * D * D, xout, gd.Np, D, D, ep, st));
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;
@@ -1104,30 +1097,6 @@ int rrt_linear16_f32(const uint16_t* A, const uint16_t* B, const float* bias, co
     ep.g = to_dev(*g);
     if (M != ep.g.Np) return RRT_E_INVALID;
   }
-  return (int)launch_linear16(A, B, C, (int)M, N, K, ep, (hipStream_t)stream);
-}
-
-int rrt_linear16_stats_f32(const uint16_t* A, const uint16_t* B, const float* bias, const float* resid, float* C,
-                           const float* ln2_gamma, const float* phi, int32_t crmsa_k, float* part, int64_t M, int32_t N,
-                           int32_t K, const rrt_grid* g, int32_t compute, void* stream) {
-  if (!A || !B || !C || !resid || !g || !ln2_gamma || !phi || !part || M <= 0 || N <= 0 || K <= 0 || crmsa_k < 1 ||
-      crmsa_k > RRT_MAX_CRMSA_K)
-    return RRT_E_INVALID;
-  if (K % 64) return unsupported("linear16: K must be a multiple of 64");
-  if (compute != RRT_COMPUTE_BF16 && compute != RRT_COMPUTE_F16) return unsupported("compute must be BF16 or F16");
-  LinearEpilogue ep{};
-  ep.prec = compute;
-  ep.bias = bias;
-  ep.resid = resid;
-  ep.g = to_dev(*g);
-  if (M != ep.g.Np) return RRT_E_INVALID;
-  if (!linear16_parts_supported((int)M, N, K))
-    return unsupported("linear16_stats: needs N % 64 == 0, N <= 512 and a product whose 64-column tiles are all resident at once "
-                       "(bags of up to ~13.7 k tokens at N = K = 512)");
-  ep.part = part;
-  ep.ln_g = ln2_gamma;
-  ep.phi = phi;
-  ep.k = crmsa_k;
   return (int)launch_linear16(A, B, C, (int)M, N, K, ep, (hipStream_t)stream);
 }
 

@@ -53,16 +53,7 @@ struct LinearEpilogue {
   int* zero64;
   // scheduling hint (rrt_encoder_desc.solo): this GEMM may use whole CUs (small-M GEMMs: split K inside a 16-wave block)
   bool solo;
-  // CR-MSA's first pass as a by-product of the un-partition epilogue (null: off; 16-bit-operand GEMMs whose tiles are
-  // 64 columns wide and all resident at once: linear16_parts_supported) -- the row records of FusedProj.part, same layout
-  float* part;
-  const float* ln_g;     // the CR-MSA TransLayer's LayerNorm weight [N]
-  const float* phi;      // [N, k]
-  int k;
 };
-// whether launch_linear16's un-partition epilogue can leave the row records for these shapes (its tile rule picks
-// 64-column tiles with one tile per block: bags of up to ~13.7 k tokens at N = K = 512)
-bool linear16_parts_supported(int M, int N, int K);
 hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N, int K,
                          const LinearEpilogue& ep, hipStream_t st);
 

@@ -282,102 +282,6 @@ __device__ __forceinline__ void store_unpart_batched(const f32x4 (&acc)[MT][NT],
   }
 }
 
-// store_unpart_batched for 64-column tiles (NT = 1) with CR-MSA's row records as a by-product (round 5; the out-projection
-// slabs of rmsa_fused_kernel do the same, see proj_slab there): the tile holds x1[token(slot m0 + m), n0 .. n0 + 63] of its
-// BM rows in registers -- per row and 64-column slab it leaves (mean_64, M2_64, d_0 .. d_k-1), d_n = sum_c x1[c] gamma[c]
-// phi[c, n], for crmsa_combine_parts_kernel.  Lane (lr, lg) of column tile `wave` writes the statistics of its 4 values of
-// row 16 i + lr to LDS (the operand ring: dead, this is the block's only tile), one thread per row merges the row's 16
-// four-column parts in column order (Chan et al.) and stores the record.  gpl [KM][64]: gamma * phi of the tile's columns.
-template <int MT, int KM>
-__device__ __forceinline__ void store_unpart_parts(const f32x4 (&acc)[MT][1], const float (&bias)[1][4], float* __restrict__ C,
-                                                   int M, int N, int m0, int n0, int wave, int lr, int lg,
-                                                   const LinearEpilogue& ep, float* lds, const float* gpl) {
-  constexpr int BM = 16 * MT, CH = 8;
-  constexpr int NF = KM <= 2 ? 1 : KM <= 6 ? 2 : 3;      // float4s per part record: (m, q, d_0, d_1) (d_2 .. d_5) (d_6, d_7)
-  const int ncol = n0 + wave * 16 + 4 * lg;
-  float4* const rec = (float4*)lds;                       // [16 parts][BM rows][NF]
-  float4 gp[KM];
-#pragma unroll
-  for (int n = 0; n < KM; ++n) gp[n] = *(const float4*)(gpl + n * 64 + wave * 16 + 4 * lg);
-#pragma unroll
-  for (int i0 = 0; i0 < MT; i0 += CH) {
-    long off[CH];
-    float4 rq[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      if (i0 + c < MT) {
-        const int m = m0 + (i0 + c) * 16 + lr;
-        int t = -1;
-        if (m < M) {
-          t = slot_to_token(m, ep.g);
-          if (t >= ep.g.L) t = -1;               // pad slot: nothing to write
-        }
-        off[c] = t < 0 ? -1L : (long)t * N + ncol;
-        rq[c] = *(const float4*)(ep.resid + (off[c] < 0 ? (long)ncol : off[c]));
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-      if (i0 + c < MT) asm volatile("" : "+v"(rq[c].x), "+v"(rq[c].y), "+v"(rq[c].z), "+v"(rq[c].w));
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      if (i0 + c < MT) {
-        const f32x4 a = acc[i0 + c][0];
-        const float4 q = rq[c];
-        const float4 v = make_float4(a[0] + bias[0][0] + q.x, a[1] + bias[0][1] + q.y, a[2] + bias[0][2] + q.z, a[3] + bias[0][3] + q.w);
-        if (off[c] >= 0) *(float4*)(C + off[c]) = v;
-        const float m = ((v.x + v.y) + (v.z + v.w)) * 0.25f;
-        const float d0 = v.x - m, d1 = v.y - m, d2 = v.z - m, d3 = v.w - m;
-        float o[4 * NF];
-        o[0] = m;
-        o[1] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-#pragma unroll
-        for (int n = 0; n < 4 * NF - 2; ++n)
-          o[2 + n] = n < KM ? (v.x * gp[n < KM ? n : 0].x + v.y * gp[n < KM ? n : 0].y) + (v.z * gp[n < KM ? n : 0].z + v.w * gp[n < KM ? n : 0].w) : 0.f;
-        float4* const r = rec + ((size_t)(wave * 4 + lg) * BM + (i0 + c) * 16 + lr) * NF;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) r[f] = make_float4(o[4 * f], o[4 * f + 1], o[4 * f + 2], o[4 * f + 3]);
-      }
-    }
-  }
-  lds_sync();                                             // (compute waves only: the loader waves have left)
-  const int m_ = wave * 64 + (lg << 4 | lr);              // compute waves are threads 0 .. 255 >= BM rows
-  if (m_ < BM && m0 + m_ < M) {
-    const int t = slot_to_token(m0 + m_, ep.g);
-    if (t < ep.g.L) {
-      float o[4 * NF];
-      {
-        const float4* r0 = rec + (size_t)m_ * NF;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const float4 x = r0[f];
-          o[4 * f] = x.x; o[4 * f + 1] = x.y; o[4 * f + 2] = x.z; o[4 * f + 3] = x.w;
-        }
-      }
-#pragma unroll
-      for (int j = 1; j < 16; ++j) {                      // (4 j values) + (4 values), column order
-        const float4* rj = rec + ((size_t)j * BM + m_) * NF;
-        float x[4 * NF];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const float4 y = rj[f];
-          x[4 * f] = y.x; x[4 * f + 1] = y.y; x[4 * f + 2] = y.z; x[4 * f + 3] = y.w;
-        }
-        const float dl = x[0] - o[0], w = 1.0f / (float)(j + 1);
-        o[0] += dl * w;
-        o[1] += x[1] + dl * dl * (4.0f * (float)j * w);
-#pragma unroll
-        for (int n = 2; n < 4 * NF; ++n) o[n] += x[n];
-      }
-      const int nf = (2 + ep.k + 3) >> 2;
-      float4* dst = (float4*)(ep.part + ((size_t)t * (N >> 6) + (n0 >> 6)) * (4 * nf));
-      dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-      if constexpr (NF > 1) if (nf > 1) dst[1] = make_float4(o[4], o[5], o[6], o[7]);
-      if constexpr (NF > 2) if (nf > 2) dst[2] = make_float4(o[8], o[9], o[10], o[11]);
-    }
-  }
-}
-
 template <int MT, int NT, int MODE, int I = 0>
 __device__ __forceinline__ void store_all_slices(const f32x4 (&acc)[MT][NT], const float (&bias)[NT][4],
                                                  float* __restrict__ C, int M, int N, int m0, int n0,
@@ -561,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float* __restrict_
 // sub-tile) and nothing is converted in the loop.
 // NLW: loader waves (2 for the MFMA-bound fp32 forms; 4 for 16-bit operands, whose K loop is bound by how many LDS-DMA
 // pieces the CU keeps in flight -- tools/ubench/dma_rows.hip: 14 B/clk/CU with four issuing waves, 21 with eight)
-template <int MT, int NT, int MODE, int PREC, bool IN16 = false, bool DEFER = true, int NLW = 2, int KM = 0>
+template <int MT, int NT, int MODE, int PREC, bool IN16 = false, bool DEFER = true, int NLW = 2>
 __global__ __launch_bounds__(64 * (4 + NLW), 2)
 void linear_ws_kernel(const void* __restrict__ Av,
                                                            const void* __restrict__ Bv,
@@ -591,19 +495,6 @@ void linear_ws_kernel(const void* __restrict__ Av,
   if (ep.zero64 != nullptr && blockIdx.x == 0 && threadIdx.x < 64) ep.zero64[threadIdx.x] = 0;
   if (first >= ntiles) return;
   const int nk = K / BKE;
-  // KM > 0 (un-partition epilogue with CR-MSA's row records, one 64-column tile per block): gamma[c] * phi[c, n] of the
-  // tile's columns (zero for n >= k) behind the operand ring and the records' area, published by the K loop's barriers
-  constexpr int REC_BYTES = KM > 0 ? 16 * BM * (KM <= 2 ? 1 : KM <= 6 ? 2 : 3) * 16 : 0;
-  constexpr int GPL_OFF = 2 * STAGE * 4 > REC_BYTES ? 2 * STAGE * 4 : REC_BYTES;
-  if constexpr (KM > 0) {
-    static_assert(MODE == MODE_UNPART && NT == 1 && !DEFER, "row records: 64-column tiles, one per block");
-    float* const gpl = (float*)(smem + GPL_OFF);
-    const int n0g = (first % tiles_n) * BN;
-    for (int e = threadIdx.x; e < 64 * KM; e += 64 * (4 + NLW)) {
-      const int n = e >> 6, c = n0g + (e & 63);
-      gpl[e] = n < ep.k ? ep.ln_g[c] * ep.phi[(size_t)c * ep.k + n] : 0.f;
-    }
-  }
   RRT_TRACE_INIT(blockIdx.x * (4 + NLW) + wave);
   RRT_TRACE_MARK();                                   // [1] entry
 
@@ -1108,14 +999,8 @@ void linear_ws_kernel(const void* __restrict__ Av,
     for (int kt = 0; kt < nk; ++kt, ++it) kstep(kt);
     if constexpr (!DEFER) {
       RRT_TRACE_MARK();                               // compute: last MFMA of the tile issued
-      if constexpr (KM > 0) {
-        // (every wave's fragment reads of the last K tile are done before the ring becomes the records' area)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        store_unpart_parts<MT, KM>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep, lds, (const float*)(smem + GPL_OFF));
-      } else {
-        if (MODE == MODE_UNPART && pref_ok) store_unpart_batched<MT, NT>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep);
-        else store_all_slices<MT, NT, MODE>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep);
-      }
+      if (MODE == MODE_UNPART && pref_ok) store_unpart_batched<MT, NT>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep);
+      else store_all_slices<MT, NT, MODE>(acc, cbias, C, M, N, m0, n0, wave, lr, lg, ep);
       RRT_TRACE_MARK();
     }
     if constexpr (DEFER) {
@@ -1285,25 +1170,6 @@ hipError_t launch_cfg16(const void* A, const void* B, float* C, int M, int N, in
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
   const int grid = ntiles < grid_cap ? ntiles : grid_cap;
-  if constexpr (MODE == MODE_UNPART && NT == 1) {
-    if (ep.part != nullptr) {                          // ... with CR-MSA's row records (linear16_parts_supported)
-      if (ntiles > grid || N % 64 || ep.q_cols != 0 || !ep.ln_g || !ep.phi || ep.k < 1 || ep.k > RRT_MAX_CRMSA_K) return hipErrorInvalidValue;
-#define RRT_PARTS16(KM_)                                                                                          \
-  do {                                                                                                            \
-    constexpr int REC = 16 * BM * (KM_ <= 6 ? 2 : 3) * 16;                                                        \
-    constexpr int LDSP = (LDS_BYTES > REC ? LDS_BYTES : REC) + 64 * KM_ * 4;                                      \
-    static_assert(LDSP <= 160 * 1024, "LDS budget (KM = 8 at 144 rows: one block per CU)");                       \
-    auto kp = linear_ws_kernel<MT, NT, MODE, PREC, true, false, NLW16, KM_>;                                      \
-    RRT_ALLOW_LDS(kp, LDSP);                                                                                      \
-    kp<<<dim3(grid), dim3(64 * (4 + NLW16)), LDSP, st>>>(A, B, C, M, N, K, tiles_n, ntiles, ep);                  \
-  } while (0)
-      if (ep.k <= 4) RRT_PARTS16(4);
-      else RRT_PARTS16(8);
-#undef RRT_PARTS16
-      return hipGetLastError();
-    }
-  }
-  if (ep.part != nullptr) return hipErrorInvalidValue;
   if (ntiles <= grid) {                                // no block gets a second tile: nothing to defer
     auto kws = linear_ws_kernel<MT, NT, MODE, PREC, true, false, NLW16>;
     RRT_ALLOW_LDS(kws, LDS_BYTES);
@@ -1491,13 +1357,6 @@ static Cfg choose16(int M, int N, int K) {
     if (sscanf(e, "%d,%d,%d", &q.mt, &q.nt, &q.cap) == 3) best = q;
   }
   return best;
-}
-
-bool linear16_parts_supported(int M, int N, int K) {
-  if (N % 64 || N > 512 || K % 64) return false;
-  const Cfg c = choose16(M, N, K);
-  const long tiles = (long)((M + 16 * c.mt - 1) / (16 * c.mt)) * (N / 64);
-  return c.nt == 1 && tiles <= c.cap && (c.mt == 4 || c.mt == 6 || c.mt == 9);
 }
 
 // C[M,N] fp32 = A16[M,K] . B16[N,K]^T with the operands already in 16 bits (ep.prec = 1 bf16 / 2 fp16); the

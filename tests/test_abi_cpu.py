@@ -67,8 +67,9 @@ def test_encoder_plan_flags(lib):
     enc = RRTEncoder()
     fl = C.c_int32(-1)
 
-    def plan(n, compute=_lib.COMPUTE_F32, e=enc):
+    def plan(n, compute=_lib.COMPUTE_F32, e=enc, solo=1):
         e._desc.compute = compute
+        e._desc.solo = solo
         assert lib.rrt_encoder_plan(C.byref(e._desc), n, C.byref(fl)) == 0
         e._desc.compute = _lib.COMPUTE_F32
         return fl.value
@@ -76,7 +77,7 @@ def test_encoder_plan_flags(lib):
     parts = both | _lib.PLAN_CRMSA_PARTS      # round 5: the merged launch of the last layer also leaves CR-MSA's row records
     assert plan(9000) == parts and plan(5000) == parts and plan(12000) == parts
     assert plan(9000, e=RRTEncoder(crmsa_mlp=True)) == both and plan(9000, e=RRTEncoder(ffn=True)) == both
-    assert plan(9000, e=RRTEncoder(cr_msa=False)) == both
+    assert plan(9000, e=RRTEncoder(cr_msa=False)) == both and plan(9000, solo=0) == both and plan(9000, e=RRTEncoder(crmsa_k=5)) == both
     assert plan(3000) == _lib.PLAN_FUSED and plan(4096) == _lib.PLAN_FUSED     # regions of <= 64 tokens: two launches
     assert plan(15000) == 0 and plan(600) == 0                                  # regions outside the fused kernel's range
     assert plan(9000, _lib.COMPUTE_BF16) == _lib.PLAN_FUSED16

@@ -1214,69 +1214,6 @@ def test_rmsa_fused_proj_stats_and_combine_parts(L, rn, k, shift):
          "dispatch weights from the records")
 
 
-@pytest.mark.parametrize("L,rn,k,compute", [(9000, 8, 3, 1), (5000, 8, 1, 1), (12000, 8, 5, 2), (3000, 8, 8, 1), (8100, 9, 3, 1)])
-def test_linear16_stats_and_combine_parts(L, rn, k, compute):
-    """The 16-bit out-projection's un-partition epilogue with CR-MSA's row records (BF16 / F16 modes; rrt_linear16_stats_f32):
-    x1 bit-identical to the epilogue without them, the records against float64 on that x1, and the combine from the records
-    against the float64 restatement of rmsa.py:303-316 on that x1."""
-    from hip_util import dev, p, stream, DEV
-    lib = _lib.load()
-    D = 512
-    g = _lib.region_grid(L, rn)
-    Np = g.H * g.H
-    o = synth.normal(f"l16s/o{Np}", (Np, D))
-    Wp = synth.uniform("l16s/wp", (D, D), -1, 1) / np.sqrt(D)
-    bp = synth.uniform("l16s/bp", (D,), -0.5, 0.5)
-    res = synth.normal(f"l16s/r{L}", (L, D))
-    d_o, d_Wp, d_bp, d_res = dev(o), dev(Wp), dev(bp), dev(res)
-    o16 = torch.empty((Np, D), dtype=torch.int16, device=DEV)
-    w16 = torch.empty((D, D), dtype=torch.int16, device=DEV)
-    _lib.check(lib.rrt_cast16(p(d_o), p(o16), Np * D, compute, stream()), "cast o")
-    _lib.check(lib.rrt_cast16(p(d_Wp), p(w16), D * D, compute, stream()), "cast w")
-    gm = dev(1.0 + synth.uniform("l16s/g", (D,), -0.3, 0.3))
-    bt = dev(synth.uniform("l16s/b", (D,), -0.2, 0.2))
-    phi = dev(synth.uniform("l16s/phi", (D, k), -1, 1) * (3.0 / np.sqrt(D)))
-    x1_plain = torch.full((L, D), float("nan"), device=DEV)
-    _lib.check(lib.rrt_linear16_f32(p(o16), p(w16), p(d_bp), p(d_res), p(x1_plain), Np, D, D, C.byref(g), compute, stream()), "linear16")
-    K2, NS = (2 + k + 3) // 4 * 4, D // 64
-    x1 = torch.full((L, D), float("nan"), device=DEV)
-    part = torch.full((L, NS, K2), float("nan"), device=DEV)
-    _lib.check(lib.rrt_linear16_stats_f32(p(o16), p(w16), p(d_bp), p(d_res), p(x1), p(gm), p(phi), k, p(part), Np, D, D, C.byref(g),
-                                          compute, stream()), "linear16_stats")
-    torch.cuda.synchronize()
-    assert torch.equal(x1, x1_plain), "the by-product must not change x1"
-    x64 = x1.cpu().numpy().astype(np.float64)
-    xs = x64.reshape(L, NS, 64)
-    got = part.cpu().numpy().astype(np.float64)[..., :2 + k]
-    assert np.isfinite(got).all()
-    m_ref = xs.mean(-1)
-    q_ref = ((xs - m_ref[..., None]) ** 2).sum(-1)
-    gphi = (gm.cpu().numpy().astype(np.float64)[:, None] * phi.cpu().numpy().astype(np.float64)).reshape(NS, 64, k)
-    assert np.abs(got[..., 0] - m_ref).max() <= 2e-6
-    assert (np.abs(got[..., 1] - q_ref) / q_ref).max() <= 2e-5
-    assert np.abs(got[..., 2:] - np.einsum("tsc,sck->tsk", xs, gphi)).max() <= 2e-5
-    g8 = _lib.region_grid(L, 8)
-    Np8, R8, P8 = g8.H * g8.H, 64, g8.s * g8.s
-    wd = torch.full((Np8, k), float("nan"), device=DEV)
-    rep = torch.full((k, R8, D), float("nan"), device=DEV)
-    _lib.check(lib.rrt_crmsa_combine_parts_f32(p(x1), p(part), p(gm), p(bt), p(phi), p(wd), p(rep), L, D, k, C.byref(g8), stream()),
-               "crmsa_combine_parts")
-    torch.cuda.synchronize()
-    gm64, bt64, phi64 = (a.cpu().numpy().astype(np.float64) for a in (gm, bt, phi))
-    mu = x64.mean(-1, keepdims=True)
-    v = (x64 - mu) / np.sqrt(((x64 - mu) ** 2).mean(-1, keepdims=True) + 1e-5) * gm64 + bt64
-    perm = O.partition_index(g8.H, g8.s)
-    V = np.concatenate([v, np.zeros((g8.add, D))], 0)[perm].reshape(R8, P8, D)
-    Lg = (V @ phi64).transpose(0, 2, 1)
-    Cw = np.exp(Lg - Lg.max(-1, keepdims=True))
-    Cw /= Cw.sum(-1, keepdims=True)
-    _cmp(rep.cpu().numpy(), (Cw @ V).transpose(1, 0, 2), 2e-5, "combine from the records (16-bit projection)")
-    # shapes the by-product does not cover report
-    gbig = _lib.region_grid(20000, 8)
-    assert lib.rrt_linear16_stats_f32(p(o16), p(w16), p(d_bp), p(d_res), p(x1), p(gm), p(phi), k, p(part), gbig.H * gbig.H, D, D,
-                                      C.byref(gbig), compute, stream()) == -2
-
-
 @pytest.mark.parametrize("n_tokens,compute", [(5000, "bf16"), (9000, "bf16"), (9000, "f16"), (5000, "f32")])
 def test_two_bags_in_flight_bit_identical_to_one(n_tokens, compute):
     """Two bags in flight through rrt_encoder_forward_f32 (two streams, two workspaces, forwards enqueued back to back so
