@@ -18,7 +18,7 @@ quoted on; the N = 1 line of that config is what the driver records):
   4  TCGA-NSCLC mix: 64 bags, N ~ randint(3000, 15001) (seed 2021), epeg_k=21 crmsa_k=5; the batch is split over
      the ranks by cost (sharding.assign_bags, longest-processing-time first) and each rank runs its share through
      the batch-of-bags executor; a step = one pass over the whole batch ("scaling": "strong")
-In configs 0-3 a step = one batch of `--streams` (default 4 in fp32, 3 in bf16) x `--bags-per-stream` (default 4) independent
+In configs 0-3 a step = one batch of `--streams` (default 4; 3 for bf16 bags of > 12 k tokens) x `--bags-per-stream` (default 4) independent
 bags per GPU: `--streams` bags in flight, each an ordinary forward on its own HIP stream with its own workspace (bags are
 independent units), and every rank owns its own bags ("scaling": "weak").  No data-path collective anywhere: RCCL carries the barrier and a MAX of the elapsed time.
 
@@ -762,11 +762,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational extra records of the default run")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("RRT_BENCH_STREAMS", "0")),
-                    help="bags in flight per GPU (one HIP stream + workspace each); a step = this many bags.  Default: 4 for "
-                         "fp32 arithmetic, 3 for bf16 / fp16 (measured optima, see the comment in main())")
+                    help="bags in flight per GPU (one HIP stream + workspace each); a step = this many bags.  Default: 4 "
+                         "(3 for bf16 / fp16 bags of > 12 k tokens and the configs[4] mix: measured optima, see main())")
     ap.add_argument("--bags-per-stream", type=int, default=0,
                     help="forwards per stream and step (configs 0-3; default 4): a step = streams x this many bags")
     ap.add_argument("--stub-cpu", action="store_true", help="rank logic only: CPU stand-in workload over gloo (tests)")
+    ap.add_argument("--module-call-only", action="store_true",
+                    help="print only the `module_call` record of this config (the default run spawns this as a child process)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -802,7 +804,9 @@ def main():
         # duration) -- what more bags in flight buy is the latency-bound CR-MSA chains of DIFFERENT bags running next to
         # each other; four streams = one per hardware pipe
         # bf16: 3 (17.8 k; 4: 17.7 k, 5: 14.4 k); the bf16 classifier of configs[2] (a longer chain per bag): 4 (9.7 k vs 9.1 k)
-        args.streams = cfg.get("streams") or (3 if (args.dtype or cfg["dtype"]) in ("bf16", "f16") else 4)
+        # round 5 (profiles/r05_final_streams_sweep.txt): bf16 N = 9000 4 -> 19.05 k (3: 18.9 k); N = 30000 and the configs[4] mix keep 3
+        lowp = (args.dtype or cfg["dtype"]) in ("bf16", "f16")
+        args.streams = cfg.get("streams") or (3 if lowp and (cfg["n"] is None or cfg["n"] > 12000) else 4)
     if args.stub_cpu:
         wl = StubWorkload(args, rank, world, dev)
     elif cfg["kind"] == "mix":
@@ -810,6 +814,12 @@ def main():
     else:
         wl = EncoderWorkload(args, rank, world, dev)
 
+    if args.module_call_only:
+        for i in range(3):
+            wl.step(i, False)
+        wl.sync()
+        print(json.dumps(module_call(wl, dev)), flush=True)
+        return
     for i in range(args.warmup):
         wl.step(i, False)
     wl.sync()
@@ -882,7 +892,7 @@ def main():
                                            "(this rank's clock, no barrier between them)"}
         rec.update(rec_extra)
         if not args.stub_cpu and world == 1 and cfg["kind"] == "encoder" and not args.no_extras:
-            rec["module_call"] = module_call(wl, dev)
+            rec["module_call"] = module_call_record(args)
         if not args.stub_cpu and args.config == 1 and world == 1 and not args.no_extras:
             rec.update(extras(wl, dev))
             for c in (0, 2, 3, 4):
@@ -978,6 +988,24 @@ def module_call(wl, dev, n_bags=64):
                    "= host thread time per forward while the device queue is not full; compare module_loop with "
                    "one_bag_in_flight.slides_per_s and forward_bags with `value` (both taken at the C ABI)")
     return out
+
+
+def module_call_record(args):
+    """`module_call` of this config from a CHILD process (bench.py --module-call-only): what a user's process gets.  In the
+    process that has just run the timed region -- its bag streams, event pools and torch's own streams already mapped to
+    hardware queues in creation order -- the executor's streams share queues with them (measured in round 5: 4.48 k slides/s
+    for forward_bags in-process against 5.1-5.2 k in a fresh process, tools/bench_bags.py)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--module-call-only", "--no-cpu-baseline"]
+    if args.dtype:
+        cmd += ["--dtype", args.dtype]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:                      # the headline line must not die with a side record
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    r["command"] = "bench.py " + " ".join(cmd[2:])
+    return r
 
 
 def config_record(c):
