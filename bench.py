@@ -893,6 +893,11 @@ def main():
         rec.update(rec_extra)
         if not args.stub_cpu and world == 1 and cfg["kind"] == "encoder" and not args.no_extras:
             rec["module_call"] = module_call_record(args)
+            if args.config == 1 and not args.dtype:      # the headline config also through the module in bf16 (the --amp path)
+                import copy
+                a16 = copy.copy(args)
+                a16.dtype = "bf16"
+                rec["module_call_bf16"] = module_call_record(a16)
         if not args.stub_cpu and args.config == 1 and world == 1 and not args.no_extras:
             rec.update(extras(wl, dev))
             for c in (0, 2, 3, 4):

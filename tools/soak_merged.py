@@ -19,6 +19,11 @@ enc = RRTEncoder(**cfg).eval()
 enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.encoder_state(**cfg).items()}, strict=True)
 enc = enc.to(dev)
 lib = _lib.load()
+# SOAK_DTYPE = f32 (default) | bf16 | f16 | f32x3; SOAK_SOLO = 0 (default) | 1 (the forward's one-bag-in-flight choices: K split
+# inside 16-wave blocks for the representatives' GEMMs, CR-MSA's row records from the projection slabs)
+enc._desc.compute = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f16": _lib.COMPUTE_F16,
+                     "f32x3": _lib.COMPUTE_F32X3}[os.environ.get("SOAK_DTYPE", "f32")]
+enc._desc.solo = int(os.environ.get("SOAK_SOLO", "0"))
 w = enc._weights()
 sizes = [9000, 6200, 7000, 12000, 5000, 10500, 8000, 9000][:max(S, 1)]
 big = torch.from_numpy(synth.bag(12000, 512, tag="soak")).to(dev)
@@ -59,5 +64,5 @@ for r in range(rounds):
             total += 1
             bad += int(not torch.equal(ys[i][j], refs[i][(r + j) & 1]))
             ys[i][j].fill_(float("nan"))
-print(f"soak: {total} forwards on {len(sizes)} streams (sizes {sizes}), {bad} differ from the solo result")
+print(f"soak [{os.environ.get('SOAK_DTYPE', 'f32')}, solo={enc._desc.solo}]: {total} forwards on {len(sizes)} streams (sizes {sizes}), {bad} differ from the solo result")
 sys.exit(1 if bad else 0)
