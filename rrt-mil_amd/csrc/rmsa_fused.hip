@@ -780,6 +780,39 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
       // lane), then compile-time indices -- row u meets output o with T[u + RUN - 1 - o]
       constexpr int NTV = (RUN + 3 + 3) / 4;
       const float4* tp4 = (const float4*)(taps + TAP_OFF - (RUN - 1));
+      // epeg_k <= 15 (every published configuration but the NSCLC one): ALL source rows of the run and every tap requested
+      // at once -- one LDS round trip instead of five dependent four-row trips (round 5; traced 5.75 K -> 5.28 K cycles: the
+      // phase is bound by its 200 v_pk_fma_f32 per thread -- 8 cycles each on this chip --, not by the trips)
+      constexpr int NFAST = RUN + 14;
+      if (nsrc <= NFAST) {
+        constexpr int NTT = (NFAST + RUN - 1 + 3) / 4;
+        float4 v[NFAST];
+        float T[4 * NTT];
+#pragma unroll
+        for (int u = 0; u < NFAST; ++u) {
+          const int rr = r0 - half + u;
+          const bool ok = rr >= 0 && rr < P;
+          const int rc = ok ? rr : 0;
+          v[u] = *(const float4*)(Qs + rc * HD + ((s ^ (rc & 15)) << 2));
+          if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NTT; ++q) {
+          const float4 t4 = tp4[q];
+          T[4 * q] = t4.x; T[4 * q + 1] = t4.y; T[4 * q + 2] = t4.z; T[4 * q + 3] = t4.w;
+        }
+#pragma unroll
+        for (int u = 0; u < NFAST; ++u) {               // (rows u >= nsrc meet taps >= k: zero in the table)
+          const f32x2 lo = {v[u].x, v[u].y}, hi = {v[u].z, v[u].w};
+#pragma unroll
+          for (int o = 0; o < RUN; ++o) {
+            const float wt = T[u + RUN - 1 - o];
+            const f32x2 w2 = {wt, wt};
+            out[o][0] = __builtin_elementwise_fma(w2, lo, out[o][0]);
+            out[o][1] = __builtin_elementwise_fma(w2, hi, out[o][1]);
+          }
+        }
+      } else
       for (int j0 = 0; j0 < nsrc; j0 += 4) {
         float4 v[4];
         float T[4 * NTV];
