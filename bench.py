@@ -807,6 +807,23 @@ def main():
         # round 5 (profiles/r05_final_streams_sweep.txt): bf16 N = 9000 4 -> 19.05 k (3: 18.9 k); N = 30000 and the configs[4] mix keep 3
         lowp = (args.dtype or cfg["dtype"]) in ("bf16", "f16")
         args.streams = cfg.get("streams") or (3 if lowp and (cfg["n"] is None or cfg["n"] > 12000) else 4)
+    if args.module_call_only and not args.stub_cpu and cfg["kind"] == "encoder":
+        # a user's process: the module, its bags, nothing else (no bench streams / workspaces / event pools, whose streams
+        # would take hardware queues in front of the executor's)
+        from rrt_mil_amd import RRTEncoder, _lib, synth
+
+        class _Bare:
+            pass
+        wl = _Bare()
+        enc = RRTEncoder(**cfg["enc"]).eval()
+        st = synth.encoder_state(**{k: v for k, v in cfg["enc"].items() if k != "region_num"})
+        enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+        wl.enc, wl.S, wl.n = enc.to(dev), args.streams, cfg["n"]
+        wl.dtype = args.dtype or cfg["dtype"]
+        wl.compute = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f16": _lib.COMPUTE_F16, "f32x3": _lib.COMPUTE_F32X3}[wl.dtype]
+        wl.bags = [torch.from_numpy(synth.bag(wl.n, DIM, tag=f"bench/r{rank}/b{i}")).to(dev) for i in range(4)]
+        print(json.dumps(module_call(wl, dev)), flush=True)
+        return
     if args.stub_cpu:
         wl = StubWorkload(args, rank, world, dev)
     elif cfg["kind"] == "mix":
@@ -814,12 +831,6 @@ def main():
     else:
         wl = EncoderWorkload(args, rank, world, dev)
 
-    if args.module_call_only:
-        for i in range(3):
-            wl.step(i, False)
-        wl.sync()
-        print(json.dumps(module_call(wl, dev)), flush=True)
-        return
     for i in range(args.warmup):
         wl.step(i, False)
     wl.sync()
@@ -960,7 +971,7 @@ def module_call(wl, dev, n_bags=64):
     out = {"unit": "slides/s", "dtype": wl.dtype, "n_tokens": wl.n}
     with torch.no_grad():
         enc.solo = True
-        for i in range(16):
+        for i in range(200):                          # (a fresh process: clocks ramp over the first tens of milliseconds)
             y = enc(bags3[i % len(bags3)])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -974,7 +985,10 @@ def module_call(wl, dev, n_bags=64):
         n_batch = 4 * n_bags                          # one executor call = one fork / join: the longer the batch, the less it weighs
         batch = [bags3[i % len(bags3)] for i in range(n_batch)]
         outs = [torch.empty_like(b[0]) for b in batch]
-        enc.forward_bags(batch[:2 * S], streams=S, outs=outs[:2 * S])
+        # one untimed call over the whole batch first: it creates the executor and TOUCHES the 256 output buffers (4.7 GB of
+        # fresh device memory: the first write to a new allocation pays for its page mapping -- round 5 measured 1.9-2.6 k
+        # slides/s for a first call against 5.0-5.2 k from the second on, tools/bench_bags.py)
+        enc.forward_bags(batch, streams=S, outs=outs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         enc.forward_bags(batch, streams=S, outs=outs)

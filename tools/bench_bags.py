@@ -33,6 +33,8 @@ def measure(kind, nb, streams):
     enc = RRTEncoder(**cfg).eval()
     enc.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.encoder_state(**cfg).items()}, strict=True)
     enc = enc.to(dev)
+    if os.environ.get("BAGS_DTYPE") == "bf16":        # the --amp path (configs[4] is quoted in bf16)
+        enc.compute_dtype = torch.bfloat16
     if kind == "uniform":
         base = [torch.from_numpy(synth.bag(9000, 512, tag=f"bb/{i}")).to(dev) for i in range(4)]
         bags = [base[i % 4] for i in range(nb)]

@@ -35,8 +35,8 @@ timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a2 -o a -- python $R/b
 python $R/tools/rocprof_summary.py /tmp/prof_a2/a_results.db > $OUT/${TAG}_bench_2streams.kernel_stats.txt
 python $R/tools/rocprof_union.py c1_f32_s2 /tmp/prof_a2/a_results.db $OUT/${TAG}_rocprof_dominant.json 22045261824 157.3
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a3 -o a -- python $R/bench.py --dtype bf16 $X > /tmp/a.log 2>&1
-python $R/tools/rocprof_summary.py /tmp/prof_a3/a_results.db > $OUT/${TAG}_bench_bf16_3streams.kernel_stats.txt
-python $R/tools/rocprof_union.py c1_bf16_s3 /tmp/prof_a3/a_results.db $OUT/${TAG}_rocprof_dominant.json 17213423616 2500
+python $R/tools/rocprof_summary.py /tmp/prof_a3/a_results.db > $OUT/${TAG}_bench_bf16_4streams.kernel_stats.txt
+python $R/tools/rocprof_union.py c1_bf16_s4 /tmp/prof_a3/a_results.db $OUT/${TAG}_rocprof_dominant.json 17213423616 2500
 cp $OUT/${TAG}_rocprof_dominant.json $R/profiles/r05_rocprof_dominant.json 2>/dev/null
 for dt in f32 bf16; do
   for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
