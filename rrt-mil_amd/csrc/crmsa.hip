@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256) void crmsa_combine_parts_kernel(const float* _
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   const float* __restrict__ phi, float* __restrict__ wdisp,
                                                                   float* __restrict__ rep, uint16_t* __restrict__ rep16,
-                                                                  int prec16, int dim, int k, int n_slabs, GridDev g) {
+                                                                  int prec16, int dim, int k, int n_slabs, int al16,
+                                                                  GridDev g) {
   constexpr int MAXS = 8;                           // slabs whose records a thread keeps in flight at once (dim <= 512: all)
   constexpr int NL = KM / 4;                        // float4s of a row's logits / coefficients
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -377,16 +378,51 @@ __global__ __launch_bounds__(256) void crmsa_combine_parts_kernel(const float* _
   __shared__ float s_gb[2 * KM];
   float ag[KM], ab[KM];
   if (wave == 3) {
+    // lane l: columns 8 l .. 8 l + 7 (dim <= 512), gamma / beta as two float4 each and the 8 k phi values as 2 k float4 --
+    // every request out before the first use (a loop over columns with its loads inside was eight dependent round trips:
+    // the block waited ~2.5 us for this wave, 8.2 -> 10.8 us per launch)
 #pragma unroll
     for (int n = 0; n < KM; ++n) ag[n] = ab[n] = 0.f;
-    for (int c = lane; c < dim; c += 64) {
-      const float gm = gamma[c], bt = beta[c];
+    const int c0 = 8 * lane;
+    if (!al16) {                                     // parameters not on 16-byte boundaries: the plain loop
+      for (int c = lane; c < dim; c += 64) {
+        const float gm = gamma[c], bt = beta[c];
 #pragma unroll
-      for (int n = 0; n < KM; ++n) {
-        const float ph = n < k ? phi[(size_t)c * k + n] : 0.f;
-        ag[n] += gm * ph;
-        ab[n] += bt * ph;
+        for (int n = 0; n < KM; ++n) {
+          const float ph = n < k ? phi[(size_t)c * k + n] : 0.f;
+          ag[n] += gm * ph;
+          ab[n] += bt * ph;
+        }
       }
+    } else if (c0 < dim) {
+      float gmv[8], btv[8], phv[8 * KM];
+      {
+        const float4 g0 = *(const float4*)(gamma + c0), g1 = *(const float4*)(gamma + c0 + 4);
+        const float4 b0 = *(const float4*)(beta + c0), b1 = *(const float4*)(beta + c0 + 4);
+        gmv[0] = g0.x; gmv[1] = g0.y; gmv[2] = g0.z; gmv[3] = g0.w; gmv[4] = g1.x; gmv[5] = g1.y; gmv[6] = g1.z; gmv[7] = g1.w;
+        btv[0] = b0.x; btv[1] = b0.y; btv[2] = b0.z; btv[3] = b0.w; btv[4] = b1.x; btv[5] = b1.y; btv[6] = b1.z; btv[7] = b1.w;
+        const float4* p4 = (const float4*)(phi + (size_t)c0 * k);      // 8 k floats, 16-byte aligned (32 k bytes per lane)
+#pragma unroll
+        for (int q = 0; q < 2 * KM; ++q)
+          if (q < 2 * k) {
+            const float4 v = p4[q];
+            phv[4 * q] = v.x; phv[4 * q + 1] = v.y; phv[4 * q + 2] = v.z; phv[4 * q + 3] = v.w;
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int n = 0; n < KM; ++n)
+          if (n < k) {
+            // phi[(c0 + j) * k + n]: element j * k + n of the lane's 8 k values (k is a run-time 1 .. KM: a select over the
+            // compile-time candidates instead of a dynamic register index)
+            float ph = 0.f;
+#pragma unroll
+            for (int kk = 1; kk <= KM; ++kk)
+              if (k == kk) ph = phv[j * kk + n < 8 * KM ? j * kk + n : 0];
+            ag[n] += gmv[j] * ph;
+            ab[n] += btv[j] * ph;
+          }
     }
   }
   const int cl = tid & 15, rg = tid >> 4;
@@ -1405,6 +1441,7 @@ hipError_t launch_crmsa_combine_parts(const float* x1, const float* part, const 
   if (!crmsa_combine_parts_supported(dim, k, g8)) return hipErrorInvalidValue;
   dim3 grid(g8.rs * g8.rs, dim / 64), block(256);
   constexpr int TR = 9;                               // P = 144: every row of the region in flight at once
+  const int al16 = (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)phi) & 15) == 0;
 #define RRT_CPARTS(KM_)                                                                                              \
   do {                                                                                                               \
     const size_t lds = combine_parts_lds(g8.P, KM_);                                                                 \
@@ -1412,7 +1449,7 @@ hipError_t launch_crmsa_combine_parts(const float* x1, const float* part, const 
     static OncePerDevice once;                                                                                       \
     if (lds > 64 * 1024 && once.first())                                                                             \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);          \
-    kern<<<grid, block, lds, st>>>(x1, part, gamma, beta, phi, wdisp, rep, rep16, prec16, dim, k, dim / 64, g8);     \
+    kern<<<grid, block, lds, st>>>(x1, part, gamma, beta, phi, wdisp, rep, rep16, prec16, dim, k, dim / 64, al16, g8); \
   } while (0)
   if (k <= 4) RRT_CPARTS(4);
   else RRT_CPARTS(8);

@@ -1212,6 +1212,20 @@ def test_rmsa_fused_proj_stats_and_combine_parts(L, rn, k, shift):
     mn, mx = Lg.min(-1, keepdims=True), Lg.max(-1, keepdims=True)
     _cmp(wd.cpu().numpy().reshape(R8, P8, k).transpose(0, 2, 1), (Lg - mn) / (mx - mn + 1e-8) * Dw, tol * 5,
          "dispatch weights from the records")
+    # parameters NOT on 16-byte boundaries (the kernel's wide loads of gamma / beta / phi are the aligned path only): same
+    # values one float further on -> same results within the reordering of two 512-term sums
+    def off1(a):
+        buf = torch.empty((a.numel() + 1,), device=DEV)
+        buf[1:] = a.reshape(-1)
+        return buf, buf[1:]
+    (kg, gm1), (kb, bt1), (kp, phi1) = off1(gm), off1(bt), off1(phi)
+    assert gm1.data_ptr() % 16 == 4 and phi1.data_ptr() % 16 == 4
+    wd1, rep1 = torch.full_like(wd, float("nan")), torch.full_like(rep, float("nan"))
+    _lib.check(lib.rrt_crmsa_combine_parts_f32(p(x1), p(part), p(gm1), p(bt1), p(phi1), p(wd1), p(rep1), L, D, k, C.byref(g8), stream()),
+               "crmsa_combine_parts (unaligned parameters)")
+    torch.cuda.synchronize()
+    _cmp(rep1.cpu().numpy(), rep.cpu().numpy().astype(np.float64), 5e-6 if shift == 0.0 else 5e-5, "unaligned parameters: rep")
+    _cmp(wd1.cpu().numpy(), wd.cpu().numpy().astype(np.float64), 5e-5 if shift == 0.0 else 5e-4, "unaligned parameters: wdisp")
 
 
 @pytest.mark.parametrize("n_tokens,compute", [(5000, "bf16"), (9000, "bf16"), (9000, "f16"), (5000, "f32")])

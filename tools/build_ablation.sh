@@ -21,7 +21,7 @@ for src in build.SOURCES:
     obj = os.path.join(od, src.replace(".hip", ".o"))
     objs.append(obj)
     d = hd.copy()
-    d.update(" ".join(build.FILE_FLAGS.get(src, [])).encode())
+    d.update(" ".join([] if (os.environ.get("ABL_PACKED") and src in os.environ["ABL_PACKED"].split(",")) else build.FILE_FLAGS.get(src, [])).encode())
     d.update(open(os.path.join(build.CSRC, src), "rb").read())
     dig = d.hexdigest()
     st = obj + ".stamp"
@@ -29,7 +29,8 @@ for src in build.SOURCES:
         continue
     if os.path.exists(st):
         os.remove(st)
-    procs.append((src, st, dig, subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, *build.FILE_FLAGS.get(src, []), "-c", os.path.join(build.CSRC, src), "-o", obj],
+    ff = [] if (os.environ.get("ABL_PACKED") and src in os.environ["ABL_PACKED"].split(",")) else build.FILE_FLAGS.get(src, [])
+    procs.append((src, st, dig, subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, *ff, "-c", os.path.join(build.CSRC, src), "-o", obj],
                                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
 bad = False
 for src, st, dig, p in procs:

@@ -47,5 +47,6 @@ for i in range(nev - 1):
     print(f"   ev{i + 1:02d}->ev{i + 2:02d}  median {np.median(x):8.0f}  p10 {np.percentile(x, 10):8.0f}  p90 {np.percentile(x, 90):8.0f}")
 print(f"   lifetime median {np.median(ts[:, -1] - ts[:, 0]):.0f}; last event (cycles after the kernel's first entry) median "
       f"{np.median(ts[:, -1] - t0.min()):.0f} max {int((ts[:, -1] - t0.min()).max())}")
-print("events: 1 entry | 2 loads requested | 3 G/B partials + row statistics (records landed) | 4 barrier | 5 logits in LDS | 6 barrier | "
-      "7 region statistics | 8 barrier | 9 coefficients + dispatch weights | 10 barrier | 11 contraction (x1 landed) | 12 barrier | 13 stored")
+print("events: 1 entry | 2 every load requested | 3 logits in LDS (records landed; wave 3: G/B first) | 4 barrier | "
+      "5 region statistics + coefficients | 6 barrier | 7 contraction (x1 rows landed) | 8 barrier | 9 representatives stored | "
+      "10 (slab 0) dispatch weights written")
