@@ -593,7 +593,7 @@ class EncoderWorkload:
             ms_per_step = elapsed / args.steps * 1e3
             per_step = self.S * self.R
             lb_ach = flops * per_step / (ms_per_step * 1e-3) / 1e12
-            consistent = busy_ms * per_step <= ms_per_step * 1.03
+            consistent = busy_ms * per_step <= ms_per_step
             ach = flops / (busy_ms * 1e-3) / 1e12 if consistent else lb_ach
             rp = rocprof_record(args.config, self.dtype, self.S)
             rec["roofline"] = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak,
@@ -614,8 +614,8 @@ class EncoderWorkload:
                                        "busy_ms_per_launch = the UNION of the launches' intervals / launches: the time during which "
                                        "this kernel was running at all (it still contains whatever the other bags' kernels took "
                                        "from it; the kernel alone is roofline_isolated).  achieved = flops_per_launch / "
-                                       "busy_ms_per_launch when busy_ms_per_launch x launches_per_step <= 1.03 ms_per_step (the "
-                                       "marker packets slow the instrumented steps), otherwise the bound that needs no events: "
+                                       "busy_ms_per_launch when busy_ms_per_launch x launches_per_step <= ms_per_step (the marker "
+                                       "packets slow the instrumented steps: a union longer than the step is not evidence), otherwise the bound that needs no events: "
                                        "frac_lower_bound = flops_per_launch x launches_per_step / ms_per_step / peak.  `rocprof` = "
                                        "mean duration and union per launch from the committed rocprofv3 --kernel-trace table of "
                                        "this command (tools/rocprof_union.py).  Rounds 1-3 printed the mean interval of 1-2 bags in "

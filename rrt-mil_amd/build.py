@@ -16,8 +16,12 @@ SOURCES = ["ln_partition.hip", "cast16.hip", "linear_f32.hip", "region_attn.hip"
 HEADERS = ["common.h", "internal.h", "fused16.h", os.path.join("..", "..", "include", "rrt_hip.h")]
 # -amdgpu-mfma-vgpr-form: gfx950 has one unified VGPR/AGPR file; keep MFMA accumulators in VGPRs so the
 # softmax / rescale VALU code does not shuttle them through v_accvgpr_read/write (hazard stalls).
+# -amdgpu-kernarg-preload-count: the leading kernel arguments (pointers, sizes: up to 16 dwords) arrive in SGPRs with the
+#   wave instead of through a cold scalar load at its entry -- 0.1-0.2 us on each of the latency-bound launches, one bag in
+#   flight 78.4 -> 77.6 us in bf16 (round 5, tools/experiments/ab_kernarg_preload.sh); the compiler keeps the loading
+#   prologue for firmware that does not preload.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
-         "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall", "-Wno-unused-function"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wall", "-Wno-unused-function"]
 
 
 # The streaming (non-MFMA) kernels are compiled WITHOUT packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).

@@ -40,7 +40,11 @@ __device__ __forceinline__ uint2 r4_pack4(float4 v) {
 
 // rows handled by one wave (independent loads in flight per wave = RW * NV float4)
 constexpr int RW = 2;             // (4 until the column guards went: 9.1 -> 7.6 us at N = 9000)
-constexpr int RW_DISPATCH = 1;    // (2 until the column guards went: 10.0 -> 9.0 us)
+#ifndef RRT_RW_DISPATCH
+#define RRT_RW_DISPATCH 1
+#endif
+constexpr int RW_DISPATCH = RRT_RW_DISPATCH;    // (2 until the column guards went: 10.0 -> 9.0 us; round 5, with every request of both
+                                                 // tokens hoisted and the representatives' rows shared: 8.8 against 7.9 -- more waves win)
 
 // FULL: dim == NV * 256 exactly (every lane's columns exist): no column guards in the row loops
 template <int NV, bool FULL>
@@ -1122,7 +1126,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
     const float* __restrict__ beta, float* __restrict__ y, int L, int dim, int k, GridDev g) {
   constexpr int RW = RW_DISPATCH;
   const int lane = threadIdx.x & 63;
-  const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  const int t0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * RW);   // wave-uniform: scalar index math
   if (t0 >= L) return;
   const int R = g.Rt;
   float4 r[RW][NV];
@@ -1152,35 +1156,47 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
     }
   }
   if (CRMSA && KB > 0) {
+    // every request of every token of the wave before the first use (round 5: the per-token form put token 1's L2 round
+    // trip behind token 0's arithmetic); tokens of one region -- neighbours in the bag almost always are -- share the
+    // representatives' rows: one fetch (the k rows are 3 x the token row's bytes through the texture path)
+    float w[RW][KB > 0 ? KB : 1];
+    float4 q[RW][KB > 0 ? KB : 1][NV];
+    int reg[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int t = t0 + i < L ? t0 + i : L - 1;
       const int slot = token_to_slot(t, g);
-      const int reg = fdiv(slot, g.P, g.inv_P);
+      reg[i] = fdiv(slot, g.P, g.inv_P);
       const float* wd = wdisp + (size_t)slot * k;
-      float w[KB > 0 ? KB : 1];
-      float4 q[KB > 0 ? KB : 1][NV];
+#pragma unroll
+      for (int n = 0; n < KB; ++n) w[i][n] = wd[n < k ? n : k - 1];      // in bounds; its weight is zeroed below
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const bool fetch = i == 0 || reg[i] != reg[0];       // wave-uniform (t0 is)
 #pragma unroll
       for (int n = 0; n < KB; ++n) {
-        const int nn = n < k ? n : k - 1;                  // in bounds; its weight is zeroed below
-        w[n] = wd[nn];
-        const float* rp = rep2 + ((size_t)nn * R + reg) * dim;
+        const int nn = n < k ? n : k - 1;
+        const float* rp = rep2 + ((size_t)nn * R + reg[i]) * dim;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int c = (v * 64 + lane) * 4;
-          q[n][v] = (FULL || c < dim) ? *(const float4*)(rp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);                 // every request is out before the first use waits
-#pragma unroll
-      for (int n = 0; n < KB; ++n) {
-        const float wn = n < k ? w[n] : 0.f;               // branch-free; same summation order as the loop form
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          r[i][v].x += wn * q[n][v].x; r[i][v].y += wn * q[n][v].y; r[i][v].z += wn * q[n][v].z; r[i][v].w += wn * q[n][v].w;
+          if (fetch) q[i][n][v] = (FULL || c < dim) ? *(const float4*)(rp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          else q[i][n][v] = q[0][n][v];
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);                   // every request is out before the first use waits
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int n = 0; n < KB; ++n) {
+        const float wn = n < k ? w[i][n] : 0.f;            // branch-free; same summation order as the loop form
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          r[i][v].x += wn * q[i][n][v].x; r[i][v].y += wn * q[i][n][v].y; r[i][v].z += wn * q[i][n][v].z; r[i][v].w += wn * q[i][n][v].w;
+        }
+      }
   } else if (CRMSA) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) {

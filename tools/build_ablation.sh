@@ -11,7 +11,16 @@ import hashlib, os, subprocess, sys
 sys.path.insert(0, "rrt-mil_amd")
 import build
 name, extra = sys.argv[1], sys.argv[2:]
-flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + extra
+flags = [f for f in build.FLAGS if not f.startswith("-W")] + extra      # the product's flags (ABL_NO= drops one: e.g. the kernarg preload)
+if os.environ.get("ABL_NO"):
+    keep = []
+    for f in flags:
+        if os.environ["ABL_NO"] in f:
+            if keep and keep[-1] == "-mllvm":
+                keep.pop()
+            continue
+        keep.append(f)
+    flags = keep
 od = f"tools/_abl/obj_{name}"
 hd = hashlib.sha256(" ".join(flags).encode())
 for h in build.HEADERS:
