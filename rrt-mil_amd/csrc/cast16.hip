@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_partition16_kernel(const float* __rest
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    r[v] = (FULL || c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[v] = (FULL || c < dim) ? ld_row<NT_LN1>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     sum += (r[v].x + r[v].y) + (r[v].z + r[v].w);
   }
   const float inv_d = 1.0f / (float)dim;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void ln_partition_split_kernel(const float* __
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int c = (v * 64 + lane) * 4;
-    r[v] = (FULL || c < dim) ? *(const float4*)(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[v] = (FULL || c < dim) ? ld_row<NT_LN1>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     sum += (r[v].x + r[v].y) + (r[v].z + r[v].w);
   }
   const float inv_d = 1.0f / (float)dim;

@@ -8,6 +8,41 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define RRT_WAVE 64
 
+// Non-temporal row accesses: the lines do not displace what the kernels of the other bags in flight keep in the L2 / MALL.
+// Measured per site on MI355X, four bags in flight (round 5, tools/experiments/ab_lib.sh; RRT_NO_NT_DISPATCH / RRT_NT_LN1
+// rebuild the other side of each comparison):
+//   * the forward's LAST kernel (crmsa_dispatch_ln): x1 read for the last time, y written and not read again by this forward
+//     -- non-temporal: bf16 18.5 k -> 19.6-19.9 k slides/s (the store alone: 19.6-19.7 k), configs[3] +2 %, configs[4] +1-2 %,
+//     configs[2] and fp32 within noise, one bag in flight never slower;
+//   * LN1's read of x (ln_partition*, cast16): x comes back as the residual 20-180 us later, and a non-temporal first read
+//     costs that second one its MALL hit -- bf16 19.2 k -> 18.8 k, one bag 79 -> 81 us: plain loads.
+__device__ __forceinline__ float4 ld_nt(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_nt(float* p, const float4 v) {
+  const f32x4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, (f32x4*)p);
+}
+template <bool NT> __device__ __forceinline__ float4 ld_row(const float* p) { if constexpr (NT) return ld_nt(p); else return *(const float4*)p; }
+template <bool NT> __device__ __forceinline__ void st_row(float* p, const float4 v) { if constexpr (NT) st_nt(p, v); else *(float4*)p = v; }
+#ifdef RRT_NT_LN1
+constexpr bool NT_LN1 = true;
+#else
+constexpr bool NT_LN1 = false;
+#endif
+#ifdef RRT_NT_RESID
+constexpr bool NT_RESID = true;      // (experiment) the out-projection's read of the residual rows, x's last use: no gain in
+                                     // any configuration, one bag in flight 1-2 us slower -- not adopted
+#else
+constexpr bool NT_RESID = false;
+#endif
+#ifdef RRT_NO_NT_DISPATCH
+constexpr bool NT_DISPATCH = false;
+#else
+constexpr bool NT_DISPATCH = true;
+#endif
+
 // Device copy of the region grid (modules/rmsa.py:175-202 geometry, 32-bit).
 struct GridDev {
   int L;    // real tokens

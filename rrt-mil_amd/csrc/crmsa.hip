@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int c = (v * 64 + lane) * 4;
-      r[i][v] = (FULL || c < dim) ? *(const float4*)(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r[i][v] = (FULL || c < dim) ? ld_row<NT_DISPATCH>(x1 + (size_t)t * dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (x0 && (FULL || c < dim)) {
         float4 s = *(const float4*)(x0 + (size_t)t * dim + c);
         r[i][v].x += s.x; r[i][v].y += s.y; r[i][v].z += s.z; r[i][v].w += s.w;
@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
           o.y = (r[i][v].y - mean[i]) * rstd[i] * gm.y + bt.y;
           o.z = (r[i][v].z - mean[i]) * rstd[i] * gm.z + bt.z;
           o.w = (r[i][v].w - mean[i]) * rstd[i] * gm.w + bt.w;
-          *(float4*)(y + (size_t)(t0 + i) * dim + c) = o;
+          st_row<NT_DISPATCH>(y + (size_t)(t0 + i) * dim + c, o);
         }
     }
   }

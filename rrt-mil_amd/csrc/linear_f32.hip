@@ -608,7 +608,7 @@ void linear_ws_kernel(const void* __restrict__ Av,
   auto resid_request = [&](unsigned off, float4 (&dst)[NT]) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      dst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off + 64u * j, 0, 0));
+      dst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off + 64u * j, 0, NT_RESID ? 2 : 0));   // aux 2 = nt
   };
   // the tile loop in two instantiations: PF = the branch-free un-partition epilogue applies (decided once per launch, so
   // that neither form's memory operations sit in the other's loop and blur its wait counts)

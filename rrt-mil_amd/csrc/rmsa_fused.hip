@@ -338,12 +338,12 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
   for (int kt = 0; kt + 2 < nk; ++kt) tile(kt);
   if constexpr (PREF) {
 #pragma unroll
-    for (int i = 0; i < RQA; ++i) rq[i] = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
+    for (int i = 0; i < RQA; ++i) rq[i] = ld_row<NT_RESID>(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
   }
   if (nk >= 2) tile(nk - 2);
   if constexpr (PREF) {
 #pragma unroll
-    for (int i = RQA; i < MT; ++i) rq[i] = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
+    for (int i = RQA; i < MT; ++i) rq[i] = ld_row<NT_RESID>(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
   }
   half(af[0], bfr[0], true, lds + ((nk - 1) % NS) * SST, 1, af[1], bfr[1]);
   lds_barrier();                                    // (the loader side counts one barrier per K tile)
@@ -362,7 +362,7 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
     for (int i = 0; i < MT; ++i) {
       float4 q;
       if constexpr (PREF) q = rq[i];
-      else q = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
+      else q = ld_row<NT_RESID>(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
       const float4 v = make_float4(acc[i][0] + bias.x + q.x, acc[i][1] + bias.y + q.y, acc[i][2] + bias.z + q.z, acc[i][3] + bias.w + q.w);
       if (toff[i] >= 0) *(float4*)(pj.out + toff[i]) = v;
     }
@@ -389,7 +389,7 @@ __device__ __forceinline__ void proj_slab(const float* __restrict__ /*U*/, const
     for (int i = 0; i < MT; ++i) {
       float4 q;
       if constexpr (PREF) q = rq[i];
-      else q = *(const float4*)(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
+      else q = ld_row<NT_RESID>(pj.resid + (toff[i] < 0 ? ncol : toff[i]));
       const float4 v = make_float4(acc[i][0] + bias.x + q.x, acc[i][1] + bias.y + q.y, acc[i][2] + bias.z + q.z, acc[i][3] + bias.w + q.w);
       if (toff[i] >= 0) *(float4*)(pj.out + toff[i]) = v;
       const float m = ((v.x + v.y) + (v.z + v.w)) * 0.25f;
@@ -479,6 +479,10 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const unsigned lds_b = lds_addr_of(lds);
+#ifdef RRT_FUSED_PRIO
+  // (experiment) this launch's waves ahead of a co-resident wave of another bag's kernel at the SIMD's issue arbiter
+  __builtin_amdgcn_s_setprio(RRT_FUSED_PRIO);
+#endif
   // XCD-aware block -> (region, head) map.  Hardware places block b on XCD b % 8 (speed heuristic
   // only): the 8 head-blocks of a region are given consecutive slots of ONE XCD, so the region's
   // U panel (P x D fp32 = 295 KB) is fetched from HBM once and served to the other 7 heads from
