@@ -479,10 +479,13 @@ __global__ __launch_bounds__(512, 1) void rmsa_fused_kernel(const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const unsigned lds_b = lds_addr_of(lds);
-#ifdef RRT_FUSED_PRIO
-  // (experiment) this launch's waves ahead of a co-resident wave of another bag's kernel at the SIMD's issue arbiter
-  __builtin_amdgcn_s_setprio(RRT_FUSED_PRIO);
+#ifndef RRT_FUSED_PRIO
+#define RRT_FUSED_PRIO 3
 #endif
+  // this launch's waves go ahead of a co-resident wave of another bag's kernel at the SIMD's issue arbiter: the small
+  // kernels are latency-bound and take the slots the matrix pipe leaves (round 5, four bags in flight: 5363 / 5365 ->
+  // 5369 / 5381 slides/s, tools/experiments/ab_lib.sh; -DRRT_FUSED_PRIO=0 rebuilds the other side)
+  if (RRT_FUSED_PRIO > 0) __builtin_amdgcn_s_setprio(RRT_FUSED_PRIO);
   // XCD-aware block -> (region, head) map.  Hardware places block b on XCD b % 8 (speed heuristic
   // only): the 8 head-blocks of a region are given consecutive slots of ONE XCD, so the region's
   // U panel (P x D fp32 = 295 KB) is fetched from HBM once and served to the other 7 heads from

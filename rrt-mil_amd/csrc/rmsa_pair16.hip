@@ -67,6 +67,9 @@ __global__ __launch_bounds__(512 * NH, 1) void rmsa_pair16_kernel(const uint16_t
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef RRT_PAIR16_PRIO
+  __builtin_amdgcn_s_setprio(RRT_PAIR16_PRIO);      // (experiment: as rmsa_fused_kernel's RRT_FUSED_PRIO)
+#endif
   const int rsel = wave / (4 * NH), rh = (wave >> 2) % NH, cw = wave & 3;   // region of the pair; row half; 16-column tile
   const int i_base = rh * MTH;                       // first row tile of this wave
   const int nt = (MT - i_base) < MTH ? (MT - i_base) : MTH;   // row tiles it owns
