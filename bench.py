@@ -729,13 +729,16 @@ class MixWorkload:
 
 
 # ------------------------------------------------------------------------------------ the rank program
-def stabilise(wl, steps_hint, max_s=3.0):
+def stabilise(wl, steps_hint, max_s=3.0, min_s=0.4):
     """Untimed: run probes of a few steps until three consecutive probe rates agree within 3 % (clock ramp,
     first-touch of the workspaces, HIP's launch pipeline) -- so that a short timed region (--steps 20) gives
-    the same rate as a long one.  Bounded by max_s seconds.  Returns the number of steps spent."""
+    the same rate as a long one -- and for at least min_s seconds: the last 0.5-0.7 % of the ramp is a drift too slow for
+    the 3 % test (round 5: `--steps 20 --warmup 5` read 5337 and then 5350, 5352, 5361 in its repeats, the 200-step default
+    5377).  Bounded by max_s seconds.  Returns the number of steps spent."""
     probe = max(4, min(20, steps_hint))
     rates, spent = [], 0
-    t_end = time.perf_counter() + max_s
+    t_begin = time.perf_counter()
+    t_end = t_begin + max_s
     while time.perf_counter() < t_end:
         wl.sync()
         t0 = time.perf_counter()
@@ -744,7 +747,7 @@ def stabilise(wl, steps_hint, max_s=3.0):
         wl.sync()
         rates.append(probe / (time.perf_counter() - t0))
         spent += probe
-        if len(rates) >= 3 and max(rates[-3:]) / min(rates[-3:]) < 1.03:
+        if len(rates) >= 3 and max(rates[-3:]) / min(rates[-3:]) < 1.03 and time.perf_counter() - t_begin >= min_s:
             break
     return spent
 
