@@ -1301,6 +1301,11 @@ __global__ __launch_bounds__(256) void crmsa_mlp_logits_kernel(const float* __re
     }
 }
 
+#ifdef RRT_NO_DISPATCH_KB5
+constexpr bool DISPATCH_KB5 = false;
+#else
+constexpr bool DISPATCH_KB5 = true;
+#endif
 template <bool CRMSA>
 hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
                            const float* rep2, const float* gamma, const float* beta, float* y, int L,
@@ -1311,6 +1316,8 @@ hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
     if (RRT_ALLOW_FULL && dim == NV * 256) {                                                                     \
       if (NV <= 2 && CRMSA && k <= 3)                                                                            \
         crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 3 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
+      else if (NV <= 2 && CRMSA && DISPATCH_KB5 && k <= 5) /* (configs[4]: crmsa_k = 5 -- five rows fetched, not eight) */  \
+        crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 5 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
       else if (NV <= 2 && CRMSA)                                                                                 \
         crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 8 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
       else                                                                                                       \
