@@ -1257,6 +1257,8 @@ int pool_predict(const float* y, const float* a_w, const float* a_b, const float
   ep.prec = compute;
   ep.bias = a_b;
   ep.act = act;
+  // (round 5: the same 16-bit-operand route as patch_to_emb's -- rows cast once, GEMM on 16-bit images -- was measured here
+  // and lost: configs[2] 10.55-10.60 k against 10.71-10.80 k slides/s; the cast's 28 MB cost more than the narrow GEMM saved)
   e = launch_linear(y, a_w, ws.hid_a, (int)N, hidden, dim, ep, st);
   if (e != hipSuccess) return (int)e;
   if (b_w) {
@@ -1375,8 +1377,11 @@ int rrt_mil_workspace_size(const rrt_mil_desc* desc, int64_t n_tokens, size_t* b
   rc = rrt_encoder_workspace_size(&desc->enc, n_tokens, &enc);
   if (rc) return rc;
   const size_t act = align_up((size_t)n_tokens * desc->enc.dim * sizeof(float), 256);
+  // (+ the 16-bit images of the feature matrix and of patch_to_emb's weight for the reduced-precision modes: the same size
+  // in every mode, so that a workspace sized once serves a module that switches modes)
   *bytes = 2 * act + align_up(enc, 256) +
-           carve_pool(n_tokens, desc->enc.dim, desc->pool_hidden, desc->pool_gated, nullptr).bytes;
+           align_up(carve_pool(n_tokens, desc->enc.dim, desc->pool_hidden, desc->pool_gated, nullptr).bytes, 256) +
+           align_up((size_t)n_tokens * desc->input_dim * 2, 256) + align_up((size_t)desc->enc.dim * desc->input_dim * 2, 256);
   return RRT_OK;
 }
 
@@ -1409,7 +1414,26 @@ int rrt_mil_forward_f32(const rrt_mil_desc* desc, const rrt_mil_weights* w, cons
   ep.prec = gemm_prec;
   ep.bias = w->emb_b;
   ep.act = desc->emb_act;
-  hipError_t e = launch_linear(x, w->emb_w, emb, (int)n_tokens, D, desc->input_dim, ep, st);
+  // Reduced-precision modes (round 5): the features and the weight are cast to 16 bits by one streaming launch and the GEMM
+  // runs on 16-bit operands through LDS-DMA.  The fp32-operand kernel rounds the same values to the same 16-bit numbers,
+  // but after staging them in LDS as fp32: twice the DMA bytes through a path that is issue-bound (41 us at
+  // N = 9000 x 1024 against ~10 + ~13 here).
+  static const bool no_fc16 = rrt_tune_env("RRT_NO_FC16") != nullptr;
+  hipError_t e;
+  if (!no_fc16 && (gemm_prec == RRT_COMPUTE_BF16 || gemm_prec == RRT_COMPUTE_F16) && desc->input_dim % 64 == 0) {
+    char* tail = enc_ws + align_up(enc_bytes, 256) + align_up(pws.bytes, 256);
+    uint16_t* x16 = (uint16_t*)tail;
+    uint16_t* w16 = (uint16_t*)(tail + align_up((size_t)n_tokens * desc->input_dim * 2, 256));
+    Cast16Jobs cj{};
+    cj.src[0] = x; cj.dst[0] = x16; cj.n4[0] = (size_t)n_tokens * desc->input_dim / 4;
+    cj.src[1] = w->emb_w; cj.dst[1] = w16; cj.n4[1] = (size_t)D * desc->input_dim / 4;
+    cj.count = 2;
+    e = launch_cast16(cj, gemm_prec, st);
+    if (e != hipSuccess) return (int)e;
+    e = launch_linear16(x16, w16, emb, (int)n_tokens, D, desc->input_dim, ep, st);
+  } else {
+    e = launch_linear(x, w->emb_w, emb, (int)n_tokens, D, desc->input_dim, ep, st);
+  }
   if (e != hipSuccess) return (int)e;
   rc = rrt_encoder_forward_f32(&desc->enc, &w->enc, emb, y, n_tokens, enc_ws, enc_bytes, stream);
   if (rc) return rc;
