@@ -1352,6 +1352,10 @@ static Cfg choose16(int M, int N, int K) {
     else if (tiles(9, 2) <= 512) best = Cfg{9, 2, 512};
     else best = Cfg{8, 1, 512};
   }
+  if (const char* e = K > 512 ? rrt_tune_env("RRT_LINEAR16_CFG_KBIG") : nullptr) {   // tuning hook, K > 512 only: "mt,nt,cap"
+    Cfg q{};
+    if (sscanf(e, "%d,%d,%d", &q.mt, &q.nt, &q.cap) == 3) best = q;
+  }
   if (const char* e = rrt_tune_env("RRT_LINEAR16_CFG")) {   // tuning hook: "mt,nt,cap"
     Cfg q{};
     if (sscanf(e, "%d,%d,%d", &q.mt, &q.nt, &q.cap) == 3) best = q;
