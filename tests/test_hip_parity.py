@@ -1457,6 +1457,16 @@ def test_cast16_and_ln_partition16(compute):
     _lib.check(lib.rrt_cast16(p(wd), p(out), w.size, compute, stream()), "cast16")
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), torch.from_numpy(w).to(_DT16[compute]).view(torch.int16))
+    # bag-sized jobs (round 5: the classifier's feature matrix goes through this kernel): one trip of four loads per thread
+    # with a ragged last load, and a job larger than the grid's cap (several trips); the canary behind the end stays
+    for n in (9000 * 1024, 4 * (4096 * 256 * 4 + 12345), 4 * 777):
+        v = synth.uniform(f"c16/big{n}", (n,), -4, 4)
+        vd = dev(v)
+        o16 = torch.full((n + 8,), 0x7FC0, dtype=torch.int16, device="cuda:0")
+        _lib.check(lib.rrt_cast16(p(vd), p(o16), n, compute, stream()), "cast16 (bag-sized)")
+        torch.cuda.synchronize()
+        assert torch.equal(o16[:n].cpu(), torch.from_numpy(v).to(_DT16[compute]).view(torch.int16))
+        assert (o16[n:] == 0x7FC0).all()
     for L, rn, D in ((9000, 8, 512), (700, 8, 128), (30000, 16, 512)):
         x = synth.bag(L, D, tag="lnp16")
         gm, bt = 1.0 + synth.uniform("lnp16/g", (D,), -0.3, 0.3), synth.uniform("lnp16/b", (D,), -0.2, 0.2)
