@@ -845,6 +845,30 @@ constexpr int R4_NB_MAX = 16;                       // blocks per region, at mos
 // stores (vmcnt 0) before the block barrier has them in memory before the arrival counter moves.
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The same scope for whole float4s (round 5): one `buffer_store_dwordx4 ... sc1` / `buffer_load_dwordx4 ... sc1` where the dword
+// forms were four instructions, each touching a quarter of every 16-byte piece -- four partial writes of every 128-byte line of
+// a record (the PMC's 7.8 MB written for ~2 MB of records) and sixteen loads per thread in the merge.  aux 0x10 = sc1 = what the
+// relaxed agent-scope atomics above compile to; the compiler tracks these as ordinary vector memory operations.
+typedef unsigned r4_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef RRT_NO_REGION4_VEC
+constexpr bool R4_VEC = false;
+#else
+constexpr bool R4_VEC = true;
+#endif
+__device__ __forceinline__ void st_agent4(__amdgpu_buffer_rsrc_t rs, float* base, float* p, const float4 v) {
+  if constexpr (R4_VEC) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(r4_u32x4, v), rs, (unsigned)((p - base) * 4), 0, 0x10);
+  } else {
+    st_agent(p, v.x); st_agent(p + 1, v.y); st_agent(p + 2, v.z); st_agent(p + 3, v.w);
+  }
+}
+__device__ __forceinline__ float4 ld_agent4(__amdgpu_buffer_rsrc_t rs, const float* base, const float* p) {
+  if constexpr (R4_VEC) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((p - base) * 4), 0, 0x10));
+  } else {
+    return make_float4(ld_agent(p), ld_agent(p + 1), ld_agent(p + 2), ld_agent(p + 3));
+  }
+}
 
 // KM: representatives the instantiation has registers for (k <= KM); KC: how many of them go through the block's
 // LDS reduction at a time (the [waves / 2][KC][512] buffer is 48 KiB at KC = 4)
@@ -997,6 +1021,8 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   // ---- this quarter's record -> workspace: the NW per-wave partials summed through LDS in a fixed order, KC
   // representatives at a time
   float* rec = part_g + (size_t)(reg * NB + q) * R4_REC;
+  const __amdgpu_buffer_rsrc_t rs_part =
+      __builtin_amdgcn_make_buffer_rsrc((void*)part_g, 0, (int)((size_t)gridDim.x * R4_REC * 4), 0x00020000);
 #pragma unroll
   for (int n0 = 0; n0 < KM; n0 += KC) {
     if (n0 >= k) break;
@@ -1031,8 +1057,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
         const float4 b = s_part[(w * KC + n) * 128 + c];
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
       }
-      float* dst = rec + (n0 + n) * (DIM + 8) + c * 4;
-      st_agent(dst, a.x); st_agent(dst + 1, a.y); st_agent(dst + 2, a.z); st_agent(dst + 3, a.w);
+      st_agent4(rs_part, part_g, rec + (n0 + n) * (DIM + 8) + c * 4, a);
     }
   }
   if (tid < k) {
@@ -1077,8 +1102,8 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
     for (int b = 0; b < NB; ++b) {
       const float* rb = rec0 + b * R4_REC + n * (DIM + 8);
       const float sc = __expf(ld_agent(rb + DIM) - s_mrg[n][0]) * s_mrg[n][1];
-      const float* vp = rb + c * 4;
-      a.x += sc * ld_agent(vp); a.y += sc * ld_agent(vp + 1); a.z += sc * ld_agent(vp + 2); a.w += sc * ld_agent(vp + 3);
+      const float4 v4 = ld_agent4(rs_part, part_g, rb + c * 4);
+      a.x += sc * v4.x; a.y += sc * v4.y; a.z += sc * v4.z; a.w += sc * v4.w;
     }
     const float c0 = s_mrg[n][2], c1 = s_mrg[n][3];
     const float4 gm = *(const float4*)(gamma + c * 4), bt = *(const float4*)(beta + c * 4);
