@@ -895,6 +895,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   __shared__ float s_stat[KM][3];                   // local max, min, sum of exp (all rows of the quarter)
   __shared__ float s_c0[KM][NW], s_c1[KM][NW];
   __shared__ float s_mrg[KM][4];                    // merge: M, 1 / L, c0 / L, c1 / L ... of the region
+  __shared__ float s_scb[KM][NB];                   // merge: exp(max_b - M) / L of block b
   __shared__ float s_mm[KM][2];                     // region min, max
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1063,9 +1064,9 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   if (tid < k) {
     const int n = tid;
     const float c0 = s_c0[n][0], c1 = s_c1[n][0];
-    float* st = rec + n * (DIM + 8) + DIM;
-    st_agent(st, s_stat[n][0]); st_agent(st + 1, s_stat[n][1]); st_agent(st + 2, s_stat[n][2]);
-    st_agent(st + 3, c0); st_agent(st + 4, c1);
+    float* st = rec + n * (DIM + 8) + DIM;            // the record's eight trailing floats: max, min, sum, c0 | c1, -, -, -
+    st_agent4(rs_part, part_g, st, make_float4(s_stat[n][0], s_stat[n][1], s_stat[n][2], c0));
+    st_agent4(rs_part, part_g, st + 4, make_float4(c1, 0.f, 0.f, 0.f));
   }
   RRT_TRACE_MARK();                                 // [6] record stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record (and the logits) are in memory ...
@@ -1078,21 +1079,38 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   if (!s_last) return;
   if (tid == 0) __hip_atomic_store(counters + reg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next forward
   const float* rec0 = part_g + (size_t)(reg * NB) * R4_REC;
+  // the logits of this thread's row (the dispatch weights at the very end) are requested here, in front of the merge: their
+  // round trip hides behind it (regions of more than 64 NW rows: the loop at the end fetches the rest)
+  float v_first[KM];
+  {
+    const int p = tid < g.P ? tid : 0;
+#pragma unroll
+    for (int n = 0; n < KM; ++n) v_first[n] = n < k ? ld_agent(logits + ((size_t)reg * g.P + p) * k + n) : 0.f;
+  }
   if (tid < k) {
     const int n = tid;
+    // every block's statistics requested at once (two float4 per block), then the arithmetic; the blocks' weights
+    // exp(max_b - M) / L go to LDS for the merge below (it fetched max_b again, per thread and block, in front of its sums)
+    float4 sa[NB], sb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float* st = rec0 + b * R4_REC + n * (DIM + 8) + DIM;
+      sa[b] = ld_agent4(rs_part, part_g, st);
+      sb[b] = ld_agent4(rs_part, part_g, st + 4);
+    }
     float M = -3.0e38f, mn = 3.0e38f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { M = fmaxf(M, sa[b].x); mn = fminf(mn, sa[b].y); }
+    float L = 0.f, c0 = 0.f, c1 = 0.f, scb[NB];
+#pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const float* st = rec0 + b * R4_REC + n * (DIM + 8) + DIM;
-      M = fmaxf(M, ld_agent(st));
-      mn = fminf(mn, ld_agent(st + 1));
+      scb[b] = __expf(sa[b].x - M);
+      L += scb[b] * sa[b].z; c0 += scb[b] * sa[b].w; c1 += scb[b] * sb[b].x;
     }
-    float L = 0.f, c0 = 0.f, c1 = 0.f;
-    for (int b = 0; b < NB; ++b) {
-      const float* st = rec0 + b * R4_REC + n * (DIM + 8) + DIM;
-      const float sc = __expf(ld_agent(st) - M);
-      L += sc * ld_agent(st + 2); c0 += sc * ld_agent(st + 3); c1 += sc * ld_agent(st + 4);
-    }
-    s_mrg[n][0] = M; s_mrg[n][1] = 1.0f / L; s_mrg[n][2] = c0 / L; s_mrg[n][3] = c1 / L;
+    const float invL = 1.0f / L;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s_scb[n][b] = scb[b] * invL;
+    s_mrg[n][0] = M; s_mrg[n][1] = invL; s_mrg[n][2] = c0 / L; s_mrg[n][3] = c1 / L;
     s_mm[n][0] = mn; s_mm[n][1] = M;
   }
   __syncthreads();
@@ -1101,7 +1119,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int b = 0; b < NB; ++b) {
       const float* rb = rec0 + b * R4_REC + n * (DIM + 8);
-      const float sc = __expf(ld_agent(rb + DIM) - s_mrg[n][0]) * s_mrg[n][1];
+      const float sc = s_scb[n][b];
       const float4 v4 = ld_agent4(rs_part, part_g, rb + c * 4);
       a.x += sc * v4.x; a.y += sc * v4.y; a.z += sc * v4.z; a.w += sc * v4.w;
     }
@@ -1126,7 +1144,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
     float mx = -3.0e38f;
 #pragma unroll
     for (int n = 0; n < KM; ++n)
-      if (n < k) { v[n] = ld_agent(logits + ((size_t)reg * g.P + p) * k + n); mx = fmaxf(mx, v[n]); }
+      if (n < k) { v[n] = p == tid ? v_first[n] : ld_agent(logits + ((size_t)reg * g.P + p) * k + n); mx = fmaxf(mx, v[n]); }
     float se = 0.f;
 #pragma unroll
     for (int n = 0; n < KM; ++n)
