@@ -929,41 +929,60 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   lds_sync();
   RRT_TRACE_MARK();                                 // [2] rows requested, phi in LDS
   const float inv_d = 1.0f / (float)DIM;
+  // The wave's NR rows in three straight-line stages -- means, variances, logits -- and the stores behind them: 2 + k
+  // wave reductions per row are dependent DPP chains, and with a row's stores (a lane-0 branch) between one row and the
+  // next the compiler ran the 15 chains of three rows one after the other (round 5, traced: 6.0 K cycles for this phase).
+  // Rows past the quarter's end compute on row 0's data and are not stored.
+  float mean_[NR], rstd_[NR], lgs[NR][KM];
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
-    const int rq = wave + NW * j, p = q * PQ + rq;
-    if (rq >= PQ || p >= g.P) continue;             // wave-uniform
     const float4 a = r[j][0], b = r[j][1];
-    const float mean = wave_sum(((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) * inv_d;
-    float sq;
-    {
-      const float a0 = a.x - mean, a1 = a.y - mean, a2 = a.z - mean, a3 = a.w - mean;
-      const float b0 = b.x - mean, b1 = b.y - mean, b2 = b.z - mean, b3 = b.w - mean;
-      sq = ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3));
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
+    mean_[j] = wave_sum(((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) * inv_d;
+  }
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const float4 a = r[j][0], b = r[j][1];
+    const float mean = mean_[j];
+    const float a0 = a.x - mean, a1 = a.y - mean, a2 = a.z - mean, a3 = a.w - mean;
+    const float b0 = b.x - mean, b1 = b.y - mean, b2 = b.z - mean, b3 = b.w - mean;
+    const float sq = ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3));
+    rstd_[j] = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
+  }
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const float4 a = r[j][0], b = r[j][1];
+    const float mean = mean_[j], rstd = rstd_[j];
     float4 v0, v1;
     v0.x = (a.x - mean) * rstd * gm0.x + bt0.x; v0.y = (a.y - mean) * rstd * gm0.y + bt0.y;
     v0.z = (a.z - mean) * rstd * gm0.z + bt0.z; v0.w = (a.w - mean) * rstd * gm0.w + bt0.w;
     v1.x = (b.x - mean) * rstd * gm1.x + bt1.x; v1.y = (b.y - mean) * rstd * gm1.y + bt1.y;
     v1.z = (b.z - mean) * rstd * gm1.z + bt1.z; v1.w = (b.w - mean) * rstd * gm1.w + bt1.w;
-    const bool real = tokv[j] >= 0;
 #pragma unroll
-    for (int n = 0; n < KM; ++n)
+    for (int n = 0; n < KM; ++n) {
+      lgs[j][n] = 0.f;
       if (n < k) {
         const float4 p0 = *(const float4*)(phi_t + n * DIM + lane * 4), p1 = *(const float4*)(phi_t + n * DIM + 256 + lane * 4);
-        const float acc = wave_sum(((v0.x * p0.x + v0.y * p0.y) + (v0.z * p0.z + v0.w * p0.w)) +
-                                   ((v1.x * p1.x + v1.y * p1.y) + (v1.z * p1.z + v1.w * p1.w)));
-        if (lane == 0) {
-          const float lgv = real ? acc : 0.f;       // pad tokens carry zero rows -> zero logits
+        lgs[j][n] = wave_sum(((v0.x * p0.x + v0.y * p0.y) + (v0.z * p0.z + v0.w * p0.w)) +
+                             ((v1.x * p1.x + v1.y * p1.y) + (v1.z * p1.z + v1.w * p1.w)));
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int rq = wave + NW * j, p = q * PQ + rq;
+    if (rq >= PQ || p >= g.P) continue;             // wave-uniform
+    const bool real = tokv[j] >= 0;
+    if (lane == 0) {
+#pragma unroll
+      for (int n = 0; n < KM; ++n)
+        if (n < k) {
+          const float lgv = real ? lgs[j][n] : 0.f;   // pad tokens carry zero rows -> zero logits
           s_lg[rq * KM + n] = lgv;
           st_agent(logits + ((size_t)reg * g.P + p) * k + n, lgv);
         }
-      }
-    if (lane == 0) {
-      s_mr[2 * rq] = real ? mean : 0.f;
-      s_mr[2 * rq + 1] = real ? rstd : 0.f;
-      if (real && mean_rstd) { mean_rstd[2 * (size_t)tokv[j]] = mean; mean_rstd[2 * (size_t)tokv[j] + 1] = rstd; }
+      s_mr[2 * rq] = real ? mean_[j] : 0.f;
+      s_mr[2 * rq + 1] = real ? rstd_[j] : 0.f;
+      if (real && mean_rstd) { mean_rstd[2 * (size_t)tokv[j]] = mean_[j]; mean_rstd[2 * (size_t)tokv[j] + 1] = rstd_[j]; }
     }
   }
   RRT_TRACE_MARK();                                 // [3] LayerNorm statistics + logits of this wave's rows
