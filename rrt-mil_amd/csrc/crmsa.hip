@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
 // of crmsa_region4_kernel's quarters (14.6 us at N = 9000 for one 18 MB read: a chain of ten latencies).
 // KM (4 / 8): representatives the instantiation carries (k <= KM; the table and phi-products of n >= k are zero) -- with a
 // run-time k every per-n loop was a chain of scalar branches: 3.8 K instructions, 13 us (traced: 23 K cycles per wave).
-template <int TR, int KM>   // x1 rows in flight per thread (16 row groups x 16 column lanes per block); representatives
+template <int TR, int KM, bool COAL = false>   // x1 rows in flight per thread (16 row groups x 16 column lanes per block); representatives;
+                                               // COAL: the records arrive coalesced and pass through LDS (see below)
 __global__ __launch_bounds__(256) void crmsa_combine_parts_kernel(const float* __restrict__ x1, const float* __restrict__ part,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   const float* __restrict__ phi, float* __restrict__ wdisp,
@@ -370,7 +371,23 @@ __global__ __launch_bounds__(256) void crmsa_combine_parts_kernel(const float* _
   const int t_mine = token_of(tid);                 // row `tid` of the region (regions of > 256 rows: the loop below)
   constexpr int NFM = KM <= 2 ? 1 : KM <= 6 ? 2 : 3;
   float4 rc[MAXS][NFM];
-  {
+  // The records of a row are n_slabs x nf float4s in a row of their own: a thread fetching ITS row's sixteen pieces makes every
+  // wave-instruction touch 64 different 128-byte lines for 16 bytes each (traced: 6.1 K cycles until the last request of the
+  // block was out -- the texture path, not the data).  Where a row's record is exactly 16 float4s (dim = 512, k = 3 / 4) and
+  // the region's rows are all in the first batch (P <= 16 TR), the block fetches them the way it fetches x1 -- thread
+  // (row group, column lane) takes piece `cl` of rows rg, rg + 16, ...: 256 contiguous bytes per row -- and passes them
+  // through LDS (pitch 17 float4s); `coal` is decided (and the LDS provided) by the launcher.
+  constexpr int RPITCH = 17;
+  constexpr bool coal = COAL && KM == 4;            // (a run-time switch sent the staging registers to scratch: 17 us)
+  float4* const s_rec = (float4*)(smem + (size_t)g.P * KM * 4 * 2 + (size_t)((g.P + 1) & ~1) * 8 + (size_t)16 * (KM + 1) * 16 * 16);
+  float4 cq[TR];
+  if constexpr (coal) {
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      const int t = token_of((tid >> 4) + 16 * u);
+      cq[u] = ((const float4*)part)[(size_t)(t < 0 ? 0 : t) * 16 + (tid & 15)];
+    }
+  } else {
     const float4* r = (const float4*)(part + (size_t)(t_mine < 0 ? 0 : t_mine) * n_slabs * (4 * nf));
 #pragma unroll
     for (int c = 0; c < MAXS; ++c)
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(256) void crmsa_combine_parts_kernel(const float* _
 #pragma unroll
     for (int n = 0; n < KM; ++n) ag[n] = ab[n] = 0.f;
     const int c0 = 8 * lane;
-    if (!al16) {                                     // parameters not on 16-byte boundaries: the plain loop
+    if (!(al16 & 1)) {                               // parameters not on 16-byte boundaries: the plain loop
       for (int c = lane; c < dim; c += 64) {
         const float gm = gamma[c], bt = beta[c];
 #pragma unroll
@@ -480,6 +497,17 @@ __global__ __launch_bounds__(256) void crmsa_combine_parts_kernel(const float* _
     for (int n = 0; n < KM; ++n) {
       const float a_ = wave_sum(ag[n]), b_ = wave_sum(ab[n]);
       if (lane == 0) { s_gb[n] = a_; s_gb[KM + n] = b_; }
+    }
+  }
+  if constexpr (coal) {
+#pragma unroll
+    for (int u = 0; u < TR; ++u) s_rec[((tid >> 4) + 16 * u) * RPITCH + (tid & 15)] = cq[u];
+    lds_sync();
+    if (tid < g.P) {
+#pragma unroll
+      for (int c = 0; c < MAXS; ++c)
+#pragma unroll
+        for (int f = 0; f < NFM; ++f) rc[c][f] = s_rec[tid * RPITCH + (c * 2 + f) % 16];
     }
   }
   if (tid < g.P) row_stats(rc, t_mine, mean_mine, rstd_mine, dn_mine);
@@ -1526,11 +1554,14 @@ hipError_t launch_crmsa_combine_parts(const float* x1, const float* part, const 
   if (!crmsa_combine_parts_supported(dim, k, g8)) return hipErrorInvalidValue;
   dim3 grid(g8.rs * g8.rs, dim / 64), block(256);
   constexpr int TR = 9;                               // P = 144: every row of the region in flight at once
-  const int al16 = (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)phi) & 15) == 0;
+  static const bool no_coal = rrt_tune_env("RRT_NO_CPARTS_COAL") != nullptr;
+  // bit 0: gamma / beta / phi on 16-byte boundaries; bit 1: the records come in coalesced and pass through LDS (see the kernel)
+  const bool coal = !no_coal && k >= 3 && k <= 4 && dim == 512 && g8.P <= 16 * TR && (((uintptr_t)part) & 15) == 0;
+  const int al16 = ((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)phi) & 15) == 0 ? 1 : 0) | (coal ? 2 : 0);
 #define RRT_CPARTS(KM_)                                                                                              \
   do {                                                                                                               \
-    const size_t lds = combine_parts_lds(g8.P, KM_);                                                                 \
-    auto kern = crmsa_combine_parts_kernel<TR, KM_>;                                                                 \
+    const size_t lds = combine_parts_lds(g8.P, KM_) + (coal ? (size_t)16 * TR * 17 * 16 : 0);                        \
+    auto kern = (coal && KM_ == 4) ? crmsa_combine_parts_kernel<TR, KM_, true> : crmsa_combine_parts_kernel<TR, KM_, false>; \
     static OncePerDevice once;                                                                                       \
     if (lds > 64 * 1024 && once.first())                                                                             \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);          \
