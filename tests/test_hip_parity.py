@@ -912,6 +912,28 @@ def test_rrtmil_autocast_bf16():
     assert np.abs(logits.float().cpu().numpy() - g["logits"]).max() <= 2e-2
 
 
+@pytest.mark.parametrize("n", [1, 7, 63, 200, 1111])
+def test_rrtmil_autocast_small_bags(n):
+    """Round 5: under autocast the classifier's patch_to_emb casts features + weight to 16 bits in one launch and multiplies
+    16-bit operands (rrt_mil_forward_f32).  Bags far smaller than a GEMM tile, ragged row counts: finite logits within the
+    bf16 tolerance of the fp32 classifier, twice in a row (the workspace's 16-bit images are rewritten every call)."""
+    from hip_util import DEV, dev
+    from rrt_mil_amd import RRTMIL
+    cfg = dict(input_dim=1024, n_classes=2, epeg_k=15, crmsa_k=1)
+    st = synth.mil_state(**cfg)
+    mil = RRTMIL(**load_golden("G8_rrtmil_n9000")["cfg"]).eval()
+    mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    mil = mil.to(DEV)
+    feats = dev(synth.bag(n, 1024, tag=f"mil/small{n}", nonneg=True)).unsqueeze(0)
+    with torch.no_grad():
+        ref = mil(feats).float().cpu().numpy()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            a = mil(feats).float().cpu().numpy()
+            b = mil(feats).float().cpu().numpy()
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert np.abs(a - ref).max() <= 3e-2 * max(1.0, np.abs(ref).max())
+
+
 # ------------------------------------------------------------------ fused R-MSA core
 @pytest.mark.parametrize("R,P,D,heads,ek,compute", [(64, 144, 512, 8, 15, 0), (9, 121, 512, 8, 15, 0),
                                                     (3, 130, 512, 8, 0, 0), (2, 144, 512, 8, 21, 0),
