@@ -45,6 +45,7 @@ matrix cores, RRT_COMPUTE_F32X3); the default run also reports bf16 and f32x3 as
 MAX over ranks, the JSON line) then runs without a GPU -- tests/test_multiproc_cpu.py drives it.
 """
 import argparse
+import contextlib
 import ctypes as C
 import json
 import os
@@ -68,6 +69,7 @@ if ROOT not in sys.path:
 DIM = 512
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (f32 in / bf16 in)
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
+FRESH_BYTES = 512 << 20                        # --fresh-inputs: distinct input bytes in rotation (2 x the 256 MiB Infinity Cache)
 def _newest(stem):
     """profiles/rNN_<stem> of the latest round that has one (the files are written by tools/, never typed in)"""
     for rnd in ("r05", "r04", "r03"):
@@ -133,12 +135,14 @@ def traffic_of(table, patterns, per_forward_of=None):
 CONFIGS = {
     0: dict(kind="encoder", n=512, dtype="f32", enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8),
             label="BASELINE configs[0]: RRTEncoder(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8).eval() forward, "
-                  "`streams_per_gpu` device-resident bags N=512 D=512 in flight per GPU (one per HIP stream) = one step"),
+                  "one step = ONE rrt_mil_amd.RRTEncoder.forward_bags call of `bags_per_step` device-resident bags N=512 D=512, "
+                  "`streams_per_gpu` of them in flight"),
     1: dict(kind="encoder", n=9000, dtype="f32", enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8),
             label="BASELINE configs[1]: RRTEncoder(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8).eval() forward, "
-                  "`streams_per_gpu` device-resident bags N=9000 D=512 in flight per GPU (one per HIP stream, each an ordinary "
-                  "forward with its own workspace), `bags_per_stream_per_step` of them back to back on every stream = one step; "
-                  "fp32, closed-form weights"),
+                  "one step = ONE call of the drop-in module's batch entry, rrt_mil_amd.RRTEncoder.forward_bags(bags, streams=S, "
+                  "outs=...), over `bags_per_step` device-resident bags N=9000 D=512 (`streams_per_gpu` bags in flight, each an "
+                  "ordinary forward with its own workspace; --raw-loop: the C-ABI entry point per bag instead); fp32, closed-form "
+                  "weights"),
     2: dict(kind="mil", n=9000, dtype="bf16", input_dim=1024, streams=4,
             enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=1, region_num=8, all_shortcut=True),
             label="BASELINE configs[2]: C16-R50 RRTMIL(input_dim=1024, epeg_k=15, crmsa_k=1, all_shortcut=True).eval() "
@@ -146,7 +150,7 @@ CONFIGS = {
                   "DAttention pooling, predictor), bf16 autocast-class arithmetic"),
     3: dict(kind="encoder", n=30000, dtype="bf16", enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=16),
             label="BASELINE configs[3]: survival long sequence, RRTEncoder(region_num=16, epeg_k=15, crmsa_k=3).eval() "
-                  "forward, device-resident bags N=30000 D=512 owned by each GPU, bf16 autocast-class arithmetic"),
+                  "forward_bags call per step over device-resident bags N=30000 D=512 owned by each GPU, bf16 autocast-class arithmetic"),
     4: dict(kind="mix", n=None, dtype="bf16", n_bags=64, enc=dict(mlp_dim=512, epeg_k=21, crmsa_k=5, region_num=8),
             label="BASELINE configs[4]: TCGA-NSCLC-R50 encoder (epeg_k=21, crmsa_k=5), one batch of 64 device-resident "
                   "bags with N ~ randint(3000, 15001) (seed 2021), split over the ranks by cost (LPT), each rank's share "
@@ -323,9 +327,21 @@ class EncoderWorkload:
         # a step = one batch of synthetic bags = S bags in flight x R bags per stream (R back to back on every stream): the
         # timed region is bracketed by device syncs, so its first bags start in lockstep and its last ones drain alone --
         # with R = 1 a 20-step region (80 bags) read 2 % under a 200-step one; with R = 4 the same 20 steps are 320 bags
-        self.R = R = max(1, getattr(args, "bags_per_stream", 0) or 4)
+        # Round 6: the timed region of the encoder configs goes through the drop-in itself -- one
+        # `rrt_mil_amd.RRTEncoder.forward_bags(bags, streams=S, outs=...)` call per step, from a caller under its own
+        # `with torch.cuda.stream(s):` (the asynchronous use INTEGRATION.md section 4 documents) -- so a step is one CALL of
+        # S x R bags, R = 16 by default: the call's fork / join is a barrier across the bag streams, paid once per step.
+        # `--raw-loop` (and the classifier of config 2, one C-ABI call per slide) keeps the rounds 1-5 region: the C-ABI entry
+        # point called per bag on S streams, R = 4.
+        self.via = "raw_loop" if (getattr(args, "raw_loop", False) or cfg["kind"] == "mil") else "forward_bags"
+        self.Rr = 4                                   # bags per stream and step of the raw C-ABI loop
+        self.R = R = max(1, getattr(args, "bags_per_stream", 0) or (self.Rr if self.via == "raw_loop" else 16))
+        if self.via == "raw_loop":
+            self.Rr = R
+        self.raw_steps = args.steps if self.via == "raw_loop" else 20      # steps of the raw pass (forward_bags runs: untimed, after the region)
         self.units_global = world * S * R
         self.scaling = "weak"
+        self.extra, self.fresh = {}, False
         self.lib = _lib.load()
         self.hev = HipEvents()
         tstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
@@ -352,6 +368,7 @@ class EncoderWorkload:
             _lib.check(self.lib.rrt_mil_workspace_size(C.byref(self.mdesc), self.n, C.byref(need)), "mil workspace")
             self.wss = [torch.empty(need.value, dtype=torch.uint8, device=dev) for _ in range(S)]
             self.outs = [torch.empty(2, dtype=torch.float32, device=dev) for _ in range(S)]
+            self._fresh(args, cfg["input_dim"], nonneg=True)
         else:
             state = synth.encoder_state(**{k: v for k, v in self.enc_cfg.items() if k != "region_num"})
             enc = RRTEncoder(**self.enc_cfg).eval()
@@ -362,6 +379,7 @@ class EncoderWorkload:
             need = self.enc._workspace(self.n, dev).numel()
             self.wss = [torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(S)]   # one workspace per bag in flight
             self.outs = [torch.empty_like(self.bags[0]) for _ in range(S)]
+            self._fresh(args, DIM, nonneg=False)
         self.enc._desc.compute = self.compute
         self.enc._desc.solo = int(S == 1)        # scheduling hint: with S > 1 the bags share the GPU (rrt_encoder_desc.solo)
         if os.environ.get("RRT_BENCH_SOLO") in ("0", "1"):     # (experiments only)
@@ -372,9 +390,9 @@ class EncoderWorkload:
         # fp32 bag and 10 % of a bf16 one -- so the window is 12 bags per stream, not the whole region; one step of 16 launches
         # read anywhere between 0.27 and 0.35 ms run to run).  Consecutive steps, all
         # streams: the launches' intervals can then be merged into the time during which the kernel was running at all.
-        self.ev_win = min(max(2, (12 if args.steps >= 100 else 4) // R), args.steps)   # (the driver's 20-step run: two steps)
-        self.ev_w0 = (args.steps - self.ev_win) // 2
-        self.ev_pairs = [(self.hev.create(), self.hev.create()) for _ in range(self.ev_win * S * R)]
+        self.ev_win = min(max(2, (12 if self.raw_steps >= 100 else 4) // self.Rr), self.raw_steps)   # (a 20-step run: two steps)
+        self.ev_w0 = (self.raw_steps - self.ev_win) // 2
+        self.ev_pairs = [(self.hev.create(), self.hev.create()) for _ in range(self.ev_win * S * self.Rr)]
         self.ev_arr = (C.c_void_p * _lib.EV_COUNT)()
         # optional phase gate (RRT_BENCH_GATE=1): the bags' MFMA-bound R-MSA cores take turns instead of time-slicing.
         # Off by default since round 2: with the denser kernels free-running streams are faster at every S
@@ -383,8 +401,42 @@ class EncoderWorkload:
         want_gate = os.environ.get("RRT_BENCH_GATE") == "1"
         if want_gate and self.mil is None:
             _lib.check(self.lib.rrt_phase_gate_create(C.byref(self.gate)), "phase gate")
-        self.extra = {}
         self._w16_mode = [None] * S      # compute mode of the 16-bit weight images in each stream's workspace
+        if self.via == "forward_bags":
+            self.enc.compute_dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "f32x3": "f32x3"}[self.dtype]
+            self.caller = torch.cuda.Stream(dev)      # the caller's stream of every forward_bags call
+            nb = S * R
+            self.call_bags = [self.bags[j % len(self.bags)] for j in range(nb)]
+            # one output per bag of the call (what a user gets); --fresh-inputs: also one distinct input per bag (self._fresh)
+            self.call_outs = ([self.outs[j] for j in range(nb)] if self.fresh else [torch.empty_like(self.bags[0]) for _ in range(nb)])
+            for o in self.call_outs:
+                o.zero_()                # first touch outside the timed region
+            self.outs_raw = self.call_outs[:S] if not self.fresh else self.outs
+        else:
+            self.outs_raw = self.outs
+
+    def _fresh(self, args, width, nonneg):
+        """--fresh-inputs: >= FRESH_BYTES of distinct input bags (the four synthetic ones + device-generated normal bags of the
+        same shape) and, for the encoder configs, one output buffer per bag -- the rotation then touches more than twice the
+        Infinity Cache between two uses of a buffer, so neither a bag nor its output is cache-resident when its forward starts."""
+        self.fresh = bool(getattr(args, "fresh_inputs", False))
+        if not self.fresh:
+            return
+        torch = self.torch
+        bag_bytes = self.n * width * 4
+        want = max(len(self.bags), 2 * self.S * self.Rr, self.S * self.R if self.via == "forward_bags" else 0,
+                   -(-FRESH_BYTES // bag_bytes))
+        gen = torch.Generator(device=self.dev)
+        gen.manual_seed(2021)
+        while len(self.bags) < want:
+            b = torch.randn(self.n, width, device=self.dev, generator=gen)
+            self.bags.append(b.relu_() if nonneg else b)
+        if self.mil is None:
+            self.outs = [torch.empty_like(b) for b in self.bags]
+            for o in self.outs:
+                o.zero_()                  # first touch (page mapping) outside the timed region
+        self.extra["fresh_inputs"] = {"distinct_bags": len(self.bags), "input_mb": round(len(self.bags) * bag_bytes / 1e6, 1),
+                                      "distinct_outputs": len(self.outs) if self.mil is None else None}
 
     def _mark(self, a, b):
         for j in range(self._lib.EV_COUNT):
@@ -393,9 +445,19 @@ class EncoderWorkload:
         return self.ev_arr
 
     def step(self, i, timed):
+        if self.via == "forward_bags":
+            with self.torch.cuda.stream(self.caller):
+                self.enc.forward_bags(self.call_bags, streams=self.S, outs=self.call_outs)
+            return
+        self.step_raw(i, timed)
+
+    def step_raw(self, i, timed):
+        """S x Rr bags through the C-ABI entry point, one call per bag, S streams (the timed region of rounds 1-5)."""
         lib, _lib = self.lib, self._lib
-        for r_, s_ in ((r_, s_) for r_ in range(self.R) for s_ in range(self.S)):
-            x = self.bags[((i * self.R + r_) * self.S + s_) % len(self.bags)]
+        for r_, s_ in ((r_, s_) for r_ in range(self.Rr) for s_ in range(self.S)):
+            bi = ((i * self.Rr + r_) * self.S + s_) % len(self.bags)
+            x = self.bags[bi]
+            y = self.outs_raw[bi] if (self.fresh and self.mil is None) else self.outs_raw[s_]
             if self.mil is not None:
                 mode = self.mdesc.enc.compute     # (as RRTMIL.forward_bag: the 16-bit weight images stay in the workspace)
                 self.mdesc.enc.weights16_valid = int(mode != _lib.COMPUTE_F32 and self._w16_mode[s_] == mode)
@@ -406,7 +468,7 @@ class EncoderWorkload:
                 _lib.check(rc, "rrt_mil_forward_f32")
                 continue
             # mark the dominant kernel: [after LN+partition, after the fused R-MSA core]
-            evs = (self._mark(*self.ev_pairs[((i - self.ev_w0) * self.R + r_) * self.S + s_])
+            evs = (self._mark(*self.ev_pairs[((i - self.ev_w0) * self.Rr + r_) * self.S + s_])
                    if (timed and self.ev_w0 <= i < self.ev_w0 + self.ev_win) else None)
             # reduced-precision modes: this stream's workspace keeps the 16-bit weight images of the (unchanged)
             # weights from its first call on, as rrt_mil_amd.RRTEncoder does between forwards (weights16_valid)
@@ -414,7 +476,7 @@ class EncoderWorkload:
             self.enc._desc.weights16_valid = int(mode != _lib.COMPUTE_F32 and self._w16_mode[s_] == mode)
             self._w16_mode[s_] = mode
             rc = lib.rrt_encoder_forward_gated_f32(C.byref(self.enc._desc), C.byref(self.w), x.data_ptr(),
-                                                   self.outs[s_].data_ptr(), self.n, self.wss[s_].data_ptr(),
+                                                   y.data_ptr(), self.n, self.wss[s_].data_ptr(),
                                                    self.wss[s_].numel(), self.streams[s_], self.gate, evs)
             _lib.check(rc, "forward")
         self.enc._desc.weights16_valid = 0
@@ -550,11 +612,26 @@ class EncoderWorkload:
     def finish(self, args, world, rank, elapsed):
         import numpy as np
         torch = self.torch
-        for o in self.outs:
+        for o in (self.call_outs if self.via == "forward_bags" else self.outs):
             assert torch.isfinite(o).all()
         if rank != 0:
             return {}
         rec = {}
+        raw_elapsed = elapsed
+        if self.via == "forward_bags":
+            # the rounds 1-5 region, untimed, after the contract's: the C-ABI entry point per bag on S streams (S x Rr bags per
+            # step), with the event marks around the dominant kernel -- printed as `raw_c_abi_loop` beside `value`
+            self.enc._desc.compute, self.enc._desc.solo = self.compute, int(self.S == 1)
+            for i in range(5):
+                self.step_raw(i, False)
+            self.sync()
+            t0 = time.perf_counter()
+            for i in range(self.raw_steps):
+                self.step_raw(i, True)
+            self.sync()
+            raw_elapsed = time.perf_counter() - t0
+            for o in self.outs_raw:
+                assert torch.isfinite(o).all()
         merged = bool(plan_flags(self.enc, self.n) & self._lib.PLAN_FUSED_PROJ)
         flops, g = fused_flops(self.n, self.enc_cfg, with_proj=merged)
         peak = PEAK_TFLOPS["bf16" if self.dtype in ("bf16", "f16") else "f32"]
@@ -590,36 +667,49 @@ class EncoderWorkload:
             # took.  The instrumented steps carry two marker packets per forward and run slower than the steps around them
             # (round 4: one 16-launch step read 0.27-0.35 ms run to run) -- when the union figure contradicts ms_per_step it
             # is not evidence, and the line falls back to the bound that follows from ms_per_step alone.
-            ms_per_step = elapsed / args.steps * 1e3
-            per_step = self.S * self.R
+            ms_per_step = raw_elapsed / self.raw_steps * 1e3          # of the raw loop (= the timed region under --raw-loop)
+            per_step = self.S * self.Rr
             lb_ach = flops * per_step / (ms_per_step * 1e-3) / 1e12
             consistent = busy_ms * per_step <= ms_per_step
             ach = flops / (busy_ms * 1e-3) / 1e12 if consistent else lb_ach
+            if self.via == "forward_bags":
+                # `frac` of the line = what the line's own ms_per_step allows for the dominant kernel: its FLOPs x the step's
+                # launches / ms_per_step / peak (every other kernel of the step counted as if it were this one's time)
+                ms_line = elapsed / args.steps * 1e3
+                ach = flops * self.S * self.R / (ms_line * 1e-3) / 1e12
             rp = rocprof_record(args.config, self.dtype, self.S)
             rec["roofline"] = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak,
                                "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "frac_source": "hip_event_union" if consistent else "lower_bound_from_ms_per_step",
-                               "frac_lower_bound": round(lb_ach / peak, 4),
+                               "frac_source": ("lower_bound_from_ms_per_step (timed region: RRTEncoder.forward_bags)" if self.via == "forward_bags"
+                                               else "hip_event_union" if consistent else "lower_bound_from_ms_per_step"),
+                               "frac_lower_bound": round((ach if self.via == "forward_bags" else lb_ach) / peak, 4),
+                               "frac_raw_loop_lower_bound": round(lb_ach / peak, 4),
                                "frac_event_union": round(flops / (busy_ms * 1e-3) / 1e12 / peak, 4),
                                "flops_per_launch": flops,
                                "avg_launch_ms": round(raw_ms, 5), "busy_ms_per_launch": round(busy_ms, 5),
-                               "launches": len(iv), "launches_per_step": per_step, "bags_in_flight": self.S,
+                               "launches": len(iv), "launches_per_step": self.S * self.R, "bags_in_flight": self.S,
                                "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
                                "rocprof": rp,
-                               "note": f"{len(iv)} launches = {self.ev_win} consecutive step(s) x {self.R} bags x {self.S} stream(s) in the middle of "
-                                       "the timed region, one HIP event pair per launch (recorded by librrt_hip on the launch "
-                                       "stream).  avg_launch_ms = mean [start, end] interval of a launch (what rocprofv3's average "
-                                       "duration of the kernel says; with several bags in flight the launches of different streams "
-                                       "overlap and time-slice the matrix cores, so it counts the same wall time several times).  "
-                                       "busy_ms_per_launch = the UNION of the launches' intervals / launches: the time during which "
-                                       "this kernel was running at all (it still contains whatever the other bags' kernels took "
-                                       "from it; the kernel alone is roofline_isolated).  achieved = flops_per_launch / "
-                                       "busy_ms_per_launch when busy_ms_per_launch x launches_per_step <= ms_per_step (the marker "
-                                       "packets slow the instrumented steps: a union longer than the step is not evidence), otherwise the bound that needs no events: "
-                                       "frac_lower_bound = flops_per_launch x launches_per_step / ms_per_step / peak.  `rocprof` = "
-                                       "mean duration and union per launch from the committed rocprofv3 --kernel-trace table of "
-                                       "this command (tools/rocprof_union.py).  Rounds 1-3 printed the mean interval of 1-2 bags in "
-                                       "flight as avg_launch_ms and round 4 the union under that name: compare `frac`, not the field"}
+                               "note": ("`frac` = flops_per_launch x launches_per_step / ms_per_step / peak of THIS line's timed region "
+                                        "(RRTEncoder.forward_bags, no event marks: the executor takes none), i.e. the whole step charged to the "
+                                        "dominant kernel.  The event fields come from the raw C-ABI loop run after it (`raw_c_abi_loop`): "
+                                        if self.via == "forward_bags" else "") +
+                                       f"{len(iv)} launches = {self.ev_win} consecutive step(s) x {self.Rr} bags x {self.S} stream(s) in the middle of "
+                                       "the raw loop, one HIP event pair per launch (recorded by librrt_hip on the launch stream).  "
+                                       "avg_launch_ms = mean [start, end] interval of a launch (what rocprofv3's average duration of the "
+                                       "kernel says; with several bags in flight the launches overlap and time-slice the matrix cores).  "
+                                       "busy_ms_per_launch = the UNION of the launches' intervals / launches.  frac_event_union = "
+                                       "flops_per_launch / busy_ms_per_launch / peak (the marker packets slow the instrumented steps: "
+                                       "it is evidence only when busy x launches <= the raw loop's ms_per_step); "
+                                       "frac_raw_loop_lower_bound = the ms_per_step bound of the raw loop.  `rocprof` = mean duration and "
+                                       "union per launch from the committed rocprofv3 --kernel-trace table (tools/rocprof_union.py)"}
+            if self.via == "forward_bags":
+                rec["raw_c_abi_loop"] = {"value": round(self.S * self.Rr * self.raw_steps / raw_elapsed, 2), "unit": "slides/s",
+                                         "steps": self.raw_steps, "bags_per_step": self.S * self.Rr,
+                                         "ms_per_step": round(raw_elapsed / self.raw_steps * 1e3, 4),
+                                         "note": "the timed region of rounds 1-5, untimed here (rank-local clock, after the contract's "
+                                                 "region): rrt_encoder_forward_gated_f32 called per bag on S streams, no executor, "
+                                                 "no fork / join; `value` / this = what the drop-in's batch call keeps of the raw rate"}
         ach = flops / (iso_ms * 1e-3) / 1e12
         iso = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                "frac": round(ach / peak, 4), "flops_per_launch": flops, "avg_launch_ms": round(iso_ms, 5),
@@ -662,6 +752,7 @@ class MixWorkload:
         big = torch.from_numpy(synth.bag(15000, DIM, tag=f"bench/mix/r{rank}")).to(dev)
         self.bags = [big[:self.sizes[i]].contiguous() for i in self.mine]
         self.outs = [torch.empty_like(b) for b in self.bags]
+        self.caller = torch.cuda.Stream(dev) if dev.type == "cuda" else None
         loads = [sum(sharding.bag_cost(self.sizes[i], region_num=e["region_num"], epeg_k=e["epeg_k"],
                                        crmsa_k=e["crmsa_k"]) for i in r) for r in self.assign]
         self.extra = {"bags_per_rank": [len(r) for r in self.assign],
@@ -670,7 +761,9 @@ class MixWorkload:
 
     def step(self, i, timed):
         if self.bags:
-            with self.torch.no_grad():
+            # (round 6) from a caller under its own torch stream: the call is asynchronous, the host prepares the next
+            # call while the GPU runs this one -- on the default stream a 64-bag call blocks the host
+            with self.torch.no_grad(), self.torch.cuda.stream(self.caller):
                 self.enc.forward_bags(self.bags, streams=self.S, outs=self.outs)
 
     def sync(self):
@@ -769,6 +862,13 @@ def main():
                          "(3 for bf16 / fp16 bags of > 12 k tokens and the configs[4] mix: measured optima, see main())")
     ap.add_argument("--bags-per-stream", type=int, default=0,
                     help="forwards per stream and step (configs 0-3; default 4): a step = streams x this many bags")
+    ap.add_argument("--fresh-inputs", action="store_true",
+                    help="configs 0-3: rotate over >= 512 MB of DISTINCT device-resident bags, each with its own output buffer "
+                         "(more than the 256 MB Infinity Cache holds), instead of cycling four bags: what a loader that hands "
+                         "over a new bag per iteration gives (main.py:434)")
+    ap.add_argument("--raw-loop", action="store_true",
+                    help="configs 0, 1, 3: time the C-ABI entry point called per bag on --streams streams (the timed region of "
+                         "rounds 1-5) instead of RRTEncoder.forward_bags")
     ap.add_argument("--stub-cpu", action="store_true", help="rank logic only: CPU stand-in workload over gloo (tests)")
     ap.add_argument("--module-call-only", action="store_true",
                     help="print only the `module_call` record of this config (the default run spawns this as a child process)")
@@ -879,6 +979,9 @@ def main():
                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                   "baseline_config_index": args.config, "dim": DIM, "bags_per_step": wl.units_global,
                   "streams_per_gpu": getattr(wl, "S", None), "bags_per_stream_per_step": getattr(wl, "R", None),
+                  "timed_region_via": {"forward_bags": "rrt_mil_amd.RRTEncoder.forward_bags (one call per step, caller under its own torch stream)",
+                                       "raw_loop": "C ABI per bag (rrt_encoder_forward_gated_f32 / rrt_mil_forward_f32)"}.get(getattr(wl, "via", None),
+                                                                                                               "RRTEncoder.forward_bags" if cfg["kind"] == "mix" else None),
                   "untimed_ramp_steps": ramp,
                   "parallelism": f"bag-parallel x{world} (no data-path collective)"}
         if cfg["n"]:
@@ -993,27 +1096,36 @@ def module_call(wl, dev, n_bags=64):
         n_batch = 4 * n_bags                          # one executor call = one fork / join: the longer the batch, the less it weighs
         batch = [bags3[i % len(bags3)] for i in range(n_batch)]
         outs = [torch.empty_like(b[0]) for b in batch]
-        # one untimed call over the whole batch first: it creates the executor and TOUCHES the 256 output buffers (4.7 GB of
+        # untimed calls over the whole batch first: they create the executor and TOUCH the 256 output buffers (4.7 GB of
         # fresh device memory: the first write to a new allocation pays for its page mapping -- round 5 measured 1.9-2.6 k
-        # slides/s for a first call against 5.0-5.2 k from the second on, tools/bench_bags.py)
-        enc.forward_bags(batch, streams=S, outs=outs)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        enc.forward_bags(batch, streams=S, outs=outs)
-        host_b = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        t1 = time.perf_counter() - t0
-        out["forward_bags"] = round(n_batch / t1, 1)
+        # slides/s for a first call against 5.0-5.2 k from the second on, tools/bench_bags.py).  Then FIVE calls back to back
+        # (rounds 4-5 timed ONE call that started on an idle, down-clocked GPU right after a device sync and read 4-15 % low:
+        # 5.06 k fp32 / 16.6 k bf16 where five consecutive calls of the same process give 5.26 k / 19.3 k, profiles/r06_probe1.txt).
+        caller = torch.cuda.Stream(dev)
+        for name, ctx in (("forward_bags_default_stream", contextlib.nullcontext()), ("forward_bags", torch.cuda.stream(caller))):
+            with ctx:
+                for _ in range(2):
+                    enc.forward_bags(batch, streams=S, outs=outs)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    enc.forward_bags(batch, streams=S, outs=outs)
+                host_b = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                t1 = time.perf_counter() - t0
+            out[name] = round(5 * n_batch / t1, 1)
+            out[name + "_host_us_per_bag"] = round(host_b / (5 * n_batch) * 1e6, 1)
         out["forward_bags_streams"] = S
         out["forward_bags_batch"] = n_batch
-        out["forward_bags_host_us_per_bag"] = round(host_b / n_batch * 1e6, 1)
         assert torch.isfinite(y).all() and torch.isfinite(outs[-1]).all()
     enc.compute_dtype, enc.solo = mode_was, solo_was
     enc._desc.compute = wl.compute
     out["note"] = (f"{n_bags} device-resident bags: `for bag in bags: enc(bag)` under no_grad through nn.Module.__call__ (one bag "
-                   f"in flight, the reference's loop) and enc.forward_bags({n_batch} bags, streams={S}) (one executor call); host_us_per_bag "
-                   "= host thread time per forward while the device queue is not full; compare module_loop with "
-                   "one_bag_in_flight.slides_per_s and forward_bags with `value` (both taken at the C ABI)")
+                   f"in flight, the reference's loop) and five consecutive enc.forward_bags({n_batch} bags, streams={S}) calls -- from the "
+                   "process's default stream (`forward_bags_default_stream`: each call blocks the host until its bags are done) and from "
+                   "a caller under `with torch.cuda.stream(s):` (`forward_bags`: asynchronous, what bench.py's timed region does); "
+                   "host_us_per_bag = host thread time per forward (for the blocking call: its wall time); compare module_loop with "
+                   "one_bag_in_flight.slides_per_s and forward_bags with `value`")
     return out
 
 

@@ -17,6 +17,8 @@ import contextlib
 import ctypes as C
 import math
 
+import numpy as np
+
 import torch
 from torch import nn
 
@@ -692,58 +694,92 @@ class RRTEncoder(nn.Module):
         """A batch of independent bags (each (N_i, D) or (1, N_i, D), any mix of sizes) -> list of outputs of
         the same shapes.  What the reference does with ``for bag in loader: model(bag)`` (main.py:466-467),
         with ``streams`` bags in flight on the library's own HIP streams (rrt_executor_forward); ordered on
-        the current stream like a normal op.  Bags are never mixed."""
+        the current stream like a normal op.  Bags are never mixed.
+
+        ``outs``: optional list of preallocated fp32 outputs (bag shapes).  Called under ``with torch.cuda.stream(s):`` the
+        call is asynchronous (the host returns once the launches are queued and prepares the next call while the GPU runs);
+        on the process's default stream a call of >= 16 bags blocks the host until the bags are done (see below)."""
         lib = _lib.load()
-        if not bags:
+        n_bags = len(bags)
+        if not n_bags:
             return []
         if self._stochastic():          # train() under no_grad: dropout / stochastic depth per bag, one bag at a time
             return [self.forward_bag(b[0]).unsqueeze(0) if b.dim() == 3 else self.forward_bag(b) for b in bags]
         dev = bags[0].device
-        xs = []
+        D, f32 = self.final_dim, torch.float32
+        # Host time per bag matters here: a blocking call leaves the GPU idle from its return to the next call's first launch,
+        # and at 50 us of GPU time per bf16 bag every microsecond of Python per bag is 2 % (round 6: the per-bag view /
+        # contiguous() / struct-field code measured 3-4 us per bag; this pass is ~1).  Fast path: fp32, contiguous, (N, D) or
+        # (1, N, D) on one device -- a (1, N, D) bag IS its (N, D) rows, no view object is made.
+        xs = bags
         for b in bags:
-            if not b.is_cuda or b.device != dev:
-                raise _lib.RRTHipError("forward_bags: every bag must be on the same HIP device (no CPU fallback)")
-            x2 = b[0] if b.dim() == 3 and b.size(0) == 1 else b
-            if x2.dim() != 2 or x2.size(1) != self.final_dim:
-                raise ValueError(f"forward_bags: expected (N, {self.final_dim}) or (1, N, {self.final_dim}) bags, "
-                                 f"got {tuple(b.shape)}")
-            if x2.dtype in (torch.bfloat16, torch.float16):
-                x2 = x2.float()
-            if x2.dtype != torch.float32:
-                raise NotImplementedError(f"unsupported bag dtype {x2.dtype}")
-            xs.append(x2.contiguous())
-        ys = [torch.empty_like(x) for x in xs] if outs is None else outs
+            nd = b.dim()
+            if (b.dtype is not f32 or b.device != dev or not b.is_contiguous() or b.size(-1) != D
+                    or not (nd == 2 or (nd == 3 and b.size(0) == 1))):
+                xs = None
+                break
+        if xs is None:                  # the general route: checks with messages, 16-bit inputs, strided bags
+            xs = []
+            for b in bags:
+                if not b.is_cuda or b.device != dev:
+                    raise _lib.RRTHipError("forward_bags: every bag must be on the same HIP device (no CPU fallback)")
+                x2 = b[0] if b.dim() == 3 and b.size(0) == 1 else b
+                if x2.dim() != 2 or x2.size(1) != D:
+                    raise ValueError(f"forward_bags: expected (N, {D}) or (1, N, {D}) bags, got {tuple(b.shape)}")
+                if x2.dtype in (torch.bfloat16, torch.float16):
+                    x2 = x2.float()
+                if x2.dtype != f32:
+                    raise NotImplementedError(f"unsupported bag dtype {x2.dtype}")
+                xs.append(x2.contiguous())
+        elif not dev.type == "cuda":
+            raise _lib.RRTHipError("forward_bags: every bag must be on the same HIP device (no CPU fallback)")
+        if outs is None:
+            ys = [torch.empty_like(x) for x in xs]
+        else:
+            ys = outs
+            if len(ys) != n_bags:
+                raise ValueError(f"forward_bags: {n_bags} bags but {len(ys)} outputs")
+            for x, y in zip(xs, ys):
+                if y.dtype is not f32 or y.device != dev or not y.is_contiguous() or y.numel() != x.numel():
+                    raise ValueError("forward_bags: every output must be a contiguous fp32 tensor of its bag's size on the bags' device")
         self._desc.compute = self._compute_mode()
         _warn_hw_queues(int(streams))
-        ex = self._executor(int(streams), max(x.size(0) for x in xs), dev)
-        arr = (_lib.Bag * len(xs))()
-        for i, (x, y) in enumerate(zip(xs, ys)):
-            arr[i].x, arr[i].y, arr[i].n_tokens = x.data_ptr(), y.data_ptr(), x.size(0)
+        tokens = [x.size(-2) for x in xs]
+        ex = self._executor(int(streams), max(tokens), dev)
+        # the rrt_bag array, filled through one int64 view (x, y, n_tokens per bag) instead of 3 n ctypes field stores
+        arr = (_lib.Bag * n_bags)()
+        tab = np.frombuffer(arr, dtype=np.int64).reshape(n_bags, 3)
+        tab[:, 0] = [x.data_ptr() for x in xs]
+        tab[:, 1] = [y.data_ptr() for y in ys]
+        tab[:, 2] = tokens
         w = self._weights()
-        with torch.cuda.device(dev):
+        with (torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else _NULL_CTX):
             cur = torch.cuda.current_stream(dev)
-            in_flight = max(1, min(int(streams), len(xs) // 4))      # the executor's rule: one stream per four bags of the call
+            in_flight = max(1, min(int(streams), n_bags // 4))      # the executor's rule: one stream per four bags of the call
             if not (cur.cuda_stream == 0 and in_flight >= 4):
                 # the call is ordered on the caller's stream, which carries the first share of the bags itself
-                rc = lib.rrt_executor_forward(ex, C.byref(w), arr, len(xs), cur.cuda_stream)
+                rc = lib.rrt_executor_forward(ex, C.byref(w), arr, n_bags, cur.cuda_stream)
             else:
                 # Four bags in flight and the caller on the process's DEFAULT stream (handle 0).  Bags on that stream next
                 # to three others run at 4.5 k slides/s instead of 5.1 k (measured, tools/bench_bags.py: with hundreds of
                 # launches queued the legacy default stream behaves like one queue more), and a default stream that merely
                 # WAITS for the bag streams (event wait) is a fifth active queue with the same cost (4.2-4.5 k).  So the
                 # call runs on a side stream, ordered behind the default stream's earlier work, and the HOST waits for it:
-                # nothing is parked on the default stream (4.8 k at 16 bags per call, 4.95 k at 64, 5.03 k at 256).  Callers
-                # that want the call asynchronous run it under their own `with torch.cuda.stream(s):` (5.07-5.09 k).
+                # nothing is parked on the default stream.  Round 6, 256 bags per call: 5.26 k fp32 / 19.3 k bf16 this way,
+                # 5.29 k / 19.8-20.2 k from a caller under its own `with torch.cuda.stream(s):` (asynchronous), 5.32 k / 20.4 k
+                # for the raw C-ABI loop of bench.py (profiles/r06_probe1.txt).
                 side = _SIDE_STREAM.get(dev)
                 if side is None:
                     side = _SIDE_STREAM[dev] = torch.cuda.Stream(dev)
                 side.wait_stream(cur)
-                rc = lib.rrt_executor_forward(ex, C.byref(w), arr, len(xs), side.cuda_stream)
+                rc = lib.rrt_executor_forward(ex, C.byref(w), arr, n_bags, side.cuda_stream)
                 side.synchronize()
         _lib.check(rc, "rrt_executor_forward")
         # xs / ys are touched on the executor's streams, but the call joins the current stream before it
         # returns, so the caching allocator's stream-ordered reuse of these buffers stays correct
-        return [y.unsqueeze(0) if b.dim() == 3 else y for b, y in zip(bags, ys)]
+        if xs is bags and outs is None:
+            return ys                   # allocated with the bags' own shapes
+        return [y.unsqueeze(0) if (b.dim() == 3 and y.dim() == 2) else y for b, y in zip(bags, ys)]
 
     def _next_drop_seed(self):
         """63-bit seed for this call's dropout masks.  ``drop_seed`` (int) pins it (tests); otherwise it comes from

@@ -293,3 +293,19 @@ def test_rrtmil_state_dict_surface():
     m2 = RRTMIL()
     assert float(m2.predictor.bias.detach().abs().max()) == 0.0
     assert float(m2.online_encoder.norm.weight.detach().min()) == 1.0
+
+
+def test_library_has_no_packed_fp32(lib):
+    """The linked library's gfx950 code (every bundle, every kernel) contains no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+    outside the kernels rrt-mil_amd/build.py::PACKED_FP32_OK names (today: none).  Compiler-formed packed fp32 next to another
+    bag's bf16-MFMA waves is what mis-summed CR-MSA's representatives in round 5; the build applies the
+    same check to every object it compiles -- this one reads the .so that actually ships (no GPU needed: llvm-objdump)."""
+    from rrt_mil_amd import build as B
+    if not os.path.exists(B.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    seen = []
+    census = B.packed_fp32_census(B.LIB, seen)
+    assert len(seen) > 300, f"only {len(seen)} device functions found: the disassembly did not see the kernels"
+    allowed = tuple(p for pats in B.PACKED_FP32_OK.values() for p in pats)
+    bad = {k: n for k, n in census.items() if not any(p in k for p in allowed)}
+    assert not bad, bad

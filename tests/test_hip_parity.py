@@ -1258,7 +1258,8 @@ def test_two_bags_in_flight_bit_identical_to_one(n_tokens, compute):
     cross-half op_sel) in a streaming kernel return run-to-run different values when the wave shares its SIMD with
     bf16-MFMA waves of the OTHER bag's kernels -- one (region, representative, 64 columns) chunk of CR-MSA's representatives
     in ~1 of 2 forwards, 1e-3 on the output.  The streaming kernels are therefore compiled without packed fp32
-    (rrt-mil_amd/build.py FILE_FLAGS); this test is what failed before."""
+    (rrt-mil_amd/build.py: packed fp32 is off unless a file and a kernel are on PACKED_FP32_OK, checked by disassembly); this
+    test is what failed before."""
     from hip_util import DEV
     lib = _lib.load()
     cfg = dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=8)

@@ -21,6 +21,15 @@ if os.environ.get("ABL_NO"):
             continue
         keep.append(f)
     flags = keep
+def file_flags(src):
+    # the product's per-file rule (packed fp32 off unless the file is in build.PACKED_FP32_OK); ABL_PACKED=a.hip,b.hip turns
+    # it ON for those files, ABL_NOPACKED=a.hip,b.hip OFF (A/B of one translation unit)
+    on = src in build.PACKED_FP32_OK
+    if src in os.environ.get("ABL_PACKED", "").split(","):
+        on = True
+    if src in os.environ.get("ABL_NOPACKED", "").split(","):
+        on = False
+    return [] if on else build.NO_PACKED_FP32
 od = f"tools/_abl/obj_{name}"
 hd = hashlib.sha256(" ".join(flags).encode())
 for h in build.HEADERS:
@@ -30,7 +39,7 @@ for src in build.SOURCES:
     obj = os.path.join(od, src.replace(".hip", ".o"))
     objs.append(obj)
     d = hd.copy()
-    d.update(" ".join([] if (os.environ.get("ABL_PACKED") and src in os.environ["ABL_PACKED"].split(",")) else build.FILE_FLAGS.get(src, [])).encode())
+    d.update(" ".join(file_flags(src)).encode())
     d.update(open(os.path.join(build.CSRC, src), "rb").read())
     dig = d.hexdigest()
     st = obj + ".stamp"
@@ -38,7 +47,7 @@ for src in build.SOURCES:
         continue
     if os.path.exists(st):
         os.remove(st)
-    ff = [] if (os.environ.get("ABL_PACKED") and src in os.environ["ABL_PACKED"].split(",")) else build.FILE_FLAGS.get(src, [])
+    ff = file_flags(src)
     procs.append((src, st, dig, subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, *ff, "-c", os.path.join(build.CSRC, src), "-o", obj],
                                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
 bad = False
