@@ -335,7 +335,9 @@ class EncoderWorkload:
         # point called per bag on S streams, R = 4.
         self.via = "raw_loop" if (getattr(args, "raw_loop", False) or cfg["kind"] == "mil") else "forward_bags"
         self.Rr = 4                                   # bags per stream and step of the raw C-ABI loop
-        self.R = R = max(1, getattr(args, "bags_per_stream", 0) or (self.Rr if self.via == "raw_loop" else 16))
+        # (64 bags per call read 2 % under the raw loop -- 5198 against 5304 slides/s fp32, same box -- and 256 bags 0.5 %:
+        #  profiles/r06_probe1.txt, r06_p2_lines.txt; long bags keep 16 per stream: a call of 48 N=30000 bags is already 8 ms)
+        self.R = R = max(1, getattr(args, "bags_per_stream", 0) or (self.Rr if self.via == "raw_loop" else 64 if cfg["n"] <= 12000 else 16))
         if self.via == "raw_loop":
             self.Rr = R
         self.raw_steps = args.steps if self.via == "raw_loop" else 20      # steps of the raw pass (forward_bags runs: untimed, after the region)
@@ -1064,6 +1066,40 @@ def h2d_inclusive(wl, dev, n_bags=96):
                     "(rrt_mil_amd/feed.py; reference loop: main.py:434)"}
 
 
+def h2d_inclusive_c2(dev, n_bags=64, n=9000, in_dim=1024):
+    """BASELINE configs[2] (the C16-R50 classifier under bf16 arithmetic) with every slide starting in PINNED HOST memory:
+    features shipped in fp32 (36.9 MB per slide) and in bf16 (18.4 MB: rrt_mil_amd.BagFeeder(dtype=torch.bfloat16); the logits
+    are bit-identical, tests/test_hip_parity.py::test_bag_feeder_16bit_features_bit_identical_logits)."""
+    import torch
+    from rrt_mil_amd import BagFeeder, RRTMIL, synth
+    mil = RRTMIL(input_dim=in_dim, n_classes=2, epeg_k=15, crmsa_k=1, all_shortcut=True).eval()
+    mst = synth.mil_state(input_dim=in_dim, n_classes=2, epeg_k=15, crmsa_k=1)
+    mil.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in mst.items()}, strict=True)
+    mil = mil.to(dev)
+    mil.online_encoder.compute_dtype = torch.bfloat16
+    host32 = [torch.randn(n, in_dim).relu_().pin_memory() for _ in range(6)]
+    host16 = [h.to(torch.bfloat16).pin_memory() for h in host32]
+    res = {}
+    with torch.no_grad():
+        for name, src, dt in (("fp32_features", host32, torch.float32), ("bf16_features", host16, torch.bfloat16)):
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for xb in BagFeeder((src[i % len(src)] for i in range(n_bags)), device=dev, depth=3, dtype=dt):
+                    lg = mil.forward_bag(xb)
+                torch.cuda.synchronize()
+                res[name] = n_bags / (time.perf_counter() - t0)
+            assert torch.isfinite(lg).all()
+    mb32 = n * in_dim * 4 / 1e6
+    return {"unit": "slides/s", "fp32_features": round(res["fp32_features"], 1), "bf16_features": round(res["bf16_features"], 1),
+            "fp32_h2d_GBps": round(res["fp32_features"] * mb32 / 1e3, 1), "bf16_h2d_GBps": round(res["bf16_features"] * mb32 / 2e3, 1),
+            "slide_mb": {"fp32": round(mb32, 1), "bf16": round(mb32 / 2, 1)}, "slides": n_bags,
+            "note": "RRTMIL (C16-R50 shape, bf16 arithmetic) fed from pinned host memory through BagFeeder, one forward stream + the "
+                    "copy stream; device-resident the same classifier runs `config2.value` slides/s: with fp32 features the link "
+                    "(~53 GB/s = ~1.4 k slides/s) is the limit, 16-bit features double it (rrt_mil_desc.input16; "
+                    "modules/rrt.py:208-229, dataloader.py:181,198)"}
+
+
 def module_call(wl, dev, n_bags=64):
     """The boundary the reference exposes is the nn.Module (modules/rrt.py:133-202), not the C ABI the timed region calls:
     the same bags through `enc(bag)` one at a time (the reference's loop, main.py:466-467; one bag in flight) and through
@@ -1187,49 +1223,47 @@ def extras(wl, dev):
     from rrt_mil_amd import RRTEncoder, RRTMIL, _lib, synth
     out = {}
     S = wl.S
+    def set_mode(mode):                       # the timed region's arithmetic: the C-ABI descriptor AND the module's compute_dtype
+        wl.enc._desc.compute = mode
+        wl.enc.compute_dtype = {_lib.COMPUTE_F32: torch.float32, _lib.COMPUTE_BF16: torch.bfloat16,
+                                _lib.COMPUTE_F16: torch.float16, _lib.COMPUTE_F32X3: "f32x3"}[mode]
+    out0 = (wl.call_outs if wl.via == "forward_bags" else wl.outs)
     # the same workload with bf16 arithmetic (the reference's --amp / autocast path, BASELINE configs[2..4])
-    wl.enc._desc.compute = _lib.COMPUTE_BF16
-    for i in range(10):
+    set_mode(_lib.COMPUTE_BF16)
+    for i in range(5):
         wl.step(i, False)
     torch.cuda.synchronize()
     ta = time.perf_counter()
-    for i in range(40):
+    for i in range(20):
         wl.step(i, False)
     torch.cuda.synchronize()
-    out["amp_bf16"] = {"value": round(wl.units_global * 40 / (time.perf_counter() - ta), 2), "unit": "slides/s", "n_gpus": 1,
-                       "note": "rank 0 only, 40 steps after the timed region; RRT_COMPUTE_BF16 (bf16 operands on the "
-                               "matrix cores, fp32 accumulate; `--config 3` / `--dtype bf16` give the full record)"}
+    out["amp_bf16"] = {"value": round(wl.units_global * 20 / (time.perf_counter() - ta), 2), "unit": "slides/s", "n_gpus": 1,
+                       "note": "rank 0 only, 20 steps after the timed region, same path (RRTEncoder.forward_bags); RRT_COMPUTE_BF16 "
+                               "(bf16 operands on the matrix cores, fp32 accumulate; `--config 3` / `--dtype bf16` give the full record)"}
     # fp32 EMULATED on the bf16 matrix cores for the two big projections (RRT_COMPUTE_F32X3; ~1e-6 from the exact path)
-    y_exact = wl.outs[0].clone()
-    wl.enc._desc.compute = _lib.COMPUTE_F32X3
-    for i in range(10):
+    set_mode(_lib.COMPUTE_F32X3)
+    for i in range(5):
         wl.step(i, False)
     torch.cuda.synchronize()
     tb = time.perf_counter()
-    for i in range(40):
+    for i in range(20):
         wl.step(i, False)
     torch.cuda.synchronize()
     tb = time.perf_counter() - tb
-    wl.enc._desc.compute = _lib.COMPUTE_F32
-    wl.step(39, False)                        # the same bags through the exact path: outs[0] of both modes side by side
+    y_x3 = out0[0].clone()
+    set_mode(_lib.COMPUTE_F32)
+    wl.step(19, False)                        # the same bags through the exact path: out0[0] of both modes side by side
     torch.cuda.synchronize()
-    y_x3 = y_exact                            # (outs[0] after the timed region held the exact result of another bag)
-    wl.enc._desc.compute = _lib.COMPUTE_F32X3
-    wl.step(39, False)
-    torch.cuda.synchronize()
-    y_x3 = wl.outs[0].clone()
-    wl.enc._desc.compute = _lib.COMPUTE_F32
-    wl.step(39, False)
-    torch.cuda.synchronize()
-    out["f32x3"] = {"value": round(wl.units_global * 40 / tb, 2), "unit": "slides/s", "n_gpus": 1,
-                    "max_abs_vs_exact_f32": float((y_x3 - wl.outs[0]).abs().max()),
-                    "note": "rank 0 only, 40 steps after the timed region; RRT_COMPUTE_F32X3: qkv / proj GEMMs of the R-MSA "
+    out["f32x3"] = {"value": round(wl.units_global * 20 / tb, 2), "unit": "slides/s", "n_gpus": 1,
+                    "max_abs_vs_exact_f32": float((y_x3 - out0[0]).abs().max()),
+                    "note": "rank 0 only, 20 steps after the timed region; RRT_COMPUTE_F32X3: qkv / proj GEMMs of the R-MSA "
                             "layers as three bf16 MFMAs per product on (hi, lo) bf16 operand pairs, fp32 accumulate; attention, "
                             "LayerNorm, CR-MSA exact fp32 (`--dtype f32x3` gives the full record)"}
 
     # PCIe-inclusive rates (the reference moves one bag per iteration with a blocking
     # bag.to(device), main.py:434): host bags -> HBM -> encoder, fp32, 18.4 MB per bag.  Never `value`.
     out["h2d_inclusive"] = h2d_inclusive(wl, dev)
+    out["h2d_inclusive_c2"] = h2d_inclusive_c2(dev)
 
     # the whole slide classifier of BASELINE configs[2] (C16-R50 shape) through the one-call path (row f1), fp32,
     # one bag in flight
@@ -1265,7 +1299,7 @@ def extras(wl, dev):
 
     def tstep():
         tenc.zero_grad(set_to_none=True)
-        (tenc(xg) * gy).sum().backward()
+        tenc(xg).backward(gy)                 # (rounds 3-5 timed `(y * g).sum().backward()`: three torch kernels, 33 us, in the step)
     for _ in range(3):
         tstep()
     torch.cuda.synchronize()

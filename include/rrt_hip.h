@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 24
+#define RRT_ABI_VERSION 25
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -388,6 +388,11 @@ typedef struct rrt_mil_desc {
   int32_t pool_hidden;     /* DAttention D = 128 (multiple of 4) */
   int32_t pool_act;        /* RRT_ACT_RELU / GELU / TANH / NONE (da_act) */
   int32_t pool_gated;      /* 1: AttentionGated (datten.py:40-83) */
+  int32_t input16;         /* (ABI 25) 0: x is fp32.  RRT_COMPUTE_BF16 / RRT_COMPUTE_F16: x points to 16-bit features of that
+                            * type [n_tokens, input_dim] (half the PCIe / HBM bytes of the bag, rrt_mil_amd.BagFeeder(dtype=...));
+                            * needs enc.compute == input16 and input_dim % 64 == 0, otherwise RRT_E_UNSUPPORTED.  Under autocast
+                            * the reference's first op (patch_to_emb Linear, rrt.py:208-229) rounds the fp32 features to exactly
+                            * these 16-bit values, so the logits are bit-identical to the fp32-fed call. */
 } rrt_mil_desc;
 
 /* Row-major fp32, state_dict layout.  Non-gated: pool_a = pool_fn.attention.attention.0,

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _f32p = C.POINTER(C.c_float)
 
@@ -60,7 +60,7 @@ class EncoderGrads(C.Structure):
 class MilDesc(C.Structure):
     _fields_ = [("enc", EncoderDesc), ("input_dim", C.c_int32), ("emb_act", C.c_int32),
                 ("n_classes", C.c_int32), ("pool_hidden", C.c_int32), ("pool_act", C.c_int32),
-                ("pool_gated", C.c_int32)]
+                ("pool_gated", C.c_int32), ("input16", C.c_int32)]
 
 
 class MilWeights(C.Structure):

@@ -1420,14 +1420,23 @@ int rrt_mil_forward_f32(const rrt_mil_desc* desc, const rrt_mil_weights* w, cons
   // N = 9000 x 1024 against ~10 + ~13 here).
   static const bool no_fc16 = rrt_tune_env("RRT_NO_FC16") != nullptr;
   hipError_t e;
+  if (desc->input16 != 0 && (desc->input16 != gemm_prec || (gemm_prec != RRT_COMPUTE_BF16 && gemm_prec != RRT_COMPUTE_F16) ||
+                             desc->input_dim % 64 != 0 || no_fc16))
+    return unsupported("rrt_mil_forward: 16-bit features (input16) need enc.compute == input16 (bf16 / f16) and input_dim % 64 == 0");
   if (!no_fc16 && (gemm_prec == RRT_COMPUTE_BF16 || gemm_prec == RRT_COMPUTE_F16) && desc->input_dim % 64 == 0) {
     char* tail = enc_ws + align_up(enc_bytes, 256) + align_up(pws.bytes, 256);
     uint16_t* x16 = (uint16_t*)tail;
     uint16_t* w16 = (uint16_t*)(tail + align_up((size_t)n_tokens * desc->input_dim * 2, 256));
     Cast16Jobs cj{};
-    cj.src[0] = x; cj.dst[0] = x16; cj.n4[0] = (size_t)n_tokens * desc->input_dim / 4;
-    cj.src[1] = w->emb_w; cj.dst[1] = w16; cj.n4[1] = (size_t)D * desc->input_dim / 4;
-    cj.count = 2;
+    if (desc->input16) {                 // the caller's features ARE the 16-bit operand: only the weight is cast
+      x16 = (uint16_t*)x;
+      cj.src[0] = w->emb_w; cj.dst[0] = w16; cj.n4[0] = (size_t)D * desc->input_dim / 4;
+      cj.count = 1;
+    } else {
+      cj.src[0] = x; cj.dst[0] = x16; cj.n4[0] = (size_t)n_tokens * desc->input_dim / 4;
+      cj.src[1] = w->emb_w; cj.dst[1] = w16; cj.n4[1] = (size_t)D * desc->input_dim / 4;
+      cj.count = 2;
+    }
     e = launch_cast16(cj, gemm_prec, st);
     if (e != hipSuccess) return (int)e;
     e = launch_linear16(x16, w16, emb, (int)n_tokens, D, desc->input_dim, ep, st);

@@ -324,6 +324,251 @@ __global__ __launch_bounds__(256) void crmsa_combine_kernel(const float* __restr
   }
 }
 
+// ---- round 6: the two chip-wide kernels for regions of more than 144 tokens (N > ~10.4 k: BASELINE configs[3] and the large
+// bags of configs[4]), dim = 512.  The round 1-5 pair above cost 8-9 us of FIXED time each on top of their bytes (N = 15000 /
+// 30000: logits 13.1 / 17.8 us, combine 13.6 / 18.6 us for 30.7 / 61.4 MB -- 3.4 TB/s at best): the logits kernel was a
+// persistent grid that staged phi through LDS behind a strided global read and then paid one exposed memory round trip per
+// two rows; the combine kernel walked the region's logits three times from global memory before its first x1 row was
+// requested, then fetched the rows in four dependent trips.  Here:
+//   * crmsa_logits512_kernel: one wave per two rows, grid = rows / 8 (as ln_partition_kernel, which streams at 6.4 TB/s), the
+//     lane's twelve gamma.phi products built in registers from direct (L2-hit) loads issued next to the row loads, the
+//     constants B_n = sum_c beta_c phi_cn once per block; logits in the CENTERED form rstd * sum_c (x_c - mean) gamma_c phi_cn
+//     + B_n (no cancellation at |mean| >> sigma);
+//   * crmsa_combine512_kernel: the first eight x1 rows of every thread are requested at kernel ENTRY (their addresses are
+//     geometry, not logits), the region's logits and (mean, rstd) are staged in LDS by one coalesced pass, every statistic is
+//     taken from LDS, and the next trip's rows are in flight while the current one is contracted.
+template <int KM>
+__global__ __launch_bounds__(256) void crmsa_logits512_kernel(const float* __restrict__ x1, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ phi,
+                                                              float* __restrict__ mean_rstd, float* __restrict__ logits,
+                                                              GridDev g) {
+  constexpr int DIM = 512, RW2 = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * 4 + wave) * RW2;
+  if (t0 >= g.Np) return;
+  float4 r[RW2][2];
+#pragma unroll
+  for (int i = 0; i < RW2; ++i) {
+    const int t = t0 + i;
+    const float* src = x1 + (size_t)(t < g.L ? t : 0) * DIM;      // rows past the bag: re-read row 0, never used
+#pragma unroll
+    for (int v = 0; v < 2; ++v) r[i][v] = *(const float4*)(src + (v * 64 + lane) * 4);
+  }
+  // gamma . phi of this lane's eight columns, B_n partial sums
+  float gp[2][4][KM];
+  float bsum[KM];
+#pragma unroll
+  for (int n = 0; n < KM; ++n) bsum[n] = 0.f;
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int c = (v * 64 + lane) * 4;
+    const float4 gm4 = *(const float4*)(gamma + c), bt4 = *(const float4*)(beta + c);
+    const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w}, bt[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
+    float pf[4 * KM];                              // phi[c .. c+3][0 .. KM): 4 KM contiguous floats = KM float4
+#pragma unroll
+    for (int j = 0; j < KM; ++j) {
+      const float4 q = *(const float4*)(phi + (size_t)c * KM + 4 * j);
+      pf[4 * j] = q.x; pf[4 * j + 1] = q.y; pf[4 * j + 2] = q.z; pf[4 * j + 3] = q.w;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int n = 0; n < KM; ++n) {
+        const float ph = pf[cc * KM + n];
+        gp[v][cc][n] = gm[cc] * ph;
+        bsum[n] += bt[cc] * ph;
+      }
+  }
+  float Bn[KM];
+#pragma unroll
+  for (int n = 0; n < KM; ++n) Bn[n] = wave_sum(bsum[n]);
+  const float inv_d = 1.0f / (float)DIM;
+#pragma unroll
+  for (int i = 0; i < RW2; ++i) {
+    const int t = t0 + i;
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) sum += (r[i][v].x + r[i][v].y) + (r[i][v].z + r[i][v].w);
+    const float mean = wave_sum(sum) * inv_d;
+    float sq = 0.f, d[KM];
+#pragma unroll
+    for (int n = 0; n < KM; ++n) d[n] = 0.f;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const float xc[4] = {r[i][v].x - mean, r[i][v].y - mean, r[i][v].z - mean, r[i][v].w - mean};
+      sq += (xc[0] * xc[0] + xc[1] * xc[1]) + (xc[2] * xc[2] + xc[3] * xc[3]);
+#pragma unroll
+      for (int n = 0; n < KM; ++n)
+        d[n] += (xc[0] * gp[v][0][n] + xc[1] * gp[v][1][n]) + (xc[2] * gp[v][2][n] + xc[3] * gp[v][3][n]);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + LN_EPS);
+    float mine = 0.f;                              // lane n keeps logit n
+#pragma unroll
+    for (int n = 0; n < KM; ++n) {
+      const float lg = rstd * wave_sum(d[n]) + Bn[n];
+      mine = lane == n ? lg : mine;
+    }
+    if (t < g.Np) {
+      if (lane < KM) logits[(size_t)token_to_slot(t, g) * KM + lane] = t < g.L ? mine : 0.f;   // pad tokens: zero rows -> zero logits
+      if (lane == 0 && t < g.L) *(float2*)(mean_rstd + 2 * (size_t)t) = make_float2(mean, rstd);
+    }
+  }
+}
+
+template <int KM>
+__global__ __launch_bounds__(256, 2) void crmsa_combine512_kernel(const float* __restrict__ x1, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ mean_rstd,
+                                                               const float* __restrict__ logits, float* __restrict__ wdisp,
+                                                               float* __restrict__ rep, uint16_t* __restrict__ rep16,
+                                                               int prec16, GridDev g) {
+  // TR rows per thread and trip, two trips in flight (a consumed while b lands): 16 float4 = 64 KB per block, two blocks per CU --
+  // what the chip needs in flight per CU to stream at ~6 TB/s is ~47 KB.  (First version: TR = 16 -> 254 VGPRs, ONE block per CU,
+  // 512 blocks in two rounds: 22.2 us at N = 30000 against 18.6 for the round-5 kernel.)
+  constexpr int DIM = 512, TR = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lgs = (float*)smem;                                   // [P][KM] logits, then the combine coefficient x rstd in place
+  float2* mr = (float2*)(lgs + (((size_t)g.P * KM + 3) & ~(size_t)3));   // [P] (mean, rstd) of the region's tokens, (0, 0) for pad
+  float4* part = (float4*)(mr + ((g.P + 1) & ~1));             // [16 row groups][KM][16 column lanes]
+  __shared__ float s_stat[KM][3];
+  __shared__ float s_c0[KM][4], s_c1[KM][4];
+  const int reg = blockIdx.x, slab = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cl = tid & 15, rg = tid >> 4;
+  const int col = slab * 64 + cl * 4;
+  const int ri = fdiv(reg, g.rs, g.inv_rs), rj = reg - ri * g.rs;
+  auto tok_of = [&](int p) -> int {                            // token of the region's p-th slot, -1 for pad / past the region
+    const int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
+    const int t = (ri * g.s + pi) * g.H + rj * g.s + pj;
+    return (p < g.P && t < g.L) ? t : -1;
+  };
+  // trip 0: this thread's first TR rows, requested before anything else
+  float4 xa[TR], xb[TR];
+  bool ra[TR], rb[TR];
+#pragma unroll
+  for (int u = 0; u < TR; ++u) {
+    const int t = tok_of(rg + 16 * u);
+    ra[u] = t >= 0;
+    xa[u] = *(const float4*)(x1 + (size_t)(t >= 0 ? t : 0) * DIM + col);
+  }
+  // the region's logits and statistics -> LDS, one coalesced pass each
+  const float* lg = logits + (size_t)reg * g.P * KM;
+  for (int idx = tid; idx < g.P * KM; idx += 256) lgs[idx] = lg[idx];
+  for (int p = tid; p < g.P; p += 256) {
+    const int t = tok_of(p);
+    mr[p] = t >= 0 ? *(const float2*)(mean_rstd + 2 * (size_t)t) : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  for (int n = wave; n < KM; n += 4) {                         // wave n: max, min, sum of exp of representative n
+    float mx = -3.0e38f, mn = 3.0e38f;
+    for (int p = lane; p < g.P; p += 64) {
+      const float v = lgs[p * KM + n];
+      mx = fmaxf(mx, v);
+      mn = fminf(mn, v);
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    float se = 0.f;
+    for (int p = lane; p < g.P; p += 64) se += __expf(lgs[p * KM + n] - mx);
+    se = wave_sum(se);
+    if (lane == 0) { s_stat[n][0] = mx; s_stat[n][1] = mn; s_stat[n][2] = 1.0f / se; }
+  }
+  __syncthreads();
+  {
+    float c0[KM], c1[KM];
+#pragma unroll
+    for (int n = 0; n < KM; ++n) c0[n] = c1[n] = 0.f;
+    for (int p = tid; p < g.P; p += 256) {
+      float v[KM];
+#pragma unroll
+      for (int n = 0; n < KM; ++n) v[n] = lgs[p * KM + n];
+      if (slab == 0) {                                         // dispatch weights of the region's tokens (rmsa.py:310-314, :324-325)
+        float mx = v[0];
+#pragma unroll
+        for (int n = 1; n < KM; ++n) mx = fmaxf(mx, v[n]);
+        float e[KM], se = 0.f;
+#pragma unroll
+        for (int n = 0; n < KM; ++n) { e[n] = __expf(v[n] - mx); se += e[n]; }
+        const float inv = 1.0f / se;
+#pragma unroll
+        for (int n = 0; n < KM; ++n)
+          wdisp[((size_t)reg * g.P + p) * KM + n] =
+              (v[n] - s_stat[n][1]) / (s_stat[n][0] - s_stat[n][1] + 1e-8f) * (e[n] * inv);
+      }
+      const float2 m = mr[p];                                  // pad: rstd = 0 -> coefficient 0
+      const bool real = m.y != 0.f;
+#pragma unroll
+      for (int n = 0; n < KM; ++n) {
+        const float c = real ? __expf(v[n] - s_stat[n][0]) * s_stat[n][2] : 0.f;
+        lgs[p * KM + n] = c * m.y;
+        c0[n] += c * m.y * m.x;
+        c1[n] += c;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < KM; ++n) {
+      const float a = wave_sum(c0[n]), b = wave_sum(c1[n]);
+      if (lane == 0) { s_c0[n][wave] = a; s_c1[n][wave] = b; }
+    }
+  }
+  __syncthreads();
+  // contraction over the region's rows: trip q covers rows rg + 16 (TR q + u)
+  float4 acc[KM];
+#pragma unroll
+  for (int n = 0; n < KM; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto request = [&](float4 (&xv)[TR], bool (&rv)[TR], int p0) {
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      const int t = tok_of(p0 + 16 * u);
+      rv[u] = t >= 0;
+      xv[u] = *(const float4*)(x1 + (size_t)(t >= 0 ? t : 0) * DIM + col);
+    }
+  };
+  auto consume = [&](const float4 (&xv)[TR], const bool (&rv)[TR], int p0) {
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      const int p = p0 + 16 * u;
+      const float4 x = rv[u] ? xv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int n = 0; n < KM; ++n) {
+        const float w = rv[u] ? lgs[p * KM + n] : 0.f;
+        acc[n].x += w * x.x; acc[n].y += w * x.y; acc[n].z += w * x.z; acc[n].w += w * x.w;
+      }
+    }
+  };
+  for (int p0 = rg; p0 < g.P; p0 += 32 * TR) {                 // two trips per iteration: b requested while a is contracted
+    const bool more = p0 + 16 * TR < g.P;
+    if (more) request(xb, rb, p0 + 16 * TR);
+    consume(xa, ra, p0);
+    if (p0 + 32 * TR < g.P) request(xa, ra, p0 + 32 * TR);
+    if (more) consume(xb, rb, p0 + 16 * TR);
+  }
+#pragma unroll
+  for (int n = 0; n < KM; ++n) part[(rg * KM + n) * 16 + cl] = acc[n];
+  __syncthreads();
+  for (int idx = tid; idx < KM * 16; idx += 256) {             // reduce the 16 row groups: thread (n, column lane)
+    const int n = idx >> 4, c = idx & 15;
+    const int cc = slab * 64 + c * 4;
+    float4 a = part[n * 16 + c];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+      const float4 b = part[(q * KM + n) * 16 + c];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const float c0 = (s_c0[n][0] + s_c0[n][1]) + (s_c0[n][2] + s_c0[n][3]);
+    const float c1 = (s_c1[n][0] + s_c1[n][1]) + (s_c1[n][2] + s_c1[n][3]);
+    const float4 gm = *(const float4*)(gamma + cc), bt = *(const float4*)(beta + cc);
+    float4 out;
+    out.x = gm.x * (a.x - c0) + bt.x * c1;
+    out.y = gm.y * (a.y - c0) + bt.y * c1;
+    out.z = gm.z * (a.z - c0) + bt.z * c1;
+    out.w = gm.w * (a.w - c0) + bt.w * c1;
+    *(float4*)(rep + ((size_t)n * g.Rt + reg) * DIM + cc) = out;   // rep [k, R, D]
+    if (rep16)
+      *(uint2*)(rep16 + ((size_t)n * g.Rt + reg) * DIM + cc) = prec16 == 2 ? r4_pack4<2>(out) : r4_pack4<1>(out);
+  }
+}
+
 // ---- combine from the projection slabs' row records (round 5) --------------------------------------------------------
 // The last R-MSA layer's out-projection leaves, per (token, 64-column slab), the record (mean_64, M2_64, d_0 .. d_k-1),
 // d_n = sum_c x1[c] gamma[c] phi[c, n] over the slab's columns (rmsa_fused.hip, proj_slab) -- LayerNorm 2's statistics and
@@ -1432,6 +1677,16 @@ RRT_TRACE_DEFINE_READER(rrt_debug_trace_crmsa)
 hipError_t launch_crmsa_logits(const float* x1, const float* gamma, const float* beta,
                                const float* phi, float* mean_rstd, float* logits, int dim, int k,
                                const GridDev& g8, hipStream_t st) {
+  static const bool old_pair = rrt_tune_env("RRT_CRMSA_OLD_PAIR") != nullptr;      // (A/B in a tuning build)
+  if (dim == 512 && k >= 1 && k <= KMAX && !old_pair) {
+    const dim3 grid2((g8.Np + 7) / 8);
+    switch (k) {
+#define RRT_LG512(K_) case K_: crmsa_logits512_kernel<K_><<<grid2, 256, 0, st>>>(x1, gamma, beta, phi, mean_rstd, logits, g8); break;
+      RRT_LG512(1) RRT_LG512(2) RRT_LG512(3) RRT_LG512(4) RRT_LG512(5) RRT_LG512(6) RRT_LG512(7) RRT_LG512(8)
+#undef RRT_LG512
+    }
+    return hipGetLastError();
+  }
   const int ngroups = (g8.Np + 4 * RW - 1) / (4 * RW);
   dim3 grid(ngroups < 1024 ? ngroups : 1024), block(256);     // <= 4 resident blocks per CU, grid-stride
   const size_t lds = (size_t)dim * k * sizeof(float);
@@ -1530,6 +1785,18 @@ hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float
   const size_t lds = ((size_t)g8.P * KMAX + ((g8.P + 3) & ~3)) * 4 + (size_t)16 * KMAX * 16 * sizeof(float4);
   if (lds > 150 * 1024) return hipErrorInvalidValue;   // P8 > ~3500 tokens per region (N > 220k)
   const bool vnorm = mean_rstd == nullptr;   // crmsa_mlp path: x1 holds LN(x1) rows in region-major order
+  static const bool old_pair = rrt_tune_env("RRT_CRMSA_OLD_PAIR") != nullptr;      // (A/B in a tuning build)
+  if (!vnorm && dim == 512 && k >= 1 && k <= KMAX && !old_pair) {
+    const size_t lds2 = (((size_t)g8.P * k + 3) & ~(size_t)3) * 4 + (size_t)((g8.P + 1) & ~1) * 8 + (size_t)16 * k * 16 * sizeof(float4);
+    if (lds2 <= 64 * 1024) {
+      switch (k) {
+#define RRT_CB512(K_) case K_: crmsa_combine512_kernel<K_><<<grid, block, lds2, st>>>(x1, gamma, beta, mean_rstd, logits, wdisp, rep, rep16, prec16, g8); break;
+        RRT_CB512(1) RRT_CB512(2) RRT_CB512(3) RRT_CB512(4) RRT_CB512(5) RRT_CB512(6) RRT_CB512(7) RRT_CB512(8)
+#undef RRT_CB512
+      }
+      return hipGetLastError();
+    }
+  }
   auto kern = vnorm ? crmsa_combine_kernel<true> : crmsa_combine_kernel<false>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

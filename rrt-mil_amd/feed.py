@@ -17,21 +17,32 @@ from typing import Iterable, Iterator, Union
 import torch
 
 
-def load_bag(item: Union[str, torch.Tensor]) -> torch.Tensor:
+def load_bag(item: Union[str, torch.Tensor], dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """A bag is an (N, D) float tensor or the path of a ``.pt`` file holding one
-    (dataloader.py:181,198 ``torch.load``)."""
+    (dataloader.py:181,198 ``torch.load``).  A bag that is already of ``dtype`` is handed on as it is (features stored
+    in 16 bits stay 16 bits); any other float type is converted."""
     if isinstance(item, str):
         item = torch.load(item, map_location="cpu")
     if item.dim() == 3 and item.size(0) == 1:
         item = item[0]
-    return item.float().contiguous()
+    return item.to(dtype).contiguous()
 
 
 class BagFeeder:
     def __init__(self, bags: Iterable[Union[str, torch.Tensor]], device="cuda", depth: int = 3,
-                 copy_threads: int = 4, stage_pageable: bool = False):
+                 copy_threads: int = 4, stage_pageable: bool = False, dtype: torch.dtype = torch.float32):
         """copy_threads: host threads for the pageable -> pinned staging copy (one thread moves only
-        ~5 GB/s, PCIe Gen5 x16 takes ~53 GB/s); bags that are already pinned skip the staging copy."""
+        ~5 GB/s, PCIe Gen5 x16 takes ~53 GB/s); bags that are already pinned skip the staging copy.
+
+        dtype (round 6): the type the bags cross the link in and arrive as.  ``torch.bfloat16`` / ``torch.float16`` halve the
+        PCIe bytes of a slide (36.9 -> 18.4 MB at N = 9000 x 1024): ``RRTMIL`` under bf16 / fp16 arithmetic takes such bags as
+        patch_to_emb's 16-bit operand directly, with logits bit-identical to the fp32-fed forward (the reference's autocast
+        rounds the features to the same 16-bit values in its first op, rrt.py:208-229, main.py:439).  Feature files already
+        stored in that type are moved as they are; fp32 bags are converted on the host while they are staged (that costs host
+        time per bag: store the features in 16 bits to get the full rate)."""
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError(f"BagFeeder: dtype must be float32, bfloat16 or float16, got {dtype}")
+        self.dtype = dtype
         self.device = torch.device(device)
         self.pool = ThreadPoolExecutor(max_workers=max(1, copy_threads))
         self.copy_threads = max(1, copy_threads)
@@ -46,12 +57,13 @@ class BagFeeder:
     def _stage(self, cpu_bag: torch.Tensor, slot: int) -> torch.Tensor:
         n = cpu_bag.numel()
         while len(self._pinned) <= slot:
-            self._pinned.append(torch.empty(0, dtype=torch.float32).pin_memory())
+            self._pinned.append(torch.empty(0, dtype=self.dtype).pin_memory())
         if self._pinned[slot].numel() < n:
-            self._pinned[slot] = torch.empty(n, dtype=torch.float32).pin_memory()
+            self._pinned[slot] = torch.empty(n, dtype=self.dtype).pin_memory()
         buf = self._pinned[slot][:n]
         src = cpu_bag.reshape(-1)
-        # pageable -> pinned host memcpy, chunked over the pool (Tensor.copy_ releases the GIL)
+        # pageable -> pinned host memcpy (converting to the feeder's dtype on the way), chunked over the pool (Tensor.copy_
+        # releases the GIL)
         step = max(1 << 18, (n + self.copy_threads - 1) // self.copy_threads)
         futs = [self.pool.submit(buf[o:o + step].copy_, src[o:o + step]) for o in range(0, n, step)]
         for f in futs:
@@ -78,8 +90,14 @@ class BagFeeder:
             slot = free_slots.popleft()
             if slot in slot_events:
                 slot_events[slot].synchronize()  # the previous H2D out of this pinned buffer is done
-            cpu_bag = load_bag(item)
-            if cpu_bag.is_pinned() or not self.stage_pageable:
+            raw = item if isinstance(item, torch.Tensor) else load_bag(item, self.dtype)
+            if raw.dim() == 3 and raw.size(0) == 1:
+                raw = raw[0]
+            if raw.dtype != self.dtype and self.stage_pageable:
+                cpu_bag = raw.contiguous()         # converted by the staging copy below (thread pool), not by one thread here
+            else:
+                cpu_bag = raw.to(self.dtype).contiguous()
+            if cpu_bag.dtype == self.dtype and (cpu_bag.is_pinned() or not self.stage_pageable):
                 # pinned: true async DMA (53 GB/s measured).  pageable: torch's own staged H2D -- it
                 # blocks this host thread but runs on the copy stream, under the compute already queued
                 # (measured 1.5 k bags/s; a Python-side pinned staging copy was slower: 0.3-0.8 k bags/s)
@@ -87,7 +105,7 @@ class BagFeeder:
             else:
                 host = self._stage(cpu_bag, slot)
             with torch.cuda.stream(self.copy_stream):
-                dev = torch.empty(host.shape, dtype=torch.float32, device=self.device)
+                dev = torch.empty(host.shape, dtype=self.dtype, device=self.device)
                 dev.copy_(host, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.copy_stream)

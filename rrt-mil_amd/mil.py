@@ -355,7 +355,7 @@ class RRTMIL(nn.Module):
         return outs
 
     def forward_bag(self, x2d, return_attn=False, no_norm=False):
-        """One bag: x2d (N, input_dim) fp32 device tensor -> logits (n_classes,) [, attention (N,)]."""
+        """One bag: x2d (N, input_dim) fp32 (or bf16 / fp16) device tensor -> logits (n_classes,) [, attention (N,)]."""
         lib = _lib.load()
         if not x2d.is_cuda:
             raise _lib.RRTHipError("rrt_mil_amd.RRTMIL runs on MI355X only: move the bag to a 'cuda' (HIP) "
@@ -363,15 +363,24 @@ class RRTMIL(nn.Module):
         if self.training and (isinstance(self.dp, nn.Dropout) or self.online_encoder._stochastic()):
             raise NotImplementedError("forward_bag is the one-call inference entry (no dropout inside); in train() "
                                       "call the module itself: forward() applies the dropouts and records a graph")
-        if x2d.dtype in (torch.bfloat16, torch.float16):
-            x2d = x2d.float()
-        if x2d.dtype != torch.float32:
-            raise NotImplementedError(f"unsupported bag dtype {x2d.dtype}")
-        x2d = x2d.contiguous()
         n, in_dim = x2d.shape
         if in_dim != self.patch_to_emb[0].in_features:
             raise ValueError(f"expected feature dim {self.patch_to_emb[0].in_features}, got {in_dim}")
-        d, w = self._mil_desc(in_dim), self._mil_weights()
+        d = self._mil_desc(in_dim)
+        if x2d.dtype in (torch.bfloat16, torch.float16):
+            # 16-bit features (rrt_mil_amd.BagFeeder(dtype=...): half the PCIe bytes of a slide).  When they are of the
+            # arithmetic's own type they ARE patch_to_emb's 16-bit operand -- under autocast the reference's first op rounds
+            # the fp32 features to exactly these values (rrt.py:208-229), the logits are bit-identical to the fp32-fed call --
+            # otherwise they are widened (exactly) and take the fp32 route
+            want = {torch.bfloat16: _lib.COMPUTE_BF16, torch.float16: _lib.COMPUTE_F16}[x2d.dtype]
+            if d.enc.compute == want and in_dim % 64 == 0:
+                d.input16 = want
+            else:
+                x2d = x2d.float()
+        elif x2d.dtype != torch.float32:
+            raise NotImplementedError(f"unsupported bag dtype {x2d.dtype}")
+        x2d = x2d.contiguous()
+        w = self._mil_weights()
         need = C.c_size_t()
         _lib.check(lib.rrt_mil_workspace_size(C.byref(d), n, C.byref(need)), "rrt_mil_workspace_size")
         if self._ws is None or self._ws.device != x2d.device or self._ws.numel() < need.value:

@@ -13,6 +13,8 @@ R=$PWD; OUT=$R/gpurun_out/r06_packed_fp32_repro.txt; mkdir -p $R/gpurun_out
     for dt in bf16 f16; do
       echo "== (2) soak, $lib, $dt, four bags in flight"
       RRT_HIP_LIB=$R/$lib SOAK_DTYPE=$dt timeout 300 python $R/tools/soak_merged.py ${2:-60} 4 2>&1 | grep -v amdgpu.ids | tail -2
+      echo "== (2b) the same with stream 0 running exact-fp32 one-bag-in-flight forwards (crmsa_combine_parts_kernel) beside the $dt bags"
+      RRT_HIP_LIB=$R/$lib SOAK_DTYPE=$dt SOAK_MIX=1 timeout 300 python $R/tools/soak_merged.py ${2:-60} 4 2>&1 | grep -v amdgpu.ids | tail -2
     done
   done
 } > $OUT 2>&1

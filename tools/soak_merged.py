@@ -24,6 +24,11 @@ lib = _lib.load()
 enc._desc.compute = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f16": _lib.COMPUTE_F16,
                      "f32x3": _lib.COMPUTE_F32X3}[os.environ.get("SOAK_DTYPE", "f32")]
 enc._desc.solo = int(os.environ.get("SOAK_SOLO", "0"))
+# SOAK_MIX=1 (round 6, the packed-fp32 hazard's setting): stream 0 runs exact-fp32 forwards with the one-bag-in-flight kernel
+# choices (CR-MSA's first pass = crmsa_combine_parts_kernel from the projection slabs' records), the other streams run the
+# SOAK_DTYPE (bf16 / f16) forwards beside it -- the streaming fp32 kernel of one bag next to another bag's 16-bit MFMA waves
+MIX = os.environ.get("SOAK_MIX") == "1"
+MODE_LOW, SOLO_LOW = enc._desc.compute, enc._desc.solo
 w = enc._weights()
 sizes = [9000, 6200, 7000, 12000, 5000, 10500, 8000, 9000][:max(S, 1)]
 big = torch.from_numpy(synth.bag(12000, 512, tag="soak")).to(dev)
@@ -41,6 +46,9 @@ for i, m in enumerate(sizes):
 
 
 def run(i, j, v=0):
+    if MIX:
+        enc._desc.compute, enc._desc.solo = (_lib.COMPUTE_F32, 1) if i == 0 else (MODE_LOW, SOLO_LOW)
+        enc._desc.weights16_valid = 0
     _lib.check(lib.rrt_encoder_forward_f32(C.byref(enc._desc), C.byref(w), xs2[i][v].data_ptr(), ys[i][j].data_ptr(), sizes[i],
                                            wss[i].data_ptr(), wss[i].numel(), streams[i].cuda_stream), "forward")
 
@@ -64,5 +72,5 @@ for r in range(rounds):
             total += 1
             bad += int(not torch.equal(ys[i][j], refs[i][(r + j) & 1]))
             ys[i][j].fill_(float("nan"))
-print(f"soak [{os.environ.get('SOAK_DTYPE', 'f32')}, solo={enc._desc.solo}]: {total} forwards on {len(sizes)} streams (sizes {sizes}), {bad} differ from the solo result")
+print(f"soak [{os.environ.get('SOAK_DTYPE', 'f32')}, solo={SOLO_LOW}{', stream 0 = exact fp32 solo' if MIX else ''}]: {total} forwards on {len(sizes)} streams (sizes {sizes}), {bad} differ from the solo result")
 sys.exit(1 if bad else 0)
