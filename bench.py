@@ -188,6 +188,66 @@ def flops_total(n, enc_cfg):
             + 6 * g8.Np * D * k + 8 * k * 64 * D * D + 4 * k * 64 * 64 * D)
 
 
+N_PARAMS = 2105984          # RRTEncoder(mlp_dim=512, ...): SURVEY.md section 8(a1); crmsa_k only moves phi (512 x k)
+
+
+def bytes_total(n, in_dim=0):
+    """Algorithmic bytes per bag, SURVEY.md section 8(d): B = (2 N D + n_params) x 4 -- the bag read once, the output written
+    once, the weights once.  The boundary tensors are fp32 in every arithmetic mode (the reference's autocast keeps the
+    module's input and output in fp32), so the 16-bit modes are priced against the same B.  Classifier (config 2): the
+    N x in_dim features in, logits out, the fc weight once."""
+    if in_dim:
+        return (n * in_dim + in_dim * DIM + DIM + N_PARAMS) * 4
+    return (2 * n * DIM + N_PARAMS) * 4
+
+
+def traffic_per_forward(config, dtype, kind):
+    """HBM-side bytes of ONE forward summed over its kernels from the tracked PMC table (None without one).  A kernel's
+    launches per forward = its dispatch count over that of the dispatch kernel (once per forward); kernels that ran for a
+    quarter to three quarters of the forwards are the classifier's own stages (the table's run also holds encoder-only
+    passes) and count once; rarer ones (weight casts, torch's finiteness checks) are not part of a steady-state forward."""
+    table = traffic_table(config, dtype)
+    if not table:
+        return None
+    base = max([v["dispatches"] for k, v in table.items() if "crmsa_dispatch_ln" in k] or [0])
+    if base == 0:
+        return None
+    total, used = 0.0, []
+    for k, v in table.items():
+        if k.startswith("at::") or k.startswith("__amd"):
+            continue
+        r = v["dispatches"] / base
+        lpf = round(r) if r >= 0.75 else (1 if (kind == "mil" and r >= 0.25) else 0)
+        if kind == "mix":
+            lpf = r                      # mixed sizes: every kernel's share of the 64-bag batch, averaged per bag
+        if lpf:
+            total += v["hbm_bytes"] * lpf
+            used.append(k.split("(")[0][:48])
+    return {"bytes": int(total), "kernels": len(used), "source": os.path.relpath(TRAFFIC_FILE, ROOT)}
+
+
+def whole_path_roofline(slides_per_s_per_gpu, flops_per_bag, bytes_per_bag, dtype, traffic):
+    """The whole forward against BOTH roofs (T_roof = max(F / peak_matrix(dtype), B / peak_HBM)):
+    what the line's own rate makes of the algorithmic FLOPs and bytes, and what the PMC-counted traffic says."""
+    mpeak = PEAK_TFLOPS["bf16" if dtype in ("bf16", "f16", "f32x3") else "f32"]
+    t = 1.0 / slides_per_s_per_gpu
+    t_m, t_h = flops_per_bag / (mpeak * 1e12), bytes_per_bag / (PEAK_HBM_GBS * 1e9)
+    rec = {"flops_per_bag": flops_per_bag, "algorithmic_bytes_per_bag": bytes_per_bag,
+           "mfma": {"achieved": round(flops_per_bag / t / 1e12, 2), "peak": mpeak, "unit": "TFLOP/s",
+                    "frac": round(t_m / t, 4)},
+           "hbm": {"achieved": round(bytes_per_bag / t / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "frac": round(t_h / t, 4)},
+           "bound": "mfma" if t_m >= t_h else "hbm", "frac": round(max(t_m, t_h) / t, 4)}
+    if traffic:
+        tb = traffic["bytes"]
+        rec["traffic"] = {"bytes_per_bag": tb, "over_algorithmic": round(tb / bytes_per_bag, 2),
+                          "rate_GBs": round(tb / t / 1e9, 1), "frac_of_hbm_peak": round(tb / t / 1e9 / PEAK_HBM_GBS, 4),
+                          "counter": "TCC_EA requests (2 x FETCH_SIZE + WRITE_SIZE, one bag in flight): includes what the "
+                                     "256 MB Infinity Cache (MALL) served, i.e. an upper bound on DRAM bytes",
+                          "source": traffic["source"]}
+    return rec
+
+
 def fused_flops(n, enc_cfg, with_proj=False):
     """The fused R-MSA kernel's share: qkv projection [Np, D] x [3D, D]^T + Q K^T + A V per (region, head) -- and, where
     the out-projection runs as a later phase of the same launch (rrt_encoder_plan: RRT_PLAN_FUSED_PROJ), [Np, D] x [D, D]^T."""
@@ -256,7 +316,16 @@ def cpu_baseline(n_tokens, enc_cfg, budget_s=22.0):
         rrt_oracle.forward_eager(x, st, enc_cfg)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
+    cpu_model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), None)
+    except OSError:
+        pass
     rec = {"value": round(1.0 / med, 3), "unit": "slides/s", "cores": cores, "kind": "port",
+           # the box this baseline was taken on (it differs from lease to lease: 6.0-9.6 slides/s over round 5's boxes)
+           "box": {"cpu_model": cpu_model, "hardware_threads": ncpu,
+                   "thread_probe_ms": {str(c): round(probe[c] * 1e3, 1) for c in cands}},
            "sample": f"{len(times)} bags of N={n_tokens} D={DIM} (median {med * 1e3:.1f} ms/bag), "
                      f"oracle/rrt_oracle.py::forward_eager (same aten op sequence as the reference, "
                      f"bit-identical to it in the build container), torch {torch.__version__} CPU, "
@@ -992,10 +1061,16 @@ def main():
             gf = flops_total(cfg["n"], enc_cfg) + extra_f
             config["gflop_per_bag"] = round(gf / 1e9, 2)
             config["whole_path_tflops"] = round(wl.units_global / world * gf / (ms_per_step * 1e-3) / 1e12, 2)
+            wp_f, wp_b = gf, bytes_total(cfg["n"], cfg.get("input_dim", 0))
         else:
-            gf = sum(flops_total(n, enc_cfg) for n in mix_sizes(cfg["n_bags"]))
+            sizes = mix_sizes(cfg["n_bags"])
+            gf = sum(flops_total(n, enc_cfg) for n in sizes)
             config["gflop_per_step"] = round(gf / 1e9, 2)
             config["whole_path_tflops"] = round(gf / (ms_per_step * 1e-3) / 1e12 / world, 2)
+            wp_f, wp_b = gf / len(sizes), sum(bytes_total(n) for n in sizes) / len(sizes)     # per average bag of the mix
+        whole_path = None
+        if not args.stub_cpu:
+            whole_path = whole_path_roofline(value / world, wp_f, wp_b, dtype, traffic_per_forward(args.config, dtype, cfg["kind"]))
         config.update(wl.extra)
         metric = ("slides/sec RRTEncoder fwd, N=9000 D=512 region_num=8" if args.config == 1
                   else f"slides/sec, BASELINE configs[{args.config}]")
@@ -1010,6 +1085,8 @@ def main():
                                    "note": f"the timed region's value followed by 3 repeats of the same {args.steps} steps "
                                            "(this rank's clock, no barrier between them)"}
         rec.update(rec_extra)
+        if whole_path is not None:
+            rec["whole_path"] = whole_path
         if not args.stub_cpu and world == 1 and cfg["kind"] == "encoder" and not args.no_extras:
             rec["module_call"] = module_call_record(args)
             if args.config == 1 and not args.dtype:      # the headline config also through the module in bf16 (the --amp path)
@@ -1212,6 +1289,8 @@ def config_record(c):
                          for st in r["roofline_kernels"]]
     if "one_bag_in_flight" in r:
         rec["one_bag_in_flight_ms"] = r["one_bag_in_flight"]["ms_per_bag"]
+    if "whole_path" in r:                       # both roofs + counted traffic over algorithmic bytes
+        rec["whole_path"] = r["whole_path"]
     rec["command"] = "bench.py " + " ".join(cmd[2:])
     rec["wall_s"] = round(time.perf_counter() - t0, 1)
     return rec
@@ -1308,8 +1387,17 @@ def extras(wl, dev):
         tstep()
     torch.cuda.synchronize()
     tt = (time.perf_counter() - tt) / 20
+    f_fwd = flops_total(wl.n, wl.enc_cfg)
+    f_train = 3.0 * f_fwd                     # forward + (dX and dW of every product of the forward); the attention
+    #                                           backward's recomputation of S in LDS is extra work, not counted
     out["train_step"] = {"ms_per_step": round(tt * 1e3, 4), "steps_per_s": round(1.0 / tt, 2),
                          "peak_mem_mb": round(torch.cuda.max_memory_allocated(dev) / 1e6, 1),
+                         "roofline": {"bound": "mfma", "flops_per_step": f_train,
+                                      "formula": "3 x F_forward (SURVEY 8(d) F; backward = dX + dW of each product; recomputed "
+                                                 "scores not counted)",
+                                      "achieved": round(f_train / tt / 1e12, 2), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
+                                      "frac": round(f_train / tt / 1e12 / PEAK_TFLOPS["f32"], 4),
+                                      "kernel_table": "profiles/r06_train_kernel_stats.txt (tools/prof_train.sh)"},
                          "note": "RRTEncoder.train() forward (stash) + backward of every parameter, N=9000 D=512, fp32, "
                                  "drop_out=0.1, one bag per step (rrt_encoder_forward_train_f32 / rrt_encoder_backward_f32)"}
     return out

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 25
+#define RRT_ABI_VERSION 26
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -320,6 +320,17 @@ int rrt_linear16_f32(const uint16_t *A, const uint16_t *B, const float *bias, co
 int rrt_rmsa_fused16(const uint16_t *u, const uint16_t *qkv_w, const float *qkv_b, const float *pe_w,
                      uint16_t *o, int32_t n_regions, int32_t P, int32_t dim, int32_t heads, int32_t epeg_k,
                      int32_t compute, void *stream);
+/* Round 6: rrt_rmsa_fused16 + rrt_linear16_f32(resid) of one R-MSA layer in ONE launch (modules/rmsa.py:100-132, :41-54,
+ * :227-228; rrt.py:125 under autocast), what rrt_encoder_forward_f32 uses in BF16 / F16 for bags of at least two rounds of
+ * (region pair, head) items -- regions of 65..96 or 113..128 tokens, a multiple of 16 regions, e.g. N = 30000 at
+ * region_num = 16: block b runs item b and then the 64-column projection slab b - 256 of a pair whose items finished a
+ * round earlier; out [L, dim] = resid + unpartition(o proj_w^T + proj_b), bit-identical to the two calls; o [Np, dim] is
+ * scratch (the 16-bit attention output); cnt: Np / (2 P) ints of scratch (zeroed by the call).  The in-launch hand-over is
+ * bounded like rrt_rmsa_fused_proj_f32's (RRT_E_HANDOVER, rrt_device_error). */
+int rrt_rmsa_pair16_proj(const uint16_t *u, const uint16_t *qkv_w, const float *qkv_b, const float *pe_w,
+                         const uint16_t *proj_w, const float *proj_b, const float *resid, float *out, uint16_t *o,
+                         int32_t *cnt, int32_t dim, int32_t heads, int32_t epeg_k, const rrt_grid *g, int32_t compute,
+                         void *stream);
 
 /* RRT_COMPUTE_F32X3 stages.  A "split image" of a row-major fp32 array holds, per 32 consecutive elements, 32 bf16 hi
  * values then 32 bf16 lo values (128 bytes; hi = bf16(x), lo = bf16(x - hi)) -- 4 bytes per element like the original.
@@ -363,6 +374,15 @@ int rrt_crmsa_region_f32(const float *x1, const float *gamma, const float *beta,
  * waits for anybody).  scratch: 256 + 64 * nb * km * 520 * 4 bytes with nb = 16 for regions of more than 288 tokens, else
  * 8, and km = 3 for k <= 3, else 8; logits must be given (the merging block reads them); mean_rstd may be NULL. */
 int rrt_crmsa_region4_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
+                          float *mean_rstd, float *logits, float *wdisp, float *rep,
+                          int64_t L, int32_t dim, int32_t k, const rrt_grid *g8,
+                          void *scratch, size_t scratch_bytes, void *stream);
+/* Round 6: the one-pass form for LARGER regions (what rrt_encoder_forward_f32 uses above 144 tokens per CR-MSA region, i.e.
+ * bags of more than ~9.2 k patches: replaces modules/rmsa.py:303-316 like the two calls at the top of this group, reading x1
+ * once instead of twice): always 4 blocks per region, each STREAMING its quarter of the rows in trips with a per-wave online
+ * softmax; records, merge, scratch layout and arguments exactly as rrt_crmsa_region4_f32 (dim = 512, k <= 8, regions of
+ * 16..576 tokens). */
+int rrt_crmsa_stream4_f32(const float *x1, const float *gamma, const float *beta, const float *phi,
                           float *mean_rstd, float *logits, float *wdisp, float *rep,
                           int64_t L, int32_t dim, int32_t k, const rrt_grid *g8,
                           void *scratch, size_t scratch_bytes, void *stream);

@@ -28,9 +28,10 @@ HW_QUEUES = _claim_hw_queues()
 from . import feed, geometry, sharding, synth  # noqa: F401,E402
 from .feed import BagFeeder  # noqa: F401,E402
 from . import _lib  # noqa: F401,E402
+from ._lib import device_error  # noqa: F401,E402
 from .mil import Attention, AttentionGated, DAttention, RRTMIL  # noqa: F401,E402
 from .encoder import (CrossRegionAttntion, InnerAttention, RegionAttntion, RRTEncoder,  # noqa: F401
                       TransLayer, initialize_weights)
 
 __all__ = ["RRTEncoder", "RRTMIL", "DAttention", "TransLayer", "RegionAttntion", "CrossRegionAttntion", "InnerAttention",
-           "initialize_weights", "geometry", "sharding", "synth"]
+           "initialize_weights", "geometry", "sharding", "synth", "device_error"]

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _f32p = C.POINTER(C.c_float)
 
@@ -117,6 +117,7 @@ SIGNATURES = {
     "rrt_linear16_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_int32,
                                                       C.c_void_p]),
     "rrt_rmsa_fused16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
+    "rrt_rmsa_pair16_proj": (C.c_int, [C.c_void_p] * 10 + [C.c_int32] * 3 + [C.POINTER(Grid), C.c_int32, C.c_void_p]),
     "rrt_cast_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rrt_ln_partition_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                          C.POINTER(Grid), C.c_void_p]),
@@ -128,6 +129,8 @@ SIGNATURES = {
                                                           C.POINTER(Grid), C.c_void_p]),
     "rrt_crmsa_region_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_void_p]),
     "rrt_crmsa_region4_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_void_p,
+                                                         C.c_size_t, C.c_void_p]),
+    "rrt_crmsa_stream4_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Grid), C.c_void_p,
                                                          C.c_size_t, C.c_void_p]),
     "rrt_crmsa_dispatch_ln_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32,
                                                               C.POINTER(Grid), C.c_void_p]),
@@ -208,11 +211,25 @@ def load(path=None):
     return lib
 
 
+E_HANDOVER = -4      # rrt_hip.h RRT_E_HANDOVER: a merged launch gave up its bounded in-launch wait (sticky, process-wide)
+
+
+def device_error(clear=False):
+    """The process's sticky hand-over error word (include/rrt_hip.h rrt_device_error): non-zero after a merged R-MSA launch
+    gave up its bounded wait; every later forward then returns RRT_E_HANDOVER until the word is cleared.  Recovery:
+    ``torch.cuda.synchronize()``, discard the outputs of the forwards that were in flight, ``device_error(clear=True)``, run
+    them again.  No device synchronisation happens here (a host read of pinned memory)."""
+    return int(load().rrt_device_error(1 if clear else 0))
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = load().rrt_strerror(rc).decode()
         if rc == -2:
             raise NotImplementedError(f"rrt_hip {what}: {msg}")
+        if rc == E_HANDOVER:
+            msg += (" -- sticky until cleared: torch.cuda.synchronize(), discard the outputs of the forwards in flight, "
+                    "rrt_mil_amd.device_error(clear=True), run them again")
         raise RRTHipError(f"rrt_hip {what} failed ({rc}): {msg}")
 
 

@@ -453,10 +453,42 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       uint16_t* u16 = (uint16_t*)ws.uo;
       uint16_t* o16 = (uint16_t*)ws.qkv;
       const uint16_t* wq16 = ws.w16 + (size_t)li * 4 * D * D;
-      RRT_TRY(launch_ln_partition16(xin, lw.norm_w, lw.norm_b, u16, D, gd, desc->compute, st));
+      // round 6: bags of at least two rounds of (pair, head) items (N = 30000 at region_num = 16: four) CAN take the
+      // out-projection as a phase of the pair launch's blocks (rmsa_pair16.hip, PROJ; bit-identical, tested) -- built on the
+      // round-5 review's request and MEASURED SLOWER than the two launches: 109-116 us against 64.5 + 35.6 at N = 30000
+      // (profiles/r06_trace_pair16_proj.txt: a slab costs a block 25 K cycles -- 13 K of DMA-issue-bound K loop, the same
+      // bound the separate projection runs at with two blocks per CU hiding each other's prologue and epilogue -- plus 4 K
+      // waiting for the write-through O stores; the block owns its CU, so nothing overlaps the slab).  Off unless a tuning
+      // build asks for it (RRT_PAIR16_PROJ=1).
+      static const bool want_merged16 = rrt_tune_env("RRT_PAIR16_PROJ") != nullptr;
+      const bool merged16 = want_merged16 && ws.proj_cnt != nullptr &&
+                            rmsa_pair16_proj_supported(gd.rs * gd.rs, gd.P, D, desc->n_heads, ek);
+      RRT_TRY(launch_ln_partition16(xin, lw.norm_w, lw.norm_b, u16, D, gd, desc->compute, st, merged16 ? ws.proj_cnt : nullptr,
+                                    merged16 ? gd.rs * gd.rs / 2 : 0));
       rrt_phase_gate* const gt16 = (gate && gd.P > 112) ? gate : nullptr;
       if (gt16 && gt16->armed) RRT_TRY(hipStreamWaitEvent(st, gt16->done, 0));
       if (li == 0) RRT_MARK(RRT_EV_LN_PARTITION);
+      if (merged16) {
+        PairProj pj{};
+        pj.Wp = wq16 + (size_t)3 * D * D;
+        pj.bias = lw.proj_b;
+        pj.resid = xin;
+        pj.out = xout;
+        pj.cnt = ws.proj_cnt;
+        pj.zero64 = ws.cr_cnt;
+        pj.g = gd;
+        RRT_TRY(launch_rmsa_pair16_proj(u16, wq16, lw.qkv_b, desc->epeg ? lw.pe_w : nullptr, o16, gd.rs * gd.rs, gd.P, D,
+                                        desc->n_heads, ek, desc->compute, pj, st));
+        if (gt16) { RRT_TRY(hipEventRecord(gt16->done, st)); gt16->armed = true; }
+        if (li == 0) { RRT_MARK(RRT_EV_QKV); RRT_MARK(RRT_EV_ATTN); RRT_MARK(RRT_EV_PROJ); }
+        xin = xout;
+        if (desc->ffn) {
+          rc = ffn_block(lw, xout, fout);
+          if (rc) return rc;
+          xin = fout;
+        }
+        continue;
+      }
       RRT_TRY(launch_rmsa_fused16(u16, wq16, lw.qkv_b, desc->epeg ? lw.pe_w : nullptr, o16, gd.rs * gd.rs, gd.P, D,
                                   desc->n_heads, ek, desc->compute, st));
       if (gt16) { RRT_TRY(hipEventRecord(gt16->done, st)); gt16->armed = true; }
@@ -689,6 +721,12 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
   } else if (crmsa_region_enabled() && crmsa_region_supported(D, k, gd8)) {
     // logits + combine in one pass over x1 (one block of 16 waves per region, the rows stay in registers)
     RRT_TRY(launch_crmsa_region(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, nullptr, ws.wdisp, ws.rep, k, gd8, st));
+  } else if (ws.cr_cnt && desc->n_rmsa_layers > 0 && gd8.P > 144 && crmsa_stream4_supported(D, k, gd8)) {
+    // round 6: regions of more than 144 tokens in ONE pass over x1 as well -- four blocks per region that stream their rows
+    // with an online softmax per wave, crmsa_region4's records and merge (crmsa_stream4_kernel); counters as above
+    RRT_TRY(launch_crmsa_stream4(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, ws.logits, ws.wdisp, ws.rep,
+                                 inner16 ? ws.rep16 : nullptr, desc->compute, ws.cr_part, ws.cr_cnt, k, gd8, st));
+    rep16_done = inner16;
   } else {
     RRT_TRY(launch_crmsa_logits(xin, cw.norm_w, cw.norm_b, w->phi, ws.mean_rstd, ws.logits, D, k, gd8, st));
     RRT_TRY(launch_crmsa_combine(xin, cw.norm_w, cw.norm_b, ws.mean_rstd, ws.logits, ws.wdisp, ws.rep,
@@ -1111,6 +1149,29 @@ int rrt_rmsa_fused16(const uint16_t* u, const uint16_t* qkv_w, const float* qkv_
   return (int)launch_rmsa_fused16(u, qkv_w, qkv_b, pe_w, o, n_regions, P, dim, heads, ek, compute, (hipStream_t)stream);
 }
 
+int rrt_rmsa_pair16_proj(const uint16_t* u, const uint16_t* qkv_w, const float* qkv_b, const float* pe_w, const uint16_t* proj_w,
+                         const float* proj_b, const float* resid, float* out, uint16_t* o, int32_t* cnt, int32_t dim,
+                         int32_t heads, int32_t epeg_k, const rrt_grid* g, int32_t compute, void* stream) {
+  if (!u || !qkv_w || !proj_w || !resid || !out || !o || !cnt || !g || dim <= 0 || heads <= 0) return RRT_E_INVALID;
+  if (compute != RRT_COMPUTE_BF16 && compute != RRT_COMPUTE_F16) return unsupported("compute must be BF16 or F16");
+  if (handover_err_peek(false)) return RRT_E_HANDOVER;
+  const GridDev gd = to_dev(*g);
+  const int ek = pe_w ? epeg_k : 0, R = gd.rs * gd.rs;
+  if (!rmsa_pair16_proj_supported(R, gd.P, dim, heads, ek))
+    return unsupported("rmsa_pair16_proj: head dim 64, regions of 65..96 or 113..128 tokens, a multiple of 16 regions, "
+                       "at least two rounds of (pair, head) items");
+  hipError_t e = hipMemsetAsync(cnt, 0, (size_t)(R / 2) * sizeof(int), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  PairProj pj{};
+  pj.Wp = proj_w;
+  pj.bias = proj_b;
+  pj.resid = resid;
+  pj.out = out;
+  pj.cnt = cnt;
+  pj.g = gd;
+  return (int)launch_rmsa_pair16_proj(u, qkv_w, qkv_b, pe_w, o, R, gd.P, dim, heads, ek, compute, pj, (hipStream_t)stream);
+}
+
 // ---- RRT_COMPUTE_F32X3 stages: fp32 as (hi, lo) bf16 pairs (cast16.hip), three bf16 MFMAs per product
 int rrt_cast_split(const float* src, void* dst, int64_t n, void* stream) {
   if (!src || !dst || n <= 0 || n % 32) return RRT_E_INVALID;
@@ -1187,6 +1248,20 @@ int rrt_crmsa_region4_f32(const float* x1, const float* gamma, const float* beta
   hipError_t e = hipMemsetAsync(scratch, 0, 256, (hipStream_t)stream);      // the arrival counters
   if (e != hipSuccess) return (int)e;
   return (int)launch_crmsa_region4(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, nullptr, 0,
+                                   (float*)((char*)scratch + 256), (int*)scratch, k, gd, (hipStream_t)stream);
+}
+
+int rrt_crmsa_stream4_f32(const float* x1, const float* gamma, const float* beta, const float* phi, float* mean_rstd,
+                          float* logits, float* wdisp, float* rep, int64_t L, int32_t dim, int32_t k, const rrt_grid* g8,
+                          void* scratch, size_t scratch_bytes, void* stream) {
+  if (!x1 || !gamma || !beta || !phi || !logits || !wdisp || !rep || !g8 || !scratch || L != g8->L) return RRT_E_INVALID;
+  const GridDev gd = to_dev(*g8);
+  if (!crmsa_stream4_supported(dim, k, gd) || !crmsa_region4_supported(dim, k, gd))
+    return unsupported("crmsa_stream4: dim = 512, k <= 8, regions of 16..576 tokens");
+  if (scratch_bytes < 256 + crmsa_region4_scratch_floats(gd, k) * sizeof(float)) return RRT_E_WORKSPACE;
+  hipError_t e = hipMemsetAsync(scratch, 0, 256, (hipStream_t)stream);      // the arrival counters
+  if (e != hipSuccess) return (int)e;
+  return (int)launch_crmsa_stream4(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, nullptr, 0,
                                    (float*)((char*)scratch + 256), (int*)scratch, k, gd, (hipStream_t)stream);
 }
 

@@ -57,7 +57,10 @@ template <int NV, int PREC, bool FULL>   // float4 per lane: dim <= NV*256; FULL
 __global__ __launch_bounds__(256) void ln_partition16_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
-                                                             uint16_t* __restrict__ u, int dim, GridDev g) {
+                                                             uint16_t* __restrict__ u, int dim, GridDev g,
+                                                             int* __restrict__ zero, int n_zero) {
+  if (zero != nullptr && blockIdx.x == 0)              // side job (as ln_partition_kernel): arrival counters of a later kernel
+    for (int i = threadIdx.x; i < n_zero; i += 256) zero[i] = 0;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);   // padded-grid token index
   if (t >= g.Np) return;
@@ -232,17 +235,17 @@ hipError_t launch_cast16(const Cast16Jobs& jobs, int prec, hipStream_t st) {
 }
 
 hipError_t launch_ln_partition16(const float* x, const float* gamma, const float* beta, uint16_t* u, int dim,
-                                 const GridDev& g, int prec, hipStream_t st) {
+                                 const GridDev& g, int prec, hipStream_t st, int* zero, int n_zero) {
   if (prec != 1 && prec != 2) return hipErrorInvalidValue;
   dim3 grid((g.Np + 3) / 4), block(256);
 #define RRT_LNP16(NV)                                                                               \
   do {                                                                                              \
     if (RRT_ALLOW_FULL && dim == NV * 256) {                                                                          \
-      if (prec == 1) ln_partition16_kernel<NV, 1, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);  \
-      else ln_partition16_kernel<NV, 2, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);           \
+      if (prec == 1) ln_partition16_kernel<NV, 1, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g, zero, n_zero);  \
+      else ln_partition16_kernel<NV, 2, true><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g, zero, n_zero);           \
     } else {                                                                                        \
-      if (prec == 1) ln_partition16_kernel<NV, 1, false><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g); \
-      else ln_partition16_kernel<NV, 2, false><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g);          \
+      if (prec == 1) ln_partition16_kernel<NV, 1, false><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g, zero, n_zero); \
+      else ln_partition16_kernel<NV, 2, false><<<grid, block, 0, st>>>(x, gamma, beta, u, dim, g, zero, n_zero);          \
     }                                                                                               \
   } while (0)
   if (dim <= 256) RRT_LNP16(1);

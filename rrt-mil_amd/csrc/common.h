@@ -176,6 +176,32 @@ __device__ __forceinline__ float wave_sum(float v) {
   return sum_xor32(sum_xor16(v));     // rows combined by lane swaps, the result in every lane (no SGPR round trip)
 #endif
 }
+// FOUR wave totals for little more than the price of one (round 6): the first two levels of the butterfly run on lane
+// swaps that fold two values into one register each -- permlane32_swap(a, b) leaves [a.lo | b.lo] and [a.hi | b.hi], whose sum
+// holds a's 32-lane partials in lanes 0-31 and b's in lanes 32-63; permlane16_swap of two such registers leaves a, c, b, d in
+// the four 16-lane rows -- and only the four row rotations are paid once per group: 2 + 2 + 2 + 4 x 2 instructions + four
+// v_readlane for four totals where four wave_sum calls are 4 x 15.  Totals come back wave-uniform (SGPRs).  The summation
+// order differs from wave_sum's (last bits).
+__device__ __forceinline__ void wave_sum4(float a, float b, float c, float d, float& ta, float& tb, float& tc, float& td) {
+  unsigned xa = __float_as_uint(a), xb = __float_as_uint(b), xc = __float_as_uint(c), xd = __float_as_uint(d);
+  RRT_PERMLANE_PAD(xa, xb);
+  const auto r0 = __builtin_amdgcn_permlane32_swap(xa, xb, false, false);
+  RRT_PERMLANE_PAD(xc, xd);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(xc, xd, false, false);
+  unsigned ab = __float_as_uint(__uint_as_float(r0[0]) + __uint_as_float(r0[1]));
+  unsigned cd = __float_as_uint(__uint_as_float(r1[0]) + __uint_as_float(r1[1]));
+  RRT_PERMLANE_PAD(ab, cd);
+  const auto r2 = __builtin_amdgcn_permlane16_swap(ab, cd, false, false);   // rows: [a, c, b, d] twice
+  float s = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+  s += RRT_DPP_ROR(s, 8);
+  s += RRT_DPP_ROR(s, 4);
+  s += RRT_DPP_ROR(s, 2);
+  s += RRT_DPP_ROR(s, 1);
+  ta = rrt_readlane(s, 0);
+  tc = rrt_readlane(s, 16);
+  tb = rrt_readlane(s, 32);
+  td = rrt_readlane(s, 48);
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, RRT_DPP_ROR(v, 8));
   v = fmaxf(v, RRT_DPP_ROR(v, 4));

@@ -1450,6 +1450,382 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   RRT_TRACE_MARK();                                 // [10] dispatch weights written
 }
 
+// ---- round 6: the one-pass form for regions of MORE than 144 tokens (BASELINE configs[3]: 484 per region; the large bags of
+// configs[4]) -- FOUR blocks per region that STREAM their quarter of the region's rows.
+// crmsa_region4_kernel keeps every row of a block in flight at once (36 per block), so larger regions meant 8 / 16 blocks per
+// region and a merge of 8 / 16 partial records by one block: slower than two chip-wide passes over x1 (history section 3,
+// "measured without gain"; 46-74 against 39 us at N = 30000), which is what the forward used above 144 tokens -- x1 read TWICE
+// (2 x 61.4 MB at N = 30000: 15.1 + 15.3 us).  Here a block is still (region, quarter) and the merge still takes four records,
+// but a wave walks its rows in trips of NR (the next trip's rows requested before the current one is reduced) and keeps an
+// ONLINE softmax of its own: running max m_n, sum Z_n, the LayerNorm-fold sums c0_n / c1_n and the contraction
+// acc_n = sum_p exp(Lg_np - m_n) rstd_p x1_p, rescaled once per trip when the max moves.  The waves' partials meet in LDS
+// (scaled to the block's max, summed in a fixed order), the block's record has crmsa_region4's layout, and the tail -- arrival
+// counter, merge by the last quarter, LayerNorm's affine, the region's dispatch weights -- is crmsa_region4's.  x1 is read ONCE.
+constexpr int S4_PQMAX = 144;                       // rows of a quarter, at most (P <= 576)
+template <int NW, int NR, int KM_>                  // waves per block, rows per wave and trip, representatives (k == KM_ exactly)
+__global__ __launch_bounds__(64 * NW) void crmsa_stream4_kernel(const float* __restrict__ x1, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ phi,
+                                                                float* __restrict__ mean_rstd, float* __restrict__ logits,
+                                                                float* __restrict__ wdisp, float* __restrict__ rep,
+                                                                uint16_t* __restrict__ rep16, int prec16,
+                                                                float* __restrict__ part_g, int* __restrict__ counters,
+                                                                GridDev g) {
+  constexpr int NB = 4, DIM = 512, KM = KM_, KC = KM_ < 4 ? KM_ : 4, k = KM_;
+  constexpr int R4_REC = KM * (DIM + 8);            // (the scratch is sized for crmsa_region4's records: at least as large)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_wst = (float*)smem;                      // [KM][NW][8]: the waves' m, min, Z, c0, c1
+  float* s_lg = s_wst + KM * NW * 8;                // [S4_PQMAX][KM]: the quarter's logits, written out after the loop
+  float* s_mr = s_lg + S4_PQMAX * KM;               // [S4_PQMAX][2]
+  float4* s_part = (float4*)(s_mr + S4_PQMAX * 2);  // [NW / 2][KC][128] float4
+  __shared__ float s_stat[KM][5];                   // the block's max, min, Z, c0, c1
+  __shared__ float s_mrg[KM][4];
+  __shared__ float s_scb[KM][NB];
+  __shared__ float s_mm[KM][2];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: the rows' validity tests become scalar branches)
+  const int reg = blockIdx.x / NB, q = blockIdx.x - reg * NB, R = g.Rt;
+  const int ri = reg / g.rs, rj = reg - ri * g.rs;
+  const int PQ = (g.P + NB - 1) / NB;
+  const int nrow = min(PQ, g.P - q * PQ);           // rows of this quarter (>= 1: the launcher checks P >= 4 NB)
+  // token of the block's row rq: >= 0 real, -1 pad slot of the region grid (zero row: zero logits, in the softmax, not in the
+  // contraction), -2 past the quarter (nothing)
+  auto tok_of = [&](int rq) -> int {
+    if (rq >= nrow) return -2;
+    const int p = q * PQ + rq;
+    const int pi = fdiv(p, g.s, g.inv_s), pj = p - pi * g.s;
+    const int t = (ri * g.s + pi) * g.H + rj * g.s + pj;
+    return t < g.L ? t : -1;
+  };
+  float4 ra[NR][2], rb[NR][2];
+  int ta[NR], tb[NR];
+  auto request = [&](float4 (&rv)[NR][2], int (&tk)[NR], int j0) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int t = tok_of(wave + NW * (j0 + j));
+      tk[j] = t;
+      const float* src = x1 + (size_t)(t < 0 ? 0 : t) * DIM;
+      rv[j][0] = *(const float4*)(src + lane * 4);
+      rv[j][1] = *(const float4*)(src + 256 + lane * 4);
+    }
+  };
+  // gamma . phi of this lane's eight columns and B_n = sum_c beta_c phi_cn (crmsa_logits512_kernel's arithmetic: the logits
+  // are bit-identical to the two-pass form's).  These loads come FIRST: they are read inside the loop, and a load that is
+  // younger than the trips' requests at loop entry makes the loop's static wait for it (vmcnt(0), executed every iteration)
+  // drain the prefetched trip as well
+  float gp[2][4][KM], Bn[KM];
+  {
+    float bsum[KM];
+#pragma unroll
+    for (int n = 0; n < KM; ++n) bsum[n] = 0.f;
+    float4 gm4[2], bt4[2], pq[2][KM];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      gm4[v] = *(const float4*)(gamma + c);
+      bt4[v] = *(const float4*)(beta + c);
+#pragma unroll
+      for (int j = 0; j < KM; ++j) pq[v][j] = *(const float4*)(phi + (size_t)c * KM + 4 * j);
+    }
+    request(ra, ta, 0);
+    request(rb, tb, NR);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const float gm[4] = {gm4[v].x, gm4[v].y, gm4[v].z, gm4[v].w}, bt[4] = {bt4[v].x, bt4[v].y, bt4[v].z, bt4[v].w};
+      float pf[4 * KM];                              // phi[c .. c+3][0 .. KM): 4 KM contiguous floats
+#pragma unroll
+      for (int j = 0; j < KM; ++j) { pf[4 * j] = pq[v][j].x; pf[4 * j + 1] = pq[v][j].y; pf[4 * j + 2] = pq[v][j].z; pf[4 * j + 3] = pq[v][j].w; }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int n = 0; n < KM; ++n) {
+          const float ph = pf[cc * KM + n];
+          gp[v][cc][n] = gm[cc] * ph;
+          bsum[n] += bt[cc] * ph;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < KM; ++n) Bn[n] = wave_sum(bsum[n]);
+  }
+  const float inv_d = 1.0f / (float)DIM;
+  float m_[KM], mn_[KM], Z_[KM], c0_[KM], c1_[KM];
+  float4 acc[KM][2];
+#pragma unroll
+  for (int n = 0; n < KM; ++n) {
+    m_[n] = -3.0e38f; mn_[n] = 3.0e38f; Z_[n] = c0_[n] = c1_[n] = 0.f;
+    acc[n][0] = acc[n][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto consume = [&](const float4 (&r)[NR][2], const int (&tk)[NR], int j0) {
+    float mean_[NR], rstd_[NR], lgs[NR][KM];
+    // the wave totals of a trip -- NR sums, then NR x (1 + KM) centred sums -- in groups of four (wave_sum4): the reductions
+    // were a quarter of the kernel's instructions, and the kernel is bound by its instruction count (24 us at N = 30000 with
+    // one wave_sum per value, for 61 MB)
+    {
+      float sm[4] = {0.f, 0.f, 0.f, 0.f};
+      static_assert(NR <= 4, "one group of sums");
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) sm[j] += (r[j][v].x + r[j][v].y) + (r[j][v].z + r[j][v].w);
+      float t4[4];
+      wave_sum4(sm[0], sm[1], sm[2], sm[3], t4[0], t4[1], t4[2], t4[3]);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) mean_[j] = t4[j] * inv_d;
+    }
+    float sq_[NR], d_[NR][KM];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const float mean = mean_[j];
+      float sq = 0.f;
+#pragma unroll
+      for (int n = 0; n < KM; ++n) d_[j][n] = 0.f;
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const float xc[4] = {r[j][v].x - mean, r[j][v].y - mean, r[j][v].z - mean, r[j][v].w - mean};
+        sq += (xc[0] * xc[0] + xc[1] * xc[1]) + (xc[2] * xc[2] + xc[3] * xc[3]);
+#pragma unroll
+        for (int n = 0; n < KM; ++n)
+          d_[j][n] += (xc[0] * gp[v][0][n] + xc[1] * gp[v][1][n]) + (xc[2] * gp[v][2][n] + xc[3] * gp[v][3][n]);
+      }
+      sq_[j] = sq;
+    }
+    {
+      constexpr int NV = NR * (1 + KM), NG = (NV + 3) / 4;
+      float vals[4 * NG], tot[4 * NG];
+#pragma unroll
+      for (int i = 0; i < 4 * NG; ++i) vals[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        vals[j * (1 + KM)] = sq_[j];
+#pragma unroll
+        for (int n = 0; n < KM; ++n) vals[j * (1 + KM) + 1 + n] = d_[j][n];
+      }
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq)
+        wave_sum4(vals[4 * gq], vals[4 * gq + 1], vals[4 * gq + 2], vals[4 * gq + 3], tot[4 * gq], tot[4 * gq + 1], tot[4 * gq + 2],
+                  tot[4 * gq + 3]);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        rstd_[j] = 1.0f / sqrtf(tot[j * (1 + KM)] * inv_d + LN_EPS);
+#pragma unroll
+        for (int n = 0; n < KM; ++n) lgs[j][n] = rstd_[j] * tot[j * (1 + KM) + 1 + n] + Bn[n];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      if (tk[j] == -2) continue;                    // wave-uniform
+      const bool real = tk[j] >= 0;
+      const int rq = wave + NW * (j0 + j);
+#pragma unroll
+      for (int n = 0; n < KM; ++n) lgs[j][n] = real ? lgs[j][n] : 0.f;     // pad tokens carry zero rows -> zero logits
+      // (to LDS, not to memory: a global store between the trips' loads leaves the wait-count pass with loads AND stores
+      //  outstanding -- one counter, no order between the two kinds -- and every wait of the loop became vmcnt(0): the
+      //  prefetched trip was waited for on the spot; the logits leave in one pass behind the loop)
+      if (lane == 0) {
+#pragma unroll
+        for (int n = 0; n < KM; ++n) s_lg[rq * KM + n] = lgs[j][n];
+        s_mr[2 * rq] = real ? mean_[j] : 0.f;
+        s_mr[2 * rq + 1] = real ? rstd_[j] : 0.f;
+      }
+    }
+    // the trip's rows into the wave's online softmax: one rescale per trip
+#pragma unroll
+    for (int n = 0; n < KM; ++n) {
+      float mx = m_[n];
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+        if (tk[j] != -2) { mx = fmaxf(mx, lgs[j][n]); mn_[n] = fminf(mn_[n], lgs[j][n]); }
+      const float sc = __expf(m_[n] - mx);
+      m_[n] = mx;
+      Z_[n] *= sc; c0_[n] *= sc; c1_[n] *= sc;
+      acc[n][0].x *= sc; acc[n][0].y *= sc; acc[n][0].z *= sc; acc[n][0].w *= sc;
+      acc[n][1].x *= sc; acc[n][1].y *= sc; acc[n][1].z *= sc; acc[n][1].w *= sc;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        if (tk[j] == -2) continue;
+        const float e = __expf(lgs[j][n] - mx);
+        Z_[n] += e;
+        if (tk[j] >= 0) {
+          const float w = e * rstd_[j];
+          c0_[n] += w * mean_[j];
+          c1_[n] += e;
+          acc[n][0].x += w * r[j][0].x; acc[n][0].y += w * r[j][0].y; acc[n][0].z += w * r[j][0].z; acc[n][0].w += w * r[j][0].w;
+          acc[n][1].x += w * r[j][1].x; acc[n][1].y += w * r[j][1].y; acc[n][1].z += w * r[j][1].z; acc[n][1].w += w * r[j][1].w;
+        }
+      }
+    }
+  };
+  const int nj = (nrow + NW - 1) / NW;              // rows of the longest wave
+  // two trips per iteration: one lands while the other is reduced.  The requests are UNCONDITIONAL (rows past the quarter
+  // re-read row 0 and are skipped by `consume`): a request under `if (more rows)` leaves the wait-count pass not knowing
+  // whether the younger loads exist, and it then waits for the older trip with vmcnt(0) -- i.e. for the prefetch as well.
+  for (int j0 = 0; j0 < nj; j0 += 2 * NR) {
+    consume(ra, ta, j0);
+    request(ra, ta, j0 + 2 * NR);
+    consume(rb, tb, j0 + NR);
+    request(rb, tb, j0 + 3 * NR);
+  }
+  // ---- the waves' partials -> the block's record: statistics first, then the contraction scaled to the block's max
+  if (lane == 0) {
+#pragma unroll
+    for (int n = 0; n < KM; ++n) {
+      float* w = s_wst + (n * NW + wave) * 8;
+      w[0] = m_[n]; w[1] = mn_[n]; w[2] = Z_[n]; w[3] = c0_[n]; w[4] = c1_[n];
+    }
+  }
+  lds_sync();
+  // the quarter's logits (the merging block reads the whole region's) and, for the stage entry point, mean / rstd
+  for (int idx = tid; idx < nrow * k; idx += 64 * NW) {
+    const int rq = idx / k, n = idx - rq * k;
+    st_agent(logits + ((size_t)reg * g.P + q * PQ + rq) * k + n, s_lg[rq * KM + n]);
+  }
+  if (mean_rstd)
+    for (int rq = tid; rq < nrow; rq += 64 * NW) {
+      const int t = tok_of(rq);
+      if (t >= 0) *(float2*)(mean_rstd + 2 * (size_t)t) = make_float2(s_mr[2 * rq], s_mr[2 * rq + 1]);
+    }
+#pragma unroll
+  for (int n = 0; n < KM; ++n) {
+    if (n >= k) continue;
+    float M = -3.0e38f;
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, s_wst[(n * NW + w) * 8]);
+    const float sc = __expf(m_[n] - M);
+    acc[n][0].x *= sc; acc[n][0].y *= sc; acc[n][0].z *= sc; acc[n][0].w *= sc;
+    acc[n][1].x *= sc; acc[n][1].y *= sc; acc[n][1].z *= sc; acc[n][1].w *= sc;
+  }
+  if (tid < k) {
+    const int n = tid;
+    float M = -3.0e38f, mn = 3.0e38f;
+    for (int w = 0; w < NW; ++w) { M = fmaxf(M, s_wst[(n * NW + w) * 8]); mn = fminf(mn, s_wst[(n * NW + w) * 8 + 1]); }
+    float Z = 0.f, c0 = 0.f, c1 = 0.f;
+    for (int w = 0; w < NW; ++w) {
+      const float* ws = s_wst + (n * NW + w) * 8;
+      const float sc = __expf(ws[0] - M);
+      Z += sc * ws[2]; c0 += sc * ws[3]; c1 += sc * ws[4];
+    }
+    s_stat[n][0] = M; s_stat[n][1] = mn; s_stat[n][2] = Z; s_stat[n][3] = c0; s_stat[n][4] = c1;
+  }
+  constexpr int HW = NW / 2;
+  float* rec = part_g + (size_t)(reg * NB + q) * R4_REC;
+  const __amdgpu_buffer_rsrc_t rs_part =
+      __builtin_amdgcn_make_buffer_rsrc((void*)part_g, 0, (int)((size_t)gridDim.x * R4_REC * 4), 0x00020000);
+#pragma unroll
+  for (int n0 = 0; n0 < KM; n0 += KC) {
+    if (n0 > 0) lds_sync();
+    if (wave >= HW) {
+#pragma unroll
+      for (int n = n0; n < n0 + KC && n < KM; ++n) {
+        s_part[((wave - HW) * KC + n - n0) * 128 + lane] = acc[n][0];
+        s_part[((wave - HW) * KC + n - n0) * 128 + 64 + lane] = acc[n][1];
+      }
+    }
+    lds_sync();
+    if (wave < HW) {
+#pragma unroll
+      for (int n = n0; n < n0 + KC && n < KM; ++n) {
+        float4 a = s_part[(wave * KC + n - n0) * 128 + lane], b = s_part[(wave * KC + n - n0) * 128 + 64 + lane];
+        a.x += acc[n][0].x; a.y += acc[n][0].y; a.z += acc[n][0].z; a.w += acc[n][0].w;
+        b.x += acc[n][1].x; b.y += acc[n][1].y; b.z += acc[n][1].z; b.w += acc[n][1].w;
+        s_part[(wave * KC + n - n0) * 128 + lane] = a;
+        s_part[(wave * KC + n - n0) * 128 + 64 + lane] = b;
+      }
+    }
+    lds_sync();
+    const int kc = min(KC, k - n0);
+    for (int idx = tid; idx < kc * 128; idx += 64 * NW) {
+      const int n = idx >> 7, c = idx & 127;
+      float4 a = s_part[n * 128 + c];
+#pragma unroll
+      for (int w = 1; w < HW; ++w) {
+        const float4 b = s_part[(w * KC + n) * 128 + c];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      st_agent4(rs_part, part_g, rec + (n0 + n) * (DIM + 8) + c * 4, a);
+    }
+  }
+  if (tid < k) {                                    // (s_stat was written by this very thread)
+    const int n = tid;
+    float* st = rec + n * (DIM + 8) + DIM;          // max, min, sum, c0 | c1, -, -, -  (crmsa_region4's record)
+    st_agent4(rs_part, part_g, st, make_float4(s_stat[n][0], s_stat[n][1], s_stat[n][2], s_stat[n][3]));
+    st_agent4(rs_part, part_g, st + 4, make_float4(s_stat[n][4], 0.f, 0.f, 0.f));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record (and the logits) are in memory ...
+  __syncthreads();
+  if (tid == 0)                                     // ... before this quarter counts as arrived
+    s_last = __hip_atomic_fetch_add(counters + reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NB - 1;
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) __hip_atomic_store(counters + reg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next forward
+  // ---- the last quarter merges the region (as crmsa_region4_kernel)
+  const float* rec0 = part_g + (size_t)(reg * NB) * R4_REC;
+  if (tid < k) {
+    const int n = tid;
+    float4 sa[NB], sb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float* st = rec0 + b * R4_REC + n * (DIM + 8) + DIM;
+      sa[b] = ld_agent4(rs_part, part_g, st);
+      sb[b] = ld_agent4(rs_part, part_g, st + 4);
+    }
+    float M = -3.0e38f, mn = 3.0e38f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { M = fmaxf(M, sa[b].x); mn = fminf(mn, sa[b].y); }
+    float L = 0.f, c0 = 0.f, c1 = 0.f, scb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      scb[b] = __expf(sa[b].x - M);
+      L += scb[b] * sa[b].z; c0 += scb[b] * sa[b].w; c1 += scb[b] * sb[b].x;
+    }
+    const float invL = 1.0f / L;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s_scb[n][b] = scb[b] * invL;
+    s_mrg[n][0] = M; s_mrg[n][1] = invL; s_mrg[n][2] = c0 / L; s_mrg[n][3] = c1 / L;
+    s_mm[n][0] = mn; s_mm[n][1] = M;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < k * 128; idx += 64 * NW) {
+    const int n = idx >> 7, c = idx & 127;
+    float4 v4[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) v4[b] = ld_agent4(rs_part, part_g, rec0 + b * R4_REC + n * (DIM + 8) + c * 4);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float sc = s_scb[n][b];
+      a.x += sc * v4[b].x; a.y += sc * v4[b].y; a.z += sc * v4[b].z; a.w += sc * v4[b].w;
+    }
+    const float c0 = s_mrg[n][2], c1 = s_mrg[n][3];
+    const float4 gm = *(const float4*)(gamma + c * 4), bt = *(const float4*)(beta + c * 4);
+    float4 out;
+    out.x = gm.x * (a.x - c0) + bt.x * c1;
+    out.y = gm.y * (a.y - c0) + bt.y * c1;
+    out.z = gm.z * (a.z - c0) + bt.z * c1;
+    out.w = gm.w * (a.w - c0) + bt.w * c1;
+    *(float4*)(rep + ((size_t)n * R + reg) * DIM + c * 4) = out;
+    if (rep16) {
+      uint16_t* d16 = rep16 + ((size_t)n * R + reg) * DIM + c * 4;
+      *(uint2*)d16 = prec16 == 2 ? r4_pack4<2>(out) : r4_pack4<1>(out);
+    }
+  }
+  // dispatch weights of the whole region (rmsa.py:310-314, :324-325) from the four quarters' logits
+  for (int p = tid; p < g.P; p += 64 * NW) {
+    float v[KM], e[KM];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) { v[n] = ld_agent(logits + ((size_t)reg * g.P + p) * k + n); mx = fmaxf(mx, v[n]); }
+    float se = 0.f;
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k) { e[n] = __expf(v[n] - mx); se += e[n]; }
+    const float inv = 1.0f / se;
+#pragma unroll
+    for (int n = 0; n < KM; ++n)
+      if (n < k)
+        wdisp[((size_t)reg * g.P + p) * k + n] = (v[n] - s_mm[n][0]) / (s_mm[n][1] - s_mm[n][0] + 1e-8f) * (e[n] * inv);
+  }
+}
+
 // KB > 0 (round 4): the dispatch weights and the representatives' rows of the first KB representatives are requested UP FRONT,
 // together with the token row, and gamma / beta with them -- the loop over n issued one dependent L2 round trip per
 // representative behind the row's HBM round trip (and a fourth one for gamma / beta behind the statistics): 8.7 us for the
@@ -1778,6 +2154,43 @@ hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float
 #undef RRT_R4
 }
 
+// one pass over x1 for regions of more than 144 tokens (crmsa_stream4_kernel): dim 512, k <= 8, 16 <= P
+bool crmsa_stream4_supported(int dim, int k, const GridDev& g8) {
+  static const bool off = rrt_tune_env("RRT_NO_CRMSA_STREAM4") != nullptr;
+  return !off && dim == 512 && k >= 1 && k <= R4_KMAX && g8.P >= 16 && g8.P <= 4 * S4_PQMAX;
+}
+template <int NW, int NR, int KM>
+static hipError_t launch_stream4_cfg(const float* x1, const float* gamma, const float* beta, const float* phi,
+                                     float* mean_rstd, float* logits, float* wdisp, float* rep, uint16_t* rep16, int prec16,
+                                     float* part_g, int* counters, const GridDev& g8, hipStream_t st) {
+  static_assert(NW >= KM && NW % 2 == 0 && KM <= R4_KMAX, "stream4 shape");
+  constexpr int KC = KM < 4 ? KM : 4;
+  const size_t lds = (size_t)(KM * NW * 8 + S4_PQMAX * (KM + 2)) * 4 + (size_t)(NW / 2) * KC * 128 * 16;
+  auto kern = crmsa_stream4_kernel<NW, NR, KM>;
+  static OncePerDevice once;
+  if (lds > 64 * 1024 && once.first())
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<dim3(g8.rs * g8.rs * 4), dim3(64 * NW), lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16,
+                                                            part_g, counters, g8);
+  return hipGetLastError();
+}
+// part_g: crmsa_region4_scratch_floats(g8, k) floats (its records are at least as large and at least as many); counters zero;
+// gamma, beta, phi on 16-byte boundaries (float4 loads, as launch_crmsa_logits' dim-512 kernel)
+hipError_t launch_crmsa_stream4(const float* x1, const float* gamma, const float* beta, const float* phi,
+                                float* mean_rstd, float* logits, float* wdisp, float* rep, uint16_t* rep16, int prec16,
+                                float* part_g, int* counters, int k, const GridDev& g8, hipStream_t st) {
+  if (!crmsa_stream4_supported(512, k, g8)) return hipErrorInvalidValue;
+  // twelve waves (three per SIMD) while the accumulators and gamma . phi of <= 3 representatives fit 168 registers; more
+  // representatives: eight waves with the 256-register budget (at twelve the k = 5 / 8 forms spilled)
+#define RRT_S4(NW_, NR_, KM_) case KM_: return launch_stream4_cfg<NW_, NR_, KM_>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, \
+                                                                                rep16, prec16, part_g, counters, g8, st)
+  switch (k) {      // (k = 7, 8: two rows per trip -- with three the 256 registers of an eight-wave block spilled)
+    RRT_S4(12, 3, 1); RRT_S4(12, 3, 2); RRT_S4(12, 3, 3); RRT_S4(8, 3, 4); RRT_S4(8, 3, 5); RRT_S4(8, 3, 6); RRT_S4(8, 2, 7); RRT_S4(8, 2, 8);
+  }
+#undef RRT_S4
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
                                 const float* mean_rstd, const float* logits, float* wdisp,
                                 float* rep, uint16_t* rep16, int prec16, int dim, int k, const GridDev& g8, hipStream_t st) {
@@ -1828,9 +2241,10 @@ hipError_t launch_crmsa_combine_parts(const float* x1, const float* part, const 
 #define RRT_CPARTS(KM_)                                                                                              \
   do {                                                                                                               \
     const size_t lds = combine_parts_lds(g8.P, KM_) + (coal ? (size_t)16 * TR * 17 * 16 : 0);                        \
-    auto kern = (coal && KM_ == 4) ? crmsa_combine_parts_kernel<TR, KM_, true> : crmsa_combine_parts_kernel<TR, KM_, false>; \
-    static OncePerDevice once;                                                                                       \
-    if (lds > 64 * 1024 && once.first())                                                                             \
+    const bool ck = coal && KM_ == 4;                                                                                \
+    auto kern = ck ? crmsa_combine_parts_kernel<TR, KM_, true> : crmsa_combine_parts_kernel<TR, KM_, false>;         \
+    static OncePerDevice once_coal, once_plain;      /* one per concrete kernel: the attribute is the kernel's own */ \
+    if (lds > 64 * 1024 && (ck ? once_coal : once_plain).first())                                                    \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);          \
     kern<<<grid, block, lds, st>>>(x1, part, gamma, beta, phi, wdisp, rep, rep16, prec16, dim, k, dim / 64, al16, g8); \
   } while (0)

@@ -67,7 +67,7 @@ struct Cast16Jobs {
 };
 hipError_t launch_cast16(const Cast16Jobs& jobs, int prec, hipStream_t st);
 hipError_t launch_ln_partition16(const float* x, const float* gamma, const float* beta, uint16_t* u, int dim,
-                                 const GridDev& g, int prec, hipStream_t st);
+                                 const GridDev& g, int prec, hipStream_t st, int* zero = nullptr, int n_zero = 0);
 // RRT_COMPUTE_F32X3: fp32 as (hi, lo) bf16 pairs, 32-element groups [32 hi | 32 lo] (cast16.hip); jobs.dst = byte images
 hipError_t launch_cast_split(const Cast16Jobs& jobs, hipStream_t st);
 hipError_t launch_ln_partition_split(const float* x, const float* gamma, const float* beta, void* u, int dim,
@@ -80,6 +80,29 @@ hipError_t launch_linear_split(const void* Asplit, const void* Bsplit, float* C,
 bool rmsa_pair16_supported(int n_regions, int P, int D, int heads, int epeg_k);
 hipError_t launch_rmsa_pair16(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
                               int n_regions, int P, int D, int heads, int epeg_k, int prec, hipStream_t st);
+// Round 6: the same launch also runs the layer's out-projection (16-bit operands) + region_reverse + un-pad + residual, as
+// rmsa_fused_kernel<.., PROJ> does in fp32: block b runs item b, block b >= lag also the 64-column slab b - lag of a region
+// PAIR once the pair's `heads` items have arrived at cnt[pair].  cnt [n_regions / 2] must be zero at launch.
+struct PairProj {
+  const uint16_t* Wp;    // [D, D] 16-bit
+  const float* bias;     // [D] or null
+  const float* resid;    // [L, D] token order
+  float* out;            // [L, D]
+  int* cnt;              // [n_regions / 2] arrival counters (zero at launch)
+  int* zero64;           // side job of block 0 (LinearEpilogue.zero64), may be null
+  int lag;               // blocks between an item and the slab of the same index (multiple of 8, >= 8 * heads); 0: the launcher's rule
+  int n_items;           // heads * n_regions / 2 (filled by the launcher)
+  GridDev g;
+  int* err;              // the process's hand-over error word (null: the launcher's), as FusedProj
+  int spin_limit;        // 0: 2^22
+  int wait_for;          // 0: heads
+};
+// sixteen-wave form with an even number of row tiles (regions of 65..96 and 113..128 tokens), whole groups of eight pairs,
+// at least two rounds of items
+bool rmsa_pair16_proj_supported(int n_regions, int P, int D, int heads, int epeg_k);
+hipError_t launch_rmsa_pair16_proj(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
+                                   int n_regions, int P, int D, int heads, int epeg_k, int prec, const PairProj& proj,
+                                   hipStream_t st);
 bool rmsa_fused_x3_supported(int P, int D, int heads, int epeg_k);
 hipError_t launch_rmsa_fused_x3(const void* Usplit, const void* Wsplit, const float* bqkv, const float* pe_w,
                                 void* Osplit, int n_regions, int P, int D, int heads, int epeg_k, hipStream_t st);
@@ -170,6 +193,12 @@ hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float
 hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float* beta, const float* phi,
                                float* mean_rstd, float* logits, float* wdisp, float* rep, int k, const GridDev& g8,
                                hipStream_t st);
+// regions of more than 144 tokens: four blocks per region that stream their rows (one pass over x1); scratch and counters as
+// launch_crmsa_region4
+bool crmsa_stream4_supported(int dim, int k, const GridDev& g8);
+hipError_t launch_crmsa_stream4(const float* x1, const float* gamma, const float* beta, const float* phi,
+                                float* mean_rstd, float* logits, float* wdisp, float* rep, uint16_t* rep16, int prec16,
+                                float* part_g, int* counters, int k, const GridDev& g8, hipStream_t st);
 hipError_t launch_crmsa_combine(const float* x1, const float* gamma, const float* beta,
                                 const float* mean_rstd, const float* logits, float* wdisp,
                                 float* rep, uint16_t* rep16, int prec16, int dim, int k, const GridDev& g8, hipStream_t st);

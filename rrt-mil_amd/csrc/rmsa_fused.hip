@@ -1261,35 +1261,34 @@ RRT_TRACE_DEFINE_READER(rrt_debug_trace_fused)
 // ---- hand-over error word: 64 bytes of pinned host memory mapped into the device's address space, one per process.
 // A slab that gives up its bounded wait stores into it with system scope; the host reads it without any device sync.
 namespace {
+// (published once through std::call_once: a second host thread launching its first merged forward at the same moment
+//  either runs the initialiser or waits for it, and then sees both pointers)
 int* g_err_host = nullptr;
 int* g_err_dev = nullptr;
-bool g_err_tried = false;
+std::once_flag g_err_once;
 void handover_err_init() {
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  if (g_err_tried) return;
   void* h = nullptr;
   if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && h != nullptr) {
     memset(h, 0, 64);
     void* d = nullptr;
     if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d != nullptr) {
-      g_err_host = (int*)h;
       g_err_dev = (int*)d;
+      __atomic_store_n(&g_err_host, (int*)h, __ATOMIC_RELEASE);   // (handover_err_peek reads it without the once-flag)
     }
   } else {
     (void)hipGetLastError();     // no pinned memory: the wait stays bounded, the error is just not reported
   }
-  g_err_tried = true;
 }
 }  // namespace
 int* handover_err_device() {
-  if (!g_err_tried) handover_err_init();
+  std::call_once(g_err_once, handover_err_init);
   return g_err_dev;
 }
 int handover_err_peek(bool clear) {
-  if (g_err_host == nullptr) return 0;
-  const int v = __atomic_load_n(g_err_host, __ATOMIC_RELAXED);
-  if (clear && v != 0) __atomic_store_n(g_err_host, 0, __ATOMIC_RELAXED);
+  int* const eh = __atomic_load_n(&g_err_host, __ATOMIC_ACQUIRE);
+  if (eh == nullptr) return 0;
+  const int v = __atomic_load_n(eh, __ATOMIC_RELAXED);
+  if (clear && v != 0) __atomic_store_n(eh, 0, __ATOMIC_RELAXED);
   return v;
 }
 

@@ -20,6 +20,22 @@
 // Rounding points (oracle: forward_f64(lowp=LowP(.., attn=True, stencil16=True))): U, W; Q log2(e) hd^-0.5 (BEFORE the
 // stencil: one rounding more than rmsa_fused16, which ran the stencil in fp32), Q~, K, V, exp2(S - max), O.
 // Regions: any P <= 176 (MT <= 11 row tiles), head dim 64, at least 8 regions; others take rmsa_fused16.
+//
+// PROJ (round 6; sixteen-wave form, an even number of row tiles, bags of >= two rounds of (pair, head) items -- BASELINE
+// configs[3]: N = 30000 at region_num = 16 is 1024 items, four rounds of the chip): the same launch CAN also run the layer's
+// out-projection + region_reverse + un-pad + residual (modules/rmsa.py:131, :41-54, :227-228; rrt.py:125), as
+// rmsa_fused_kernel<.., PROJ> does in fp32: block b runs item b and then the 64-column projection SLAB b - lag of a pair
+// whose eight head items finished a round earlier (pair_slab below).  Arithmetic and summation order of a slab are
+// linear_ws_kernel<.., IN16>'s (K tiles ascending, two 32-wide halves each; (acc + bias) + residual): bit-identical to the
+// two launches (tests/test_hip_parity.py::test_rmsa_pair16_proj).  MEASURED, AND NOT USED BY THE FORWARD: 109 us (two-stage
+// slab ring) / 116 us (three-stage) against 64.5 + 35.6 us for the two launches at N = 30000.  The in-kernel timeline
+// (profiles/r06_trace_pair16_proj.txt): an item is 39.2 K cycles, a slab adds 25 K -- 1.1 K waiting for the counter, 6.9 K
+// until its first two stages are issued (cold code, sixteen waves' first DMA pieces), 13 K of K loop (1.4 K per K tile:
+// the DMA-issue bound of sixteen issuing waves -- the separate projection's bound too), 2.8 K of epilogue -- and the item
+// itself waits 4 K for its write-through O stores before it may count as arrived.  In fp32 the merged launch won because
+// the separate projection ran in lockstep at 2/3 of its MFMA bound; the 16-bit projection already runs at its (DMA-issue)
+// bound with two blocks per CU covering each other's prologue and epilogue, and a slab inside a block that owns its CU has
+// nothing to overlap with.  The code stays as the measured answer to "merge the 16-bit launches" (round-5 review, item 1a).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -28,20 +44,190 @@
 namespace {
 using namespace f16k;
 
+// write-through 16-byte store (sc0 sc1: the line reaches memory, not just this XCD's L2 -- the slab that reads it may in
+// principle run on another XCD; + the wait states a > 64-bit inline-asm store needs before its data registers are reused)
+typedef unsigned p16_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt16(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  const p16_u32x4 v = {a, b, c, d};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PROJ phase: one 64-column slab of one region PAIR's out-projection, by the whole block (sixteen waves):
+//     Y[2P x 64] = O16[rows of the pair, D] . Wp16[64 c .. 64 c + 63, :]^T ;  out[token] = resid[token] + (Y + b)
+// All sixteen waves issue DMA pieces and multiply (as in the item's projection phase): wave (rg, cw) owns the row tiles
+// 4 rg' .. of its quarter of the 2 MT row tiles and the 16-column tile cw.  Two-stage ring of (32 MT + 64) rows x 128 B in
+// the item's (dead) LDS.  A slab's loader never reads O rows outside its own pair: rows past 2 P re-read the pair's last row.
+#ifdef RRT_TRACE
+#define RRT_PSLAB_TRACE_ARG , WaveTrace& _tr
+#define RRT_PSLAB_TRACE_PASS , _tr
+#else
+#define RRT_PSLAB_TRACE_ARG
+#define RRT_PSLAB_TRACE_PASS
+#endif
+template <int MT, int PREC>
+__device__ __forceinline__ void pair_slab(const uint16_t* __restrict__ O, const int n_rows, const int P, const int D,
+                                          const int heads_rt, const PairProj& pj, char* smem, int* s_abort RRT_PSLAB_TRACE_ARG) {
+  using H = H16<PREC>;
+  using Frag = typename H::frag;
+  static_assert(MT % 2 == 0, "pair_slab: the 2 MT row tiles are shared out over four wave groups");
+  constexpr int MT2 = 2 * MT, RT = MT2 / 4;           // row tiles of the pair; per wave
+  constexpr int BM2 = 16 * MT2;
+  constexpr int STG_B = (BM2 + HD) * ROWB;            // bytes per stage
+  constexpr int NA = BM2 / 8, NBp = HD / 8, NP = NA + NBp, LP = (NP + 15) / 16;
+  // the ring lives in the item's (dead) tiles: three stages where they fit (MT = 6, 8: they do).  With two, every K tile
+  // waited for the DMA round trip of a stage issued one short compute step earlier: a slab took 22 K cycles, as long as the
+  // separate launch's tile, and the merged launch was SLOWER than the two (109 against 100 us at N = 30000)
+  constexpr int MAIN_B = (2 * (2 * 16 * MT * ROWB + 64 * VT_PITCH) > 4 * 16 * MT * ROWB + 2 * BN * ROWB)
+                             ? 2 * (2 * 16 * MT * ROWB + 64 * VT_PITCH) : 4 * 16 * MT * ROWB + 2 * BN * ROWB;
+  constexpr int NS = 3 * STG_B <= MAIN_B ? 3 : 2;
+  const int b = (int)blockIdx.x;
+  if (b < pj.lag) return;
+  const int sidx = b - pj.lag;                        // < n_items by the grid size
+  RRT_TRACE_MARK();                                   // slab [1] entry
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  int pair, col;
+  {
+    const int xcd = sidx & 7, idx = sidx >> 3;        // (the item map of the kernel; PROJ launches have whole groups of 8 pairs)
+    const int grp = idx / heads_rt;
+    pair = grp * 8 + xcd;
+    col = idx - grp * heads_rt;
+  }
+  // the pair's `heads` items have arrived (their O rows are in memory): blocks with lower indices.  Bounded wait, as
+  // rmsa_fused.hip::proj_slab (in-order workgroup dispatch is an assumption, not a guarantee): a slab that gives up raises
+  // the process's hand-over error word and writes nothing.
+  if (tid == 0) {
+    int spins = 0, bad = 0;
+    while (__hip_atomic_load(pj.cnt + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pj.wait_for) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > pj.spin_limit) { bad = 1; break; }
+    }
+    if (bad && pj.err != nullptr) __hip_atomic_store(pj.err, 1 + 2 * pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    *s_abort = bad;
+  }
+  __syncthreads();
+  if (*s_abort) return;                               // (block-uniform)
+  RRT_TRACE_MARK();                                   // slab [2] the pair's items have arrived
+  const int row0 = 2 * pair * P;                      // first O row of the pair; its 2 P rows are contiguous
+  const int nrows = 2 * P;
+  const unsigned lds_b = lds_addr_of(smem);
+  unsigned off[LP];
+#pragma unroll
+  for (int q = 0; q < LP; ++q) {
+    const int piece = q * 16 + wave;
+    const int pp = lane & 7;
+    if (piece < NA) {
+      const int srow = piece * 8 + (lane >> 3);
+      int gr = row0 + (srow < nrows ? srow : nrows - 1);
+      gr = gr < n_rows ? gr : n_rows - 1;
+      off[q] = (unsigned)gr * (unsigned)D * 2u + (unsigned)((pp ^ ((srow >> 1) & 7)) << 4);
+    } else {
+      const int wrow = (piece - NA) * 8 + (lane >> 3);          // [0, 64): output column 64 col + wrow
+      off[q] = (unsigned)(col * HD + wrow) * (unsigned)D * 2u + (unsigned)((pp ^ ((wrow >> 1) & 7)) << 4);
+    }
+  }
+  auto stage = [&](int kt, unsigned buf) {
+    const char* ob = (const char*)O + kt * ROWB;
+    const char* wb = (const char*)pj.Wp + kt * ROWB;
+#pragma unroll
+    for (int q = 0; q < LP; ++q) {
+      const int piece = q * 16 + wave;
+      if (piece < NA) dma16s(ob, off[q], buf + piece * 1024);
+      else if (piece < NP) dma16s(wb, off[q], buf + BM2 * ROWB + (piece - NA) * 1024);
+    }
+  };
+  const int nk = D / 64;
+  const int cw = wave & 3, rg = wave >> 2;            // 16-column tile; quarter of the row tiles
+  const int ncol = col * HD + 16 * cw + 4 * lg;       // this lane's four output columns
+  // un-partition map of this lane's RT rows (region_reverse, rmsa.py:41-54) and their residual rows, requested FIRST: they
+  // are older than every DMA piece, so the loop's counted waits (loads return in order) cover them, and they land under it
+  int toff[RT];
+  float4 rq[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    const int m = (rg * RT + i) * 16 + lr;            // row of the pair
+    const int rsel = m >= P ? 1 : 0;
+    const int mm = m - rsel * P;
+    const int reg = 2 * pair + rsel;
+    const int ri = fdiv(reg, pj.g.rs, pj.g.inv_rs), rj = reg - ri * pj.g.rs;
+    const int pi = fdiv(mm, pj.g.s, pj.g.inv_s), pjj = mm - pi * pj.g.s;
+    const int t = (ri * pj.g.s + pi) * pj.g.H + rj * pj.g.s + pjj;
+    toff[i] = (m < nrows && t < pj.g.L) ? t * D + ncol : -1;
+    rq[i] = *(const float4*)(pj.resid + (toff[i] < 0 ? 0 : toff[i]));
+  }
+  const float4 bias = pj.bias ? *(const float4*)(pj.bias + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x4 acc[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  asm volatile("" ::: "memory");                      // (the residual requests stay in front of the DMA pieces)
+  // pieces this wave issues per stage: the loop waits until only the NEXT stage's are still in flight
+  int mine = 0;
+#pragma unroll
+  for (int q = 0; q < LP; ++q) mine += (q * 16 + wave < NP) ? 1 : 0;
+  auto wait_mine = [&] {                              // s_waitcnt vmcnt(mine), mine in 1 .. 4 (wave-uniform)
+    if (mine <= 1) wait_vmcnt<1>(); else if (mine == 2) wait_vmcnt<2>(); else if (mine == 3) wait_vmcnt<3>(); else wait_vmcnt<4>();
+  };
+  stage(0, lds_b);
+  if (NS == 3 && nk > 1) stage(1, lds_b + STG_B);
+  RRT_TRACE_MARK();                                   // slab [3] first stages issued
+  for (int kt = 0; kt < nk; ++kt) {
+    if (NS == 3 && kt + 1 < nk) wait_mine(); else wait_vm0();
+    if (kt == 0 || kt == 4) RRT_TRACE_MARK();         // slab [4,6] K tile 0 / 4 landed
+    lds_sync();                                       // K tile kt is complete; everyone is done with K tile kt - 1
+    if (kt == 0 || kt == 4) RRT_TRACE_MARK();         // slab [5,7] barrier passed
+    {
+      const int nx = kt + NS - 1;                     // into the buffer K tile kt - 1 just left
+      if (nx < nk) stage(nx, lds_b + (nx % NS) * STG_B);
+    }
+    const char* As = smem + (kt % NS) * STG_B;
+    const char* Bs = As + BM2 * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int cslot = 4 * kk + lg;
+      Frag a8[RT], b8;
+      {
+        const int row = 16 * cw + lr;
+        b8 = *(const Frag*)(Bs + row * ROWB + ((cslot ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const int row = (rg * RT + i) * 16 + lr;
+        a8[i] = *(const Frag*)(As + row * ROWB + ((cslot ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i) acc[i] = H::mfma(b8, a8[i], acc[i]);   // reg r = C[m = .. + lr][n = 16 cw + 4 lg + r]
+    }
+  }
+  RRT_TRACE_MARK();                                   // slab [8] last MFMA issued
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    if (toff[i] < 0) continue;
+    const float4 q = rq[i];
+    float4 v;
+    v.x = (acc[i][0] + bias.x) + q.x; v.y = (acc[i][1] + bias.y) + q.y;
+    v.z = (acc[i][2] + bias.z) + q.z; v.w = (acc[i][3] + bias.w) + q.w;
+    *(float4*)(pj.out + toff[i]) = v;
+  }
+  RRT_TRACE_MARK();                                   // slab [9] stores issued
+}
+
 constexpr int VQ_B = 64 * VT_PITCH;
 constexpr bool PAIR16_NH2_DEFAULT = true;    // sixteen-wave form for 6..9 row tiles: see launch_rmsa_pair16     // per region: V^T [64][512 B]; before that, Q^T [64][512 B] for the stencil
 
 // NH = 1: eight waves, wave (region, c) owns all row tiles of its region for its 16-column tile of Q / K / V.
 // NH = 2: sixteen waves (<= 128 VGPRs), wave (region, row half, c) owns half the row tiles: twice the issuing waves for the
 //         DMA pieces (the stream's rate grows with them) and eighteen query tiles on sixteen waves instead of eight.
-template <int MT, int PREC, int NH>
+template <int MT, int PREC, int NH, bool PROJ = false>
 __global__ __launch_bounds__(512 * NH, 1) void rmsa_pair16_kernel(const uint16_t* __restrict__ U,
                                                                   const uint16_t* __restrict__ W,
                                                                   const float* __restrict__ bqkv,
                                                                   const float* __restrict__ pe_w,
                                                                   uint16_t* __restrict__ O, int n_rows, int n_regions, int P,
                                                                   int D, int heads_rt, int epeg_k, float q_scale,
-                                                                  int qs_pitch, int H8, int nstep) {
+                                                                  int qs_pitch, int H8, int nstep, const PairProj pj) {
+  static_assert(!PROJ || (NH == 2 && MT % 2 == 0), "the projection phase: sixteen waves, an even number of row tiles");
   using H = H16<PREC>;
   using Frag = typename H::frag;
   using E = typename H::elem;
@@ -77,10 +263,16 @@ __global__ __launch_bounds__(512 * NH, 1) void rmsa_pair16_kernel(const uint16_t
   const unsigned lds_b = lds_addr_of(smem);
   // XCD-aware block -> (pair, head) map: the head-blocks of a pair sit on ONE XCD (its U panels are fetched from HBM
   // once and served to the other heads from that XCD's L2)
-  int head, pair;
-  {
+  __shared__ int s_abort;
+  const int n_items = PROJ ? pj.n_items : (int)gridDim.x;
+  const bool has_item = !PROJ || (int)blockIdx.x < n_items;
+  if constexpr (PROJ) {
+    if (pj.zero64 != nullptr && blockIdx.x == 0 && threadIdx.x < 64) pj.zero64[threadIdx.x] = 0;
+  }
+  int head = 0, pair = 0;
+  if (has_item) {
     const int b = blockIdx.x;
-    const int n_pairs = gridDim.x / heads_rt;
+    const int n_pairs = n_items / heads_rt;
     const int full = (n_pairs >> 3) * 8 * heads_rt;
     if (b < full) {
       const int xcd = b & 7, idx = b >> 3;
@@ -93,6 +285,8 @@ __global__ __launch_bounds__(512 * NH, 1) void rmsa_pair16_kernel(const uint16_t
       head = rem % heads_rt;
     }
   }
+  RRT_TRACE_INIT(blockIdx.x * NWV + wave);
+  if (has_item) {
   const int reg = 2 * pair + rsel;
   const bool valid = reg < n_regions;                // (odd region count: the last pair's second half is a dummy)
   const int row0 = (valid ? reg : 2 * pair) * P;
@@ -117,7 +311,6 @@ __global__ __launch_bounds__(512 * NH, 1) void rmsa_pair16_kernel(const uint16_t
     tfrag[(s_ * 2) * 64 + l_] = hi8;
     tfrag[(s_ * 2 + 1) * 64 + l_] = lo8;
   }
-  RRT_TRACE_INIT(blockIdx.x * NWV + wave);
   RRT_TRACE_MARK();                                 // [1] entry
 
   // ================================================================== phase 1: projection, both regions against one W tile
@@ -399,11 +592,25 @@ __global__ __launch_bounds__(512 * NH, 1) void rmsa_pair16_kernel(const uint16_t
       uint2 q2 = pack4<PREC>(oacc[0][2] * inv, oacc[1][2] * inv, oacc[2][2] * inv, oacc[3][2] * inv);
       uint2 q3 = pack4<PREC>(oacc[0][3] * inv, oacc[1][3] * inv, oacc[2][3] * inv, oacc[3][3] * inv);
       uint16_t* dst = O + (size_t)(row0 + i) * D + head * HD + 16 * lg;
-      *(uint4*)dst = make_uint4(q0.x, q0.y, q1.x, q1.y);
-      *(uint4*)(dst + 8) = make_uint4(q2.x, q2.y, q3.x, q3.y);
+      if constexpr (PROJ) {
+        store_wt16(dst, q0.x, q0.y, q1.x, q1.y);
+        store_wt16(dst + 8, q2.x, q2.y, q3.x, q3.y);
+      } else {
+        *(uint4*)dst = make_uint4(q0.x, q0.y, q1.x, q1.y);
+        *(uint4*)(dst + 8) = make_uint4(q2.x, q2.y, q3.x, q3.y);
+      }
     }
     RRT_TRACE_MARK();                               // tile: O stored
   }
+  // ---------------------------------------------------------------- PROJ: this item has arrived
+  if constexpr (PROJ) {
+    wait_vm0();                                     // this thread's write-through stores of O are in memory ...
+    __syncthreads();                                // ... and everybody's; the tiles in LDS are dead
+    RRT_TRACE_MARK();                               // item: O in memory
+    if (tid == 0) __hip_atomic_fetch_add(pj.cnt + pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  }   // has_item
+  if constexpr (PROJ) pair_slab<MT, PREC>(O, n_rows, P, D, heads_rt, pj, smem, &s_abort RRT_PSLAB_TRACE_PASS);
 }
 
 // stencil geometry for a tap count: zero halo H8 (k/2 rounded up to 8), 32-wide MFMA steps, bytes of a Q^T row in use
@@ -437,7 +644,49 @@ hipError_t launch_pair(const uint16_t* U, const uint16_t* W, const float* bqkv, 
   const float q_scale = 1.0f / sqrtf((float)HD);
   const int pairs = (n_regions + 1) / 2;
   kern<<<dim3(heads * pairs), dim3(512 * NH), LDS, st>>>(U, W, bqkv, pe_w, O, n_regions * P, n_regions, P, D, heads, ek, q_scale,
-                                                        g.pitch, g.H8, g.nstep);
+                                                        g.pitch, g.H8, g.nstep, PairProj{});
+  return hipGetLastError();
+}
+
+// one "round" of the chip between an item and the slab of the same index (one block per CU: LDS); a multiple of 8 so that
+// a slab stays on its pair's XCD
+int pair_proj_lag(int n_items) {
+  static int cus[64] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  d &= 63;
+  if (cus[d] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    cus[d] = n;
+  }
+  int lag = cus[d] & ~7;
+  if (lag > n_items) lag = n_items & ~7;
+  return lag;
+}
+
+template <int MT, int PREC>
+hipError_t launch_pair_proj(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
+                            int n_regions, int P, int D, int heads, int epeg_k, PairProj pj, hipStream_t st) {
+  constexpr int NH = 2, BM = 16 * MT;
+  constexpr size_t USTG = (size_t)2 * BM * ROWB, WSTG = (size_t)BN * ROWB;
+  constexpr size_t RING = 2 * USTG + 2 * WSTG;
+  constexpr size_t TILES = (size_t)2 * (2 * BM * ROWB + VQ_B);
+  constexpr size_t SLAB = (size_t)2 * (2 * BM + HD) * ROWB;          // the slab's two-stage ring
+  constexpr size_t MAIN = RING > TILES ? RING : TILES;
+  static_assert(SLAB <= MAIN, "the slab's ring lives in the item's LDS");
+  constexpr size_t LDS = MAIN + 6 * 1024;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  const int ek = pe_w ? epeg_k : 0;
+  const StencilGeo g = stencil_geo(BM, ek);
+  if (g.pitch > VT_PITCH || g.nstep > 3) return hipErrorInvalidValue;
+  auto kern = rmsa_pair16_kernel<MT, PREC, NH, true>;
+  static OncePerDevice once;
+  if (once.first())
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+  const float q_scale = 1.0f / sqrtf((float)HD);
+  kern<<<dim3(pj.n_items + pj.lag), dim3(512 * NH), LDS, st>>>(U, W, bqkv, pe_w, O, n_regions * P, n_regions, P, D, heads, ek,
+                                                              q_scale, g.pitch, g.H8, g.nstep, pj);
   return hipGetLastError();
 }
 
@@ -476,4 +725,35 @@ hipError_t launch_rmsa_pair16(const uint16_t* U, const uint16_t* W, const float*
   if (P > 32) { RRT_PAIR16(4) }
   RRT_PAIR16(2)
 #undef RRT_PAIR16
+}
+
+// The projection as a phase of the pair launch: where the launch has at least two rounds of items (a slab then runs a whole
+// item behind the blocks it waits for) and every item a slab waits for has a LOWER block index (whole groups of 8 pairs:
+// a pair's items span 8 * heads consecutive indices, lag >= that).
+bool rmsa_pair16_proj_supported(int n_regions, int P, int D, int heads, int epeg_k) {
+  static const bool off = rrt_tune_env("RRT_NO_PAIR16_PROJ") != nullptr;
+  if (off || !rmsa_pair16_supported(n_regions, P, D, heads, epeg_k)) return false;
+  const bool mt6 = P > 64 && P <= 96, mt8 = P > 112 && P <= 128;
+  if (!(mt6 || mt8) || (n_regions & 15) != 0 || D % 64 != 0) return false;
+  const int n_items = (n_regions / 2) * heads, lag = pair_proj_lag(n_items);
+  return n_items >= 2 * lag && lag >= 8 * heads && (long)n_regions * P * D * 2 < 4000000000L;
+}
+
+hipError_t launch_rmsa_pair16_proj(const uint16_t* U, const uint16_t* W, const float* bqkv, const float* pe_w, uint16_t* O,
+                                   int n_regions, int P, int D, int heads, int epeg_k, int prec, const PairProj& proj,
+                                   hipStream_t st) {
+  if ((prec != 1 && prec != 2) || !rmsa_pair16_proj_supported(n_regions, P, D, heads, pe_w ? epeg_k : 0)) return hipErrorInvalidValue;
+  if (proj.Wp == nullptr || proj.resid == nullptr || proj.out == nullptr || proj.cnt == nullptr) return hipErrorInvalidValue;
+  PairProj pj = proj;
+  pj.n_items = (n_regions / 2) * heads;
+  if (pj.lag <= 0) pj.lag = pair_proj_lag(pj.n_items);
+  if (pj.lag < 8 * heads || pj.lag > pj.n_items || (pj.lag & 7)) return hipErrorInvalidValue;
+  if (pj.wait_for <= 0) pj.wait_for = heads;
+  if (pj.spin_limit <= 0) pj.spin_limit = 1 << 22;
+  if (pj.err == nullptr) pj.err = handover_err_device();
+  if (P > 112)
+    return prec == 1 ? launch_pair_proj<8, 1>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, pj, st)
+                     : launch_pair_proj<8, 2>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, pj, st);
+  return prec == 1 ? launch_pair_proj<6, 1>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, pj, st)
+                   : launch_pair_proj<6, 2>(U, W, bqkv, pe_w, O, n_regions, P, D, heads, epeg_k, pj, st);
 }

@@ -270,11 +270,17 @@ class RRTMIL(nn.Module):
         self.__dict__.setdefault("_ws", None)
 
     # ------------------------------------------------------------------ the one-call HIP path
-    def _mil_desc(self, input_dim):
+    def _mil_desc(self, input_dim, solo=False):
         enc = self.online_encoder
         d = _lib.MilDesc()
         C.memmove(C.byref(d.enc), C.byref(enc._desc), C.sizeof(_lib.EncoderDesc))
         d.enc.compute = enc._compute_mode()
+        # per-call scheduling hint, never inherited from whatever the encoder's last call left in its descriptor
+        # (rrt_encoder_desc.solo also picks between bit-different CR-MSA fronts: a classifier's logits must not depend on call
+        # history).  The classifier keeps 0 -- the kernels that are right with several slides in flight -- for forward_bag and
+        # forward_bags alike, so that a slide's bits are the same alone and in a batch (test_rrtmil_forward_bags); what solo = 1
+        # buys one fp32 slide on its own is ~1 us of ~270
+        d.enc.solo = int(bool(solo))
         d.input_dim = input_dim
         d.emb_act = _lib.ACT_BY_NAME.get(self._act_name, _lib.ACT_NONE)
         d.n_classes = self.predictor.out_features
@@ -354,8 +360,9 @@ class RRTMIL(nn.Module):
                 st.synchronize()      # host wait: nothing is parked on the caller's stream
         return outs
 
-    def forward_bag(self, x2d, return_attn=False, no_norm=False):
-        """One bag: x2d (N, input_dim) fp32 (or bf16 / fp16) device tensor -> logits (n_classes,) [, attention (N,)]."""
+    def forward_bag(self, x2d, return_attn=False, no_norm=False, solo=False):
+        """One bag: x2d (N, input_dim) fp32 (or bf16 / fp16) device tensor -> logits (n_classes,) [, attention (N,)].
+        ``solo``: rrt_encoder_desc.solo of this call (see _mil_desc; False everywhere by default)."""
         lib = _lib.load()
         if not x2d.is_cuda:
             raise _lib.RRTHipError("rrt_mil_amd.RRTMIL runs on MI355X only: move the bag to a 'cuda' (HIP) "
@@ -366,7 +373,7 @@ class RRTMIL(nn.Module):
         n, in_dim = x2d.shape
         if in_dim != self.patch_to_emb[0].in_features:
             raise ValueError(f"expected feature dim {self.patch_to_emb[0].in_features}, got {in_dim}")
-        d = self._mil_desc(in_dim)
+        d = self._mil_desc(in_dim, solo=solo)
         if x2d.dtype in (torch.bfloat16, torch.float16):
             # 16-bit features (rrt_mil_amd.BagFeeder(dtype=...): half the PCIe bytes of a slide).  When they are of the
             # arithmetic's own type they ARE patch_to_emb's 16-bit operand -- under autocast the reference's first op rounds
