@@ -1098,6 +1098,7 @@ def main():
             rec.update(extras(wl, dev))
             for c in (0, 2, 3, 4):
                 rec[f"config{c}"] = config_record(c)
+            rec["fresh_inputs"] = fresh_inputs_record()
         if not args.stub_cpu and world == 1 and not args.no_cpu_baseline:
             n_cpu = cfg["n"] or 9000          # config 4: the typical bag of the mix
             rec["cpu_baseline"] = cpu_baseline(n_cpu, enc_cfg)
@@ -1294,6 +1295,37 @@ def config_record(c):
     rec["command"] = "bench.py " + " ".join(cmd[2:])
     rec["wall_s"] = round(time.perf_counter() - t0, 1)
     return rec
+
+
+def fresh_inputs_record():
+    """Review item 5 (round 5): the same lines with FRESH inputs -- every step's bags taken from >= 512 MB of distinct
+    device-resident bags (twice the 256 MiB Infinity Cache) and written to as many distinct outputs, so that neither a bag
+    nor its output is cache-resident when its forward starts (the reference moves one new bag per iteration, main.py:434).
+    One child process per line; the cycled-input value of the same child command stands beside it."""
+    import subprocess
+    out = {"note": "bench.py --fresh-inputs: >= 512 MB of distinct inputs in rotation (config 2: distinct 1024-wide feature bags), "
+                   "one distinct output per bag; `cycled` = the same command without the flag (4 bags / 2 at N = 30000 reused: "
+                   "MALL-resident).  The HBM-bound stage fractions of `roofline_kernels` refer to the cycled inputs of the one-bag-"
+                   "in-flight pass (DESIGN.md section 5)"}
+    for key, args, steps in (("config1_f32", ["--config", "1", "--dtype", "f32"], 6), ("config1_bf16", ["--config", "1", "--dtype", "bf16"], 8),
+                             ("config2", ["--config", "2"], 40), ("config3", ["--config", "3"], 8), ("config4", ["--config", "4"], 8)):
+        row = {}
+        if key == "config4":      # its one batch IS 64 distinct bags (1.2 GB of inputs, as many outputs): fresh by construction
+            row["distinct"] = "the batch's 64 bags of 3 k .. 15 k tokens: 1.2 GB of distinct inputs per step"
+        for name, extra in ((("fresh", []),) if key == "config4" else (("fresh", ["--fresh-inputs"]), ("cycled", []))):
+            cmd = [sys.executable, os.path.abspath(__file__)] + args + ["--steps", str(steps), "--warmup", "3", "--no-extras",
+                                                                      "--no-cpu-baseline"] + extra
+            try:
+                r = json.loads(subprocess.run(cmd, capture_output=True, text=True, timeout=240).stdout.strip().splitlines()[-1])
+                row[name] = r["value"]
+                if name == "fresh":
+                    row["distinct"] = r["config"].get("fresh_inputs")
+            except Exception as e:
+                row[name] = f"{type(e).__name__}: {e}"[:200]
+        if isinstance(row.get("fresh"), float) and isinstance(row.get("cycled"), float):
+            row["fresh_over_cycled"] = round(row["fresh"] / row["cycled"], 4)
+        out[key] = row
+    return out
 
 
 def extras(wl, dev):

@@ -7,6 +7,7 @@ end and ~1e-5 relative per stage; see DESIGN.md for the error budget.
 """
 import contextlib
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1649,6 +1650,22 @@ def test_rmsa_pair16_proj_refuses_small_bags():
     z = torch.zeros(16, device=DEV)
     rc = lib.rrt_rmsa_pair16_proj(p(z), p(z), None, None, p(z), None, p(z), p(z), p(z), p(z), 512, 8, 15, C.byref(g), 1, stream())
     assert rc == -2
+
+
+@pytest.mark.parametrize("dtype,mix", [("bf16", "0"), ("bf16", "1"), ("f32", "0")])
+def test_soak_bags_in_flight_short(dtype, mix):
+    """Round 6 (review item 6): a SHORT soak in the suite -- tools/soak_merged.py in its own process (its own stream -> hardware
+    queue map), four bags of different sizes in flight on four streams, 30 rounds x 16 forwards, every output bit for bit
+    against the solo result of its (stream, size).  mix = 1: stream 0 runs exact-fp32 one-bag-in-flight forwards
+    (crmsa_combine_parts_kernel) beside the 16-bit bags -- the setting in which compiler-formed packed fp32 instructions
+    mis-summed: with the build's packed-fp32 census this is the run-time half of that guard."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOAK_DTYPE=dtype, SOAK_MIX=mix, GPU_MAX_HW_QUEUES="16")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_merged.py"), "30", "4"], capture_output=True, text=True,
+                         env=env, timeout=300)
+    assert out.returncode == 0 and " 0 differ" in out.stdout, (out.stdout[-400:], out.stderr[-400:])
 
 
 def _fused16_ref(u, w, b, pe_w, R, P, D, heads, ek, dt, pair=False):
