@@ -312,6 +312,10 @@ static int ffn_apply(const rrt_encoder_desc* desc, const rrt_attn_weights& lw, c
 // time and save ~6 us of the latency-bound CR-MSA front -- one bag in flight 0.2238 -> 0.2218 ms, but with four bags in
 // flight the tail hides behind other bags' tails anyway and the matrix pipe is the scarce thing: 5.26 k against 5.31 k
 // slides/s (round 5, same box); likewise k > 4 representatives (twice the record) stay with the region kernels
+// smallest CR-MSA region (tokens) that takes crmsa_stream4_kernel instead of crmsa_region4_kernel (A/B builds: -DRRT_STREAM4_MIN_P=16)
+#ifndef RRT_STREAM4_MIN_P
+#define RRT_STREAM4_MIN_P 145
+#endif
 static bool crmsa_parts_wanted(const rrt_encoder_desc& d, const Workspace& ws, const GridDev& g8, bool stops_before_crmsa) {
   return d.solo != 0 && d.cr_msa && !d.crmsa_mlp && !d.ffn && d.crmsa_k <= 4 && !stops_before_crmsa && ws.cr_pstat != nullptr &&
          crmsa_combine_parts_supported(d.dim, d.crmsa_k, g8);
@@ -319,7 +323,11 @@ static bool crmsa_parts_wanted(const rrt_encoder_desc& d, const Workspace& ws, c
 
 static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_weights* w, const float* x,
                            float* y, int64_t n_tokens, void* workspace, size_t workspace_bytes,
-                           void* stream, void** events, rrt_phase_gate* gate = nullptr, float* rmsa_out = nullptr) {
+                           void* stream, void** events, rrt_phase_gate* gate = nullptr, float* rmsa_out = nullptr,
+                           uint16_t* y16 = nullptr, bool* y16_done = nullptr) {
+  // y16 / y16_done (the slide classifier, 16-bit modes): where the forward's last kernel is CR-MSA's dispatch + LayerNorm it
+  // also leaves the output rows as 16-bit values there and sets the flag
+  if (y16_done) *y16_done = false;
   if (!desc_in || !w || !x || !y || x == y) return RRT_E_INVALID;
   int rc = check_desc(desc_in, n_tokens);
   if (rc) return rc;
@@ -709,7 +717,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     RRT_TRY(launch_crmsa_combine_parts(xin, ws.cr_pstat, cw.norm_w, cw.norm_b, w->phi, ws.wdisp, ws.rep,
                                        inner16 ? ws.rep16 : nullptr, desc->compute, D, k, gd8, st));
     rep16_done = inner16;
-  } else if (ws.cr_cnt && desc->n_rmsa_layers > 0 && crmsa_region4_supported(D, k, gd8) && gd8.P <= 144) {
+  } else if (ws.cr_cnt && desc->n_rmsa_layers > 0 && crmsa_region4_supported(D, k, gd8) && gd8.P < RRT_STREAM4_MIN_P) {
     // logits + combine in one pass over x1: four blocks per region, the last to arrive merges (crmsa_region4_kernel).
     // Its counters were zeroed by this forward's last R-MSA out-projection.  Regions of more than 144 tokens (8 / 16
     // blocks per region: the kernel covers them, tests) stay with the two chip-wide kernels: measured on MI355X
@@ -721,7 +729,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
   } else if (crmsa_region_enabled() && crmsa_region_supported(D, k, gd8)) {
     // logits + combine in one pass over x1 (one block of 16 waves per region, the rows stay in registers)
     RRT_TRY(launch_crmsa_region(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, nullptr, ws.wdisp, ws.rep, k, gd8, st));
-  } else if (ws.cr_cnt && desc->n_rmsa_layers > 0 && gd8.P > 144 && crmsa_stream4_supported(D, k, gd8)) {
+  } else if (ws.cr_cnt && desc->n_rmsa_layers > 0 && gd8.P >= RRT_STREAM4_MIN_P && crmsa_stream4_supported(D, k, gd8)) {
     // round 6: regions of more than 144 tokens in ONE pass over x1 as well -- four blocks per region that stream their rows
     // with an online softmax per wave, crmsa_region4's records and merge (crmsa_stream4_kernel); counters as above
     RRT_TRY(launch_crmsa_stream4(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, ws.logits, ws.wdisp, ws.rep,
@@ -768,8 +776,10 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     RRT_MARK(RRT_EV_END);
     return RRT_OK;
   }
+  const bool want16 = y16 != nullptr && (desc->compute == RRT_COMPUTE_BF16 || desc->compute == RRT_COMPUTE_F16) && D % 4 == 0;
   RRT_TRY(launch_crmsa_dispatch_ln(xin, x0, ws.wdisp, ws.rep2, w->norm_w, w->norm_b, y, D, k,
-                                   gd8, st));
+                                   gd8, st, want16 ? y16 : nullptr, want16 ? desc->compute : 0));
+  if (want16 && y16_done) *y16_done = true;
   RRT_MARK(RRT_EV_END);
 #undef RRT_TRY
 #undef RRT_MARK
@@ -1326,20 +1336,28 @@ int check_pool(int64_t N, int dim, int hidden, int act, int n_classes) {
 int pool_predict(const float* y, const float* a_w, const float* a_b, const float* b_w, const float* b_b,
                  const float* c_w, const float* c_b, const float* pred_w, const float* pred_b, float* pooled,
                  float* logits, float* attn, int no_norm, int64_t N, int dim, int hidden, int act,
-                 int n_classes, int compute, const PoolWs& ws, hipStream_t st) {
+                 int n_classes, int compute, const PoolWs& ws, hipStream_t st, const uint16_t* y16 = nullptr,
+                 const uint16_t* a_w16 = nullptr, const uint16_t* b_w16 = nullptr) {
   hipError_t e;
   LinearEpilogue ep{};
   ep.prec = compute;
   ep.bias = a_b;
   ep.act = act;
-  // (round 5: the same 16-bit-operand route as patch_to_emb's -- rows cast once, GEMM on 16-bit images -- was measured here
-  // and lost: configs[2] 10.55-10.60 k against 10.71-10.80 k slides/s; the cast's 28 MB cost more than the narrow GEMM saved)
-  e = launch_linear(y, a_w, ws.hid_a, (int)N, hidden, dim, ep, st);
+  // (round 5: the 16-bit-operand route as patch_to_emb's -- rows cast once by a launch of their own, GEMM on 16-bit images --
+  // was measured here and lost: configs[2] 10.55-10.60 k against 10.71-10.80 k slides/s; the cast's 28 MB cost more than the
+  // narrow GEMM saved.  Round 6: the encoder's last kernel leaves the rows in 16 bits as a by-product (y16: 9 MB more written,
+  // no launch, no second read of y) and the weights ride in the classifier's one cast launch: the fp32-operand product --
+  // 23 us for 1.2 GFLOP: 142 blocks on 256 CUs, twice the bytes through the LDS-DMA path -- becomes a 16-bit-operand one)
+  const bool p16 = y16 != nullptr && a_w16 != nullptr && (!b_w || b_w16 != nullptr) && dim % 64 == 0 &&
+                   (compute == RRT_COMPUTE_BF16 || compute == RRT_COMPUTE_F16);
+  e = p16 ? launch_linear16(y16, a_w16, ws.hid_a, (int)N, hidden, dim, ep, st)
+          : launch_linear(y, a_w, ws.hid_a, (int)N, hidden, dim, ep, st);
   if (e != hipSuccess) return (int)e;
   if (b_w) {
     ep.bias = b_b;
     ep.act = RRT_ACT_SIGMOID;
-    e = launch_linear(y, b_w, ws.hid_b, (int)N, hidden, dim, ep, st);
+    e = p16 ? launch_linear16(y16, b_w16, ws.hid_b, (int)N, hidden, dim, ep, st)
+            : launch_linear(y, b_w, ws.hid_b, (int)N, hidden, dim, ep, st);
     if (e != hipSuccess) return (int)e;
   }
   e = launch_pool_partial(y, ws.hid_a, b_w ? ws.hid_b : nullptr, c_w, c_b, ws.a_raw, ws.part, (int)N, dim,
@@ -1456,7 +1474,9 @@ int rrt_mil_workspace_size(const rrt_mil_desc* desc, int64_t n_tokens, size_t* b
   // in every mode, so that a workspace sized once serves a module that switches modes)
   *bytes = 2 * act + align_up(enc, 256) +
            align_up(carve_pool(n_tokens, desc->enc.dim, desc->pool_hidden, desc->pool_gated, nullptr).bytes, 256) +
-           align_up((size_t)n_tokens * desc->input_dim * 2, 256) + align_up((size_t)desc->enc.dim * desc->input_dim * 2, 256);
+           align_up((size_t)n_tokens * desc->input_dim * 2, 256) + align_up((size_t)desc->enc.dim * desc->input_dim * 2, 256) +
+           // (round 6) the encoder's output rows in 16 bits + the pooling Linears' 16-bit weight images
+           align_up((size_t)n_tokens * desc->enc.dim * 2, 256) + 2 * align_up((size_t)desc->pool_hidden * desc->enc.dim * 2, 256);
   return RRT_OK;
 }
 
@@ -1494,6 +1514,9 @@ int rrt_mil_forward_f32(const rrt_mil_desc* desc, const rrt_mil_weights* w, cons
   // but after staging them in LDS as fp32: twice the DMA bytes through a path that is issue-bound (41 us at
   // N = 9000 x 1024 against ~10 + ~13 here).
   static const bool no_fc16 = rrt_tune_env("RRT_NO_FC16") != nullptr;
+  static const bool no_pool16 = rrt_tune_env("RRT_NO_POOL16") != nullptr;
+  uint16_t *y16 = nullptr, *pa16 = nullptr, *pb16 = nullptr;
+  bool pool16 = false, y16_done = false;
   hipError_t e;
   if (desc->input16 != 0 && (desc->input16 != gemm_prec || (gemm_prec != RRT_COMPUTE_BF16 && gemm_prec != RRT_COMPUTE_F16) ||
                              desc->input_dim % 64 != 0 || no_fc16))
@@ -1502,6 +1525,9 @@ int rrt_mil_forward_f32(const rrt_mil_desc* desc, const rrt_mil_weights* w, cons
     char* tail = enc_ws + align_up(enc_bytes, 256) + align_up(pws.bytes, 256);
     uint16_t* x16 = (uint16_t*)tail;
     uint16_t* w16 = (uint16_t*)(tail + align_up((size_t)n_tokens * desc->input_dim * 2, 256));
+    y16 = (uint16_t*)((char*)w16 + align_up((size_t)D * desc->input_dim * 2, 256));
+    pa16 = (uint16_t*)((char*)y16 + align_up((size_t)n_tokens * D * 2, 256));
+    pb16 = (uint16_t*)((char*)pa16 + align_up((size_t)desc->pool_hidden * D * 2, 256));
     Cast16Jobs cj{};
     if (desc->input16) {                 // the caller's features ARE the 16-bit operand: only the weight is cast
       x16 = (uint16_t*)x;
@@ -1512,6 +1538,14 @@ int rrt_mil_forward_f32(const rrt_mil_desc* desc, const rrt_mil_weights* w, cons
       cj.src[1] = w->emb_w; cj.dst[1] = w16; cj.n4[1] = (size_t)D * desc->input_dim / 4;
       cj.count = 2;
     }
+    // the pooling Linears' weights in the same launch (their 16-bit-operand product reads the encoder's y16, below)
+    pool16 = !no_pool16 && D % 64 == 0 && ((size_t)desc->pool_hidden * D) % 4 == 0 && cj.count + 2 <= CAST16_MAX_JOBS;
+    if (pool16) {
+      cj.src[cj.count] = w->pool_a_w; cj.dst[cj.count] = pa16; cj.n4[cj.count++] = (size_t)desc->pool_hidden * D / 4;
+      if (desc->pool_gated) {
+        cj.src[cj.count] = w->pool_b_w; cj.dst[cj.count] = pb16; cj.n4[cj.count++] = (size_t)desc->pool_hidden * D / 4;
+      }
+    }
     e = launch_cast16(cj, gemm_prec, st);
     if (e != hipSuccess) return (int)e;
     e = launch_linear16(x16, w16, emb, (int)n_tokens, D, desc->input_dim, ep, st);
@@ -1519,11 +1553,14 @@ int rrt_mil_forward_f32(const rrt_mil_desc* desc, const rrt_mil_weights* w, cons
     e = launch_linear(x, w->emb_w, emb, (int)n_tokens, D, desc->input_dim, ep, st);
   }
   if (e != hipSuccess) return (int)e;
-  rc = rrt_encoder_forward_f32(&desc->enc, &w->enc, emb, y, n_tokens, enc_ws, enc_bytes, stream);
+  rc = encoder_forward(&desc->enc, &w->enc, emb, y, n_tokens, enc_ws, enc_bytes, stream, nullptr, nullptr, nullptr,
+                       pool16 ? y16 : nullptr, &y16_done);
   if (rc) return rc;
+  const bool p16 = pool16 && y16_done;
   return pool_predict(y, w->pool_a_w, w->pool_a_b, desc->pool_gated ? w->pool_b_w : nullptr, w->pool_b_b,
                       w->pool_c_w, w->pool_c_b, w->pred_w, w->pred_b, nullptr, logits, attn, no_norm, n_tokens,
-                      D, desc->pool_hidden, desc->pool_act, desc->n_classes, gemm_prec, pws, st);
+                      D, desc->pool_hidden, desc->pool_act, desc->n_classes, gemm_prec, pws, st, p16 ? y16 : nullptr,
+                      p16 ? pa16 : nullptr, (p16 && desc->pool_gated) ? pb16 : nullptr);
 }
 
 }  // extern "C"

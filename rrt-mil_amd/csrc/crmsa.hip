@@ -1834,7 +1834,10 @@ template <int NV, bool CRMSA, bool FULL, int KB = 0>   // FULL: dim == NV * 256,
 __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
     const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ wdisp,
     const float* __restrict__ rep2, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ y, int L, int dim, int k, GridDev g) {
+    const float* __restrict__ beta, float* __restrict__ y, int L, int dim, int k, GridDev g,
+    uint16_t* __restrict__ y16, int prec16) {
+  // y16 (round 6, may be null): the output rows once more as 16-bit values (prec16 = 1 bf16 / 2 fp16) -- the A operand of the
+  // slide classifier's pooling-score Linear under autocast (modules/datten.py:28-38), which then needs no fp32-operand GEMM
   constexpr int RW = RW_DISPATCH;
   const int lane = threadIdx.x & 63;
   const int t0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * RW);   // wave-uniform: scalar index math
@@ -1981,6 +1984,8 @@ __global__ __launch_bounds__(256) void crmsa_dispatch_ln_kernel(
           o.z = (r[i][v].z - mean[i]) * rstd[i] * gm.z + bt.z;
           o.w = (r[i][v].w - mean[i]) * rstd[i] * gm.w + bt.w;
           st_row<NT_DISPATCH>(y + (size_t)(t0 + i) * dim + c, o);
+          if (y16 != nullptr)
+            *(uint2*)(y16 + (size_t)(t0 + i) * dim + c) = prec16 == 2 ? r4_pack4<2>(o) : r4_pack4<1>(o);
         }
     }
   }
@@ -2020,21 +2025,21 @@ constexpr bool DISPATCH_KB5 = true;
 template <bool CRMSA>
 hipError_t launch_dispatch(const float* x1, const float* x0, const float* wdisp,
                            const float* rep2, const float* gamma, const float* beta, float* y, int L,
-                           int dim, int k, const GridDev& g, hipStream_t st) {
+                           int dim, int k, const GridDev& g, hipStream_t st, uint16_t* y16 = nullptr, int prec16 = 0) {
   dim3 grid((L + 4 * RW_DISPATCH - 1) / (4 * RW_DISPATCH)), block(256);
 #define RRT_DISPATCH(NV)                                                                                         \
   do {                                                                                                           \
     if (RRT_ALLOW_FULL && dim == NV * 256) {                                                                     \
       if (NV <= 2 && CRMSA && k <= 3)                                                                            \
-        crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 3 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
+        crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 3 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g, y16, prec16); \
       else if (NV <= 2 && CRMSA && DISPATCH_KB5 && k <= 5) /* (configs[4]: crmsa_k = 5 -- five rows fetched, not eight) */  \
-        crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 5 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
+        crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 5 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g, y16, prec16); \
       else if (NV <= 2 && CRMSA)                                                                                 \
-        crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 8 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
+        crmsa_dispatch_ln_kernel<NV, CRMSA, true, (NV <= 2 ? 8 : 0)><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g, y16, prec16); \
       else                                                                                                       \
-        crmsa_dispatch_ln_kernel<NV, CRMSA, true><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g);  \
+        crmsa_dispatch_ln_kernel<NV, CRMSA, true><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g, y16, prec16);  \
     } else                                                                                                       \
-      crmsa_dispatch_ln_kernel<NV, CRMSA, false><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g); \
+      crmsa_dispatch_ln_kernel<NV, CRMSA, false><<<grid, block, 0, st>>>(x1, x0, wdisp, rep2, gamma, beta, y, L, dim, k, g, y16, prec16); \
   } while (0)
   if (dim <= 256) RRT_DISPATCH(1);
   else if (dim <= 512) RRT_DISPATCH(2);
@@ -2263,8 +2268,9 @@ hipError_t launch_crmsa_mlp_logits(const float* hid, const float* w2, float* log
 hipError_t launch_crmsa_dispatch_ln(const float* x1, const float* x0, const float* wdisp,
                                     const float* rep2, const float* gamma,
                                     const float* beta, float* y, int dim, int k, const GridDev& g8,
-                                    hipStream_t st) {
-  return launch_dispatch<true>(x1, x0, wdisp, rep2, gamma, beta, y, g8.L, dim, k, g8, st);
+                                    hipStream_t st, uint16_t* y16, int prec16) {
+  if (y16 != nullptr && (gamma == nullptr || (prec16 != 1 && prec16 != 2) || dim % 4 != 0)) return hipErrorInvalidValue;
+  return launch_dispatch<true>(x1, x0, wdisp, rep2, gamma, beta, y, g8.L, dim, k, g8, st, y16, prec16);
 }
 
 hipError_t launch_layernorm(const float* x1, const float* x0, const float* gamma,

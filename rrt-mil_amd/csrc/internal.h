@@ -215,7 +215,7 @@ hipError_t launch_crmsa_mlp_logits(const float* hid, const float* w2, float* log
 hipError_t launch_crmsa_dispatch_ln(const float* x1, const float* x0, const float* wdisp,
                                     const float* rep2, const float* gamma,
                                     const float* beta, float* y, int dim, int k, const GridDev& g8,
-                                    hipStream_t st);
+                                    hipStream_t st, uint16_t* y16 = nullptr, int prec16 = 0);   // y16: the rows also in 16 bits
 hipError_t launch_layernorm(const float* x1, const float* x0, const float* gamma,
                             const float* beta, float* y, int L, int dim, hipStream_t st);
 
