@@ -72,11 +72,11 @@ PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB
 FRESH_BYTES = 512 << 20                        # --fresh-inputs: distinct input bytes in rotation (2 x the 256 MiB Infinity Cache)
 def _newest(stem):
     """profiles/rNN_<stem> of the latest round that has one (the files are written by tools/, never typed in)"""
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_{stem}")
         if os.path.exists(f):
             return f
-    return os.path.join(ROOT, "profiles", f"r05_{stem}")
+    return os.path.join(ROOT, "profiles", f"r06_{stem}")
 
 
 TRAFFIC_FILE = _newest("traffic.json")             # tools/pmc_to_traffic.py, from the PMC passes
@@ -1098,7 +1098,7 @@ def main():
             rec.update(extras(wl, dev))
             for c in (0, 2, 3, 4):
                 rec[f"config{c}"] = config_record(c)
-            rec["fresh_inputs"] = fresh_inputs_record()
+            rec["fresh_inputs"] = fresh_inputs_record(rec)
         if not args.stub_cpu and world == 1 and not args.no_cpu_baseline:
             n_cpu = cfg["n"] or 9000          # config 4: the typical bag of the mix
             rec["cpu_baseline"] = cpu_baseline(n_cpu, enc_cfg)
@@ -1297,31 +1297,30 @@ def config_record(c):
     return rec
 
 
-def fresh_inputs_record():
+def fresh_inputs_record(rec):
     """Review item 5 (round 5): the same lines with FRESH inputs -- every step's bags taken from >= 512 MB of distinct
     device-resident bags (twice the 256 MiB Infinity Cache) and written to as many distinct outputs, so that neither a bag
     nor its output is cache-resident when its forward starts (the reference moves one new bag per iteration, main.py:434).
-    One child process per line; the cycled-input value of the same child command stands beside it."""
+    One child process per line; `cycled` = the value of this run's own record of the same configuration (4 bags, 2 at
+    N = 30000, reused: MALL-resident)."""
     import subprocess
     out = {"note": "bench.py --fresh-inputs: >= 512 MB of distinct inputs in rotation (config 2: distinct 1024-wide feature bags), "
-                   "one distinct output per bag; `cycled` = the same command without the flag (4 bags / 2 at N = 30000 reused: "
-                   "MALL-resident).  The HBM-bound stage fractions of `roofline_kernels` refer to the cycled inputs of the one-bag-"
-                   "in-flight pass (DESIGN.md section 5)"}
+                   "one distinct output per bag; `cycled` = this run's record of the same configuration.  config 4's one batch IS "
+                   "64 distinct bags (1.2 GB of inputs per step): fresh by construction, no second line.  The HBM-bound stage "
+                   "fractions of `roofline_kernels` refer to the cycled inputs of the one-bag-in-flight pass (DESIGN.md section 5)"}
+    cyc = {"config1_f32": rec.get("value"), "config1_bf16": (rec.get("amp_bf16") or {}).get("value"),
+           "config2": (rec.get("config2") or {}).get("value"), "config3": (rec.get("config3") or {}).get("value")}
     for key, args, steps in (("config1_f32", ["--config", "1", "--dtype", "f32"], 6), ("config1_bf16", ["--config", "1", "--dtype", "bf16"], 8),
-                             ("config2", ["--config", "2"], 40), ("config3", ["--config", "3"], 8), ("config4", ["--config", "4"], 8)):
-        row = {}
-        if key == "config4":      # its one batch IS 64 distinct bags (1.2 GB of inputs, as many outputs): fresh by construction
-            row["distinct"] = "the batch's 64 bags of 3 k .. 15 k tokens: 1.2 GB of distinct inputs per step"
-        for name, extra in ((("fresh", []),) if key == "config4" else (("fresh", ["--fresh-inputs"]), ("cycled", []))):
-            cmd = [sys.executable, os.path.abspath(__file__)] + args + ["--steps", str(steps), "--warmup", "3", "--no-extras",
-                                                                      "--no-cpu-baseline"] + extra
-            try:
-                r = json.loads(subprocess.run(cmd, capture_output=True, text=True, timeout=240).stdout.strip().splitlines()[-1])
-                row[name] = r["value"]
-                if name == "fresh":
-                    row["distinct"] = r["config"].get("fresh_inputs")
-            except Exception as e:
-                row[name] = f"{type(e).__name__}: {e}"[:200]
+                             ("config2", ["--config", "2"], 40), ("config3", ["--config", "3"], 8)):
+        row = {"cycled": cyc.get(key)}
+        cmd = [sys.executable, os.path.abspath(__file__)] + args + ["--steps", str(steps), "--warmup", "3", "--no-extras",
+                                                                  "--no-cpu-baseline", "--fresh-inputs"]
+        try:
+            r = json.loads(subprocess.run(cmd, capture_output=True, text=True, timeout=240).stdout.strip().splitlines()[-1])
+            row["fresh"] = r["value"]
+            row["distinct"] = r["config"].get("fresh_inputs")
+        except Exception as e:
+            row["fresh"] = f"{type(e).__name__}: {e}"[:200]
         if isinstance(row.get("fresh"), float) and isinstance(row.get("cycled"), float):
             row["fresh_over_cycled"] = round(row["fresh"] / row["cycled"], 4)
         out[key] = row

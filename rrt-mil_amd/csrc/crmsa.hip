@@ -2155,6 +2155,10 @@ hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float
   if (g8.P > 144) { RRT_R4(8, 12, 3); }
   if (cfg == 8 && g8.P > 96 && k <= 3)
     return launch_region4_cfg<8, 4, 5, 3>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, part_g, counters, k, g8, st);
+  // (round 6) k = 4, 5 (BASELINE configs[4]: crmsa_k = 5) at the four-block shape: registers and loops for five representatives,
+  // not eight (the records are smaller than the scratch's eight-representative ones: the layout is the kernel's own)
+  if (g8.P <= 144 && cfg == 4 && k > 3 && k <= 5)
+    return launch_region4_cfg<4, 12, 3, 5>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, part_g, counters, k, g8, st);
   RRT_R4(4, 12, 3);
 #undef RRT_R4
 }

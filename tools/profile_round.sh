@@ -3,10 +3,10 @@
 # + PMC passes (separate --pmc runs with --kernel-trace only, each under its own timeout) -> profiles-ready files.
 # Run on the GPU box from the repo root:
 #     tools/profile_round.sh <tag>        -> gpurun_out/<tag>_*.{txt,json} and gpurun_out/<tag>_traffic.json
-# Order: the PMC passes first (they produce <tag>_traffic.json, which bench.py reads as profiles/r05_traffic.json when it
+# Order: the PMC passes first (they produce <tag>_traffic.json, which bench.py reads as profiles/<round>_traffic.json (round = the tag up to its first "_") when it
 # is copied there BEFORE the bench lines are taken -- the script does that copy on the box so one call gives a consistent set).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06_final}
 R=$PWD
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -24,7 +24,7 @@ for spec in "c1_f32:--config 1 --dtype f32" "c1_bf16:--config 1 --dtype bf16" "c
     python $R/tools/pmc_to_traffic.py $key /tmp/pmc_${key}_FETCH_SIZE/p_results.db /tmp/pmc_${key}_WRITE_SIZE/p_results.db $OUT/${TAG}_traffic.json "bench.py $args --streams 1 --steps 5 --warmup 2"
   fi
 done
-cp $OUT/${TAG}_traffic.json $R/profiles/r05_traffic.json 2>/dev/null
+cp $OUT/${TAG}_traffic.json $R/profiles/${TAG%%_*}_traffic.json 2>/dev/null
 # the dominant kernel's duration in a rocprofv3 kernel trace of the DEFAULT command (bench.py reads it back as roofline.rocprof)
 rm -f $OUT/${TAG}_rocprof_dominant.json
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o a -- python $R/bench.py $X > /tmp/a.log 2>&1
@@ -37,7 +37,7 @@ python $R/tools/rocprof_union.py c1_f32_s2 /tmp/prof_a2/a_results.db $OUT/${TAG}
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_a3 -o a -- python $R/bench.py --dtype bf16 $X > /tmp/a.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_a3/a_results.db > $OUT/${TAG}_bench_bf16_4streams.kernel_stats.txt
 python $R/tools/rocprof_union.py c1_bf16_s4 /tmp/prof_a3/a_results.db $OUT/${TAG}_rocprof_dominant.json 17213423616 2500
-cp $OUT/${TAG}_rocprof_dominant.json $R/profiles/r05_rocprof_dominant.json 2>/dev/null
+cp $OUT/${TAG}_rocprof_dominant.json $R/profiles/${TAG%%_*}_rocprof_dominant.json 2>/dev/null
 for dt in f32 bf16; do
   for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     rm -rf /tmp/pmc_x
@@ -80,5 +80,13 @@ if [ -f $R/tools/_abl/librrt_trace.so ]; then
   RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_pair16.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_pair16_wave_timeline.txt
 fi
 [ -x $R/tools/_abl/dma_rows ] && timeout 120 $R/tools/_abl/dma_rows > $OUT/${TAG}_ubench_dma_rows.txt 2>&1
+[ -x $R/tools/_abl/dma_loaders_mfma ] && timeout 120 $R/tools/_abl/dma_loaders_mfma > $OUT/${TAG}_ubench_dma_loaders_mfma.txt 2>&1
+[ -x $R/tools/_abl/mfma_valu_overlap ] && timeout 120 $R/tools/_abl/mfma_valu_overlap > $OUT/${TAG}_ubench_mfma_valu_overlap.txt 2>&1
+if [ -f $R/tools/_abl/librrt_trace.so ]; then
+  RRT_HIP_LIB=$R/tools/_abl/librrt_trace.so timeout 120 python $R/tools/trace_pair16_proj.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_trace_pair16_proj_wave_timeline.txt
+fi
+bash $R/tools/prof_train.sh $TAG 9000 30 > /dev/null 2>&1
+SWEEP_OUT=$OUT/${TAG}_sweep_n.txt; timeout 300 python $R/tools/sweep_n.py 2>/dev/null | grep -v amdgpu.ids > $SWEEP_OUT
+SWEEP_DTYPE=bf16 timeout 300 python $R/tools/sweep_n.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_sweep_n_bf16.txt
 tail -1 $OUT/${TAG}_bench_default.bench.json | cut -c1-300
 head -14 $OUT/${TAG}_bench_1stream.kernel_stats.txt
