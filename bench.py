@@ -996,7 +996,8 @@ def main():
         wl.dtype = args.dtype or cfg["dtype"]
         wl.compute = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f16": _lib.COMPUTE_F16, "f32x3": _lib.COMPUTE_F32X3}[wl.dtype]
         wl.bags = [torch.from_numpy(synth.bag(wl.n, DIM, tag=f"bench/r{rank}/b{i}")).to(dev) for i in range(4)]
-        print(json.dumps(module_call(wl, dev)), flush=True)
+        var = os.environ.get("RRT_BENCH_MC_VARIANTS")
+        print(json.dumps(module_call(wl, dev, variants=tuple(var.split(",")) if var else ("loop", "default", "async"))), flush=True)
         return
     if args.stub_cpu:
         wl = StubWorkload(args, rank, world, dev)
@@ -1178,35 +1179,43 @@ def h2d_inclusive_c2(dev, n_bags=64, n=9000, in_dim=1024):
                     "modules/rrt.py:208-229, dataloader.py:181,198)"}
 
 
-def module_call(wl, dev, n_bags=64):
+def module_call(wl, dev, n_bags=64, variants=("loop", "default", "async")):
     """The boundary the reference exposes is the nn.Module (modules/rrt.py:133-202), not the C ABI the timed region calls:
     the same bags through `enc(bag)` one at a time (the reference's loop, main.py:466-467; one bag in flight) and through
     `enc.forward_bags(bags, streams=S)` (S in flight), with the host's own time per forward (the Python + ctypes cost of one
     call, measured while the GPU queue is far from full, i.e. not waiting for the device)."""
     import torch
     enc, S = wl.enc, wl.S
+    # the asynchronous caller's stream is created FIRST, before the executor creates the process's bag streams: HIP maps streams to
+    # hardware queues in creation order, and a caller stream created after them (as rounds 5-6 did here) came to share a queue
+    # with a bag stream -- its fork / join waits then serialise that stream's bags (4.5 k fp32 / 12.6 k bf16 where the timed
+    # region, whose caller exists from the workload's construction on, gets 5.27 k / 19.4 k)
+    caller = torch.cuda.Stream(dev)
     bags3 = [b.unsqueeze(0) for b in wl.bags]
     mode_was, solo_was = enc.compute_dtype, enc.__dict__.get("solo", True)
     enc.compute_dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "f32x3": "f32x3"}[wl.dtype]
     out = {"unit": "slides/s", "dtype": wl.dtype, "n_tokens": wl.n}
     with torch.no_grad():
         enc.solo = True
+        y = None
         for i in range(200):                          # (a fresh process: clocks ramp over the first tens of milliseconds)
             y = enc(bags3[i % len(bags3)])
         torch.cuda.synchronize()
         reps = []
-        for _ in range(5):                            # 64 forwards are 14 ms: one host hiccup (round 5 saw 3.7 k among 4.5 k) would be the record
+        n_loop = 5 if "loop" in variants else 0
+        for _ in range(n_loop):                       # 64 forwards are 14 ms: one host hiccup (round 5 saw 3.7 k among 4.5 k) would be the record
             t0 = time.perf_counter()
             for i in range(n_bags):
                 y = enc(bags3[i % len(bags3)])
             host = time.perf_counter() - t0           # enqueue only: n_bags forwards are ~600 packets, the queue does not fill
             torch.cuda.synchronize()
             reps.append((time.perf_counter() - t0, host))
-        reps.sort()
-        t1, host = reps[len(reps) // 2]               # the median repeat
-        out["module_loop"] = round(n_bags / t1, 1)
-        out["module_loop_repeats"] = [round(n_bags / t, 1) for t, _ in reps]
-        out["host_us_per_bag"] = round(host / n_bags * 1e6, 1)
+        if reps:
+            reps.sort()
+            t1, host = reps[len(reps) // 2]           # the median repeat
+            out["module_loop"] = round(n_bags / t1, 1)
+            out["module_loop_repeats"] = [round(n_bags / t, 1) for t, _ in reps]
+            out["host_us_per_bag"] = round(host / n_bags * 1e6, 1)
         n_batch = 4 * n_bags                          # one executor call = one fork / join: the longer the batch, the less it weighs
         batch = [bags3[i % len(bags3)] for i in range(n_batch)]
         outs = [torch.empty_like(b[0]) for b in batch]
@@ -1215,8 +1224,13 @@ def module_call(wl, dev, n_bags=64):
         # slides/s for a first call against 5.0-5.2 k from the second on, tools/bench_bags.py).  Then FIVE calls back to back
         # (rounds 4-5 timed ONE call that started on an idle, down-clocked GPU right after a device sync and read 4-15 % low:
         # 5.06 k fp32 / 16.6 k bf16 where five consecutive calls of the same process give 5.26 k / 19.3 k, profiles/r06_probe1.txt).
-        caller = torch.cuda.Stream(dev)
+        # ONE caller stream per process (round 6, tools/experiments/r06_probe_modcall.py): whichever of the two variants ran second in
+        # one process read 4.5 k fp32 / 12.9 k bf16 -- the executor carries the first share of a call's bags on the CALLER's
+        # stream, so a second caller is a fifth hardware queue in use, and the chip schedules four.
+        # module_call_record therefore measures the two in two child processes.
         for name, ctx in (("forward_bags_default_stream", contextlib.nullcontext()), ("forward_bags", torch.cuda.stream(caller))):
+            if ("default" if name.endswith("default_stream") else "async") not in variants:
+                continue
             with ctx:
                 for _ in range(2):
                     enc.forward_bags(batch, streams=S, outs=outs)
@@ -1231,7 +1245,7 @@ def module_call(wl, dev, n_bags=64):
             out[name + "_host_us_per_bag"] = round(host_b / (5 * n_batch) * 1e6, 1)
         out["forward_bags_streams"] = S
         out["forward_bags_batch"] = n_batch
-        assert torch.isfinite(y).all() and torch.isfinite(outs[-1]).all()
+        assert (y is None or torch.isfinite(y).all()) and torch.isfinite(outs[-1]).all()
     enc.compute_dtype, enc.solo = mode_was, solo_was
     enc._desc.compute = wl.compute
     out["note"] = (f"{n_bags} device-resident bags: `for bag in bags: enc(bag)` under no_grad through nn.Module.__call__ (one bag "
@@ -1252,12 +1266,18 @@ def module_call_record(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--module-call-only", "--no-cpu-baseline"]
     if args.dtype:
         cmd += ["--dtype", args.dtype]
-    try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-        r = json.loads(out.stdout.strip().splitlines()[-1])
-    except Exception as e:                      # the headline line must not die with a side record
-        return {"error": f"{type(e).__name__}: {e}"[:300]}
-    r["command"] = "bench.py " + " ".join(cmd[2:])
+    r = None
+    for var in ("loop,default", "async"):       # one caller stream per process (module_call's note)
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, RRT_BENCH_MC_VARIANTS=var))
+            q = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as e:                  # the headline line must not die with a side record
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+        if r is None:
+            r = q
+        else:
+            r.update({k: v for k, v in q.items() if k.startswith("forward_bags") and not k.startswith("forward_bags_default")})
+    r["command"] = "RRT_BENCH_MC_VARIANTS=loop,default | async  bench.py " + " ".join(cmd[2:])
     return r
 
 
