@@ -388,6 +388,8 @@ class EncoderWorkload:
         from rrt_mil_amd import RRTEncoder, RRTMIL, _lib, synth
         self.torch, self._lib = torch, _lib
         cfg = self.cfg = CONFIGS[args.config]
+        if os.environ.get("RRT_BENCH_N") and cfg["kind"] == "encoder":      # (experiments only: another bag size for the same line)
+            cfg = self.cfg = dict(cfg, n=int(os.environ["RRT_BENCH_N"]))
         self.dev, self.n, self.enc_cfg = dev, cfg["n"], cfg["enc"]
         self.dtype = args.dtype or cfg["dtype"]
         self.compute = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f16": _lib.COMPUTE_F16,

@@ -507,6 +507,7 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
       ep.resid = xin;
       ep.g = gd;
       ep.zero64 = ws.cr_cnt;
+      ep.solo = desc->solo != 0;          // (picks the tile shape: one bag in flight / several, launch_linear16)
       RRT_TRY(launch_linear16(o16, wq16 + (size_t)3 * D * D, xout, gd.Np, D, D, ep, st));
       if (li == 0) RRT_MARK(RRT_EV_PROJ);
       xin = xout;

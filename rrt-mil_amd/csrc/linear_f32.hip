@@ -1321,7 +1321,7 @@ hipError_t launch_linear_split(const void* A, const void* B, float* C, int M, in
 }
 
 // tile shape of the 16-bit-operand GEMMs (launch_linear16)
-static Cfg choose16(int M, int N, int K) {
+static Cfg choose16(int M, int N, int K, bool solo) {
   Cfg best{9, 1, 512};
   {
     // (three 96-row blocks per CU first: at equal cost they keep more of the DMA-issue-bound loop in flight than two
@@ -1351,6 +1351,18 @@ static Cfg choose16(int M, int N, int K) {
     else if (tiles(8, 2) <= 512) best = Cfg{8, 2, 512};
     else if (tiles(9, 2) <= 512) best = Cfg{9, 2, 512};
     else best = Cfg{8, 1, 512};
+    // Round 6: the rule above was swept with ONE bag in flight.  With several (ep.solo == false: the executor with more than
+    // one stream) a bag costs the sum of its chip-wide kernels, and this one is bound by the bytes it
+    // moves through the CUs' LDS-DMA path: 128-column tiles read the A panel four times instead of eight.  Four bags in
+    // flight, bf16 (tools/experiments/r06_probe13.sh, profiles/r06_proj16_tiles_in_flight.txt), slides/s against the rule
+    // above: N = 7000 +2.5 %, 8000 +2.7 %, 9000 +2.5-4 % (96 x 128 tiles, all resident), 10500 +2.5 %; N = 12000 +1.6 %,
+    // 15000 +2.4 %, 30000 +1-2 % (128 x 128 tiles, one per CU); below ~6.5 k rows the small tiles stay.  One bag in flight
+    // the same shapes LOSE 4-8 % (0.0755 -> 0.080-0.083 ms at N = 9000): hence the hint.  The bits do not depend on the
+    // tile shape (a tile's K-sum order is the same in every shape).
+    if (!solo) {
+      if (M > 11500) best = Cfg{8, 2, 256};
+      else if (M > 6600) best = Cfg{6, 2, 512};
+    }
   }
   if (const char* e = K > 512 ? rrt_tune_env("RRT_LINEAR16_CFG_KBIG") : nullptr) {   // tuning hook, K > 512 only: "mt,nt,cap"
     Cfg q{};
@@ -1370,7 +1382,7 @@ hipError_t launch_linear16(const void* A, const void* B, float* C, int M, int N,
                            hipStream_t st) {
   if ((ep.prec != PREC_BF16 && ep.prec != PREC_F16) || K % 64 || ep.drop_on) return hipErrorInvalidValue;
   const bool u = ep.resid != nullptr;
-  const Cfg c = choose16(M, N, K);
+  const Cfg c = choose16(M, N, K, ep.solo);
 #define RRT_MODES16(MT_, NT_, P_)                                                                  \
   (u ? launch_cfg16<MT_, NT_, MODE_UNPART, P_>(A, B, C, M, N, K, c.cap, ep, st)                    \
      : ep.act ? launch_cfg16<MT_, NT_, MODE_ACT, P_>(A, B, C, M, N, K, c.cap, ep, st)              \
@@ -1385,6 +1397,7 @@ hipError_t launch_linear16(const void* A, const void* B, float* C, int M, int N,
   RRT_CASE16(6, 1);
   RRT_CASE16(4, 1);
   RRT_CASE16(2, 1);
+  RRT_CASE16(6, 2);      // (round 6: several bags in flight, 6.6 k .. 11.5 k rows)
 #ifdef RRT_TUNING        // wide tiles for the round-4 sweep (fewer bytes through the CU's memory pipe per output)
   RRT_CASE16(5, 4);
   RRT_CASE16(4, 4);
@@ -1392,7 +1405,6 @@ hipError_t launch_linear16(const void* A, const void* B, float* C, int M, int N,
   RRT_CASE16(8, 4);
   RRT_CASE16(3, 4);
   RRT_CASE16(5, 2);
-  RRT_CASE16(6, 2);
   RRT_CASE16(4, 2);
 #endif
 #undef RRT_CASE16
