@@ -151,7 +151,7 @@ CONFIGS = {
     3: dict(kind="encoder", n=30000, dtype="bf16", enc=dict(mlp_dim=512, epeg_k=15, crmsa_k=3, region_num=16),
             label="BASELINE configs[3]: survival long sequence, RRTEncoder(region_num=16, epeg_k=15, crmsa_k=3).eval() "
                   "forward_bags call per step over device-resident bags N=30000 D=512 owned by each GPU, bf16 autocast-class arithmetic"),
-    4: dict(kind="mix", n=None, dtype="bf16", n_bags=64, enc=dict(mlp_dim=512, epeg_k=21, crmsa_k=5, region_num=8),
+    4: dict(kind="mix", n=None, dtype="bf16", n_bags=64, streams=4, enc=dict(mlp_dim=512, epeg_k=21, crmsa_k=5, region_num=8),
             label="BASELINE configs[4]: TCGA-NSCLC-R50 encoder (epeg_k=21, crmsa_k=5), one batch of 64 device-resident "
                   "bags with N ~ randint(3000, 15001) (seed 2021), split over the ranks by cost (LPT), each rank's share "
                   "through the batch-of-bags executor"),
@@ -981,6 +981,7 @@ def main():
         # each other; four streams = one per hardware pipe
         # bf16: 3 (17.8 k; 4: 17.7 k, 5: 14.4 k); the bf16 classifier of configs[2] (a longer chain per bag): 4 (9.7 k vs 9.1 k)
         # round 5 (profiles/r05_final_streams_sweep.txt): bf16 N = 9000 4 -> 19.05 k (3: 18.9 k); N = 30000 and the configs[4] mix keep 3
+        # round 6 (same box, 2 / 3 / 4 bags in flight): configs[3] 5.90 / 6.02 / 5.97 k -> 3 stays; configs[4] 14.3 / 15.6 / 15.85 k -> 4
         lowp = (args.dtype or cfg["dtype"]) in ("bf16", "f16")
         args.streams = cfg.get("streams") or (3 if lowp and (cfg["n"] is None or cfg["n"] > 12000) else 4)
     if args.module_call_only and not args.stub_cpu and cfg["kind"] == "encoder":

@@ -1145,7 +1145,10 @@ __device__ __forceinline__ float4 ld_agent4(__amdgpu_buffer_rsrc_t rs, const flo
 
 // KM: representatives the instantiation has registers for (k <= KM); KC: how many of them go through the block's
 // LDS reduction at a time (the [waves / 2][KC][512] buffer is 48 KiB at KC = 4)
-template <int NB, int R4_WAVES, int R4_ROWS, int KM_>     // blocks per region, waves per block, rows per wave
+// GPR (round 6; k == KM_ exactly): gamma . phi of the lane's eight columns in registers and the logits in crmsa_logits512's
+// centred form -- no phi table staged through LDS behind a block barrier in front of the first row, no per-element
+// normalisation -- and the rows' wave totals four at a time (wave_sum4), as crmsa_stream4_kernel
+template <int NB, int R4_WAVES, int R4_ROWS, int KM_, bool GPR = false>     // blocks per region, waves per block, rows per wave
 __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const float* __restrict__ x1,
                                                                       const float* __restrict__ gamma,
                                                                       const float* __restrict__ beta,
@@ -1195,11 +1198,40 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   }
   const float4 gm0 = *(const float4*)(gamma + lane * 4), gm1 = *(const float4*)(gamma + 256 + lane * 4);
   const float4 bt0 = *(const float4*)(beta + lane * 4), bt1 = *(const float4*)(beta + 256 + lane * 4);
-  for (int idx = tid; idx < DIM * k; idx += 64 * NW) {      // after the row loads: one memory round trip, not two
-    const int d = idx / k, n = idx - d * k;
-    phi_t[n * DIM + d] = phi[idx];
+  float gp[GPR ? 2 : 1][4][KM], Bn[KM];
+  if constexpr (GPR) {
+    float bsum[KM];
+#pragma unroll
+    for (int n = 0; n < KM; ++n) bsum[n] = 0.f;
+    float4 pq[2][KM];
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int jj = 0; jj < KM; ++jj) pq[v][jj] = *(const float4*)(phi + (size_t)((v * 64 + lane) * 4) * KM + 4 * jj);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const float4 g4 = v ? gm1 : gm0, b4 = v ? bt1 : bt0;
+      const float gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+      float pf[4 * KM];
+#pragma unroll
+      for (int jj = 0; jj < KM; ++jj) { pf[4 * jj] = pq[v][jj].x; pf[4 * jj + 1] = pq[v][jj].y; pf[4 * jj + 2] = pq[v][jj].z; pf[4 * jj + 3] = pq[v][jj].w; }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int n = 0; n < KM; ++n) {
+          gp[v][cc][n] = gm[cc] * pf[cc * KM + n];
+          bsum[n] += bt[cc] * pf[cc * KM + n];
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < KM; ++n) Bn[n] = wave_sum(bsum[n]);
+  } else {
+    for (int idx = tid; idx < DIM * k; idx += 64 * NW) {      // after the row loads: one memory round trip, not two
+      const int d = idx / k, n = idx - d * k;
+      phi_t[n * DIM + d] = phi[idx];
+    }
+    lds_sync();
   }
-  lds_sync();
   RRT_TRACE_MARK();                                 // [2] rows requested, phi in LDS
   const float inv_d = 1.0f / (float)DIM;
   // The wave's NR rows in three straight-line stages -- means, variances, logits -- and the stores behind them: 2 + k
@@ -1207,6 +1239,47 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
   // next the compiler ran the 15 chains of three rows one after the other (round 5, traced: 6.0 K cycles for this phase).
   // Rows past the quarter's end compute on row 0's data and are not stored.
   float mean_[NR], rstd_[NR], lgs[NR][KM];
+  if constexpr (GPR) {
+    static_assert(NR <= 4, "one group of sums");
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, t4[4];
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) sm[j] += (r[j][v].x + r[j][v].y) + (r[j][v].z + r[j][v].w);
+    wave_sum4(sm[0], sm[1], sm[2], sm[3], t4[0], t4[1], t4[2], t4[3]);
+    constexpr int NV = NR * (1 + KM), NG = (NV + 3) / 4;
+    float vals[4 * NG], tot[4 * NG];
+#pragma unroll
+    for (int i = 0; i < 4 * NG; ++i) vals[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const float mean = mean_[j] = t4[j] * inv_d;
+      float sq = 0.f, d[KM];
+#pragma unroll
+      for (int n = 0; n < KM; ++n) d[n] = 0.f;
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const float xc[4] = {r[j][v].x - mean, r[j][v].y - mean, r[j][v].z - mean, r[j][v].w - mean};
+        sq += (xc[0] * xc[0] + xc[1] * xc[1]) + (xc[2] * xc[2] + xc[3] * xc[3]);
+#pragma unroll
+        for (int n = 0; n < KM; ++n)
+          d[n] += (xc[0] * gp[v][0][n] + xc[1] * gp[v][1][n]) + (xc[2] * gp[v][2][n] + xc[3] * gp[v][3][n]);
+      }
+      vals[j * (1 + KM)] = sq;
+#pragma unroll
+      for (int n = 0; n < KM; ++n) vals[j * (1 + KM) + 1 + n] = d[n];
+    }
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq)
+      wave_sum4(vals[4 * gq], vals[4 * gq + 1], vals[4 * gq + 2], vals[4 * gq + 3], tot[4 * gq], tot[4 * gq + 1], tot[4 * gq + 2],
+                tot[4 * gq + 3]);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      rstd_[j] = 1.0f / sqrtf(tot[j * (1 + KM)] * inv_d + LN_EPS);
+#pragma unroll
+      for (int n = 0; n < KM; ++n) lgs[j][n] = rstd_[j] * tot[j * (1 + KM) + 1 + n] + Bn[n];
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     const float4 a = r[j][0], b = r[j][1];
@@ -1240,6 +1313,7 @@ __global__ __launch_bounds__(64 * R4_WAVES) void crmsa_region4_kernel(const floa
       }
     }
   }
+  }   // !GPR
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     const int rq = wave + NW * j, p = q * PQ + rq;
@@ -2121,14 +2195,14 @@ size_t crmsa_region4_scratch_floats(const GridDev& g8, int k) {
   const int nb = g8.P > 288 ? 16 : 8;               // (8 also covers the tuning build's eight-block shape of small regions)
   return (size_t)g8.rs * g8.rs * nb * (k <= 3 ? 3 : R4_KMAX) * (512 + 8);
 }
-template <int NB, int NW, int NR, int KM>
+template <int NB, int NW, int NR, int KM, bool GPR = false>
 static hipError_t launch_region4_cfg(const float* x1, const float* gamma, const float* beta, const float* phi,
                                      float* mean_rstd, float* logits, float* wdisp, float* rep, uint16_t* rep16, int prec16,
                                      float* part_g, int* counters, int k, const GridDev& g8, hipStream_t st) {
   static_assert(NB <= R4_NB_MAX && NW >= KM && NW % 2 == 0 && KM <= R4_KMAX, "region4 shape");
   constexpr int PQM = NR * NW, KC = KM < 4 ? KM : 4;
   const size_t lds = (size_t)(KM * 512 + PQM * (2 * KM + 2)) * 4 + (size_t)(NW / 2) * KC * 128 * 16;
-  auto kern = crmsa_region4_kernel<NB, NW, NR, KM>;
+  auto kern = crmsa_region4_kernel<NB, NW, NR, KM, GPR>;
   static OncePerDevice once;
   if (lds > 64 * 1024 && once.first())
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2145,6 +2219,7 @@ hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float
                 : launch_region4_cfg<NB_, NW_, NR_, 8>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, \
                                                        part_g, counters, k, g8, st)
   static const int cfg = rrt_tune_env("RRT_REGION4_CFG") ? atoi(rrt_tune_env("RRT_REGION4_CFG")) : 4;
+  static const bool r4_gpr = rrt_tune_env("RRT_NO_REGION4_GPR") == nullptr;
 #ifdef RRT_TUNING
   if (cfg == 86 && g8.P <= 576) { RRT_R4(8, 12, 6); }        // 8 blocks x 12 waves x 6 rows
   if (cfg == 164 && g8.P <= 512) { RRT_R4(16, 8, 4); }       // 16 blocks x 8 waves x 4 rows
@@ -2157,8 +2232,15 @@ hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float
     return launch_region4_cfg<8, 4, 5, 3>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, part_g, counters, k, g8, st);
   // (round 6) k = 4, 5 (BASELINE configs[4]: crmsa_k = 5) at the four-block shape: registers and loops for five representatives,
   // not eight (the records are smaller than the scratch's eight-representative ones: the layout is the kernel's own)
-  if (g8.P <= 144 && cfg == 4 && k > 3 && k <= 5)
+  if (g8.P <= 144 && cfg == 4 && k > 3 && k <= 5 && !(k == 5 && r4_gpr))
     return launch_region4_cfg<4, 12, 3, 5>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, part_g, counters, k, g8, st);
+  // (round 6) the representative counts of the BASELINE configs with gamma . phi in registers and wave totals four at a time
+  // (16-byte-aligned gamma / beta / phi: float4 loads)
+  if (g8.P <= 144 && cfg == 4 && r4_gpr && ((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)phi) & 15) == 0)) {
+#define RRT_R4G(K_) if (k == K_) return launch_region4_cfg<4, 12, 3, K_, true>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, part_g, counters, k, g8, st)
+    RRT_R4G(1); RRT_R4G(3); RRT_R4G(5);
+#undef RRT_R4G
+  }
   RRT_R4(4, 12, 3);
 #undef RRT_R4
 }
