@@ -701,6 +701,10 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
   const GridDev gd8 = to_dev(g8);
   const int k = desc->crmsa_k, R8 = gd8.rs * gd8.rs;
   bool rep16_done = false;
+  static const bool no_region_inflight = rrt_tune_env("RRT_NO_REGION_INFLIGHT") != nullptr;
+  static const bool region_lowp = rrt_tune_env("RRT_REGION_INFLIGHT_LOWP") != nullptr;      // (A/B: also in the 16-bit modes)
+  const bool region_inflight = !no_region_inflight && !desc->solo && !desc->crmsa_mlp && !parts_done && !x3 &&
+                               (desc->compute == RRT_COMPUTE_F32 || region_lowp) && crmsa_region_supported(D, k, gd8);
   if (desc->crmsa_mlp) {
     // MLP phi (rmsa.py:248-252,305): v = LN(x1) materialised in region-major order, hidden = v W1^T on
     // the matrix cores, logits = tanh(hidden) W2^T; the combine then runs on the normalised rows
@@ -717,6 +721,16 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     // independent blocks (crmsa_combine_parts_kernel)
     RRT_TRY(launch_crmsa_combine_parts(xin, ws.cr_pstat, cw.norm_w, cw.norm_b, w->phi, ws.wdisp, ws.rep,
                                        inner16 ? ws.rep16 : nullptr, desc->compute, D, k, gd8, st));
+    rep16_done = inner16;
+  } else if (region_inflight) {
+    // round 6: exact fp32 with SEVERAL bags in flight -- logits + combine as ONE sixteen-wave block per region
+    // (crmsa_region_kernel, its k = 1 .. 3 forms with gamma . phi in registers): 64 blocks, so three quarters of the chip stay
+    // with the other bags' fused R-MSA launches, which is what the line is made of (the fused launches' union is 187 of the
+    // 189 us a bag takes).  Same box, four bags in flight: 5.30-5.31 k -> 5.36-5.38 k slides/s with the round-1 kernel
+    // (profiles/r06_region1_in_flight_ab.txt); one bag in flight it loses (20 us on a quarter of the chip): the hint decides.
+    // The 16-bit modes keep crmsa_region4 (their chip-wide kernels are short: a 64-block front becomes the critical path).
+    RRT_TRY(launch_crmsa_region(xin, cw.norm_w, cw.norm_b, w->phi, nullptr, nullptr, ws.wdisp, ws.rep, k, gd8, st,
+                                inner16 ? ws.rep16 : nullptr, desc->compute));
     rep16_done = inner16;
   } else if (ws.cr_cnt && desc->n_rmsa_layers > 0 && crmsa_region4_supported(D, k, gd8) && gd8.P < RRT_STREAM4_MIN_P) {
     // logits + combine in one pass over x1: four blocks per region, the last to arrive merges (crmsa_region4_kernel).

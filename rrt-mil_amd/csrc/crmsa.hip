@@ -899,6 +899,12 @@ __global__ __launch_bounds__(256) void crmsa_combine_parts_kernel(const float* _
 // w, then eight per column) and LayerNorm's affine is applied once:  rep = gamma * (W.X1 - c0) + beta * c1.
 constexpr int REGION_NR_MAX = 9;
 constexpr int REGION_KMAX = 3;
+// GK (round 6): 0 = the round-1 arithmetic (phi through LDS, normalised rows, one wave_sum per value, run-time k <= 3);
+// 1, 2, 3 = k exactly, gamma . phi of the lane's eight columns in registers, centred logits, the rows' wave totals four at a
+// time (wave_sum4) in chunks of three rows -- 45 wave reductions per wave become 12 groups -- and the representatives also as
+// 16-bit values (rep16, may be null): the form the forward takes with SEVERAL bags in flight in exact fp32, where a front
+// of 64 blocks leaves three quarters of the chip to the other bags' fused R-MSA launches (api.hip)
+template <int GK>
 __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restrict__ x1,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -906,8 +912,10 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
                                                             float* __restrict__ mean_rstd,
                                                             float* __restrict__ logits,
                                                             float* __restrict__ wdisp,
-                                                            float* __restrict__ rep, int k, GridDev g) {
+                                                            float* __restrict__ rep, uint16_t* __restrict__ rep16, int prec16,
+                                                            int k, GridDev g) {
   constexpr int DIM = 512, NR = REGION_NR_MAX, KM = REGION_KMAX;
+  constexpr bool GPR = GK > 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* phi_t = (float*)smem;                      // [KM][DIM]
   float* s_lg = phi_t + KM * DIM;                   // [P][KM] logits
@@ -919,9 +927,11 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int reg = blockIdx.x, R = g.Rt;
   const int ri = reg / g.rs, rj = reg - ri * g.rs;
-  for (int idx = tid; idx < DIM * k; idx += 1024) {
-    const int d = idx / k, n = idx - d * k;
-    phi_t[n * DIM + d] = phi[idx];
+  if constexpr (!GPR) {
+    for (int idx = tid; idx < DIM * k; idx += 1024) {
+      const int d = idx / k, n = idx - d * k;
+      phi_t[n * DIM + d] = phi[idx];
+    }
   }
   // ---- this wave's rows: every load in flight at once
   float4 r[NR][2];
@@ -942,9 +952,92 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
   }
   const float4 gm0 = *(const float4*)(gamma + lane * 4), gm1 = *(const float4*)(gamma + 256 + lane * 4);
   const float4 bt0 = *(const float4*)(beta + lane * 4), bt1 = *(const float4*)(beta + 256 + lane * 4);
+  const float inv_d = 1.0f / (float)DIM;
+  if constexpr (GPR) {
+    constexpr int K = GK;
+    float gp[2][4][K], Bn[K];
+    {
+      float bsum[K];
+#pragma unroll
+      for (int n = 0; n < K; ++n) bsum[n] = 0.f;
+      float4 pq[2][K];
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int jj = 0; jj < K; ++jj) pq[v][jj] = *(const float4*)(phi + (size_t)((v * 64 + lane) * 4) * K + 4 * jj);
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const float4 g4 = v ? gm1 : gm0, b4 = v ? bt1 : bt0;
+        const float gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+        float pf[4 * K];
+#pragma unroll
+        for (int jj = 0; jj < K; ++jj) { pf[4 * jj] = pq[v][jj].x; pf[4 * jj + 1] = pq[v][jj].y; pf[4 * jj + 2] = pq[v][jj].z; pf[4 * jj + 3] = pq[v][jj].w; }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+          for (int n = 0; n < K; ++n) {
+            gp[v][cc][n] = gm[cc] * pf[cc * K + n];
+            bsum[n] += bt[cc] * pf[cc * K + n];
+          }
+      }
+#pragma unroll
+      for (int n = 0; n < K; ++n) Bn[n] = wave_sum(bsum[n]);
+    }
+    static_assert(NR % 3 == 0, "rows in chunks of three");
+#pragma unroll
+    for (int c3 = 0; c3 < NR; c3 += 3) {
+      if (wave + 16 * c3 >= g.P) continue;          // wave-uniform: the whole chunk lies past the region
+      float sm[4] = {0.f, 0.f, 0.f, 0.f}, t4[4];
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) sm[u] += (r[c3 + u][v].x + r[c3 + u][v].y) + (r[c3 + u][v].z + r[c3 + u][v].w);
+      wave_sum4(sm[0], sm[1], sm[2], sm[3], t4[0], t4[1], t4[2], t4[3]);
+      constexpr int NV = 3 * (1 + K), NG = (NV + 3) / 4;
+      float vals[4 * NG], tot[4 * NG], mean3[3];
+#pragma unroll
+      for (int i = 0; i < 4 * NG; ++i) vals[i] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const float mean = mean3[u] = t4[u] * inv_d;
+        float sq = 0.f, d[K];
+#pragma unroll
+        for (int n = 0; n < K; ++n) d[n] = 0.f;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const float4 x = r[c3 + u][v];
+          const float xc[4] = {x.x - mean, x.y - mean, x.z - mean, x.w - mean};
+          sq += (xc[0] * xc[0] + xc[1] * xc[1]) + (xc[2] * xc[2] + xc[3] * xc[3]);
+#pragma unroll
+          for (int n = 0; n < K; ++n)
+            d[n] += (xc[0] * gp[v][0][n] + xc[1] * gp[v][1][n]) + (xc[2] * gp[v][2][n] + xc[3] * gp[v][3][n]);
+        }
+        vals[u * (1 + K)] = sq;
+#pragma unroll
+        for (int n = 0; n < K; ++n) vals[u * (1 + K) + 1 + n] = d[n];
+      }
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq)
+        wave_sum4(vals[4 * gq], vals[4 * gq + 1], vals[4 * gq + 2], vals[4 * gq + 3], tot[4 * gq], tot[4 * gq + 1], tot[4 * gq + 2],
+                  tot[4 * gq + 3]);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int p = wave + 16 * (c3 + u);
+        if (p >= g.P) continue;
+        const float rstd = 1.0f / sqrtf(tot[u * (1 + K)] * inv_d + LN_EPS);
+        const bool real = tokv[c3 + u] >= 0;
+        if (lane == 0) {
+#pragma unroll
+          for (int n = 0; n < K; ++n) s_lg[p * KM + n] = real ? rstd * tot[u * (1 + K) + 1 + n] + Bn[n] : 0.f;
+          s_mr[2 * p] = real ? mean3[u] : 0.f;
+          s_mr[2 * p + 1] = real ? rstd : 0.f;
+          if (real && mean_rstd) { mean_rstd[2 * (size_t)tokv[c3 + u]] = mean3[u]; mean_rstd[2 * (size_t)tokv[c3 + u] + 1] = rstd; }
+        }
+      }
+    }
+  } else {
   __syncthreads();                                  // phi_t staged
   // ---- LayerNorm statistics + logits per row (the arithmetic of crmsa_logits_kernel)
-  const float inv_d = 1.0f / (float)DIM;
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     const int p = wave + 16 * j;
@@ -978,6 +1071,7 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
       if (real && mean_rstd) { mean_rstd[2 * (size_t)tokv[j]] = mean; mean_rstd[2 * (size_t)tokv[j] + 1] = rstd; }
     }
   }
+  }   // !GPR
   __syncthreads();
   // ---- region statistics: wave n handles representative n
   if (wave < k) {
@@ -1097,6 +1191,7 @@ __global__ __launch_bounds__(1024) void crmsa_region_kernel(const float* __restr
     out.z = gm.z * (a.z - c0) + bt.z * c1;
     out.w = gm.w * (a.w - c0) + bt.w * c1;
     *(float4*)(rep + ((size_t)n * R + reg) * DIM + c * 4) = out;   // rep [k, R, D]
+    if (rep16) *(uint2*)(rep16 + ((size_t)n * R + reg) * DIM + c * 4) = prec16 == 2 ? r4_pack4<2>(out) : r4_pack4<1>(out);
   }
 }
 
@@ -2170,16 +2265,29 @@ bool crmsa_region_enabled() {
   static const bool on = rrt_tune_env("RRT_CRMSA_REGION") != nullptr;
   return on;
 }
-hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float* beta, const float* phi,
-                               float* mean_rstd, float* logits, float* wdisp, float* rep, int k, const GridDev& g8,
-                               hipStream_t st) {
+template <int GK>
+static hipError_t launch_region_gk(const float* x1, const float* gamma, const float* beta, const float* phi, float* mean_rstd,
+                                   float* logits, float* wdisp, float* rep, uint16_t* rep16, int prec16, int k, const GridDev& g8,
+                                   hipStream_t st) {
   const size_t lds = (size_t)(REGION_KMAX * 512 + REGION_NR_MAX * 16 * (2 * REGION_KMAX + 2)) * 4 +
                      (size_t)8 * REGION_KMAX * 128 * 16;
-  auto kern = crmsa_region_kernel;
+  auto kern = crmsa_region_kernel<GK>;
   static OncePerDevice once;
   if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  kern<<<dim3(g8.rs * g8.rs), dim3(1024), lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, k, g8);
+  kern<<<dim3(g8.rs * g8.rs), dim3(1024), lds, st>>>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, k, g8);
   return hipGetLastError();
+}
+hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float* beta, const float* phi,
+                               float* mean_rstd, float* logits, float* wdisp, float* rep, int k, const GridDev& g8,
+                               hipStream_t st, uint16_t* rep16, int prec16) {
+  static const bool no_gpr = rrt_tune_env("RRT_NO_REGION_GPR") != nullptr;
+  const bool al16 = ((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)phi) & 15) == 0);
+  if (!no_gpr && al16) {
+    if (k == 1) return launch_region_gk<1>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, k, g8, st);
+    if (k == 2) return launch_region_gk<2>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, k, g8, st);
+    if (k == 3) return launch_region_gk<3>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, k, g8, st);
+  }
+  return launch_region_gk<0>(x1, gamma, beta, phi, mean_rstd, logits, wdisp, rep, rep16, prec16, k, g8, st);
 }
 
 // Shapes.  Regions of <= 144 tokens (bags up to ~9.2 k patches): four blocks of 12 waves x 3 rows per region (fewest

@@ -192,7 +192,7 @@ hipError_t launch_crmsa_region4(const float* x1, const float* gamma, const float
                                 float* part_g, int* counters, int k, const GridDev& g8, hipStream_t st);
 hipError_t launch_crmsa_region(const float* x1, const float* gamma, const float* beta, const float* phi,
                                float* mean_rstd, float* logits, float* wdisp, float* rep, int k, const GridDev& g8,
-                               hipStream_t st);
+                               hipStream_t st, uint16_t* rep16 = nullptr, int prec16 = 0);
 // regions of more than 144 tokens: four blocks per region that stream their rows (one pass over x1); scratch and counters as
 // launch_crmsa_region4
 bool crmsa_stream4_supported(int dim, int k, const GridDev& g8);
