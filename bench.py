@@ -436,7 +436,7 @@ class EncoderWorkload:
                                       "f32x3": "f32x3"}[self.dtype]
             self.bags = [torch.from_numpy(synth.bag(self.n, cfg["input_dim"], tag=f"bench/mil/r{rank}/b{i}",
                                                     nonneg=True)).to(dev) for i in range(4)]
-            self.mdesc, self.mw = self.mil._mil_desc(cfg["input_dim"]), self.mil._mil_weights()
+            self.mdesc, self.mw = self.mil._mil_desc(cfg["input_dim"], solo=(S == 1)), self.mil._mil_weights()
             need = C.c_size_t()
             _lib.check(self.lib.rrt_mil_workspace_size(C.byref(self.mdesc), self.n, C.byref(need)), "mil workspace")
             self.wss = [torch.empty(need.value, dtype=torch.uint8, device=dev) for _ in range(S)]

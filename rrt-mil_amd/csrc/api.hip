@@ -773,11 +773,12 @@ static int encoder_forward(const rrt_encoder_desc* desc_in, const rrt_encoder_we
     ep.bias = cw.proj_b;
     RRT_TRY(launch_linear16(ws.repo16, ws.wcr16 + (size_t)3 * D * D, ws.rep2, k * R8, D, D, ep, st));
   } else {
-    RRT_TRY(inner_attention(ws.rep, k, R8, cw, D, desc->crmsa_heads, 0, ws.rep_qkv, ws.rep_o, desc->compute, desc->solo != 0, st));
+    static const bool inner_solo = rrt_tune_env("RRT_INNER_SOLO") != nullptr;     // (A/B: the K-split 16-wave GEMMs also with bags in flight)
+    RRT_TRY(inner_attention(ws.rep, k, R8, cw, D, desc->crmsa_heads, 0, ws.rep_qkv, ws.rep_o, desc->compute, desc->solo != 0 || inner_solo, st));
     LinearEpilogue ep{};
     ep.prec = desc->compute;
     ep.bias = cw.proj_b;
-    ep.solo = desc->solo != 0;
+    ep.solo = desc->solo != 0 || inner_solo;
     RRT_TRY(launch_linear(ws.rep_o, cw.proj_w, ws.rep2, k * R8, D, D, ep, st));
   }
   RRT_MARK(RRT_EV_CR_INNER);

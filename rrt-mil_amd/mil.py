@@ -270,16 +270,17 @@ class RRTMIL(nn.Module):
         self.__dict__.setdefault("_ws", None)
 
     # ------------------------------------------------------------------ the one-call HIP path
-    def _mil_desc(self, input_dim, solo=False):
+    def _mil_desc(self, input_dim, solo=True):
         enc = self.online_encoder
         d = _lib.MilDesc()
         C.memmove(C.byref(d.enc), C.byref(enc._desc), C.sizeof(_lib.EncoderDesc))
         d.enc.compute = enc._compute_mode()
         # per-call scheduling hint, never inherited from whatever the encoder's last call left in its descriptor
-        # (rrt_encoder_desc.solo also picks between bit-different CR-MSA fronts: a classifier's logits must not depend on call
-        # history).  The classifier keeps 0 -- the kernels that are right with several slides in flight -- for forward_bag and
-        # forward_bags alike, so that a slide's bits are the same alone and in a batch (test_rrtmil_forward_bags); what solo = 1
-        # buys one fp32 slide on its own is ~1 us of ~270
+        # (rrt_encoder_desc.solo also picks between CR-MSA fronts that differ in summation order, ~1e-7: a classifier's logits
+        # must not depend on call history): 1 = this slide has the GPU to itself (forward_bag on its own, the module call),
+        # 0 = it shares it with the other slides of a forward_bags call -- what the encoder's executor does with
+        # solo = (n_streams == 1).  Since round 6 the hint decides more than a microsecond (fp32: the front as 64 blocks that
+        # leave the chip to the other slides; 16-bit: the out-projection's tile shape), in both directions.
         d.enc.solo = int(bool(solo))
         d.input_dim = input_dim
         d.emb_act = _lib.ACT_BY_NAME.get(self._act_name, _lib.ACT_NONE)
@@ -344,7 +345,7 @@ class RRTMIL(nn.Module):
                 x2 = b[0] if b.dim() == 3 else b
                 self._ws, self.__dict__["_w16_key"] = slots.get((dev, s_), (None, None))
                 with torch.cuda.stream(pool[s_]):
-                    o = self.forward_bag(x2, return_attn=return_attn, no_norm=no_norm)
+                    o = self.forward_bag(x2, return_attn=return_attn, no_norm=no_norm, solo=(S == 1))
                 slots[(dev, s_)] = (self._ws, self.__dict__.get("_w16_key"))
                 # the outputs were allocated under the bag stream (the caching allocator ties a block to the stream it was
                 # taken on) and are consumed on the caller's: tell the allocator, so that a freed logits / attention row
@@ -360,9 +361,9 @@ class RRTMIL(nn.Module):
                 st.synchronize()      # host wait: nothing is parked on the caller's stream
         return outs
 
-    def forward_bag(self, x2d, return_attn=False, no_norm=False, solo=False):
+    def forward_bag(self, x2d, return_attn=False, no_norm=False, solo=True):
         """One bag: x2d (N, input_dim) fp32 (or bf16 / fp16) device tensor -> logits (n_classes,) [, attention (N,)].
-        ``solo``: rrt_encoder_desc.solo of this call (see _mil_desc; False everywhere by default)."""
+        ``solo``: the slide has the GPU to itself (forward_bags passes False when it keeps several slides in flight)."""
         lib = _lib.load()
         if not x2d.is_cuda:
             raise _lib.RRTHipError("rrt_mil_amd.RRTMIL runs on MI355X only: move the bag to a 'cuda' (HIP) "

@@ -708,7 +708,14 @@ def test_rrtmil_forward_bags(dt):
         again = mil.forward_bags(bags, streams=4, return_attn=True)          # cached 16-bit weight images per stream slot
     torch.cuda.synchronize()
     for (lg, at), (rl, ra), l3, (lg2, _) in zip(outs, ref, outs3, again):
-        assert torch.equal(lg, rl[0]) and torch.equal(at, ra[0]) and torch.equal(l3, rl) and torch.equal(lg2, rl[0])
+        # slides in flight: bit for bit among themselves, whatever the width of the call ...
+        assert torch.equal(l3[0], lg) and torch.equal(lg2, lg)
+        # ... and against the slide alone (rrt_encoder_desc.solo = 1: another CR-MSA front in exact fp32, ~1e-7; the 16-bit
+        # modes take the same kernels either way -- only a tile shape differs, not the bits)
+        if dt is None:
+            assert torch.allclose(lg, rl[0], rtol=2e-5, atol=2e-6) and torch.allclose(at, ra[0], rtol=2e-5, atol=2e-6)
+        else:
+            assert torch.equal(lg, rl[0]) and torch.equal(at, ra[0])
     assert mil.forward_bags([]) == []
 
 
