@@ -261,6 +261,7 @@ def _warn_hw_queues(streams):
 
 _NULL_CTX = contextlib.nullcontext()
 _SIDE_STREAM = {}         # device -> the stream an executor call runs on when the caller sits on the default stream
+_LEAD_STREAM = {}         # device -> handle of THE stream that carries the first share of every multi-bag call of this process
 _BAG_STREAMS = {}          # device -> [torch.cuda.Stream]: the streams every executor of this process runs its bags on
 
 
@@ -756,7 +757,23 @@ class RRTEncoder(nn.Module):
         with (torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else _NULL_CTX):
             cur = torch.cuda.current_stream(dev)
             in_flight = max(1, min(int(streams), n_bags // 4))      # the executor's rule: one stream per four bags of the call
-            if not (cur.cuda_stream == 0 and in_flight >= 4):
+            # ONE lead stream per process and device (round 6).  The executor carries the first share of a call's bags on the
+            # stream the call is ordered on; a process that called from the default stream and later from a stream of its own
+            # (or from two of its own) had then used FIVE streams for bags, and from the second caller on every call ran at the
+            # one-bag-in-flight rate -- 5.23 -> 4.56 k slides/s fp32, 17.3 -> 12.9 k bf16, in either order
+            # (tools/experiments/r06_probe_modcall.py): the chip schedules four queues.  So the first multi-bag call fixes the
+            # lead -- the caller's own stream (asynchronous calls), or the side stream of the default-stream case below -- and a
+            # call from any OTHER stream runs on the lead behind the caller's earlier work while the HOST waits for it (as the
+            # default-stream case always did): blocking instead of asynchronous, but at the four-in-flight rate.
+            lead = _LEAD_STREAM.get(dev)
+            multi = in_flight >= 2
+            if multi and lead is None and cur.cuda_stream != 0:
+                lead = _LEAD_STREAM[dev] = cur
+            if multi and lead is not None and cur.cuda_stream != 0 and lead.cuda_stream != cur.cuda_stream:
+                lead.wait_stream(cur)
+                rc = lib.rrt_executor_forward(ex, C.byref(w), arr, n_bags, lead.cuda_stream)
+                lead.synchronize()
+            elif not (cur.cuda_stream == 0 and in_flight >= 4):
                 # the call is ordered on the caller's stream, which carries the first share of the bags itself
                 rc = lib.rrt_executor_forward(ex, C.byref(w), arr, n_bags, cur.cuda_stream)
             else:
@@ -768,9 +785,11 @@ class RRTEncoder(nn.Module):
                 # nothing is parked on the default stream.  Round 6, 256 bags per call: 5.26 k fp32 / 19.3 k bf16 this way,
                 # 5.29 k / 19.8-20.2 k from a caller under its own `with torch.cuda.stream(s):` (asynchronous), 5.32 k / 20.4 k
                 # for the raw C-ABI loop of bench.py (profiles/r06_probe1.txt).
-                side = _SIDE_STREAM.get(dev)
+                side = lead if lead is not None else _SIDE_STREAM.get(dev)
                 if side is None:
                     side = _SIDE_STREAM[dev] = torch.cuda.Stream(dev)
+                if lead is None:
+                    _LEAD_STREAM[dev] = side
                 side.wait_stream(cur)
                 rc = lib.rrt_executor_forward(ex, C.byref(w), arr, n_bags, side.cuda_stream)
                 side.synchronize()
