@@ -247,6 +247,17 @@ __device__ __forceinline__ void dma16s(const void* sbase /* wave-uniform */, uns
       : "v"(voff), "s"(lds_addr), "s"(sbase)
       : "memory");
 }
+// ... with the non-temporal hint: rows that are read for the last time (a 16-bit intermediate on its way into the next product)
+__device__ __forceinline__ void dma16s_nt(const void* sbase /* wave-uniform */, unsigned voff,
+                                          unsigned lds_addr /* wave-uniform */) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %2 nt"
+      :
+      : "v"(voff), "s"(lds_addr), "s"(sbase)
+      : "memory");
+}
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // LDS byte address of a __shared__ pointer
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {

@@ -523,7 +523,13 @@ void linear_ws_kernel(const void* __restrict__ Av,
     auto stage = [&](const char* abase, const char* bbase, unsigned buf) {
 #pragma unroll
       for (int qi = 0; qi < LA; ++qi)
-        if (qi * NLW + lw < NA) dma16s(abase, aoff[qi], buf + (qi * NLW + lw) * 1024);
+        if (qi * NLW + lw < NA) {
+#ifdef RRT_NT_A16_PROJ
+          if (IN16 && MODE == MODE_UNPART) dma16s_nt(abase, aoff[qi], buf + (qi * NLW + lw) * 1024);
+          else
+#endif
+          dma16s(abase, aoff[qi], buf + (qi * NLW + lw) * 1024);
+        }
 #pragma unroll
       for (int qi = 0; qi < LB; ++qi)
         if (qi * NLW + lw < NB) dma16s(bbase, boff[qi], buf + BM * BK * 4 + (qi * NLW + lw) * 1024);

@@ -337,7 +337,11 @@ __global__ __launch_bounds__(512 * NH, 1) void rmsa_pair16_kernel(const uint16_t
 #pragma unroll
     for (int q = 0; q < LP; ++q) {
       const int piece = q * NWV + wave;
+#ifdef RRT_NT_A16_PAIR
+      if (piece < NA) dma16s_nt(ub, off[q], buf + piece * 1024);
+#else
       if (piece < NA) dma16s(ub, off[q], buf + piece * 1024);
+#endif
     }
   };
   auto stage_w = [&](int kt, unsigned buf) {
