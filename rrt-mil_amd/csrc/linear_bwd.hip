@@ -72,13 +72,26 @@ constexpr int TN_BN = 128, TN_BK = 128, TN_BM = 32, TN_PITCH = 144;
 template <bool FAST>
 __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       float* __restrict__ part, float* __restrict__ dbpart, int M, int N, int K,
-                                                      int rows_per_chunk) {
+                                                      int rows_per_chunk, int xcd_tiles_n) {
   __shared__ __attribute__((aligned(16))) float As[TN_BM * TN_PITCH];
   __shared__ __attribute__((aligned(16))) float Bs[TN_BM * TN_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int wn = wave >> 1, wk = wave & 1;
-  const int n0 = blockIdx.x * TN_BN, k0 = blockIdx.y * TN_BK, s = blockIdx.z;
+  // Which (n tile, k tile, row chunk) this block owns.  xcd_tiles_n = 0: the plain 3-D grid.  Otherwise (1-D grid, the number of
+  // row chunks a multiple of 8): consecutive block ids go to the 8 XCDs in turn, so chunk s = (id % 8) + 8 * ... puts ALL tiles
+  // of a row chunk on one XCD -- its L2 then fetches each row of dY and X once for the tiles_n * tiles_k blocks that read it,
+  // where the plain order spread a chunk's tiles over every L2 (a 128 x 128 tile reads 32 flop/B: at the fp32 matrix rate that
+  // is 4.9 TB/s of operand reads, which only the L2s can serve).
+  int bx = blockIdx.x, by = blockIdx.y, s = blockIdx.z;
+  if (xcd_tiles_n > 0) {
+    const int tiles_k = (K + TN_BK - 1) / TN_BK, T = xcd_tiles_n * tiles_k;
+    const int id = blockIdx.x, j = id >> 3, t = j % T;
+    s = (id & 7) + 8 * (j / T);
+    bx = t % xcd_tiles_n;
+    by = t / xcd_tiles_n;
+  }
+  const int n0 = bx * TN_BN, k0 = by * TN_BK;
   const int m_begin = s * rows_per_chunk;
   const int m_end = min(M, m_begin + rows_per_chunk);
   const bool vecA = (N & 3) == 0, vecB = (K & 3) == 0;
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_db = dbpart != nullptr && blockIdx.y == 0;
+  const bool do_db = dbpart != nullptr && by == 0;
   float colsum = 0.f;                               // column n0 + tid of this block's rows (tid < 128)
 
   // Stage = 32 rows x 128 columns of each operand: 1024 float4 per operand, 4 per thread.  The rows of stage s + 1 are
@@ -319,14 +332,27 @@ hipError_t launch_reduce_partials(const float* part, float* out, int S, size_t n
   return hipGetLastError();
 }
 
+// grid of the TN product: 1-D with the XCD-aware order (kernel comment) when the chunks divide over the 8 XCDs, else 3-D
+static dim3 tn_grid(int N, int K, int S, int* xcd_tiles_n) {
+  const int tn = (N + TN_BN - 1) / TN_BN, tk = (K + TN_BK - 1) / TN_BK;
+  static const bool plain = rrt_tune_env("RRT_TN_PLAIN_GRID") != nullptr;       // (A/B, tuning build only)
+  if (S % 8 == 0 && !plain) {
+    *xcd_tiles_n = tn;
+    return dim3((unsigned)(tn * tk * S));
+  }
+  *xcd_tiles_n = 0;
+  return dim3(tn, tk, S);
+}
+
 // dW[N,K] = dY[M,N]^T . X[M,K] ; scratch: S * N * K floats
 hipError_t launch_gemm_tn(const float* dY, const float* X, float* dW, float* scratch, int M, int N, int K,
                           hipStream_t st) {
   int rpc;
   const int S = linear_bwd_chunks(M, N, K, &rpc);
-  dim3 grid((N + TN_BN - 1) / TN_BN, (K + TN_BK - 1) / TN_BK, S);
-  if (N % TN_BN == 0 && K % TN_BK == 0) gemm_tn_kernel<true><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, nullptr, M, N, K, rpc);
-  else gemm_tn_kernel<false><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, nullptr, M, N, K, rpc);
+  int xt = 0;
+  const dim3 grid = tn_grid(N, K, S, &xt);
+  if (N % TN_BN == 0 && K % TN_BK == 0) gemm_tn_kernel<true><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, nullptr, M, N, K, rpc, xt);
+  else gemm_tn_kernel<false><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, nullptr, M, N, K, rpc, xt);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || S == 1) return e;
   return launch_reduce_partials(scratch, dW, S, (size_t)N * K, st);
@@ -337,10 +363,11 @@ static hipError_t launch_gemm_tn_db(const float* dY, const float* X, float* dW, 
                                     int N, int K, hipStream_t st) {
   int rpc;
   const int S = linear_bwd_chunks(M, N, K, &rpc);
-  dim3 grid((N + TN_BN - 1) / TN_BN, (K + TN_BK - 1) / TN_BK, S);
+  int xt = 0;
+  const dim3 grid = tn_grid(N, K, S, &xt);
   if (N % TN_BN == 0 && K % TN_BK == 0)
-    gemm_tn_kernel<true><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, S == 1 ? db : dbscratch, M, N, K, rpc);
-  else gemm_tn_kernel<false><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, S == 1 ? db : dbscratch, M, N, K, rpc);
+    gemm_tn_kernel<true><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, S == 1 ? db : dbscratch, M, N, K, rpc, xt);
+  else gemm_tn_kernel<false><<<grid, 256, 0, st>>>(dY, X, S == 1 ? dW : scratch, S == 1 ? db : dbscratch, M, N, K, rpc, xt);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || S == 1) return e;
   const unsigned nb1 = (unsigned)(((size_t)N * K + 255) / 256), nb2 = (unsigned)((N + 255) / 256);
