@@ -1903,6 +1903,8 @@ struct BwdWs {
   float *dx2, *dxa, *dxb, *dz, *dO, *dqkv, *lnpart, *attnpart, *dWd, *dC, *dlg, *Cw, *d_rep2, *d_rep_o,
       *d_rep_qkv, *d_rep, *rows, *dxpart, *th, *dhid, *dvphi, *w1t, *tnscratch, *fh, *fdh, *fdu, *attnpart_cr, *dpe, *smap;
   char *lin, *pegws;
+  float* tappart[RRT_MAX_RMSA_LAYERS];     // the EPEG taps' partials of each layer (summed by the deferred reduce launch)
+  size_t lnpart_stride;                    // lnpart holds one partial buffer per LayerNorm backward of the pass
   float *wt_qkv[RRT_MAX_RMSA_LAYERS], *wt_proj[RRT_MAX_RMSA_LAYERS], *wt_cr_qkv, *wt_cr_proj;   // W^T images, made in one launch
   size_t bytes;
 };
@@ -1921,7 +1923,8 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
   w.dx2 = take((size_t)N * D);
   w.dxa = take((size_t)N * D);
   w.dxb = take((size_t)N * D);
-  w.lnpart = take(ln_bwd_workspace((int)D) / sizeof(float));
+  w.lnpart_stride = align_up(ln_bwd_workspace((int)D), 256) / sizeof(float);
+  w.lnpart = take(w.lnpart_stride * (size_t)(2 * (d.n_rmsa_layers + 1) + 1));      // final + (norm, norm2) per layer + CR-MSA's norm2
   size_t lin = 0;
   if (d.n_rmsa_layers > 0) {
     w.dz = take(Np * D);
@@ -1934,6 +1937,8 @@ BwdWs carve_bwd(const rrt_encoder_desc& d, int64_t N, const rrt_grid& g, const r
       w.attnpart = take(64);
     } else {
       w.attnpart = take(attn_bwd_workspace(R, g.s * g.s, (int)D, d.n_heads, (d.epeg && !evalue) ? d.epeg_k : 0) / sizeof(float));
+      if (d.epeg && !evalue)
+        for (int li = 0; li < d.n_rmsa_layers; ++li) w.tappart[li] = take((size_t)R * d.n_heads * d.epeg_k);
     }
     if (evalue) w.dpe = take(Np * D);
     lin = linear_bwd_workspace((int)Np, 3 * (int)D, (int)D);
@@ -2217,6 +2222,7 @@ int rrt_encoder_forward_train_f32(const rrt_encoder_desc* desc, const rrt_encode
     ep2.drop_on = dc.thresh || bsc != 1.0f;
     ep2.drop_seed = dc.seed(drop_seed, DROP_LAYER_CRMSA);
     ep2.prec = ep2.drop_on ? RRT_COMPUTE_F32 : desc->compute;
+    ep2.solo = true;                            // (as the qkv product above: K split inside the block, dropout epilogue included)
     RRT_TRY(launch_linear(s.rep_o, cw.proj_w, s.rep2, k * R8, D, D, ep2, st));
     if (desc->ffn) {
       // CR-MSA's TransLayer: x1 + dispatch -> xcr, FFN -> xf, then the shortcut, then the final LayerNorm
@@ -2284,8 +2290,16 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     if (tj_bad) return RRT_E_INVALID;
     RRT_TRY(launch_transpose_batch(tj, st));
   }
+  // Parameter-gradient sums that nothing downstream reads leave the dependent chain: the stages below append their reduce
+  // jobs here and one launch at the end of the pass runs them all (round 6: four 5-9 us launches -> one).  Each stage
+  // therefore gets partial buffers of its own (ln_part(), tappart[li], dxpart).
+  ReduceJobs rj{};
+  static const bool no_defer = rrt_tune_env("RRT_NO_DEFER_REDUCE") != nullptr;      // (A/B, tuning build only)
+  ReduceJobs* const defer = no_defer ? nullptr : &rj;
+  int ln_calls = 0;
+  auto ln_part = [&]() { return b.lnpart + (size_t)(ln_calls++) * b.lnpart_stride; };
   // final LayerNorm
-  RRT_TRY(launch_ln_backward(dy, s.x2, w->norm_w, nullptr, b.dx2, gr->norm, b.lnpart, N, D, nullptr, st));
+  RRT_TRY(launch_ln_backward(dy, s.x2, w->norm_w, nullptr, b.dx2, gr->norm, ln_part(), N, D, nullptr, st, defer));
   const float* cur = b.dx2;   // gradient w.r.t. the activations entering the stage being undone
   // FFN backward (ffn = 1): given d xf in `cur`, the gradient w.r.t. the FFN's input xi goes to the other
   // ping-pong buffer; fc2 / fc1 through the linear backward, the activation through its own pass, LN2 last
@@ -2310,7 +2324,7 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     fe = launch_linear_backward(b.fdh, s.ffn_u[idx], lw.fc1_w, b.fdu, lg.fc1_w, lg.fc1_b, N, Hd, D, desc->compute, b.lin, st);
     if (fe != hipSuccess) return (int)fe;
     float* nxt = (cur == b.dxa) ? b.dxb : b.dxa;
-    fe = launch_ln_backward(b.fdu, xi, lw.norm2_w, cur, nxt, lg.norm2, b.lnpart, N, D, nullptr, st);
+    fe = launch_ln_backward(b.fdu, xi, lw.norm2_w, cur, nxt, lg.norm2, ln_part(), N, D, nullptr, st, defer);
     if (fe != hipSuccess) return (int)fe;
     cur = nxt;
     return RRT_OK;
@@ -2371,9 +2385,15 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
       } else {                                             // hidden width not a GEMM K tile (dim % 128 != 0)
         RRT_TRY(launch_small_k_matmul(b.dhid, w->phi0_w, b.dvphi, gd8.Np, D, hdim, st));
       }
+      // (the reduce launch writes LayerNorm's gradients where they belong when the caller's buffer takes 16-byte stores: the
+      //  4 KB copy -- and, below, the transpose of d phi -- were two 5 us launches of the dependent chain)
+      const bool direct = ((uintptr_t)cg.norm & 15) == 0;
       RRT_TRY(launch_crmsa_bwd_dx(x1, up, s.mean_rstd, cw.norm_w, cw.norm_b, b.dvphi, b.Cw, b.dlg, b.d_rep, dx1,
-                                  b.rows, b.dxpart, D, k, gd8, true, st));
-      RRT_TRY(hipMemcpyAsync(cg.norm, b.rows, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+                                  direct ? cg.norm : b.rows, b.dxpart, D, k, gd8, true, st, nullptr, direct ? defer : nullptr));
+      if (!direct) RRT_TRY(hipMemcpyAsync(cg.norm, b.rows, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else if (((uintptr_t)cg.norm & 15) == 0) {
+      RRT_TRY(launch_crmsa_bwd_dx(x1, up, s.mean_rstd, cw.norm_w, cw.norm_b, w->phi, b.Cw, b.dlg, b.d_rep, dx1,
+                                  cg.norm, b.dxpart, D, k, gd8, false, st, gr->phi, defer));
     } else {
       RRT_TRY(launch_crmsa_bwd_dx(x1, up, s.mean_rstd, cw.norm_w, cw.norm_b, w->phi, b.Cw, b.dlg, b.d_rep, dx1,
                                   b.rows, b.dxpart, D, k, gd8, false, st));
@@ -2424,11 +2444,11 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     } else
     RRT_TRY(launch_attention_backward(s.qkv[li], desc->epeg ? lw.pe_w : nullptr, s.o[li], b.dO, b.dqkv,
                                       desc->epeg ? lg.pe_w : nullptr, b.attnpart, gd.rs * gd.rs, gd.P, D,
-                                      desc->n_heads, desc->epeg ? desc->epeg_k : 0, st));
+                                      desc->n_heads, desc->epeg ? desc->epeg_k : 0, st, defer, b.tappart[li]));
     RRT_TRY(launch_linear_backward(b.dqkv, s.u[li], lw.qkv_w, b.dz, lg.qkv_w, lg.qkv_b, gd.Np, 3 * D, D, desc->compute, b.lin,
                                    st, b.wt_qkv[li]));                         // dU -> dz (dead)
     float* nxt = (cur == b.dxa) ? b.dxb : b.dxa;
-    RRT_TRY(launch_ln_backward(b.dz, xin, lw.norm_w, cur, nxt, lg.norm, b.lnpart, N, D, &gd, st));
+    RRT_TRY(launch_ln_backward(b.dz, xin, lw.norm_w, cur, nxt, lg.norm, ln_part(), N, D, &gd, st, defer));
     cur = nxt;
     if (pos_in) {
       rc = peg_backward(xprev);
@@ -2440,6 +2460,7 @@ int rrt_encoder_backward_f32(const rrt_encoder_desc* desc, const rrt_encoder_wei
     if (rc) return rc;
   }
   if (dx) RRT_TRY(launch_layernorm(cur, desc->all_shortcut ? b.dx2 : nullptr, nullptr, nullptr, dx, N, D, st));
+  RRT_TRY(launch_reduce_jobs(rj, st));
 #undef RRT_TRY
   return RRT_OK;
 }

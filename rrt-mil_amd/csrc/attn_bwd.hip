@@ -1250,9 +1250,12 @@ size_t attn_bwd_workspace(int n_regions, int P, int D, int heads, int epeg_k) {
 // dqkv [n_regions*P, 3D] (gradient w.r.t. the qkv linear's raw output); dpe [heads, epeg_k] or null
 hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const float* O, const float* dO,
                                      float* dqkv, float* dpe, float* dpe_part, int n_regions, int P, int D,
-                                     int heads, int epeg_k, hipStream_t st) {
+                                     int heads, int epeg_k, hipStream_t st, ReduceJobs* defer, float* defer_part) {
   if (pe_w == nullptr) epeg_k = 0;
   hipError_t e;
+  float* const ws_base = dpe_part;                          // the streaming variant's buffers sit behind the partials' slot
+  if (defer && defer_part) dpe_part = defer_part;           // partials that must outlive this call (summed at the end)
+  else defer = nullptr;
   if (D / heads != HD) {
     const size_t lds = (size_t)2 * P * P * sizeof(float);
     if (lds > 64 * 1024)
@@ -1264,7 +1267,7 @@ hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const 
   static const bool force_stream = rrt_tune_env("RRT_ATTN_BWD_STREAM") != nullptr;   // tuning hook
   if (P > 208 || (force_stream && P > 48)) {
     const size_t rows = (size_t)n_regions * P;
-    char* base = (char*)dpe_part + ((size_t)n_regions * heads * (epeg_k > 0 ? epeg_k : 1) * sizeof(float) + 255) / 256 * 256;
+    char* base = (char*)ws_base + ((size_t)n_regions * heads * (epeg_k > 0 ? epeg_k : 1) * sizeof(float) + 255) / 256 * 256;
     float* qt = (float*)base;
     float* tmp = qt + rows * D;
     float* lse_g = tmp + rows * D;
@@ -1300,5 +1303,5 @@ hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const 
   else if (P > 64) e = launch_bwd_mt<6>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   else e = launch_bwd_mt<4>(qkv, pe_w, O, dO, dqkv, dpe_part, n_regions, P, D, heads, epeg_k, st);
   if (e != hipSuccess || epeg_k == 0 || dpe == nullptr) return e;
-  return launch_reduce_partials(dpe_part, dpe, n_regions, (size_t)heads * epeg_k, st);
+  return reduce_or_defer(defer, dpe_part, dpe, n_regions, (size_t)heads * epeg_k, st);
 }

@@ -441,10 +441,12 @@ hipError_t launch_crmsa_mlp_bwd_hidden(const float* hid, const float* dlg, const
 }
 
 // out_rows [2 + k, dim]: d gamma2, d beta2, d phi^T.  mlp: `phi` = d v_phi rows [Np8, dim], out_rows [2, dim]
+// dphi_t (not mlp; out_rows 16-byte aligned): out_rows takes only [2, dim] and d phi leaves as phi's own [dim, k] from the
+// same reduce launch
 hipError_t launch_crmsa_bwd_dx(const float* x1, const float* dx2, const float* mean_rstd, const float* gamma,
                                const float* beta, const float* phi, const float* Cw, const float* dlg,
                                const float* drep, float* dx1, float* out_rows, float* part, int dim, int k,
-                               const GridDev& g, bool mlp, hipStream_t st) {
+                               const GridDev& g, bool mlp, hipStream_t st, float* dphi_t, ReduceJobs* defer) {
   if (dim > 1024) return hipErrorInvalidValue;
   const int need = (g.L + 3) / 4;
   const int blocks = need < DXB_BLOCKS ? need : DXB_BLOCKS;
@@ -465,5 +467,7 @@ hipError_t launch_crmsa_bwd_dx(const float* x1, const float* dx2, const float* m
 #undef RRT_DX
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return launch_reduce_partials(part, out_rows, blocks, (size_t)rows * dim, st);
+  if (dphi_t && !mlp)
+    return reduce_or_defer(defer, part, out_rows, blocks, (size_t)rows * dim, st, (size_t)2 * dim, dphi_t, dim, k);
+  return reduce_or_defer(defer, part, out_rows, blocks, (size_t)rows * dim, st);
 }

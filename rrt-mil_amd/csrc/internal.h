@@ -251,20 +251,41 @@ struct TransposeJobs {           // out[j] [C, R] = in[j] [R, C]^T, one launch (
 };
 hipError_t launch_transpose_batch(TransposeJobs& jobs, hipStream_t st);
 hipError_t launch_reduce_partials(const float* part, float* out, int S, size_t n, hipStream_t st);
+// Parameter-gradient reductions nothing downstream reads (LayerNorm's d gamma | d beta, the EPEG taps, CR-MSA's norm / phi rows)
+// can leave the backward's dependent chain: a stage appends its job here instead of launching its reduce, and ONE launch at the
+// end of the backward sums them all (each stage then needs partial buffers of its own until that launch).
+constexpr int REDUCE_MAX_JOBS = 16;
+struct ReduceJobs {
+  const float* part[REDUCE_MAX_JOBS];
+  float* out[REDUCE_MAX_JOBS];
+  float* out_tr[REDUCE_MAX_JOBS];          // optional transposed tail (launch_reduce_partials_scatter), else null
+  unsigned long long n[REDUCE_MAX_JOBS], split[REDUCE_MAX_JOBS];
+  int S[REDUCE_MAX_JOBS], tr_dim[REDUCE_MAX_JOBS], tr_k[REDUCE_MAX_JOBS];
+  unsigned blk0[REDUCE_MAX_JOBS + 1];      // filled by the launcher
+  int count;
+};
+// defer == null or full: launches now.  (out_tr == null: plain)
+hipError_t reduce_or_defer(ReduceJobs* defer, const float* part, float* out, int S, size_t n, hipStream_t st,
+                           size_t split = 0, float* out_tr = nullptr, int tr_dim = 0, int tr_k = 0);
+hipError_t launch_reduce_jobs(ReduceJobs& jobs, hipStream_t st);
+hipError_t launch_reduce_partials_scatter(const float* part, float* out, int S, size_t n, size_t split, float* out_tr,
+                                          int tr_dim, int tr_k, hipStream_t st);
 hipError_t launch_gemm_tn(const float* dY, const float* X, float* dW, float* scratch, int M, int N, int K,
                           hipStream_t st);
 hipError_t launch_colsum(const float* Y, float* out, float* scratch, int M, int N, hipStream_t st);
 // LayerNorm backward; dgb = [2, dim] (dgamma, dbeta); g != null: dy rows are region-major slots; add: residual grad
 size_t ln_bwd_workspace(int dim);
 hipError_t launch_ln_backward(const float* dy, const float* x, const float* gamma, const float* add, float* dx,
-                              float* dgb, float* part, int L, int dim, const GridDev* g, hipStream_t st);
+                              float* dgb, float* part, int L, int dim, const GridDev* g, hipStream_t st,
+                              ReduceJobs* defer = nullptr);
 // region attention backward (attn_bwd.hip): head dim 64, P <= 144.  dqkv: gradient w.r.t. the qkv linear's raw
 // output [n_regions*P, 3D]; dpe [heads, epeg_k] or null; dpe_part: attn_bwd_workspace bytes
 bool attn_bwd_supported(int P, int D, int heads, int epeg_k);
 size_t attn_bwd_workspace(int n_regions, int P, int D, int heads, int epeg_k);
 hipError_t launch_attention_backward(const float* qkv, const float* pe_w, const float* O, const float* dO,
                                      float* dqkv, float* dpe, float* dpe_part, int n_regions, int P, int D,
-                                     int heads, int epeg_k, hipStream_t st);
+                                     int heads, int epeg_k, hipStream_t st, ReduceJobs* defer = nullptr,
+                                     float* defer_part = nullptr);   // defer_part [n_regions, heads * epeg_k]: the taps' partials
 // dst [Np, dim] region-major <- src [L, dim]; pads 0; optional dropout mask (thresh != 0) regenerated per element
 hipError_t launch_partition_rows(const float* src, float* dst, int dim, const GridDev& g, unsigned drop_thresh,
                                  unsigned drop_seed, float drop_scale, hipStream_t st);
@@ -281,7 +302,8 @@ size_t crmsa_bwd_dx_workspace(int dim, int k);
 hipError_t launch_crmsa_bwd_dx(const float* x1, const float* dx2, const float* mean_rstd, const float* gamma,
                                const float* beta, const float* phi, const float* Cw, const float* dlg,
                                const float* drep, float* dx1, float* out_rows, float* part, int dim, int k,
-                               const GridDev& g, bool mlp, hipStream_t st);
+                               const GridDev& g, bool mlp, hipStream_t st, float* dphi_t = nullptr,
+                               ReduceJobs* defer = nullptr);
 hipError_t launch_crmsa_mlp_bwd_hidden(const float* hid, const float* dlg, const float* w2, float* th, float* dhid,
                                        size_t rows, int hdim, int k, hipStream_t st);
 // FFN activation as a pass (n % 4 == 0): h = act(hpre) ; dh *= act'(hpre)   (act = RRT_ACT_GELU / RRT_ACT_RELU)

@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
 template <int NWV>
 __global__ __launch_bounds__(NWV * 64) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               int S, size_t n, const float* __restrict__ part2,
-                                                              float* __restrict__ out2, size_t n2, unsigned nb1) {
+                                                              float* __restrict__ out2, size_t n2, unsigned nb1,
+                                                              float* __restrict__ out_tr = nullptr, size_t split = 0,
+                                                              int tr_dim = 0, int tr_k = 0) {
   __shared__ float4 comb[NWV - 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned blk = blockIdx.x;
@@ -257,11 +259,102 @@ __global__ __launch_bounds__(NWV * 64) void reduce_partials_kernel(const float* 
       const float4 o = comb[w][lane];
       a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
     }
-    if (vec) *(float4*)(out + i) = a;
+    if (out_tr && i >= split) {
+      // the tail [tr_k, tr_dim] of the reduced vector leaves transposed, as [tr_dim, tr_k] (CR-MSA's d phi: the copy and the
+      // transpose launches that used to follow were 10 us of the backward's dependent chain)
+      const float t[4] = {a.x, a.y, a.z, a.w};
+      for (int e = 0; e < 4; ++e)
+        if (i + e < n) {
+          const size_t q = i + e - split;
+          out_tr[(q % tr_dim) * tr_k + q / tr_dim] = t[e];
+        }
+    } else if (vec) *(float4*)(out + i) = a;
     else {
       const float t[4] = {a.x, a.y, a.z, a.w};
       for (int e = 0; e < 4; ++e)
         if (i + e < n) out[i + e] = t[e];
+    }
+  }
+}
+
+// ---- several such reductions in one launch (ReduceJobs, internal.h).  The jobs are short vectors with hundreds of partials
+//      (LayerNorm: 512 x [2, dim]; CR-MSA: 512 x [2 + k, dim]): 256 elements per block is a handful of blocks that each pull
+//      0.5 MB through one CU (15 us for the default encoder's four jobs).  Here a block owns 32 consecutive elements = one
+//      128-byte line of every partial: a wave reads eight partials per load (lane = 8 * partial + float4), sixteen waves 128,
+//      up to twelve loads in flight; the 128 lane-sums of an element meet in LDS and are added in a fixed order.
+constexpr int RJ_ELEMS = 32;
+__global__ __launch_bounds__(1024) void reduce_jobs_kernel(ReduceJobs jobs) {
+  __shared__ float4 comb[128][8];          // [16 waves x 8 partial slots][float4 of the line]
+  __shared__ float4 comb2[16][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < REDUCE_MAX_JOBS; ++q)
+    if (q < jobs.count && blockIdx.x >= jobs.blk0[q]) j = q;
+  const float* __restrict__ part = jobs.part[j];
+  const size_t n = jobs.n[j];
+  const int S = jobs.S[j];
+  const int sub = lane >> 3, c = lane & 7;
+  const size_t i = ((size_t)(blockIdx.x - jobs.blk0[j]) * 8 + c) * 4;      // this lane's first element
+  const bool vec = (n & 3) == 0 && i + 3 < n;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+    for (int s0 = wave * 8 + sub; s0 < S; s0 += 12 * 128) {
+      float4 b[12];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int s = s0 + 128 * u;
+        b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < S) {
+          const float* src = part + (size_t)s * n + i;
+          if (vec) b[u] = *(const float4*)src;
+          else {
+            b[u].x = src[0];
+            if (i + 1 < n) b[u].y = src[1];
+            if (i + 2 < n) b[u].z = src[2];
+            if (i + 3 < n) b[u].w = src[3];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 12; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+    }
+  }
+  comb[wave * 8 + sub][c] = a;
+  __syncthreads();
+  if (threadIdx.x < 128) {                 // thread (w, c): the eight partial slots of wave w
+    const int w = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    float4 t = comb[w * 8][cc];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      const float4 o = comb[w * 8 + q][cc];
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    comb2[w][cc] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && i < n) {          // (threads 0..7: sub = 0, c = threadIdx.x, so `i` is this thread's element)
+    float4 t = comb2[0][c];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+      const float4 o = comb2[w][c];
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    float* __restrict__ out = jobs.out[j];
+    float* __restrict__ out_tr = jobs.out_tr[j];
+    const size_t split = jobs.split[j];
+    const float v[4] = {t.x, t.y, t.z, t.w};
+    if (out_tr && i >= split) {
+      const int tr_dim = jobs.tr_dim[j], tr_k = jobs.tr_k[j];
+      for (int e = 0; e < 4; ++e)
+        if (i + e < n) {
+          const size_t q = i + e - split;
+          out_tr[(q % tr_dim) * tr_k + q / tr_dim] = v[e];
+        }
+    } else if (vec && (((size_t)out) & 15) == 0) *(float4*)(out + i) = t;
+    else {
+      for (int e = 0; e < 4; ++e)
+        if (i + e < n) out[i + e] = v[e];
     }
   }
 }
@@ -329,6 +422,49 @@ hipError_t launch_reduce_partials(const float* part, float* out, int S, size_t n
   const unsigned nb = (unsigned)((n + 255) / 256);
   if (S >= 64 && nb <= 64) reduce_partials_kernel<16><<<dim3(nb), 1024, 0, st>>>(part, out, S, n, nullptr, nullptr, 0, nb);
   else reduce_partials_kernel<4><<<dim3(nb), 256, 0, st>>>(part, out, S, n, nullptr, nullptr, 0, nb);
+  return hipGetLastError();
+}
+
+// out[0, split) = the head of the reduced vector, out_tr[tr_dim, tr_k] = its tail [tr_k, tr_dim] transposed (split % 4 == 0)
+hipError_t launch_reduce_partials_scatter(const float* part, float* out, int S, size_t n, size_t split, float* out_tr,
+                                          int tr_dim, int tr_k, hipStream_t st) {
+  if (split % 4 != 0 || split > n || (n - split) != (size_t)tr_dim * tr_k) return hipErrorInvalidValue;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  if (S >= 64 && nb <= 64)
+    reduce_partials_kernel<16><<<dim3(nb), 1024, 0, st>>>(part, out, S, n, nullptr, nullptr, 0, nb, out_tr, split, tr_dim, tr_k);
+  else reduce_partials_kernel<4><<<dim3(nb), 256, 0, st>>>(part, out, S, n, nullptr, nullptr, 0, nb, out_tr, split, tr_dim, tr_k);
+  return hipGetLastError();
+}
+
+hipError_t reduce_or_defer(ReduceJobs* defer, const float* part, float* out, int S, size_t n, hipStream_t st, size_t split,
+                           float* out_tr, int tr_dim, int tr_k) {
+  if (out_tr && (split % 4 != 0 || split > n || (n - split) != (size_t)tr_dim * tr_k)) return hipErrorInvalidValue;
+  if (defer && defer->count < REDUCE_MAX_JOBS) {
+    const int j = defer->count++;
+    defer->part[j] = part;
+    defer->out[j] = out;
+    defer->out_tr[j] = out_tr;
+    defer->n[j] = n;
+    defer->split[j] = split;
+    defer->S[j] = S;
+    defer->tr_dim[j] = tr_dim;
+    defer->tr_k[j] = tr_k;
+    return hipSuccess;
+  }
+  if (out_tr) return launch_reduce_partials_scatter(part, out, S, n, split, out_tr, tr_dim, tr_k, st);
+  return launch_reduce_partials(part, out, S, n, st);
+}
+
+hipError_t launch_reduce_jobs(ReduceJobs& jobs, hipStream_t st) {
+  if (jobs.count == 0) return hipSuccess;
+  unsigned nb = 0;
+  for (int j = 0; j < jobs.count; ++j) {
+    jobs.blk0[j] = nb;
+    nb += (unsigned)((jobs.n[j] + RJ_ELEMS - 1) / RJ_ELEMS);
+  }
+  jobs.blk0[jobs.count] = nb;
+  reduce_jobs_kernel<<<dim3(nb), 1024, 0, st>>>(jobs);
+  jobs.count = 0;
   return hipGetLastError();
 }
 

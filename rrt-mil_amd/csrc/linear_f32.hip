@@ -1055,7 +1055,9 @@ void linear_ws_kernel(const void* __restrict__ Av,
 // partial accumulators are summed through LDS in a fixed order and group 0 runs the epilogue.  Four times fewer
 // dependent steps; the MFMA work per SIMD is unchanged (wave g * 4 + c sits on SIMD c).  Exact fp32, plain epilogue
 // (bias, q-scale): what the inner MSA's qkv and proj need.
-template <int MT, int KG>
+// DROP: the training forward's projection (round 6: it ran the generic kernel's 48 blocks of sixteen dependent K tiles, 18 us
+// against 8.7 us here); the mask is the generic epilogue's, a function of (seed, element index).
+template <int MT, int KG, bool DROP = false>
 __global__ __launch_bounds__(256 * KG, 1) void linear_splitk_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                      float* __restrict__ C, int M, int N, int K, int tiles_n,
                                                                      LinearEpilogue ep) {
@@ -1151,7 +1153,7 @@ __global__ __launch_bounds__(256 * KG, 1) void linear_splitk_kernel(const float*
       out[i][0] = a;
     }
     RRT_TRACE_INIT(1 << 30);
-    store_tile<MT, 1, MODE_PLAIN>(out, C, M, N, m0, n0, cw, lr, lg, ep RRT_EPI_TRACE_PASS);
+    store_tile<MT, 1, DROP ? MODE_DROP : MODE_PLAIN>(out, C, M, N, m0, n0, cw, lr, lg, ep RRT_EPI_TRACE_PASS);
   }
 }
 
@@ -1425,10 +1427,10 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
   // the GEMMs of CR-MSA's representatives (M = 64 k <= 512 rows), when the forward has the GPU to itself: K split inside
   // the block (linear_splitk_kernel; its 16-wave, 80-96 KiB blocks do not fit next to another bag's fused R-MSA block)
   static const bool no_splitk = rrt_tune_env("RRT_NO_SPLITK") != nullptr;
-  if (!no_splitk && ep.solo && ep.prec == PREC_F32 && !u && !ep.act && !ep.drop_on && !ep.zero64 && M <= 512 && K % (4 * BK) == 0 && K >= 256) {
+  if (!no_splitk && ep.solo && ep.prec == PREC_F32 && !u && !ep.act && !ep.zero64 && M <= 512 && K % (4 * BK) == 0 && K >= 256) {
     constexpr int KG = 4;
     const int tiles_n = (N + 63) / 64;
-    if (N >= 1024) {                                // qkv: 32-row tiles (6 x 24 = 144 blocks at k = 3)
+    if (N >= 1024 && !ep.drop_on) {                 // qkv: 32-row tiles (6 x 24 = 144 blocks at k = 3)
       constexpr int MT = 2;
       constexpr int LDS_BYTES = KG * 2 * (16 * MT + 64) * BK * 4;
       auto kern = linear_splitk_kernel<MT, KG>;
@@ -1437,9 +1439,15 @@ hipError_t launch_linear(const float* A, const float* B, float* C, int M, int N,
     } else {                                        // proj: 16-row tiles (12 x 8 = 96 blocks)
       constexpr int MT = 1;
       constexpr int LDS_BYTES = KG * 2 * (16 * MT + 64) * BK * 4;
-      auto kern = linear_splitk_kernel<MT, KG>;
-      RRT_ALLOW_LDS(kern, LDS_BYTES);
-      kern<<<dim3(((M + 16 * MT - 1) / (16 * MT)) * tiles_n), dim3(256 * KG), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ep);
+      if (ep.drop_on) {
+        auto kern = linear_splitk_kernel<MT, KG, true>;
+        RRT_ALLOW_LDS(kern, LDS_BYTES);
+        kern<<<dim3(((M + 16 * MT - 1) / (16 * MT)) * tiles_n), dim3(256 * KG), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ep);
+      } else {
+        auto kern = linear_splitk_kernel<MT, KG>;
+        RRT_ALLOW_LDS(kern, LDS_BYTES);
+        kern<<<dim3(((M + 16 * MT - 1) / (16 * MT)) * tiles_n), dim3(256 * KG), LDS_BYTES, st>>>(A, B, C, M, N, K, tiles_n, ep);
+      }
     }
     return hipGetLastError();
   }

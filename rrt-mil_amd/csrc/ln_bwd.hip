@@ -231,7 +231,8 @@ size_t ln_bwd_workspace(int dim) { return (size_t)LNB_BLOCKS * 2 * dim * sizeof(
 
 // dgb: [2, dim] = dgamma then dbeta.  g == nullptr: dy is in token order.
 hipError_t launch_ln_backward(const float* dy, const float* x, const float* gamma, const float* add, float* dx,
-                              float* dgb, float* part, int L, int dim, const GridDev* g, hipStream_t st) {
+                              float* dgb, float* part, int L, int dim, const GridDev* g, hipStream_t st,
+                              ReduceJobs* defer) {
   const int need = (L + 3) / 4;
   const int blocks = need < LNB_BLOCKS ? need : LNB_BLOCKS;
   GridDev gd{};
@@ -246,5 +247,5 @@ hipError_t launch_ln_backward(const float* dy, const float* x, const float* gamm
 #undef RRT_LNB
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return launch_reduce_partials(part, dgb, blocks, (size_t)2 * dim, st);
+  return reduce_or_defer(defer, part, dgb, blocks, (size_t)2 * dim, st);
 }
