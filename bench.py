@@ -1451,7 +1451,7 @@ def extras(wl, dev):
                                                  "scores not counted)",
                                       "achieved": round(f_train / tt / 1e12, 2), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
                                       "frac": round(f_train / tt / 1e12 / PEAK_TFLOPS["f32"], 4),
-                                      "kernel_table": "profiles/r06_train_kernel_stats.txt (tools/prof_train.sh)"},
+                                      "kernel_table": "profiles/r06_final_train_kernel_stats.txt (tools/prof_train.sh)"},
                          "note": "RRTEncoder.train() forward (stash) + backward of every parameter, N=9000 D=512, fp32, "
                                  "drop_out=0.1, one bag per step (rrt_encoder_forward_train_f32 / rrt_encoder_backward_f32)"}
     return out
