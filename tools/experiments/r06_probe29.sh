@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 6, probe 29: eight waves per block in ln_backward / crmsa_bwd_dx (rows per wave 4.4 -> 2.2 at N = 9000; dx2 / add rows
-# requested with the row): tests, training step A/B against RRT_LNB_NW4=1 RRT_DXB_NW4=1 (tuning build), kernel table
+# requested with the row): tests, training step A/B against RRT_LNB_NW4=1 RRT_DXB_NW4=1 (tuning build), kernel table.
+# The kernels under test (ln_backward_kernel<NV, NW>, crmsa_bwd_dx_kernel<NV, MLP, NW, KM> and their two switches) were NOT kept:
+# no gain (profiles/r06_bwd_rows_8waves_ab.txt); with the tree's sources both legs of this script run the same four-wave kernels.
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
 export RRT_HIP_LIB=$R/tools/_abl/librrt_tune.so
 timeout 1200 python -m pytest tests -m gpu -x -q -k "backward or gradients or training or train or dropout or drop_path or grad or ffn or peg or ablation or autocast or layernorm" 2>&1 | tail -3 > $OUT/r06_p29_tests.txt; cat $OUT/r06_p29_tests.txt
