@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 26
+#define RRT_ABI_VERSION 27
 #define RRT_MAX_RMSA_LAYERS 8
 #define RRT_MAX_CRMSA_K 8
 
@@ -519,6 +519,15 @@ int rrt_region_attention_backward_f32(const float *qkv, const float *pe_w, const
 int rrt_layernorm_backward_f32(const float *dy, const float *x, const float *gamma, const float *add,
                                float *dx, float *dgamma_dbeta, int64_t L, int32_t dim, const rrt_grid *g,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* Fixed-order sum of S partial vectors: out[i] = sum_s part[s * n + i] (the parameter-gradient reductions of the backward:
+ * LayerNorm's d gamma | d beta, the EPEG taps, CR-MSA's norm / phi rows, the weight gradients' split-K chunks).
+ * out_tr != NULL: out takes only [0, split) and the tail [tr_k, tr_dim] (n - split = tr_k * tr_dim, split % 4 == 0) leaves
+ * transposed in out_tr [tr_dim, tr_k].  deferred = 0: the stage's own launch (256 elements per block); 1: through the
+ * backward's job list and its one launch at the end of the pass (a block per 128-byte line of every partial), the job queued
+ * `copies` (1 .. 16) times -- copy c reads the same partials and writes out + c * n (out_tr + c * tr_dim * tr_k).
+ * Bit-reproducible in either form; the two forms sum in different orders. */
+int rrt_reduce_partials_f32(const float *part, float *out, float *out_tr, int32_t S, int64_t n, int64_t split,
+                            int32_t tr_dim, int32_t tr_k, int32_t deferred, int32_t copies, void *stream);
 int rrt_linear_backward_workspace_size(int64_t M, int32_t N, int32_t K, size_t *bytes);
 int rrt_linear_backward_f32(const float *dY, const float *X, const float *W, float *dX, float *dW,
                             float *db, int64_t M, int32_t N, int32_t K, int32_t compute,

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "librrt_hip.so")
 
 RRT_MAX_RMSA_LAYERS = 8
 RRT_MAX_CRMSA_K = 8
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _f32p = C.POINTER(C.c_float)
 
@@ -158,6 +158,7 @@ SIGNATURES = {
                                                                                        C.c_void_p]),
     "rrt_layernorm_backward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.POINTER(Grid), C.c_void_p,
                                                                 C.c_size_t, C.c_void_p]),
+    "rrt_reduce_partials_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int32, C.c_int64, C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "rrt_linear_backward_workspace_size": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "rrt_linear_backward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                              C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -1814,6 +1814,26 @@ int rrt_layernorm_backward_f32(const float* dy, const float* x, const float* gam
                                  g ? &gd : nullptr, (hipStream_t)stream);
 }
 
+int rrt_reduce_partials_f32(const float* part, float* out, float* out_tr, int32_t S, int64_t n, int64_t split,
+                            int32_t tr_dim, int32_t tr_k, int32_t deferred, int32_t copies, void* stream) {
+  if (!part || !out || S <= 0 || n <= 0 || S > (1 << 20)) return RRT_E_INVALID;
+  if (out_tr && (split < 0 || split % 4 || split > n || tr_dim <= 0 || tr_k <= 0 || n - split != (int64_t)tr_dim * tr_k))
+    return RRT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (!deferred) {
+    if (out_tr) return (int)launch_reduce_partials_scatter(part, out, S, (size_t)n, (size_t)split, out_tr, tr_dim, tr_k, st);
+    return (int)launch_reduce_partials(part, out, S, (size_t)n, st);
+  }
+  if (copies < 1 || copies > REDUCE_MAX_JOBS) return RRT_E_INVALID;
+  ReduceJobs rj{};
+  for (int c = 0; c < copies; ++c) {
+    hipError_t e = reduce_or_defer(&rj, part, out + (size_t)c * n, S, (size_t)n, st, (size_t)(out_tr ? split : 0),
+                                   out_tr ? out_tr + (size_t)c * tr_dim * tr_k : nullptr, tr_dim, tr_k);
+    if (e != hipSuccess) return (int)e;
+  }
+  return (int)launch_reduce_jobs(rj, st);
+}
+
 int rrt_linear_backward_workspace_size(int64_t M, int32_t N, int32_t K, size_t* bytes) {
   if (!bytes || M <= 0 || N <= 0 || K <= 0 || M > (int64_t)16000000) return RRT_E_INVALID;
   *bytes = linear_bwd_workspace((int)M, N, K);

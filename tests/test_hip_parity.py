@@ -1381,6 +1381,61 @@ def test_bag_feeder_16bit_features_bit_identical_logits(dt):
 
 
 # ------------------------------------------------------------------ row f2 building blocks (backward stages)
+@pytest.mark.parametrize("S,n,scatter", [(512, 1024, None), (512, 2560, (1024, 512, 3)), (64, 120, None), (1, 32, None),
+                                         (3, 7, None), (2250, 1026, None), (16, 786432, None), (130, 4 + 5 * 96, (4, 96, 5)),
+                                         (48, 33, None)])
+def test_reduce_partials_immediate_and_deferred(S, n, scatter):
+    """out[i] = sum_s part[s][i] in a fixed order: the stage's own launch and the backward's deferred job list (one launch,
+    here with the job queued three times), against float64; ragged lengths, one partial, the transposed tail (CR-MSA's
+    d phi), unaligned outputs; twice in a row bit for bit."""
+    from hip_util import dev, p, stream, DEV
+    lib = _lib.load()
+    part = synth.normal(f"rp/{S}x{n}", (S, n))
+    want = part.astype(np.float64).sum(0)
+    d_part = dev(part)
+    tol = 2e-6 * np.sqrt(S) * 4
+    split, trd, trk = scatter if scatter else (0, 0, 0)
+
+    def check(out, out_tr, what):
+        got = out.cpu().numpy().astype(np.float64)
+        if scatter:
+            np.testing.assert_allclose(got[:split], want[:split], rtol=0, atol=tol, err_msg=what)
+            gt = out_tr.cpu().numpy().astype(np.float64)                    # [tr_dim, tr_k]
+            np.testing.assert_allclose(gt, want[split:].reshape(trk, trd).T, rtol=0, atol=tol, err_msg=what + " (tail)")
+        else:
+            np.testing.assert_allclose(got, want, rtol=0, atol=tol, err_msg=what)
+
+    for off in (0, 1):                                                      # off = 1: an output that takes no 16-byte stores
+        if off and scatter:
+            continue                                                        # (the scatter form needs an aligned head, api.hip)
+        if not off:                                                         # immediate (the stage launch stores float4s: aligned outputs only)
+            out = torch.full((n,), float("nan"), device=DEV)
+            out_tr = torch.full((trd, trk), float("nan"), device=DEV) if scatter else None
+            _lib.check(lib.rrt_reduce_partials_f32(p(d_part), out.data_ptr(), out_tr.data_ptr() if scatter else None, S, n,
+                                                   split, trd, trk, 0, 1, stream()), "reduce_partials immediate")
+            torch.cuda.synchronize()
+            check(out, out_tr, "immediate")
+        # deferred, three copies of the job in one launch
+        runs = []
+        for rep in range(2):
+            buf3 = torch.full((3 * n + 4,), float("nan"), device=DEV)
+            o3 = buf3[off:off + 3 * n]
+            t3 = torch.full((3, trd, trk), float("nan"), device=DEV) if scatter else None
+            _lib.check(lib.rrt_reduce_partials_f32(p(d_part), o3.data_ptr(), t3.data_ptr() if scatter else None, S, n, split,
+                                                   trd, trk, 1, 3, stream()), "reduce_partials deferred")
+            torch.cuda.synchronize()
+            for c in range(3):
+                check(o3[c * n:(c + 1) * n], t3[c] if scatter else None, f"deferred copy {c} (offset {off})")
+            if scatter:
+                assert torch.isnan(o3[split:n]).all()                       # the head buffer's tail is not written
+            runs.append((o3.clone(), t3.clone() if scatter else None))
+        assert torch.equal(runs[0][0].nan_to_num(7.0), runs[1][0].nan_to_num(7.0))
+        if scatter:
+            assert torch.equal(runs[0][1], runs[1][1])
+    assert lib.rrt_reduce_partials_f32(p(d_part), None, None, S, n, 0, 0, 0, 1, 1, stream()) == -1
+    assert lib.rrt_reduce_partials_f32(p(d_part), p(d_part), None, S, n, 0, 0, 0, 1, 17, stream()) == -1
+
+
 @pytest.mark.parametrize("M,N,K", [(9216, 1536, 512), (9216, 512, 512), (192, 1536, 512), (192, 512, 512),
                                    (1000, 160, 96), (300, 192, 64), (3136, 512, 2048), (77, 32, 40)])
 def test_linear_backward(M, N, K):
